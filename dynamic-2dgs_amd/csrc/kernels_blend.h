@@ -1,0 +1,282 @@
+// kernels_blend.h -- per-tile forward and backward alpha blend for gfx950.
+//
+// One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 16x4 pixel strip
+// rows 4w..4w+3, so all 64 lanes of a wave consume the same staged surfel at the same time.
+// The tile's depth-sorted list is consumed in batches of 256 entries whose packed 80-B records are
+// gathered into LDS as five float4 planes (20 KB); the inner loop reads them with wave-uniform
+// addresses (LDS broadcast, conflict free).  Replaces renderCUDA of forward.cu:265-463 and
+// backward.cu:143-449.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "surfel_math.h"
+
+namespace dgs {
+
+constexpr int kBatch = 256;
+
+__device__ __forceinline__ Quad as_quad(const float4& v) { return Quad{v.x, v.y, v.z, v.w}; }
+
+struct BlendFwdArgs {
+    const uint2* ranges;         // [T]
+    const uint32_t* point_list;  // [R] sorted surfel ids
+    const float4* rec;           // [P*5]
+    int W, H, tiles_x, tiles_y;
+    const float* bg;             // [3] device
+    float* final_T;              // [3][T*256] tile-major: T, dist1, dist2
+    uint32_t* n_contrib;         // [2][T*256] tile-major: last contributor, median contributor
+    uint32_t* tile_last;         // [T] max over the tile of `last contributor`
+    float* out_color;            // [3,H,W]
+    float* out_others;           // [8,H,W]
+};
+
+// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md), each
+// XCD has a private 4 MiB L2.  Give every XCD a contiguous run of row-major tiles so that the
+// surfel records shared by neighbouring tiles are fetched into one L2 instead of eight.
+__device__ __forceinline__ int xcd_tile_index(int bid, int ntiles)
+{
+    constexpr int kXcd = 8;
+    const int per = (ntiles + kXcd - 1) / kXcd;
+    const int t = (bid % kXcd) * per + bid / kXcd;
+    return t;  // may be >= ntiles for the padded tail; caller checks
+}
+
+__global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
+{
+    __shared__ float4 s_rec[kRecQuads][kBatch];
+    __shared__ int s_flag[4];
+    __shared__ uint32_t s_max[4];
+
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = xcd_tile_index(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int px = tx * kTileX + (tid & 15), py = ty * kTileY + (tid >> 4);
+    const bool inside = px < a.W && py < a.H;
+    const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+
+    const uint2 range = a.ranges[tile];
+    int todo = (int)(range.y - range.x);
+    const int rounds = (todo + kBatch - 1) / kBatch;
+
+    PixFwd st;
+    pixfwd_init(st);
+    bool done = !inside;
+
+    for (int b = 0; b < rounds; b++, todo -= kBatch) {
+        // workgroup vote: leave when all four waves have finished (forward.cu:334-336)
+        const bool wave_done = (__ballot(!done) == 0ull);
+        if (lane == 0) s_flag[wave] = wave_done ? 1 : 0;
+        __syncthreads();  // also fences the previous batch's LDS reads
+        if (s_flag[0] & s_flag[1] & s_flag[2] & s_flag[3]) break;
+
+        const int n = todo < kBatch ? todo : kBatch;
+        if (tid < n) {
+            const uint32_t id = a.point_list[range.x + (uint32_t)(b * kBatch + tid)];
+            const float4* src = a.rec + (size_t)id * kRecQuads;
+#pragma unroll
+            for (int c = 0; c < kRecQuads; c++) s_rec[c][tid] = src[c];
+        }
+        __syncthreads();
+
+        if (!wave_done) {
+            for (int j = 0; j < n; j++) {
+                if (__ballot(!done) == 0ull) break;  // wave-level early out
+                if (done) continue;
+                st.contributor++;
+                PairEval e;
+                if (!pair_eval(pfx, pfy, as_quad(s_rec[0][j]), as_quad(s_rec[1][j]), as_quad(s_rec[2][j]), e)) continue;
+                if (!pixfwd_blend(st, e, as_quad(s_rec[3][j]), as_quad(s_rec[4][j]))) done = true;
+            }
+        }
+    }
+
+    // per-tile maximum of the last contributor: the backward starts there instead of walking the
+    // whole list (backward.cu:276-279 skips those entries one by one)
+    uint32_t m = inside ? st.last : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t mm = s_max[0];
+        mm = s_max[1] > mm ? s_max[1] : mm;
+        mm = s_max[2] > mm ? s_max[2] : mm;
+        mm = s_max[3] > mm ? s_max[3] : mm;
+        a.tile_last[tile] = mm;
+    }
+
+    const size_t plane = (size_t)ntiles * kTilePix;
+    const size_t slot = (size_t)tile * kTilePix + tid;
+    a.final_T[slot] = st.T;
+    a.final_T[plane + slot] = st.dist1;
+    a.final_T[2 * plane + slot] = st.dist2;
+    a.n_contrib[slot] = st.last;
+    a.n_contrib[plane + slot] = st.med_c;
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = (size_t)py * a.W + px;
+        a.out_color[pix] = st.C[0] + st.T * a.bg[0];
+        a.out_color[HW + pix] = st.C[1] + st.T * a.bg[1];
+        a.out_color[2 * HW + pix] = st.C[2] + st.T * a.bg[2];
+        a.out_others[pix] = st.D;                 // DEPTH_OFFSET 0   (auxiliary.h:25-30)
+        a.out_others[HW + pix] = 1.f - st.T;      // ALPHA_OFFSET 1
+        a.out_others[2 * HW + pix] = st.N[0];     // NORMAL_OFFSET 2..4
+        a.out_others[3 * HW + pix] = st.N[1];
+        a.out_others[4 * HW + pix] = st.N[2];
+        a.out_others[5 * HW + pix] = st.med_d;    // MIDDEPTH_OFFSET 5
+        a.out_others[6 * HW + pix] = st.distortion;  // DISTORTION_OFFSET 6
+        a.out_others[7 * HW + pix] = st.med_w;    // MEDIAN_WEIGHT_OFFSET 7
+    }
+}
+
+struct BlendBwdArgs {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float4* rec;
+    int W, H, tiles_x, tiles_y;
+    const float* bg;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const uint32_t* tile_last;
+    const float* dL_dpix;     // [3,H,W]
+    const float* dL_dothers;  // [8,H,W]
+    float* acc;               // [P, kAccFloats], zeroed
+};
+
+// Reduce 16 per-lane values over the 64 lanes of a wave with a halving butterfly: 8+4+2+1 exchanges
+// bring value k to the lanes with (lane >> 2) == k, two more finish the quad.  17 cross-lane ops
+// instead of 16 * 6.  On return every lane of quad k holds the wave total of v[k].
+__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane)
+{
+    float a8[8], a4[4], a2[2], a1;
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float keep = h5 ? v[i + 8] : v[i];
+        const float send = h5 ? v[i] : v[i + 8];
+        a8[i] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float keep = h4 ? a8[i + 4] : a8[i];
+        const float send = h4 ? a8[i] : a8[i + 4];
+        a4[i] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float keep = h3 ? a4[i + 2] : a4[i];
+        const float send = h3 ? a4[i] : a4[i + 2];
+        a2[i] = keep + __shfl_xor(send, 8, 64);
+    }
+    {
+        const float keep = h2 ? a2[1] : a2[0];
+        const float send = h2 ? a2[0] : a2[1];
+        a1 = keep + __shfl_xor(send, 4, 64);
+    }
+    a1 += __shfl_xor(a1, 2, 64);
+    a1 += __shfl_xor(a1, 1, 64);
+    return a1;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(kTilePix) blend_bwd_kernel(BlendBwdArgs a)
+{
+    __shared__ float4 s_rec[kRecQuads][kBatch];
+    __shared__ uint32_t s_id[kBatch];
+
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = xcd_tile_index(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int L = (int)a.tile_last[tile];  // entries [0, L) can contribute to some pixel of the tile
+    if (L == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int px = tx * kTileX + (tid & 15), py = ty * kTileY + (tid >> 4);
+    const bool inside = px < a.W && py < a.H;
+    const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+    const uint2 range = a.ranges[tile];
+
+    const size_t plane = (size_t)ntiles * kTilePix;
+    const size_t slot = (size_t)tile * kTilePix + tid;
+    PixBwd st;
+    {
+        float gpix[3] = {0.f, 0.f, 0.f}, goth[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (inside) {
+            const size_t HW = (size_t)a.H * a.W;
+            const size_t pix = (size_t)py * a.W + px;
+#pragma unroll
+            for (int c = 0; c < 3; c++) gpix[c] = a.dL_dpix[c * HW + pix];
+#pragma unroll
+            for (int c = 0; c < 8; c++) goth[c] = a.dL_dothers[c * HW + pix];
+        }
+        const int last = inside ? (int)a.n_contrib[slot] : 0;
+        const int medc = inside ? (int)a.n_contrib[plane + slot] : 0;
+        pixbwd_init(st, inside ? a.final_T[slot] : 0.f, a.final_T[plane + slot], a.final_T[2 * plane + slot], last, medc, gpix,
+                    goth, a.bg);
+    }
+    // highest entry any lane of this wave needs
+    int wave_last = st.last_contributor;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        int o = __shfl_xor(wave_last, d, 64);
+        wave_last = o > wave_last ? o : wave_last;
+    }
+
+    const int rounds = (L + kBatch - 1) / kBatch;
+    for (int b = 0; b < rounds; b++) {
+        __syncthreads();
+        // back to front: batch entry j holds list entry e = L-1 - (b*256 + j)
+        const int e_mine = L - 1 - (b * kBatch + tid);
+        if (e_mine >= 0) {
+            const uint32_t id = a.point_list[range.x + (uint32_t)e_mine];
+            s_id[tid] = id;
+            const float4* src = a.rec + (size_t)id * kRecQuads;
+#pragma unroll
+            for (int c = 0; c < kRecQuads; c++) s_rec[c][tid] = src[c];
+        }
+        __syncthreads();
+        const int n = (L - b * kBatch) < kBatch ? (L - b * kBatch) : kBatch;
+        for (int j = 0; j < n; j++) {
+            const int e = L - 1 - (b * kBatch + j);  // 0-based list index == the reference's `contributor`
+            if (e >= wave_last) continue;            // wave-uniform skip
+            float out[kAccFloats];
+#pragma unroll
+            for (int c = 0; c < 18; c++) out[c] = 0.f;
+            bool contrib = false, flat = false;
+            if (e < st.last_contributor) {
+                PairEval ev;
+                const Quad q0 = as_quad(s_rec[0][j]), q1 = as_quad(s_rec[1][j]), q2 = as_quad(s_rec[2][j]);
+                if (pair_eval(pfx, pfy, q0, q1, q2, ev)) {
+                    pixbwd_step(st, ev, e, pfx, pfy, q1, q2, as_quad(s_rec[3][j]), as_quad(s_rec[4][j]), out);
+                    contrib = true;
+                    flat = !ev.use3d;
+                }
+            }
+            if (__ballot(contrib) == 0ull) continue;
+            float* dst = a.acc + (size_t)s_id[j] * kAccFloats;
+            float v16[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) v16[c] = out[c];
+            const float tot = wave_reduce16(v16, lane);
+            if ((lane & 3) == 0) atomicAdd(dst + (lane >> 2), tot);
+            if (__ballot(flat) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                const float mx = wave_sum(out[kAccMean2D + 0]);
+                const float my = wave_sum(out[kAccMean2D + 1]);
+                if (lane == 0) { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+            }
+        }
+    }
+}
+
+}  // namespace dgs

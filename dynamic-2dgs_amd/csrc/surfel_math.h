@@ -1,0 +1,526 @@
+// surfel_math.h -- per-surfel and per-(pixel,surfel) arithmetic of the MI355X surfel rasterizer.
+//
+// Written from scratch for gfx950; the behaviour it reproduces is cited per function against
+// the reference (paths relative to submodules/diff-surfel-rasterization/ of hustvl/Dynamic-2DGS).
+// Every function is __host__ __device__ so that tests/ can compile this header with g++ and check
+// the arithmetic against the CPU oracle without a GPU (tests/hostmath/); the shipped library only
+// ever calls it from HIP kernels.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DGS_HD __host__ __device__ __forceinline__
+#else
+#define DGS_HD inline
+#endif
+
+namespace dgs {
+
+// ---- compile-time constants of the reference (cuda_rasterizer/config.h:15-17, auxiliary.h:18-37)
+constexpr int kTileX = 16;
+constexpr int kTileY = 16;
+constexpr int kTilePix = 256;
+constexpr float kFilterSize = 0.70710678118654752f;
+constexpr float kNear = 0.2f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kTmin = 0.0001f;
+
+// ---- packed per-surfel record written by the preprocess kernel and gathered by the blend kernels.
+// 20 floats = 80 B = five 16-B chunks, so one surfel is 5 dwordx4 transactions:
+//   q0 = (Tu.x Tu.y Tu.z Tv.x)  q1 = (Tv.y Tv.z Tw.x Tw.y)  q2 = (Tw.z xy.x xy.y opacity)   <- alpha part
+//   q3 = (n.x n.y n.z r)        q4 = (g b depth flags)                                      <- shading part
+constexpr int kRecFloats = 20;
+constexpr int kRecQuads = 5;
+
+struct Quad { float x, y, z, w; };
+
+struct SurfelRec {
+    float Tu[3], Tv[3], Tw[3];
+    float xy[2];
+    float opacity;
+    float normal[3];
+    float rgb[3];
+    float depth;
+    uint32_t flags;  // bit c set: colour channel c was clamped at 0 (forward.cu:66-69)
+};
+static_assert(sizeof(SurfelRec) == kRecFloats * 4, "record must be 80 bytes");
+
+// ---- per-surfel gradient accumulator slots written by the backward blend (one 80-B row per surfel)
+constexpr int kAccFloats = 20;
+enum AccSlot { kAccColor = 0, kAccNormal = 3, kAccT = 6, kAccOpacity = 15, kAccMean2D = 16 };
+
+DGS_HD float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+DGS_HD float fast_exp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+
+struct Camera {
+    const float* view;    // [16] world_view_transform flattened: W2C column-major, translation at [12..14]
+    const float* campos;  // [3]   (both are read where the kernel runs: device pointers in the library)
+    float focal_x, focal_y;
+    float tan_fovx, tan_fovy;
+    int width, height;
+    int tiles_x, tiles_y;
+};
+
+// auxiliary.h:64-74 getRect: tile rectangle [min,max) touched by a disc of integer radius.
+DGS_HD void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1)
+{
+    int v;
+    v = (int)((px - radius) / kTileX); v = v < 0 ? 0 : v; x0 = v < gx ? v : gx;
+    v = (int)((py - radius) / kTileY); v = v < 0 ? 0 : v; y0 = v < gy ? v : gy;
+    v = (int)((px + radius + kTileX - 1) / kTileX); v = v < 0 ? 0 : v; x1 = v < gx ? v : gx;
+    v = (int)((py + radius + kTileY - 1) / kTileY); v = v < 0 ? 0 : v; y1 = v < gy ? v : gy;
+}
+
+// auxiliary.h:188-210: rotation matrix columns from a (r,x,y,z) quaternion, normalised on the fly.
+DGS_HD void quat_columns(const float* q, float c0[3], float c1[3], float c2[3])
+{
+    float s = 1.0f / sqrtf(q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    float w = q[0] * s, x = q[1] * s, y = q[2] * s, z = q[3] * s;
+    c0[0] = 1.f - 2.f * (y * y + z * z); c0[1] = 2.f * (x * y + w * z);       c0[2] = 2.f * (x * z - w * y);
+    c1[0] = 2.f * (x * y - w * z);       c1[1] = 1.f - 2.f * (x * x + z * z); c1[2] = 2.f * (y * z + w * x);
+    c2[0] = 2.f * (x * z + w * y);       c2[1] = 2.f * (y * z - w * x);       c2[2] = 1.f - 2.f * (x * x + y * y);
+}
+
+DGS_HD void view_rotate(const float* vm, const float* v, float* r)  // W * v, forward.cu:79-83
+{
+    r[0] = vm[0] * v[0] + vm[4] * v[1] + vm[8] * v[2];
+    r[1] = vm[1] * v[0] + vm[5] * v[1] + vm[9] * v[2];
+    r[2] = vm[2] * v[0] + vm[6] * v[1] + vm[10] * v[2];
+}
+
+DGS_HD void view_rotate_T(const float* vm, const float* v, float* r)  // W^T * v, auxiliary.h:108-116
+{
+    r[0] = vm[0] * v[0] + vm[1] * v[1] + vm[2] * v[2];
+    r[1] = vm[4] * v[0] + vm[5] * v[1] + vm[6] * v[2];
+    r[2] = vm[8] * v[0] + vm[9] * v[1] + vm[10] * v[2];
+}
+
+// forward.cu:20-71 computeColorFromSH.  `sh` points at this surfel's [M,3] coefficients.
+DGS_HD uint32_t sh_to_rgb(int deg, const float* sh, const float* pos, const float* campos, float rgb[3])
+{
+    float dx = pos[0] - campos[0], dy = pos[1] - campos[1], dz = pos[2] - campos[2];
+    float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    float x = dx / len, y = dy / len, z = dz / len;
+    uint32_t flags = 0;
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    for (int c = 0; c < 3; c++) {
+        float r = C0 * sh[c];
+        if (deg > 0) {
+            r = r - C1 * y * sh[3 + c] + C1 * z * sh[6 + c] - C1 * x * sh[9 + c];
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + C2[0] * xy * sh[12 + c] + C2[1] * yz * sh[15 + c] + C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] +
+                    C2[3] * xz * sh[21 + c] + C2[4] * (xx - yy) * sh[24 + c];
+                if (deg > 2) {
+                    r = r + C3[0] * y * (3.0f * xx - yy) * sh[27 + c] + C3[1] * xy * z * sh[30 + c] +
+                        C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] + C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                        C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] + C3[5] * z * (xx - yy) * sh[42 + c] +
+                        C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
+                }
+            }
+        }
+        r += 0.5f;
+        if (r < 0.f) flags |= (1u << c);
+        rgb[c] = r > 0.f ? r : 0.f;
+    }
+    return flags;
+}
+
+// forward.cu:166-260 preprocessCUDA with computeTransMat (:75-128), computeAABB (:133-163) and the
+// near cull of in_frustum (auxiliary.h:160-185).  Returns the integer radius (0 = culled) and the
+// tile count.  Contraction is switched off so that the culling / ceil / (int) decisions are taken on
+// the same IEEE values as the CPU oracle.
+DGS_HD int preprocess_surfel(const Camera& cam, const float* pos, const float* scale, const float* quat, float opacity,
+                             int deg, const float* sh /*or null*/, const float* color_precomp /*or null*/,
+                             SurfelRec& rec, int& tiles)
+{
+#pragma clang fp contract(off)
+    tiles = 0;
+    const float* vm = cam.view;
+    float pv[3];
+    pv[0] = vm[0] * pos[0] + vm[4] * pos[1] + vm[8] * pos[2] + vm[12];
+    pv[1] = vm[1] * pos[0] + vm[5] * pos[1] + vm[9] * pos[2] + vm[13];
+    pv[2] = vm[2] * pos[0] + vm[6] * pos[1] + vm[10] * pos[2] + vm[14];
+    if (pv[2] <= 0.2f) return 0;
+
+    float c0[3], c1[3], c2[3];
+    quat_columns(quat, c0, c1, c2);
+    float rs0[3] = {c0[0] * scale[0], c0[1] * scale[0], c0[2] * scale[0]};
+    float rs1[3] = {c1[0] * scale[1], c1[1] * scale[1], c1[2] * scale[1]};
+    float m0[3], m1[3], tn[3];
+    view_rotate(vm, rs0, m0);
+    view_rotate(vm, rs1, m1);
+    view_rotate(vm, c2, tn);
+    float cosv = -tn[0] * pv[0] + -tn[1] * pv[1] + -tn[2] * pv[2];
+    if (cosv == 0.0f) return 0;
+    float flip = cosv > 0 ? 1.f : -1.f;
+
+    const float cx = (float)cam.width / 2.0f, cy = (float)cam.height / 2.0f;
+    float Tu[3] = {cam.focal_x * m0[0] + cx * m0[2], cam.focal_x * m1[0] + cx * m1[2], cam.focal_x * pv[0] + cx * pv[2]};
+    float Tv[3] = {cam.focal_y * m0[1] + cy * m0[2], cam.focal_y * m1[1] + cy * m1[2], cam.focal_y * pv[1] + cy * pv[2]};
+    float Tw[3] = {m0[2], m1[2], pv[2]};
+
+    float d = Tw[0] * Tw[0] + Tw[1] * Tw[1] - Tw[2] * Tw[2];
+    if (d == 0.0f) return 0;
+    float inv = 1.0f / d;
+    float f[3] = {inv, inv, -inv};
+    float px = f[0] * (Tu[0] * Tw[0]) + f[1] * (Tu[1] * Tw[1]) + f[2] * (Tu[2] * Tw[2]);
+    float py = f[0] * (Tv[0] * Tw[0]) + f[1] * (Tv[1] * Tw[1]) + f[2] * (Tv[2] * Tw[2]);
+    float h0x = px * px - (f[0] * (Tu[0] * Tu[0]) + f[1] * (Tu[1] * Tu[1]) + f[2] * (Tu[2] * Tu[2]));
+    float h0y = py * py - (f[0] * (Tv[0] * Tv[0]) + f[1] * (Tv[1] * Tv[1]) + f[2] * (Tv[2] * Tv[2]));
+    float ex = sqrtf(h0x > 0.f ? h0x : 0.f), ey = sqrtf(h0y > 0.f ? h0y : 0.f);
+    float emax = ex > ey ? ex : ey;
+    // forward.cu:231: ceil(3.f * max(max(ex,ey), FilterSize)) with FilterSize a double literal
+    double em = (double)emax > 0.7071067811865476 ? (double)emax : 0.7071067811865476;
+    int radius = (int)(float)ceil(3.0 * em);
+    int x0, y0, x1, y1;
+    tile_rect(px, py, radius, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
+    int cnt = (x1 - x0) * (y1 - y0);
+    if (cnt == 0) return 0;
+
+    for (int c = 0; c < 3; c++) { rec.Tu[c] = Tu[c]; rec.Tv[c] = Tv[c]; rec.Tw[c] = Tw[c]; rec.normal[c] = tn[c] * flip; }
+    rec.xy[0] = px; rec.xy[1] = py;
+    rec.opacity = opacity;
+    rec.depth = pv[2];
+    if (color_precomp) {
+        rec.rgb[0] = color_precomp[0]; rec.rgb[1] = color_precomp[1]; rec.rgb[2] = color_precomp[2];
+        rec.flags = 0;
+    } else {
+        rec.flags = sh_to_rgb(deg, sh, pos, cam.campos, rec.rgb);
+    }
+    tiles = cnt;
+    return radius;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-(pixel, surfel) evaluation shared by the forward and backward blend (forward.cu:359-399,
+// backward.cu:283-323).
+struct PairEval {
+    float kx, ky, kz, lx, ly, lz;  // the two homogeneous planes
+    float pz;                      // z of their cross product
+    float sx, sy;                  // intersection in splat space
+    float dx, dy;                  // projected centre minus pixel centre
+    float G, alpha, depth;
+    bool use3d;                    // rho3d <= rho2d
+};
+
+DGS_HD bool pair_eval(float pfx, float pfy, const Quad& q0, const Quad& q1, const Quad& q2, PairEval& e)
+{
+    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y, Twx = q1.z, Twy = q1.w, Twz = q2.x;
+    e.kx = pfx * Twx - Tux; e.ky = pfx * Twy - Tuy; e.kz = pfx * Twz - Tuz;
+    e.lx = pfy * Twx - Tvx; e.ly = pfy * Twy - Tvy; e.lz = pfy * Twz - Tvz;
+    float ppx = e.ky * e.lz - e.kz * e.ly;
+    float ppy = e.kz * e.lx - e.kx * e.lz;
+    e.pz = e.kx * e.ly - e.ky * e.lx;
+    if (e.pz == 0.0f) return false;
+    float inv = fast_rcp(e.pz);
+    e.sx = ppx * inv; e.sy = ppy * inv;
+    float rho3d = e.sx * e.sx + e.sy * e.sy;
+    e.dx = q2.y - pfx; e.dy = q2.z - pfy;
+    float rho2d = 2.0f * (e.dx * e.dx + e.dy * e.dy);   // FilterInvSquare == 2, auxiliary.h:20-21
+    e.use3d = rho3d <= rho2d;
+    float rho = e.use3d ? rho3d : rho2d;
+    e.depth = e.use3d ? (e.sx * Twx + e.sy * Twy) + Twz : Twz;
+    if (e.depth < kNear) return false;                  // float 0.2f: same set as (double)depth < 0.2
+    float power = -0.5f * rho;
+    if (power > 0.0f) return false;
+    e.G = fast_exp(power);
+    float a = q2.w * e.G;
+    e.alpha = a < kAlphaMax ? a : kAlphaMax;
+    return !(e.alpha < kAlphaMin);
+}
+
+DGS_HD float mapped_depth(float depth)  // (FAR*d - FAR*NEAR) / ((FAR-NEAR)*d), forward.cu:412
+{
+    return (100.0f * depth - 20.0f) / (99.8f * depth);
+}
+
+// Running per-pixel state of the forward blend (forward.cu:313-329).
+struct PixFwd {
+    float T;
+    float C[3];
+    float D;
+    float N[3];
+    float dist1, dist2, distortion;
+    float med_d, med_w;
+    uint32_t contributor, last, med_c;
+};
+
+DGS_HD void pixfwd_init(PixFwd& s)
+{
+    s.T = 1.f; s.C[0] = s.C[1] = s.C[2] = 0.f; s.D = 0.f; s.N[0] = s.N[1] = s.N[2] = 0.f;
+    s.dist1 = s.dist2 = s.distortion = 0.f; s.med_d = s.med_w = 0.f; s.contributor = 0; s.last = 0; s.med_c = 0;
+}
+
+// forward.cu:400-438 for one contributing entry. Returns false when the pixel saturates (T < 1e-4).
+DGS_HD bool pixfwd_blend(PixFwd& s, const PairEval& e, const Quad& q3, const Quad& q4)
+{
+    float test_T = s.T * (1.f - e.alpha);
+    if (test_T < kTmin) return false;
+    float w = e.alpha * s.T;
+    float A = 1.f - s.T;
+    float m = mapped_depth(e.depth);
+    float err = m * m * A + s.dist2 - 2.f * m * s.dist1;
+    s.distortion += err * w;
+    if (s.T > 0.5f) { s.med_d = e.depth; s.med_w = w; s.med_c = s.contributor; }
+    s.N[0] += q3.x * w; s.N[1] += q3.y * w; s.N[2] += q3.z * w;
+    s.D += e.depth * w;
+    s.dist1 += m * w;
+    s.dist2 += m * m * w;
+    s.C[0] += q3.w * w; s.C[1] += q4.x * w; s.C[2] += q4.y * w;
+    s.T = test_T;
+    s.last = s.contributor;
+    return true;
+}
+
+// Running per-pixel state of the backward blend (backward.cu:191-247).
+struct PixBwd {
+    float T, T_final;
+    float last_alpha;
+    float accum_rec[3], last_color[3];
+    float accum_depth_rec, last_depth;
+    float accum_alpha_rec;
+    float accum_normal_rec[3], last_normal[3];
+    float last_dL_dT;
+    float final_D, final_D2, final_A;
+    float g_pix[3];      // dL/dcolour
+    float g_depth, g_alpha, g_normal[3], g_meddepth, g_dist, g_medw;
+    float bg_dot;        // dot(bg, g_pix)
+    int last_contributor, med_c;
+};
+
+DGS_HD void pixbwd_init(PixBwd& s, float T_final, float dist1, float dist2, int last, int med_c, const float* gpix,
+                        const float* gothers /*8*/, const float* bg)
+{
+    s.T = s.T_final = T_final;
+    s.last_alpha = 0.f;
+    for (int c = 0; c < 3; c++) { s.accum_rec[c] = s.last_color[c] = 0.f; s.accum_normal_rec[c] = s.last_normal[c] = 0.f; s.g_pix[c] = gpix[c]; }
+    s.accum_depth_rec = s.last_depth = s.accum_alpha_rec = 0.f;
+    s.last_dL_dT = 0.f;
+    s.final_D = dist1; s.final_D2 = dist2; s.final_A = 1.f - T_final;
+    s.g_depth = gothers[0]; s.g_alpha = gothers[1];
+    s.g_normal[0] = gothers[2]; s.g_normal[1] = gothers[3]; s.g_normal[2] = gothers[4];
+    s.g_meddepth = gothers[5]; s.g_dist = gothers[6]; s.g_medw = gothers[7];
+    s.bg_dot = bg[0] * gpix[0] + bg[1] * gpix[1] + bg[2] * gpix[2];
+    s.last_contributor = last; s.med_c = med_c;
+}
+
+// backward.cu:325-446 for one contributing entry (`contributor` = 0-based list index).
+// Writes this pixel's 18 partial derivatives into out[kAccFloats] (slots of AccSlot).
+DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, int contributor, float pfx, float pfy, const Quad& q1, const Quad& q2,
+                        const Quad& q3, const Quad& q4, float* out)
+{
+    const float alpha = e.alpha, G = e.G;
+    const float one_m_a = 1.f - alpha;
+    s.T = s.T / one_m_a;
+    const float w = alpha * s.T;
+    const float col[3] = {q3.w, q4.x, q4.y};
+    const float nrm[3] = {q3.x, q3.y, q3.z};
+    float dL_dalpha = 0.f;
+    for (int c = 0; c < 3; c++) {
+        s.accum_rec[c] = s.last_alpha * s.last_color[c] + (1.f - s.last_alpha) * s.accum_rec[c];
+        s.last_color[c] = col[c];
+        dL_dalpha += (col[c] - s.accum_rec[c]) * s.g_pix[c];
+        out[kAccColor + c] = w * s.g_pix[c];
+    }
+    float dL_dz = 0.f, dL_dweight = 0.f;
+    const float c_d = e.depth;
+    const float m_d = mapped_depth(c_d);
+    const float dmd_dd = 20.0f / (99.8f * c_d * c_d);
+    if (contributor == s.med_c - 1) { dL_dz += s.g_meddepth; dL_dweight += s.g_medw; }
+    dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2.f * m_d * s.final_D) * s.g_dist;
+    dL_dalpha += dL_dweight - s.last_dL_dT;
+    s.last_dL_dT = dL_dweight * alpha + one_m_a * s.last_dL_dT;
+    const float dL_dmd = 2.0f * w * (m_d * s.final_A - s.final_D) * s.g_dist;
+    dL_dz += dL_dmd * dmd_dd;
+    s.accum_depth_rec = s.last_alpha * s.last_depth + (1.f - s.last_alpha) * s.accum_depth_rec;
+    s.last_depth = c_d;
+    dL_dalpha += (c_d - s.accum_depth_rec) * s.g_depth;
+    s.accum_alpha_rec = s.last_alpha + (1.f - s.last_alpha) * s.accum_alpha_rec;
+    dL_dalpha += (1.f - s.accum_alpha_rec) * s.g_alpha;
+    for (int c = 0; c < 3; c++) {
+        s.accum_normal_rec[c] = s.last_alpha * s.last_normal[c] + (1.f - s.last_alpha) * s.accum_normal_rec[c];
+        s.last_normal[c] = nrm[c];
+        dL_dalpha += (nrm[c] - s.accum_normal_rec[c]) * s.g_normal[c];
+        out[kAccNormal + c] = w * s.g_normal[c];
+    }
+    dL_dalpha *= s.T;
+    s.last_alpha = alpha;
+    dL_dalpha += (-s.T_final / one_m_a) * s.bg_dot;
+    const float dL_dG = q2.w * dL_dalpha;
+    dL_dz += w * s.g_depth;
+
+    const float Twx = q1.z, Twy = q1.w;
+    if (e.use3d) {
+        const float dsx = dL_dG * -G * e.sx + dL_dz * Twx;
+        const float dsy = dL_dG * -G * e.sy + dL_dz * Twy;
+        const float inv = 1.0f / e.pz;
+        const float ax = dsx * inv, ay = dsy * inv;
+        const float dpx = ax, dpy = ay, dpz = -(ax * e.sx + ay * e.sy);
+        // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
+        const float dkx = e.ly * dpz - e.lz * dpy, dky = e.lz * dpx - e.lx * dpz, dkz = e.lx * dpy - e.ly * dpx;
+        const float dlx = dpy * e.kz - dpz * e.ky, dly = dpz * e.kx - dpx * e.kz, dlz = dpx * e.ky - dpy * e.kx;
+        out[kAccT + 0] = -dkx; out[kAccT + 1] = -dky; out[kAccT + 2] = -dkz;
+        out[kAccT + 3] = -dlx; out[kAccT + 4] = -dly; out[kAccT + 5] = -dlz;
+        out[kAccT + 6] = pfx * dkx + pfy * dlx + dL_dz * e.sx;
+        out[kAccT + 7] = pfx * dky + pfy * dly + dL_dz * e.sy;
+        out[kAccT + 8] = pfx * dkz + pfy * dlz + dL_dz;
+        out[kAccMean2D + 0] = 0.f; out[kAccMean2D + 1] = 0.f;
+    } else {
+        for (int c = 0; c < 8; c++) out[kAccT + c] = 0.f;
+        out[kAccT + 8] = dL_dz;
+        out[kAccMean2D + 0] = dL_dG * (-G * 2.0f * e.dx);
+        out[kAccMean2D + 1] = dL_dG * (-G * 2.0f * e.dy);
+    }
+    out[kAccOpacity] = G * dL_dalpha;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-surfel backward: computeAABB vjp (backward.cu:599-649), computeTransMat vjp (:451-529),
+// quaternion vjp (auxiliary.h:213-257) and SH vjp (backward.cu:20-139).
+struct SurfelGrads {
+    float dmean3D[3];
+    float dscale[2];
+    float drot[4];
+    float dmean2D[2];   // densification signal, backward.cu:645-648
+    float dT[9];        // total dL/dtransMat
+};
+
+DGS_HD void sh_backward(int deg, const float* sh, const float* pos, const float* campos, uint32_t flags, const float* dL_dcolor,
+                        float* dsh /*[M,3], entries up to (deg+1)^2 written*/, float* dmean /*+=*/)
+{
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    float ox = pos[0] - campos[0], oy = pos[1] - campos[1], oz = pos[2] - campos[2];
+    float len = sqrtf(ox * ox + oy * oy + oz * oz);
+    float x = ox / len, y = oy / len, z = oz / len;
+    float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+    for (int c = 0; c < 3; c++) {
+        const float g = ((flags >> c) & 1u) ? 0.f : dL_dcolor[c];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        dsh[c] = C0 * g;
+        if (deg > 0) {
+            dsh[3 + c] = (-C1 * y) * g; dsh[6 + c] = (C1 * z) * g; dsh[9 + c] = (-C1 * x) * g;
+            gx = -C1 * sh[9 + c]; gy = -C1 * sh[3 + c]; gz = C1 * sh[6 + c];
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                dsh[12 + c] = (C2[0] * xy) * g; dsh[15 + c] = (C2[1] * yz) * g; dsh[18 + c] = (C2[2] * (2.f * zz - xx - yy)) * g;
+                dsh[21 + c] = (C2[3] * xz) * g; dsh[24 + c] = (C2[4] * (xx - yy)) * g;
+                gx += C2[0] * y * sh[12 + c] + C2[2] * 2.f * -x * sh[18 + c] + C2[3] * z * sh[21 + c] + C2[4] * 2.f * x * sh[24 + c];
+                gy += C2[0] * x * sh[12 + c] + C2[1] * z * sh[15 + c] + C2[2] * 2.f * -y * sh[18 + c] + C2[4] * 2.f * -y * sh[24 + c];
+                gz += C2[1] * y * sh[15 + c] + C2[2] * 2.f * 2.f * z * sh[18 + c] + C2[3] * x * sh[21 + c];
+                if (deg > 2) {
+                    dsh[27 + c] = (C3[0] * y * (3.f * xx - yy)) * g; dsh[30 + c] = (C3[1] * xy * z) * g;
+                    dsh[33 + c] = (C3[2] * y * (4.f * zz - xx - yy)) * g; dsh[36 + c] = (C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g;
+                    dsh[39 + c] = (C3[4] * x * (4.f * zz - xx - yy)) * g; dsh[42 + c] = (C3[5] * z * (xx - yy)) * g;
+                    dsh[45 + c] = (C3[6] * x * (xx - 3.f * yy)) * g;
+                    gx += C3[0] * sh[27 + c] * 3.f * 2.f * xy + C3[1] * sh[30 + c] * yz + C3[2] * sh[33 + c] * -2.f * xy +
+                          C3[3] * sh[36 + c] * -3.f * 2.f * xz + C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
+                          C3[5] * sh[42 + c] * 2.f * xz + C3[6] * sh[45 + c] * 3.f * (xx - yy);
+                    gy += C3[0] * sh[27 + c] * 3.f * (xx - yy) + C3[1] * sh[30 + c] * xz + C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) +
+                          C3[3] * sh[36 + c] * -3.f * 2.f * yz + C3[4] * sh[39 + c] * -2.f * xy + C3[5] * sh[42 + c] * -2.f * yz +
+                          C3[6] * sh[45 + c] * -3.f * 2.f * xy;
+                    gz += C3[1] * sh[30 + c] * xy + C3[2] * sh[33 + c] * 4.f * 2.f * yz + C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) +
+                          C3[4] * sh[39 + c] * 4.f * 2.f * xz + C3[5] * sh[42 + c] * (xx - yy);
+                }
+            }
+        }
+        ddx += gx * g; ddy += gy * g; ddz += gz * g;
+    }
+    // through dir = v/|v| (auxiliary.h:126-137)
+    float sum2 = ox * ox + oy * oy + oz * oz;
+    float invs = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmean[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invs;
+    dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invs;
+    dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invs;
+}
+
+// `acc` = this surfel's accumulated row from the backward blend (AccSlot layout).
+DGS_HD void surfel_backward(const Camera& cam, const float* pos, const float* scale, const float* quat, const SurfelRec& rec,
+                            const float* acc, SurfelGrads& g)
+{
+    const float* vm = cam.view;
+    const float* Tu = rec.Tu; const float* Tv = rec.Tv; const float* Tw = rec.Tw;
+    float dT[9];
+    for (int c = 0; c < 9; c++) dT[c] = acc[kAccT + c];
+    // ---- AABB chain: d(centre)/dT applied to the raw screen-space gradient
+    {
+        const float gmx = acc[kAccMean2D + 0], gmy = acc[kAccMean2D + 1];
+        const float d = Tw[0] * Tw[0] + Tw[1] * Tw[1] - Tw[2] * Tw[2];
+        const float inv = 1.0f / d;
+        const float f[3] = {inv, inv, -inv};
+        const float sgn[3] = {1.f, 1.f, -1.f};
+        float dLdf_dot_f = 0.f;
+        for (int c = 0; c < 3; c++) dLdf_dot_f += (gmx * Tu[c] * Tw[c] + gmy * Tv[c] * Tw[c]) * f[c];
+        const float dL_dd = dLdf_dot_f * (-1.0f / d);
+        for (int c = 0; c < 3; c++) {
+            dT[c] += gmx * f[c] * Tw[c];
+            dT[3 + c] += gmy * f[c] * Tw[c];
+            dT[6 + c] += gmx * f[c] * Tu[c] + gmy * f[c] * Tv[c] + dL_dd * (sgn[c] * Tw[c] * 2.0f);
+        }
+    }
+    for (int c = 0; c < 9; c++) g.dT[c] = dT[c];
+    const float Wh = cam.focal_x * cam.tan_fovx, Hh = cam.focal_y * cam.tan_fovy;  // backward.cu:680-681
+    g.dmean2D[0] = dT[2] * Tw[2] * Wh;
+    g.dmean2D[1] = dT[5] * Tw[2] * Hh;
+    // ---- transMat chain
+    const float cx = Wh, cy = Hh;  // backward.cu:565
+    float dM0[3], dM1[3], dM2[3];
+    dM0[0] = cam.focal_x * dT[0]; dM0[1] = cam.focal_y * dT[3]; dM0[2] = cx * dT[0] + cy * dT[3] + dT[6];
+    dM1[0] = cam.focal_x * dT[1]; dM1[1] = cam.focal_y * dT[4]; dM1[2] = cx * dT[1] + cy * dT[4] + dT[7];
+    dM2[0] = cam.focal_x * dT[2]; dM2[1] = cam.focal_y * dT[5]; dM2[2] = cx * dT[2] + cy * dT[5] + dT[8];
+    float dRS0[3], dRS1[3], dpw[3], dtn[3];
+    view_rotate_T(vm, dM0, dRS0);
+    view_rotate_T(vm, dM1, dRS1);
+    view_rotate_T(vm, dM2, dpw);
+    view_rotate_T(vm, acc + kAccNormal, dtn);
+    float c0[3], c1[3], c2[3];
+    quat_columns(quat, c0, c1, c2);
+    // dual-visible flip (backward.cu:509-514): recompute the sign from W*R2 . p_view
+    float tn[3], wp[3];
+    view_rotate(vm, c2, tn);
+    view_rotate(vm, pos, wp);
+    const float pvx = wp[0] + vm[12], pvy = wp[1] + vm[13], pvz = wp[2] + vm[14];
+    const float cosv = -tn[0] * pvx + -tn[1] * pvy + -tn[2] * pvz;
+    const float flip = cosv > 0 ? 1.f : -1.f;
+    // v_R columns
+    float v0[3] = {dRS0[0] * scale[0], dRS0[1] * scale[0], dRS0[2] * scale[0]};
+    float v1[3] = {dRS1[0] * scale[1], dRS1[1] * scale[1], dRS1[2] * scale[1]};
+    float v2[3] = {dtn[0] * flip, dtn[1] * flip, dtn[2] * flip};
+    {
+        float s = 1.0f / sqrtf(quat[3] * quat[3] + quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2]);
+        float w = quat[0] * s, x = quat[1] * s, y = quat[2] * s, z = quat[3] * s;
+        // vR[c][r] = v{c}[r]
+        g.drot[0] = 2.f * (x * (v1[2] - v2[1]) + y * (v2[0] - v0[2]) + z * (v0[1] - v1[0]));
+        g.drot[1] = 2.f * (-2.f * x * (v1[1] + v2[2]) + y * (v0[1] + v1[0]) + z * (v0[2] + v2[0]) + w * (v1[2] - v2[1]));
+        g.drot[2] = 2.f * (x * (v0[1] + v1[0]) - 2.f * y * (v0[0] + v2[2]) + z * (v1[2] + v2[1]) + w * (v2[0] - v0[2]));
+        g.drot[3] = 2.f * (x * (v0[2] + v2[0]) + y * (v1[2] + v2[1]) - 2.f * z * (v0[0] + v1[1]) + w * (v0[1] - v1[0]));
+    }
+    g.dscale[0] = dRS0[0] * c0[0] + dRS0[1] * c0[1] + dRS0[2] * c0[2];
+    g.dscale[1] = dRS1[0] * c1[0] + dRS1[1] * c1[1] + dRS1[2] * c1[2];
+    g.dmean3D[0] = dpw[0]; g.dmean3D[1] = dpw[1]; g.dmean3D[2] = dpw[2];
+}
+
+}  // namespace dgs

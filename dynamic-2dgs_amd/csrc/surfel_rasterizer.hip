@@ -1,0 +1,442 @@
+// surfel_rasterizer.hip -- host orchestration + C ABI (include/dgs_surfel_rasterizer.h) of the
+// MI355X surfel rasterizer.  Stage order follows CudaRasterizer::Rasterizer::forward / backward
+// (rasterizer_impl.cu:198-342, :346-448 of the reference); everything runs on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dgs_surfel_rasterizer.h"
+#include "kernels_blend.h"
+#include "kernels_preprocess.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define DGS_HIP(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(DGS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));             \
+    } while (0)
+
+// CHECK_CUDA equivalent (auxiliary.h:271-278): with debug, synchronise after the stage
+#define DGS_STAGE(name, debug, stream)                                                                 \
+    do {                                                                                               \
+        hipError_t e__ = hipGetLastError();                                                            \
+        if (e__ == hipSuccess && (debug)) e__ = hipStreamSynchronize(stream);                          \
+        if (e__ != hipSuccess) return fail(DGS_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {  // 128-byte aligned sub-allocation, like obtain() in rasterizer_impl.h:22-27
+    size_t off = 0;
+    size_t take(size_t bytes)
+    {
+        off = align_up(off, 128);
+        size_t o = off;
+        off += bytes;
+        return o;
+    }
+};
+
+struct GeomLayout {
+    size_t rec, block_sums, total, internal_radii, acc, bytes;
+    int nblocks;
+    explicit GeomLayout(int P)
+    {
+        Carver c;
+        nblocks = (P + dgs::kSurfelBlock - 1) / dgs::kSurfelBlock;
+        rec = c.take((size_t)P * dgs::kRecFloats * 4);
+        block_sums = c.take((size_t)(nblocks > 0 ? nblocks : 1) * 4);
+        total = c.take(4);
+        internal_radii = c.take((size_t)P * 4);
+        acc = c.take((size_t)P * dgs::kAccFloats * 4);
+        bytes = align_up(c.off, 128);
+    }
+};
+
+struct ImageLayout {
+    size_t final_T, n_contrib, ranges, tile_last, bytes;
+    int tiles_x, tiles_y, ntiles;
+    ImageLayout(int W, int H)
+    {
+        tiles_x = (W + dgs::kTileX - 1) / dgs::kTileX;
+        tiles_y = (H + dgs::kTileY - 1) / dgs::kTileY;
+        ntiles = tiles_x * tiles_y;
+        Carver c;
+        const size_t plane = (size_t)ntiles * dgs::kTilePix;
+        final_T = c.take(3 * plane * 4);
+        n_contrib = c.take(2 * plane * 4);
+        ranges = c.take((size_t)ntiles * 8);
+        tile_last = c.take((size_t)ntiles * 4);
+        bytes = align_up(c.off, 128);
+    }
+};
+
+int sort_end_bit(int ntiles)  // bits needed for tile ids (getHigherMsb, rasterizer_impl.cu:35-50)
+{
+    int bit = 0;
+    while ((1u << bit) < (unsigned)ntiles && bit < 31) bit++;
+    if (bit == 0) bit = 1;
+    return 32 + bit;
+}
+
+struct BinningLayout {
+    size_t keys_unsorted, keys, vals_unsorted, point_list, sort_temp, bytes;
+    size_t temp_bytes;
+    int err = 0;
+    BinningLayout(int R, int ntiles)
+    {
+        Carver c;
+        const size_t n = (size_t)(R > 0 ? R : 1);
+        keys_unsorted = c.take(n * 8);
+        keys = c.take(n * 8);
+        vals_unsorted = c.take(n * 4);
+        point_list = c.take(n * 4);
+        temp_bytes = 0;
+        if (R > 0) {
+            hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)R, 0u,
+                                                     (unsigned)sort_end_bit(ntiles), (hipStream_t)0);
+            if (e != hipSuccess) err = 1;
+        }
+        sort_temp = c.take(temp_bytes > 0 ? temp_bytes : 4);
+        bytes = align_up(c.off, 128);
+    }
+};
+
+dgs::Camera make_camera(const float* view_dev, const float* campos_dev, int W, int H, float tan_fovx, float tan_fovy)
+{
+    dgs::Camera cam;
+    cam.view = view_dev;
+    cam.campos = campos_dev;
+    cam.focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:223-224
+    cam.focal_x = W / (2.0f * tan_fovx);
+    cam.tan_fovx = tan_fovx;
+    cam.tan_fovy = tan_fovy;
+    cam.width = W;
+    cam.height = H;
+    cam.tiles_x = (W + dgs::kTileX - 1) / dgs::kTileX;
+    cam.tiles_y = (H + dgs::kTileY - 1) / dgs::kTileY;
+    return cam;
+}
+
+// Small pinned staging word for num_rendered (the one device->host read of the forward).
+struct HostStage {
+    uint32_t* u = nullptr;   // num_rendered
+    std::mutex mu;
+    int ensure()
+    {
+        if (u) return 0;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 256, hipHostMallocDefault) != hipSuccess) return -1;
+        u = (uint32_t*)p;
+        return 0;
+    }
+};
+HostStage g_stage;
+
+// ---- optional kernel timing (bench.py roofline leg) ------------------------------------------------
+struct Prof {
+    bool on = false;
+    std::mutex mu;
+    struct Pair { hipEvent_t a, b; int kind; };
+    std::vector<Pair> pending;
+    std::vector<Pair> pool;
+    double ms[2] = {0, 0};
+    long n[2] = {0, 0};
+};
+Prof g_prof;
+
+bool prof_begin(int kind, hipStream_t s, Prof::Pair& p)
+{
+    if (!g_prof.on) return false;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.pool.empty()) {
+        p = g_prof.pool.back();
+        g_prof.pool.pop_back();
+    } else {
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return false;
+    }
+    p.kind = kind;
+    (void)hipEventRecord(p.a, s);
+    return true;
+}
+
+void prof_end(hipStream_t s, Prof::Pair& p)
+{
+    (void)hipEventRecord(p.b, s);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.pending.push_back(p);
+}
+
+int check_common(int P, int W, int H, const void* means3D)
+{
+    if (P < 0 || W <= 0 || H <= 0) return fail(DGS_ERR_INVALID_ARGUMENT, "P, width, height must be non-negative / positive");
+    if (P > 0 && !means3D) return fail(DGS_ERR_INVALID_ARGUMENT, "means3D is NULL");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dgs_abi_version(void) { return DGS_ABI_VERSION; }
+
+const char* dgs_last_error(void) { return g_err.c_str(); }
+
+void dgs_profile_enable(int on) { g_prof.on = on != 0; }
+
+void dgs_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto& p : g_prof.pending) g_prof.pool.push_back(p);
+    g_prof.pending.clear();
+    g_prof.ms[0] = g_prof.ms[1] = 0;
+    g_prof.n[0] = g_prof.n[1] = 0;
+}
+
+int dgs_profile_read(double* out, int cap)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto& p : g_prof.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_prof.ms[p.kind] += ms;
+            g_prof.n[p.kind] += 1;
+        }
+        g_prof.pool.push_back(p);
+    }
+    g_prof.pending.clear();
+    const double v[4] = {g_prof.ms[0], (double)g_prof.n[0], g_prof.ms[1], (double)g_prof.n[1]};
+    int k = cap < 4 ? cap : 4;
+    for (int i = 0; i < k; i++) out[i] = v[i];
+    return k;
+}
+
+int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* offsets, int cap)
+{
+    std::vector<size_t> v;
+    if (which == 0) {
+        GeomLayout g(P);
+        v = {g.rec, g.block_sums, g.total, g.internal_radii, g.acc, g.bytes};
+    } else if (which == 1) {
+        ImageLayout m(width, height);
+        v = {m.final_T, m.n_contrib, m.ranges, m.tile_last, m.bytes};
+    } else if (which == 2) {
+        ImageLayout m(width, height);
+        BinningLayout b(R, m.ntiles);
+        v = {b.keys_unsorted, b.keys, b.vals_unsorted, b.point_list, b.sort_temp, b.bytes};
+    } else {
+        return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_debug_layout: which must be 0, 1 or 2");
+    }
+    int n = (int)v.size() < cap ? (int)v.size() : cap;
+    for (int i = 0; i < n; i++) offsets[i] = v[i];
+    return n;
+}
+
+int dgs_rasterizer_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                unsigned char* present, void* stream_)
+{
+    (void)projmatrix;  // only feeds a dead expression in the reference (auxiliary.h:170-172)
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0) return fail(DGS_ERR_INVALID_ARGUMENT, "P < 0");
+    if (P == 0) return DGS_OK;
+    if (!means3D || !viewmatrix || !present) return fail(DGS_ERR_INVALID_ARGUMENT, "NULL pointer");
+    hipLaunchKernelGGL(dgs::mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+    DGS_STAGE("mark_visible", 0, stream);
+    return DGS_OK;
+}
+
+int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_alloc_fn binning_alloc, void* binning_ctx,
+                           dgs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                           int height, const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                           const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                           float* out_others, int* radii, int debug, void* stream_)
+{
+    (void)scale_modifier; (void)projmatrix; (void)prefiltered;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int e = check_common(P, width, height, means3D)) return e;
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(DGS_ERR_INVALID_ARGUMENT, "allocator callback is NULL");
+    if (!out_color || !out_others || !background || !viewmatrix || !cam_pos) return fail(DGS_ERR_INVALID_ARGUMENT, "NULL pointer");
+    if (transMat_precomp) return fail(DGS_ERR_UNSUPPORTED, "transMat_precomp (cov3D_precomp) is not supported; pass scales and rotations");
+    if (P == 0) return 0;  // rasterize_points.cu:106
+    if (!opacities || !scales || !rotations) return fail(DGS_ERR_INVALID_ARGUMENT, "opacities/scales/rotations NULL");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(DGS_ERR_INVALID_ARGUMENT, "provide exactly one of shs / colors_precomp");
+    if (shs && (M <= 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+        return fail(DGS_ERR_INVALID_ARGUMENT, "SH degree / coefficient count mismatch");
+    if (D < 0) D = 0;
+
+    GeomLayout gl(P);
+    ImageLayout il(width, height);
+    char* geom = geometry_alloc(geometry_ctx, gl.bytes);
+    char* img = image_alloc(image_ctx, il.bytes);
+    if (!geom || !img) return fail(DGS_ERR_ALLOC, "geometry/image allocator returned NULL");
+    if (!radii) radii = (int*)(geom + gl.internal_radii);  // rasterizer_impl.cu:230-233
+
+    const dgs::Camera cam = make_camera(viewmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
+
+    // ---- K2 preprocess + per-block tile counts
+    dgs::PreprocessArgs pa;
+    pa.P = P; pa.D = D; pa.M = M;
+    pa.means3D = means3D; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities;
+    pa.shs = shs; pa.colors_precomp = colors_precomp; pa.cam = cam;
+    pa.radii = radii;
+    pa.rec = (float4*)(geom + gl.rec);
+    pa.block_sums = (uint32_t*)(geom + gl.block_sums);
+    hipLaunchKernelGGL(dgs::preprocess_fwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, pa);
+    DGS_STAGE("preprocess_fwd", debug, stream);
+    // ---- K3 scan of the block sums (replaces cub::DeviceScan::InclusiveSum over P values)
+    hipLaunchKernelGGL(dgs::scan_block_sums_kernel, dim3(1), dim3(dgs::kSurfelBlock), 0, stream, pa.block_sums, gl.nblocks,
+                       (uint32_t*)(geom + gl.total));
+    DGS_STAGE("scan_block_sums", debug, stream);
+
+    // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285)
+    uint32_t R_u = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_stage.mu);
+        if (g_stage.ensure()) return fail(DGS_ERR_HIP, "hipHostMalloc failed");
+        DGS_HIP(hipMemcpyAsync(g_stage.u, geom + gl.total, 4, hipMemcpyDeviceToHost, stream));
+        DGS_HIP(hipStreamSynchronize(stream));
+        R_u = *g_stage.u;
+    }
+    if (R_u > 0x7fffffffu) return fail(DGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
+    const int R = (int)R_u;
+
+    BinningLayout bl(R, il.ntiles);
+    if (bl.err) return fail(DGS_ERR_HIP, "rocprim::radix_sort_pairs size query failed");
+    char* bin = binning_alloc(binning_ctx, bl.bytes);
+    if (!bin) return fail(DGS_ERR_ALLOC, "binning allocator returned NULL");
+
+    uint2* ranges = (uint2*)(img + il.ranges);
+    DGS_HIP(hipMemsetAsync(ranges, 0, (size_t)il.ntiles * 8, stream));  // rasterizer_impl.cu:311
+    if (R > 0) {
+        // ---- K4 key emission
+        dgs::EmitArgs ea;
+        ea.P = P; ea.radii = radii; ea.rec = pa.rec; ea.block_offsets = pa.block_sums;
+        ea.keys = (uint64_t*)(bin + bl.keys_unsorted);
+        ea.vals = (uint32_t*)(bin + bl.vals_unsorted);
+        ea.tiles_x = il.tiles_x; ea.tiles_y = il.tiles_y;
+        hipLaunchKernelGGL(dgs::emit_keys_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, ea);
+        DGS_STAGE("emit_keys", debug, stream);
+        // ---- K5 stable LSD radix sort on (tile | depth) keys (rasterizer_impl.cu:304-309)
+        size_t temp_bytes = bl.temp_bytes;
+        DGS_HIP(rocprim::radix_sort_pairs((void*)(bin + bl.sort_temp), temp_bytes, (const uint64_t*)ea.keys,
+                                          (uint64_t*)(bin + bl.keys), (const uint32_t*)ea.vals,
+                                          (uint32_t*)(bin + bl.point_list), (size_t)R, 0u,
+                                          (unsigned)sort_end_bit(il.ntiles), stream));
+        DGS_STAGE("radix_sort", debug, stream);
+        // ---- K6 tile ranges
+        hipLaunchKernelGGL(dgs::tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R,
+                           (const uint64_t*)(bin + bl.keys), ranges);
+        DGS_STAGE("tile_ranges", debug, stream);
+    }
+
+    // ---- K7 forward blend
+    dgs::BlendFwdArgs fa;
+    fa.ranges = ranges;
+    fa.point_list = (const uint32_t*)(bin + bl.point_list);
+    fa.rec = pa.rec;
+    fa.W = width; fa.H = height; fa.tiles_x = il.tiles_x; fa.tiles_y = il.tiles_y;
+    fa.bg = background;
+    fa.final_T = (float*)(img + il.final_T);
+    fa.n_contrib = (uint32_t*)(img + il.n_contrib);
+    fa.tile_last = (uint32_t*)(img + il.tile_last);
+    fa.out_color = out_color;
+    fa.out_others = out_others;
+    const int grid = ((il.ntiles + 7) / 8) * 8;
+    Prof::Pair pp;
+    const bool timed = prof_begin(0, stream, pp);
+    hipLaunchKernelGGL(dgs::blend_fwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, fa);
+    if (timed) prof_end(stream, pp);
+    DGS_STAGE("blend_fwd", debug, stream);
+    return R;
+}
+
+int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                            const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                            char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                            const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+                            float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
+                            float* dL_drot, int debug, void* stream_)
+{
+    (void)scale_modifier; (void)projmatrix;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int e = check_common(P, width, height, means3D)) return e;
+    if (P == 0) return DGS_OK;  // rasterize_points.cu:204
+    if (transMat_precomp) return fail(DGS_ERR_UNSUPPORTED, "transMat_precomp (cov3D_precomp) is not supported");
+    if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail(DGS_ERR_INVALID_ARGUMENT, "scratch buffer is NULL");
+    if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dtransMat ||
+        !dL_dscale || !dL_drot || !scales || !rotations || !viewmatrix || !campos || !background)
+        return fail(DGS_ERR_INVALID_ARGUMENT, "NULL pointer");
+    if (shs && colors_precomp == nullptr && !dL_dsh) return fail(DGS_ERR_INVALID_ARGUMENT, "dL_dsh is NULL");
+    if (D < 0) D = 0;
+
+    GeomLayout gl(P);
+    ImageLayout il(width, height);
+    BinningLayout bl(R, il.ntiles);
+    if (!radii) radii = (const int*)(geom_buffer + gl.internal_radii);
+
+    const dgs::Camera cam = make_camera(viewmatrix, campos, width, height, tan_fovx, tan_fovy);
+
+    float* acc = (float*)(geom_buffer + gl.acc);
+    DGS_HIP(hipMemsetAsync(acc, 0, (size_t)P * dgs::kAccFloats * 4, stream));
+
+    // ---- K8 backward blend
+    if (R > 0) {
+        dgs::BlendBwdArgs ba;
+        ba.ranges = (const uint2*)(img_buffer + il.ranges);
+        ba.point_list = (const uint32_t*)(binning_buffer + bl.point_list);
+        ba.rec = (const float4*)(geom_buffer + gl.rec);
+        ba.W = width; ba.H = height; ba.tiles_x = il.tiles_x; ba.tiles_y = il.tiles_y;
+        ba.bg = background;
+        ba.final_T = (const float*)(img_buffer + il.final_T);
+        ba.n_contrib = (const uint32_t*)(img_buffer + il.n_contrib);
+        ba.tile_last = (const uint32_t*)(img_buffer + il.tile_last);
+        ba.dL_dpix = dL_dpix;
+        ba.dL_dothers = dL_depths;
+        ba.acc = acc;
+        const int grid = ((il.ntiles + 7) / 8) * 8;
+        Prof::Pair pp;
+        const bool timed = prof_begin(1, stream, pp);
+        hipLaunchKernelGGL(dgs::blend_bwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+        if (timed) prof_end(stream, pp);
+        DGS_STAGE("blend_bwd", debug, stream);
+    }
+
+    // ---- K9 + K10 fused per-surfel backward
+    dgs::SurfelBwdArgs sa;
+    sa.P = P; sa.D = D; sa.M = M;
+    sa.means3D = means3D; sa.scales = scales; sa.rotations = rotations;
+    sa.shs = colors_precomp ? nullptr : shs;
+    sa.cam = cam;
+    sa.radii = radii;
+    sa.rec = (const float4*)(geom_buffer + gl.rec);
+    sa.acc = acc;
+    sa.dL_dmean2D = dL_dmean2D; sa.dL_dnormal = dL_dnormal; sa.dL_dopacity = dL_dopacity; sa.dL_dcolor = dL_dcolor;
+    sa.dL_dmean3D = dL_dmean3D; sa.dL_dtransMat = dL_dtransMat; sa.dL_dsh = dL_dsh; sa.dL_dscale = dL_dscale; sa.dL_drot = dL_drot;
+    hipLaunchKernelGGL(dgs::surfel_bwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, sa);
+    DGS_STAGE("surfel_bwd", debug, stream);
+    return DGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+"""Binding of libdgs_surfel_rasterizer.so (include/dgs_surfel_rasterizer.h) for PyTorch-ROCm tensors.
+
+Plays the role of the reference's pybind module ``diff_surfel_rasterization._C``
+(submodules/diff-surfel-rasterization/ext.cpp:15-19) with the same three functions, argument order
+and return tuples as rasterize_points.cu:39-141 / :143-240 / :242-261, but goes through the C ABI
+with ctypes: torch only owns the memory and supplies the current HIP stream.
+
+There is NO CPU path here: if the HIP library is missing, or a tensor is not on a HIP device, the
+call fails loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+LIB_NAME = "libdgs_surfel_rasterizer.so"
+LIB_PATH = os.path.join(_CSRC, LIB_NAME)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+_SOURCES = ["surfel_rasterizer.hip", "kernels_blend.h", "kernels_preprocess.h", "surfel_math.h"]
+
+_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+_lib = None
+
+_EXPORTS = ("dgs_abi_version", "dgs_last_error", "dgs_rasterizer_mark_visible", "dgs_rasterizer_forward",
+            "dgs_rasterizer_backward", "dgs_debug_layout", "dgs_profile_enable", "dgs_profile_reset", "dgs_profile_read")
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_times = [os.path.getmtime(os.path.join(_CSRC, s)) for s in _SOURCES]
+    hdr = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dgs_surfel_rasterizer.h")
+    src_times.append(os.path.getmtime(hdr))
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(src_times):
+        return LIB_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + [os.path.join(_CSRC, "surfel_rasterizer.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and declare the prototypes of include/dgs_surfel_rasterizer.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s not found: the MI355X surfel rasterizer has no CPU fallback. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    lib.dgs_abi_version.restype = ci
+    lib.dgs_abi_version.argtypes = []
+    lib.dgs_last_error.restype = ctypes.c_char_p
+    lib.dgs_last_error.argtypes = []
+    lib.dgs_rasterizer_mark_visible.restype = ci
+    lib.dgs_rasterizer_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    lib.dgs_rasterizer_forward.restype = ci
+    lib.dgs_rasterizer_forward.argtypes = (
+        [_ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
+         cf, cf, ci, vp, vp, vp, ci, vp])
+    lib.dgs_rasterizer_backward.restype = ci
+    lib.dgs_rasterizer_backward.argtypes = (
+        [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+         vp, vp, vp, vp, vp, ci, vp])
+    lib.dgs_debug_layout.restype = ci
+    lib.dgs_debug_layout.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(sz), ci]
+    lib.dgs_profile_enable.restype = None
+    lib.dgs_profile_enable.argtypes = [ci]
+    lib.dgs_profile_reset.restype = None
+    lib.dgs_profile_reset.argtypes = []
+    lib.dgs_profile_read.restype = ci
+    lib.dgs_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ci]
+    if lib.dgs_abi_version() != 1:
+        raise RuntimeError("libdgs_surfel_rasterizer.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return _EXPORTS
+
+
+def _raise(lib, code, where):
+    msg = lib.dgs_last_error().decode("utf-8", "replace")
+    raise RuntimeError("%s failed (status %d): %s" % (where, code, msg))
+
+
+def _need_device(**tensors):
+    for name, t in tensors.items():
+        if not t.is_cuda:  # mirrors CHECK_INPUT, rasterize_points.cu:27-28
+            raise RuntimeError("%s must be a CUDA (HIP) tensor" % name)
+
+
+def _ptr(t):
+    """Device pointer or NULL for an empty tensor (the reference's nullptr convention)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected float32 tensor, got %s" % t.dtype)
+    return t.contiguous()
+
+
+class _Resizer:
+    """resizeFunctional of rasterize_points.cu:31-37 as a C callback."""
+
+    def __init__(self, device):
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _ALLOC_FN(self._alloc)
+
+    def _alloc(self, _ctx, nbytes):
+        try:
+            self.tensor.resize_(int(nbytes))
+            return self.tensor.data_ptr()
+        except Exception:  # surfaces as DGS_ERR_ALLOC
+            return 0
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """-> (num_rendered, out_color[3,H,W], out_others[8,H,W], radii[P] i32, geomBuffer, binningBuffer, imgBuffer)"""
+    lib = load()
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if scales.dim() != 2 or scales.size(1) != 2:
+        raise RuntimeError("scales must have dimensions (num_points, 2)")
+    if rotations.dim() != 2 or rotations.size(1) != 4:
+        raise RuntimeError("rotations must have dimensions (num_points, 4)")
+    _need_device(background=background, means3D=means3D, colors=colors, opacity=opacity, scales=scales, rotations=rotations,
+                 transMat_precomp=transMat_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, sh=sh, campos=campos)
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    out_others = torch.zeros((8, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
+    rendered = 0
+    if P != 0:
+        M = sh.size(1) if sh.numel() != 0 else 0
+        bg, m3, col, opa = _f32c(background), _f32c(means3D), _f32c(colors), _f32c(opacity)
+        sc, rot, tm = _f32c(scales), _f32c(rotations), _f32c(transMat_precomp)
+        vm, pm, shc, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(sh), _f32c(campos)
+        with torch.cuda.device(dev):
+            rendered = lib.dgs_rasterizer_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(bg), W, H, _ptr(m3), _ptr(shc),
+                _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp),
+                float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), out_color.data_ptr(), out_others.data_ptr(),
+                radii.data_ptr(), int(bool(debug)), _stream(dev))
+        if rendered < 0:
+            _raise(lib, rendered, "rasterize_gaussians")
+    return rendered, out_color, out_others, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, transMat_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, sh, degree,
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
+    dL_dscales[P,2], dL_drotations[P,4])  -- rasterize_points.cu:239"""
+    lib = load()
+    _need_device(background=background, means3D=means3D, radii=radii, colors=colors, scales=scales, rotations=rotations,
+                 transMat_precomp=transMat_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, sh=sh, campos=campos,
+                 binningBuffer=binningBuffer, imageBuffer=imageBuffer, geomBuffer=geomBuffer)
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    opts = dict(dtype=torch.float32, device=dev)
+    dL_dmeans3D = torch.zeros((P, 3), **opts)
+    dL_dmeans2D = torch.zeros((P, 3), **opts)
+    dL_dcolors = torch.zeros((P, 3), **opts)
+    dL_dnormal = torch.zeros((P, 3), **opts)
+    dL_dopacity = torch.zeros((P, 1), **opts)
+    dL_dtransMat = torch.zeros((P, 9), **opts)
+    dL_dsh = torch.zeros((P, M, 3), **opts)
+    dL_dscales = torch.zeros((P, 2), **opts)
+    dL_drotations = torch.zeros((P, 4), **opts)
+    if P != 0:
+        bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
+        sc, rot, tm = _f32c(scales), _f32c(rotations), _f32c(transMat_precomp)
+        vm, pm, shc, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(sh), _f32c(campos)
+        gc, go = _f32c(dL_dout_color), _f32c(dL_dout_others)
+        rad = radii.contiguous()
+        gb, bb, ib = geomBuffer.contiguous(), binningBuffer.contiguous(), imageBuffer.contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.dgs_rasterizer_backward(
+                P, int(degree), int(M), int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc), float(scale_modifier),
+                _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx), float(tan_fovy), _ptr(rad), _ptr(gb),
+                _ptr(bb), _ptr(ib), _ptr(gc), _ptr(go), dL_dmeans2D.data_ptr(), dL_dnormal.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(),
+                dL_drotations.data_ptr(), int(bool(debug)), _stream(dev))
+        if rc < 0:
+            _raise(lib, rc, "rasterize_gaussians_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool[P], view-space z > 0.2 (rasterize_points.cu:242-261)."""
+    lib = load()
+    _need_device(means3D=means3D, viewmatrix=viewmatrix, projmatrix=projmatrix)
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        m3, vm, pm = _f32c(means3D), _f32c(viewmatrix), _f32c(projmatrix)
+        with torch.cuda.device(means3D.device):
+            rc = lib.dgs_rasterizer_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), present.data_ptr(), _stream(means3D.device))
+        if rc < 0:
+            _raise(lib, rc, "mark_visible")
+    return present
+
+
+# ---- introspection for tests / bench (not part of the reference surface) -----------------------------
+
+def debug_layout(which, P=0, width=1, height=1, R=0):
+    lib = load()
+    buf = (ctypes.c_size_t * 8)()
+    n = lib.dgs_debug_layout(int(which), int(P), int(width), int(height), int(R), buf, 8)
+    if n < 0:
+        _raise(lib, n, "debug_layout")
+    return [int(buf[i]) for i in range(n)]
+
+
+def profile_enable(on=True):
+    load().dgs_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    load().dgs_profile_reset()
+
+
+def profile_read():
+    """{'fwd_ms', 'fwd_n', 'bwd_ms', 'bwd_n'} accumulated over timed blend-kernel launches."""
+    out = (ctypes.c_double * 4)()
+    load().dgs_profile_read(out, 4)
+    return {"fwd_ms": out[0], "fwd_n": int(out[1]), "bwd_ms": out[2], "bwd_n": int(out[3])}

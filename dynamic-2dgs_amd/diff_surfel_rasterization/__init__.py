@@ -1,0 +1,126 @@
+"""MI355X-native ``diff_surfel_rasterization``: the operator surface of the reference's 2D-Gaussian
+surfel rasterizer, backed by hand-written gfx950 kernels.
+
+Drop-in for submodules/diff-surfel-rasterization/diff_surfel_rasterization/__init__.py of
+hustvl/Dynamic-2DGS: ``gaussian_renderer.render()`` (gaussian_renderer/__init__.py:14,61-76,141-150)
+imports ``GaussianRasterizationSettings`` and ``GaussianRasterizer`` from this package name and calls
+them unchanged.  Contract kept from the reference (file:line in the reference package):
+
+* ``GaussianRasterizationSettings``: 12-field NamedTuple, same names and order (:158-170).
+* ``GaussianRasterizer(settings)(means3D, means2D, opacities, shs|colors_precomp, scales, rotations)``
+  -> ``(color[3,H,W], radii[P] int32, allmap[8,H,W])`` (:188-222); ``markVisible(positions)`` (:177-186).
+* gradient order ``(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+  None)`` (:144-156); ``means2D`` is a carrier whose ``.grad[:, :2]`` holds the densification signal.
+* same exception text for the exactly-one-of argument checks (:192-196); ``debug=True`` writes
+  ``snapshot_fw.dump`` / ``snapshot_bw.dump`` with the CPU copy of the arguments before re-raising
+  (:83-90,133-140).
+
+Documented deviation: ``cov3D_precomp`` (a [P,9] transMat in the reference, whose backward dereferences
+null scales/rotations) is rejected with an explicit error; see DESIGN.md.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU copy of an argument tuple (tensors cloned) for the debug dumps."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _guarded(fn, args, debug, dump_name, what):
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)  # before anything can be corrupted
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print("\nAn error occured in %s. Writing %s for debugging.\n" % (what, dump_name))
+        raise
+
+
+class _SurfelRasterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cfg):
+        call = (cfg.bg, means3D, colors_precomp, opacities, scales, rotations, cfg.scale_modifier, cov3Ds_precomp,
+                cfg.viewmatrix, cfg.projmatrix, cfg.tanfovx, cfg.tanfovy, cfg.image_height, cfg.image_width, sh,
+                cfg.sh_degree, cfg.campos, cfg.prefiltered, cfg.debug)
+        n_rendered, color, allmap, radii, geom, binning, img = _guarded(
+            _C.rasterize_gaussians, call, cfg.debug, "snapshot_fw.dump", "forward")
+        ctx.cfg = cfg
+        ctx.n_rendered = n_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, allmap
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii, g_allmap):
+        cfg = ctx.cfg
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        if g_color is None:
+            g_color = torch.zeros((3, cfg.image_height, cfg.image_width), dtype=torch.float32, device=means3D.device)
+        if g_allmap is None:
+            g_allmap = torch.zeros((8, cfg.image_height, cfg.image_width), dtype=torch.float32, device=means3D.device)
+        call = (cfg.bg, means3D, radii, colors_precomp, scales, rotations, cfg.scale_modifier, cov3Ds_precomp,
+                cfg.viewmatrix, cfg.projmatrix, cfg.tanfovx, cfg.tanfovy, g_color, g_allmap, sh, cfg.sh_degree, cfg.campos,
+                geom, ctx.n_rendered, binning, img, cfg.debug)
+        (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
+            _C.rasterize_gaussians_backward, call, cfg.debug, "snapshot_bw.dump", "backward")
+        return (g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_transMat, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _SurfelRasterFn.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                 raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: surfel centres in front of the near plane of this camera."""
+        cfg = self.raster_settings
+        with torch.no_grad():
+            return _C.mark_visible(positions, cfg.viewmatrix, cfg.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        cfg = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if cov3D_precomp is not None:
+            raise NotImplementedError(
+                "cov3D_precomp (precomputed transMat) is not supported by the MI355X rasterizer; pass scales and rotations")
+
+        def empty():
+            return torch.empty(0, dtype=torch.float32, device=means3D.device)
+
+        shs = empty() if shs is None else shs
+        colors_precomp = empty() if colors_precomp is None else colors_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, empty(), cfg)

@@ -1,0 +1,107 @@
+/*
+ * dgs_surfel_rasterizer.h -- C ABI of the MI355X-native differentiable 2D-Gaussian surfel rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of hustvl/Dynamic-2DGS: the three entry points below
+ * are what the reference's Python extension binds through
+ *     submodules/diff-surfel-rasterization/cuda_rasterizer/rasterizer.h:20-87
+ *         CudaRasterizer::Rasterizer::{markVisible, forward, backward}
+ * (called from rasterize_points.cu:39-141, :143-240, :242-261).  Argument order and meaning follow
+ * that header one for one; the only changes a C ABI forces are
+ *   - std::function<char*(size_t)> allocator closures  ->  (dgs_alloc_fn, void* ctx) pairs,
+ *   - an explicit HIP stream (the reference launches on the legacy default stream),
+ *   - bool -> int, exceptions -> negative return code + dgs_last_error().
+ *
+ * All pointers are DEVICE pointers to contiguous fp32 (int32 for radii) arrays unless noted.
+ * Pointer arguments that select a mode may be NULL exactly where the reference accepts nullptr:
+ *   shs XOR colors_precomp (rasterizer_impl.cu:322), radii (rasterizer_impl.cu:230-233).
+ * `rotations` and `dL_drot` must be 16-byte aligned.
+ *
+ * The geometry / binning / image scratch buffers are private to the library but must be kept alive,
+ * unmodified, between a forward call and its backward call (the reference returns them to Python for
+ * exactly this reason, diff_surfel_rasterization/__init__.py:97).
+ */
+#ifndef DGS_SURFEL_RASTERIZER_H
+#define DGS_SURFEL_RASTERIZER_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGS_ABI_VERSION 1
+
+/* Replaces std::function<char*(size_t N)> (rasterizer.h:31-33, rasterize_points.cu:31-37): must return a
+ * device buffer of at least `bytes` bytes, 128-byte aligned, usable on `stream`. */
+typedef char* (*dgs_alloc_fn)(void* ctx, size_t bytes);
+
+enum dgs_status {
+    DGS_OK = 0,
+    DGS_ERR_INVALID_ARGUMENT = -1, /* AT_ERROR shape checks, rasterize_points.cu:61-71 */
+    DGS_ERR_UNSUPPORTED = -2,      /* e.g. transMat_precomp, see DESIGN.md */
+    DGS_ERR_ALLOC = -3,            /* an allocator callback returned NULL */
+    DGS_ERR_HIP = -4               /* a HIP call / kernel failed (CHECK_CUDA, auxiliary.h:271-278) */
+};
+
+int dgs_abi_version(void);
+
+/* Message for the most recent error on the calling thread ("" if none). */
+const char* dgs_last_error(void);
+
+/* CudaRasterizer::Rasterizer::markVisible, rasterizer.h:24-29 / rasterizer_impl.cu:141-153.
+ * present: device array of P bytes (bool). Returns DGS_OK or a negative dgs_status. */
+int dgs_rasterizer_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                unsigned char* present, void* stream);
+
+/* CudaRasterizer::Rasterizer::forward, rasterizer.h:31-57 / rasterizer_impl.cu:198-342.
+ * Returns num_rendered (>= 0) or a negative dgs_status.
+ *   P surfels, D active SH degree, M SH coefficients per surfel (0 with colors_precomp)
+ *   background[3]; out_color[3,H,W]; out_others[8,H,W]; radii[P] (int32, may be NULL)
+ *   viewmatrix/projmatrix: 16 floats each, the reference's transposed (row-vector) matrices
+ *   scale_modifier is accepted and ignored, as in the reference (forward.cu:95)
+ *   transMat_precomp must be NULL (DGS_ERR_UNSUPPORTED otherwise)
+ *   prefiltered: accepted; a culled surfel is skipped (the reference would __trap, auxiliary.h:177-181)
+ *   debug != 0: synchronise and check after every stage. */
+int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_alloc_fn binning_alloc, void* binning_ctx,
+                           dgs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                           int height, const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                           const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                           float* out_others, int* radii, int debug, void* stream);
+
+/* CudaRasterizer::Rasterizer::backward, rasterizer.h:59-87 / rasterizer_impl.cu:346-448.
+ * R = the value forward returned. All dL_d* outputs must be zero-initialised by the caller
+ * (rasterize_points.cu:194-202). Shapes: dL_dpix[3,H,W], dL_depths[8,H,W], dL_dmean2D[P,3],
+ * dL_dnormal[P,3], dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
+ * dL_dscale[P,2], dL_drot[P,4].  Returns DGS_OK or a negative dgs_status. */
+int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                            const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                            char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                            const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+                            float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
+                            float* dL_drot, int debug, void* stream);
+
+/* ---- introspection used by the parity tests and bench.py (not part of the reference surface) ---- */
+
+/* Byte offsets of the private sub-arrays inside the three scratch buffers, so tests can compare each
+ * stage with the oracle.  which: 0 geometry (P), 1 image (W,H), 2 binning (R).  Writes up to `cap`
+ * offsets, returns the number of sub-arrays; the last entry written is the total size.
+ *   geometry: rec[P*20 f32], block_sums[u32], total[u32], internal_radii[P i32], acc[P*20 f32]
+ *   image   : final_T[3*T*256 f32], n_contrib[2*T*256 u32], ranges[T uint2], tile_last[T u32]
+ *   binning : keys_unsorted[R u64], keys[R u64], vals_unsorted[R u32], point_list[R u32], sort temp */
+int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* offsets, int cap);
+
+/* Kernel timing hook for bench.py: when enabled, the library brackets the forward and backward blend
+ * kernels with HIP events on the launch stream; dgs_profile_read returns accumulated milliseconds and
+ * launch counts since the last reset: out[0..1] fwd blend (ms, n), out[2..3] bwd blend (ms, n). */
+void dgs_profile_enable(int on);
+void dgs_profile_reset(void);
+int dgs_profile_read(double* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGS_SURFEL_RASTERIZER_H */

@@ -1,0 +1,99 @@
+"""Helpers for the -m gpu parity tests: run the HIP operator through the drop-in Python surface
+(which goes through the C ABI) and unpack its private scratch buffers for stage-level comparison."""
+import numpy as np
+import torch
+
+from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+
+
+def settings_from_case(case, dev, debug=False):
+    return GaussianRasterizationSettings(
+        image_height=case["image_height"], image_width=case["image_width"], tanfovx=case["tanfovx"], tanfovy=case["tanfovy"],
+        bg=case["bg"].to(dev), scale_modifier=1.0, viewmatrix=case["viewmatrix"].to(dev), projmatrix=case["projmatrix"].to(dev),
+        sh_degree=case["sh_degree"], campos=case["campos"].to(dev), prefiltered=False, debug=debug)
+
+
+def run_hip(case, gc=None, go=None, colors_precomp=None, dev="cuda:0", debug=True):
+    """Forward (+ backward when cotangents are given). Returns dict of numpy arrays."""
+    cfg = settings_from_case(case, dev, debug)
+    rast = GaussianRasterizer(cfg)
+    leaves = {k: case[k].to(dev).clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    kw = {}
+    if colors_precomp is not None:
+        cp = torch.as_tensor(colors_precomp, dtype=torch.float32, device=dev).clone().requires_grad_(True)
+        kw["colors_precomp"] = cp
+    else:
+        kw["shs"] = leaves["shs"]
+    color, radii, allmap = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                scales=leaves["scales"], rotations=leaves["rotations"], **kw)
+    out = dict(color=color.detach().cpu().numpy(), allmap=allmap.detach().cpu().numpy(), radii=radii.cpu().numpy())
+    fn = color.grad_fn
+    if gc is not None:
+        loss = (color * torch.as_tensor(gc, device=dev)).sum() + (allmap * torch.as_tensor(go, device=dev)).sum()
+        loss.backward()
+        out.update(
+            dL_dmeans3D=leaves["means3D"].grad.cpu().numpy(), dL_dmeans2D=means2D.grad.cpu().numpy(),
+            dL_dscales=leaves["scales"].grad.cpu().numpy(), dL_drotations=leaves["rotations"].grad.cpu().numpy(),
+            dL_dopacity=leaves["opacities"].grad.cpu().numpy())
+        if colors_precomp is not None:
+            out["dL_dcolors"] = kw["colors_precomp"].grad.cpu().numpy()
+        else:
+            out["dL_dsh"] = leaves["shs"].grad.cpu().numpy()
+    torch.cuda.synchronize()
+    return out
+
+
+def run_hip_raw(case, dev="cuda:0"):
+    """Calls the extension entry point directly and unpacks the private buffers (layout from
+    dgs_debug_layout)."""
+    P, H, W = case["means3D"].shape[0], case["image_height"], case["image_width"]
+    e = torch.empty(0, device=dev)
+    t = lambda k: case[k].to(dev).contiguous()
+    R, color, allmap, radii, geom, binning, img = _C.rasterize_gaussians(
+        t("bg"), t("means3D"), e, t("opacities"), t("scales"), t("rotations"), 1.0, e, t("viewmatrix"), t("projmatrix"),
+        case["tanfovx"], case["tanfovy"], H, W, t("shs"), case["sh_degree"], t("campos"), False, True)
+    torch.cuda.synchronize()
+    g_off = _C.debug_layout(0, P=P)
+    i_off = _C.debug_layout(1, width=W, height=H)
+    b_off = _C.debug_layout(2, width=W, height=H, R=R)
+    gb, bb, ib = geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()
+    tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
+    T = tiles_x * tiles_y
+    rec = gb[g_off[0]:g_off[0] + P * 80].view(np.float32).reshape(P, 20)
+    plane = T * 256
+
+    def untile(a):  # [T,256] tile-major -> [H,W]
+        a = a.reshape(tiles_y, tiles_x, 16, 16).transpose(0, 2, 1, 3).reshape(tiles_y * 16, tiles_x * 16)
+        return a[:H, :W]
+
+    fT = ib[i_off[0]:i_off[0] + 3 * plane * 4].view(np.float32).reshape(3, plane)
+    nc = ib[i_off[1]:i_off[1] + 2 * plane * 4].view(np.uint32).reshape(2, plane)
+    out = dict(
+        R=R, color=color.cpu().numpy(), allmap=allmap.cpu().numpy(), radii=radii.cpu().numpy(), rec=rec,
+        final_T=np.stack([untile(fT[i]) for i in range(3)]), n_contrib=np.stack([untile(nc[i]) for i in range(2)]),
+        ranges=ib[i_off[2]:i_off[2] + T * 8].view(np.uint32).reshape(T, 2),
+        tile_last=ib[i_off[3]:i_off[3] + T * 4].view(np.uint32),
+        point_list=bb[b_off[3]:b_off[3] + R * 4].view(np.uint32) if R > 0 else np.zeros(0, np.uint32),
+        keys=bb[b_off[1]:b_off[1] + R * 8].view(np.uint64) if R > 0 else np.zeros(0, np.uint64),
+    )
+    return out
+
+
+def frac_close(a, b, atol, rtol=0.0, max_bad_frac=0.0, hard_atol=None, name=""):
+    """|a-b| <= atol + rtol*|b| everywhere except a fraction max_bad_frac of entries (discrete
+    contributor flips at the 1/255 and 1e-4 thresholds), which must still be within hard_atol."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    bad = err > (atol + rtol * np.abs(b))
+    frac = float(bad.mean()) if bad.size else 0.0
+    assert frac <= max_bad_frac, "%s: %.3e of entries off (max err %.3e)" % (name, frac, float(err.max()))
+    if hard_atol is not None and err.size:
+        assert float(err.max()) <= hard_atol, "%s: max err %.3e > hard %.3e" % (name, float(err.max()), hard_atol)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

@@ -1,0 +1,123 @@
+// hostmath.cpp -- compiles the PRODUCT arithmetic header (dynamic-2dgs_amd/csrc/surfel_math.h) for the
+// host with g++ and drives it with plain loops, so the CPU test-suite can compare the exact code the
+// HIP kernels inline against the oracle without a GPU.  Test infrastructure only: the shipped library
+// never runs this; control flow of the kernels (LDS staging, wave reductions, atomics) is NOT covered
+// here and is checked by the -m gpu tests.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../dynamic-2dgs_amd/csrc/surfel_math.h"
+
+using namespace dgs;
+
+static Camera make_cam(const float* view, const float* campos, int W, int H, float tx, float ty)
+{
+    Camera c;
+    c.view = view; c.campos = campos;
+    c.focal_y = H / (2.0f * ty); c.focal_x = W / (2.0f * tx);
+    c.tan_fovx = tx; c.tan_fovy = ty; c.width = W; c.height = H;
+    c.tiles_x = (W + 15) / 16; c.tiles_y = (H + 15) / 16;
+    return c;
+}
+
+static Quad Q(const float* r, int i) { return Quad{r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]}; }
+
+extern "C" {
+
+void hm_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rots, const float* opac,
+                   const float* shs, const float* colors_precomp, const float* view, const float* campos, int W, int H, float tx,
+                   float ty, int* radii, float* rec /*[P,20]*/, int* tiles)
+{
+    Camera cam = make_cam(view, campos, W, H, tx, ty);
+    for (int i = 0; i < P; i++) {
+        SurfelRec r;
+        std::memset(&r, 0, sizeof(r));
+        int t = 0;
+        radii[i] = preprocess_surfel(cam, means3D + 3 * i, scales + 2 * i, rots + 4 * i, opac[i], D,
+                                     colors_precomp ? nullptr : shs + (size_t)i * M * 3, colors_precomp ? colors_precomp + 3 * i : nullptr, r, t);
+        tiles[i] = t;
+        std::memcpy(rec + (size_t)i * kRecFloats, &r, sizeof(r));
+    }
+}
+
+// planar [c,H,W] outputs like the reference's image state
+void hm_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, const float* bg,
+                  float* out_color, float* out_others, float* final_T, uint32_t* n_contrib)
+{
+    const int tiles_x = (W + 15) / 16, HW = W * H;
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / 16) * tiles_x + px / 16;
+            const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+            PixFwd st;
+            pixfwd_init(st);
+            for (uint32_t e = ranges[2 * tile]; e < ranges[2 * tile + 1]; e++) {
+                const float* r = rec + (size_t)point_list[e] * kRecFloats;
+                st.contributor++;
+                PairEval ev;
+                if (!pair_eval(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
+                if (!pixfwd_blend(st, ev, Q(r, 3), Q(r, 4))) break;
+            }
+            const int pix = py * W + px;
+            final_T[pix] = st.T; final_T[HW + pix] = st.dist1; final_T[2 * HW + pix] = st.dist2;
+            n_contrib[pix] = st.last; n_contrib[HW + pix] = st.med_c;
+            for (int c = 0; c < 3; c++) out_color[c * HW + pix] = st.C[c] + st.T * bg[c];
+            out_others[pix] = st.D; out_others[HW + pix] = 1.f - st.T;
+            for (int c = 0; c < 3; c++) out_others[(2 + c) * HW + pix] = st.N[c];
+            out_others[5 * HW + pix] = st.med_d; out_others[6 * HW + pix] = st.distortion; out_others[7 * HW + pix] = st.med_w;
+        }
+}
+
+void hm_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, const float* bg,
+                  const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dothers,
+                  float* acc /*[P,20]*/)
+{
+    const int tiles_x = (W + 15) / 16, HW = W * H;
+    std::vector<double> dacc((size_t)P * kAccFloats, 0.0);
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / 16) * tiles_x + px / 16;
+            const int pix = py * W + px;
+            const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+            float gp[3], go[8];
+            for (int c = 0; c < 3; c++) gp[c] = dL_dpix[c * HW + pix];
+            for (int c = 0; c < 8; c++) go[c] = dL_dothers[c * HW + pix];
+            PixBwd st;
+            pixbwd_init(st, final_T[pix], final_T[HW + pix], final_T[2 * HW + pix], (int)n_contrib[pix], (int)n_contrib[HW + pix], gp, go, bg);
+            const uint32_t r0 = ranges[2 * tile];
+            for (int e = st.last_contributor - 1; e >= 0; e--) {
+                const uint32_t id = point_list[r0 + (uint32_t)e];
+                const float* r = rec + (size_t)id * kRecFloats;
+                PairEval ev;
+                if (!pair_eval(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
+                float out[kAccFloats] = {0};
+                pixbwd_step(st, ev, e, pfx, pfy, Q(r, 1), Q(r, 2), Q(r, 3), Q(r, 4), out);
+                for (int c = 0; c < 18; c++) dacc[(size_t)id * kAccFloats + c] += out[c];
+            }
+        }
+    for (size_t i = 0; i < dacc.size(); i++) acc[i] = (float)dacc[i];
+}
+
+void hm_surfel_bwd(int P, int D, int M, const float* means3D, const float* scales, const float* rots, const float* shs,
+                   const float* view, const float* campos, int W, int H, float tx, float ty, const int* radii, const float* rec,
+                   const float* acc, float* dmean2D /*[P,3]*/, float* dmean3D, float* dT, float* dsh, float* dscale, float* drot)
+{
+    Camera cam = make_cam(view, campos, W, H, tx, ty);
+    for (int i = 0; i < P; i++) {
+        if (!(radii[i] > 0)) continue;
+        SurfelRec r;
+        std::memcpy(&r, rec + (size_t)i * kRecFloats, sizeof(r));
+        SurfelGrads g;
+        surfel_backward(cam, means3D + 3 * i, scales + 2 * i, rots + 4 * i, r, acc + (size_t)i * kAccFloats, g);
+        if (shs) sh_backward(D, shs + (size_t)i * M * 3, means3D + 3 * i, campos, r.flags, acc + (size_t)i * kAccFloats + kAccColor,
+                             dsh + (size_t)i * M * 3, g.dmean3D);
+        for (int c = 0; c < 3; c++) dmean3D[3 * i + c] = g.dmean3D[c];
+        dmean2D[3 * i] = g.dmean2D[0]; dmean2D[3 * i + 1] = g.dmean2D[1];
+        for (int c = 0; c < 9; c++) dT[9 * i + c] = g.dT[c];
+        dscale[2 * i] = g.dscale[0]; dscale[2 * i + 1] = g.dscale[1];
+        for (int c = 0; c < 4; c++) drot[4 * i + c] = g.drot[c];
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""The arithmetic the HIP kernels inline (dynamic-2dgs_amd/csrc/surfel_math.h), compiled for the
+host and driven by plain loops (tests/hostmath/hostmath.cpp), against the CPU oracle.  Catches
+maths errors in the product header without a GPU; kernel control flow is covered by -m gpu tests."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from scene_utils import oracle_from_case, small_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostmath", "hostmath.cpp")
+LIB = os.path.join(HERE, "hostmath", "libhostmath.so")
+HDR = os.path.join(os.path.dirname(HERE), "dynamic-2dgs_amd", "csrc", "surfel_math.h")
+
+
+@pytest.fixture(scope="module")
+def hm():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", LIB])
+    return ctypes.CDLL(LIB)
+
+
+def p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def f32(t):
+    return np.ascontiguousarray(t.numpy().astype(np.float32))
+
+
+CASES = [
+    dict(P=400, H=48, W=64, seed=4, view=5, scale_mul=1.5, sh_degree=3),
+    dict(P=250, H=40, W=36, seed=7, view=1, scale_mul=2.5, sh_degree=2, bg=(1.0, 1.0, 1.0)),
+    dict(P=300, H=33, W=47, seed=8, view=2, scale_mul=1.0, sh_degree=0, radius=2.5),  # some surfels behind / near the camera
+]
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_hostmath_pipeline_matches_oracle(hm, cfg):
+    case = small_case(**cfg)
+    orc = oracle_from_case(case)
+    P, H, W = case["means3D"].shape[0], case["image_height"], case["image_width"]
+    m3, sc, rot, op, sh = (f32(case[k]) for k in ("means3D", "scales", "rotations", "opacities", "shs"))
+    vm, cp, bg = f32(case["viewmatrix"]).reshape(-1), f32(case["campos"]), f32(case["bg"])
+    D, M = case["sh_degree"], sh.shape[1]
+    radii = np.zeros(P, np.int32)
+    rec = np.zeros((P, 20), np.float32)
+    tiles = np.zeros(P, np.int32)
+    hm.hm_preprocess(P, D, M, p(m3), p(sc), p(rot), p(op), p(sh), None, p(vm), p(cp), W, H,
+                     ctypes.c_float(case["tanfovx"]), ctypes.c_float(case["tanfovy"]), p(radii), p(rec), p(tiles))
+    # ---- preprocess: bit-exact (same IEEE operations, contraction off on both sides)
+    assert np.array_equal(radii, orc.radii)
+    assert np.array_equal(tiles.astype(np.uint32), orc.field("tiles_touched"))
+    vis = radii > 0
+    assert vis.sum() > 20
+    assert np.array_equal(rec[vis, 0:9], orc.field("transMat")[vis])
+    assert np.array_equal(rec[vis, 9:11], orc.field("means2D")[vis])
+    assert np.array_equal(rec[vis, 11], orc.field("normal_opacity")[vis, 3])
+    assert np.array_equal(rec[vis, 12:15], orc.field("normal_opacity")[vis, :3])
+    assert np.array_equal(rec[vis, 15:18], orc.field("rgb")[vis])
+    assert np.array_equal(rec[vis, 18], orc.field("depths")[vis])
+    flags = rec[:, 19].view(np.uint32)
+    cl = orc.field("clamped")
+    assert np.array_equal(((flags[vis, None] >> np.arange(3)[None, :]) & 1).astype(np.uint8), cl[vis])
+
+    # ---- forward blend on the oracle's lists
+    ranges, plist = orc.field("ranges"), orc.field("point_list")
+    color = np.zeros((3, H, W), np.float32)
+    others = np.zeros((8, H, W), np.float32)
+    final_T = np.zeros((3, H, W), np.float32)
+    ncontrib = np.zeros((2, H, W), np.uint32)
+    hm.hm_blend_fwd(W, H, p(ranges), p(plist), p(rec), p(bg), p(color), p(others), p(final_T), p(ncontrib))
+    assert np.abs(color - orc.color).max() < 2e-6
+    assert np.abs(others - orc.allmap).max() < 2e-5
+    assert np.array_equal(ncontrib, orc.field("n_contrib"))
+    assert np.abs(final_T - orc.field("final_T")).max() < 2e-6
+
+    # ---- backward blend + per-surfel backward
+    g = np.random.default_rng(3)
+    gc = g.standard_normal((3, H, W)).astype(np.float32)
+    go = g.standard_normal((8, H, W)).astype(np.float32)
+    og = orc.backward(gc, go)
+    acc = np.zeros((P, 20), np.float32)
+    hm.hm_blend_bwd(P, W, H, p(ranges), p(plist), p(rec), p(bg), p(final_T), p(ncontrib), p(gc), p(go), p(acc))
+    dmean2D = np.zeros((P, 3), np.float32)
+    dmean3D = np.zeros((P, 3), np.float32)
+    dT = np.zeros((P, 9), np.float32)
+    dsh = np.zeros((P, M, 3), np.float32)
+    dscale = np.zeros((P, 2), np.float32)
+    drot = np.zeros((P, 4), np.float32)
+    hm.hm_surfel_bwd(P, D, M, p(m3), p(sc), p(rot), p(sh), p(vm), p(cp), W, H, ctypes.c_float(case["tanfovx"]),
+                     ctypes.c_float(case["tanfovy"]), p(radii), p(rec), p(acc), p(dmean2D), p(dmean3D), p(dT), p(dsh), p(dscale), p(drot))
+
+    def close(a, b, name, tol=2e-4):
+        scale = max(1e-6, float(np.abs(b).max()))
+        err = float(np.abs(a - b).max())
+        assert err <= tol * scale, "%s: %.3e vs scale %.3e" % (name, err, scale)
+
+    close(acc[:, 0:3], og["dL_dcolors"], "dL_dcolors")
+    close(acc[:, 3:6], og["dL_dnormal"], "dL_dnormal")
+    close(acc[:, 15], og["dL_dopacity"][:, 0], "dL_dopacity")
+    close(dT, og["dL_dtransMat"], "dL_dtransMat")
+    close(dmean2D, og["dL_dmeans2D"], "dL_dmeans2D")
+    close(dmean3D, og["dL_dmeans3D"], "dL_dmeans3D")
+    close(dsh, og["dL_dsh"], "dL_dsh")
+    close(dscale, og["dL_dscales"], "dL_dscales")
+    close(drot, og["dL_drotations"], "dL_drotations")

@@ -1,0 +1,60 @@
+"""Quick fwd/bwd timing of the rasterizer alone at a given size (development aid, GPU only)."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+
+from diff_surfel_rasterization import GaussianRasterizer, _C
+from gpu_utils import settings_from_case
+from scene_utils import small_case
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--P", type=int, default=200000)
+ap.add_argument("--H", type=int, default=800)
+ap.add_argument("--W", type=int, default=800)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--views", type=int, default=8)
+a = ap.parse_args()
+dev = "cuda:0"
+cases = [small_case(P=a.P, H=a.H, W=a.W, seed=0, view=v * (64 // a.views), n_views=64) for v in range(a.views)]
+leaf = {k: cases[0][k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+rasts = [GaussianRasterizer(settings_from_case(c, dev)) for c in cases]
+gc = torch.randn(3, a.H, a.W, device=dev)
+go = torch.randn(8, a.H, a.W, device=dev)
+
+
+def step(i, bwd=True):
+    m2 = torch.zeros_like(leaf["means3D"], requires_grad=True)
+    color, radii, allmap = rasts[i % len(rasts)](means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"],
+                                                 scales=leaf["scales"], rotations=leaf["rotations"])
+    if bwd:
+        torch.autograd.backward([color, allmap], [gc, go])
+        for v in leaf.values():
+            v.grad = None
+    return color
+
+
+for i in range(3):
+    step(i)
+torch.cuda.synchronize()
+_C.profile_enable(True)
+_C.profile_reset()
+t = time.time()
+for i in range(a.iters):
+    step(i, bwd=False)
+torch.cuda.synchronize()
+tf = (time.time() - t) / a.iters
+t = time.time()
+for i in range(a.iters):
+    step(i)
+torch.cuda.synchronize()
+tfb = (time.time() - t) / a.iters
+pr = _C.profile_read()
+print("P=%d %dx%d fwd %.3f ms, fwd+bwd %.3f ms" % (a.P, a.W, a.H, tf * 1e3, tfb * 1e3))
+print("blend fwd %.3f ms/launch (%d), blend bwd %.3f ms/launch (%d)" % (
+    pr["fwd_ms"] / max(pr["fwd_n"], 1), pr["fwd_n"], pr["bwd_ms"] / max(pr["bwd_n"], 1), pr["bwd_n"]))
