@@ -53,7 +53,7 @@ enum AccSlot { kAccColor = 0, kAccNormal = 3, kAccT = 6, kAccOpacity = 15, kAccM
 
 DGS_HD float fast_rcp(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DGS_PRECISE_MATH)
     return __builtin_amdgcn_rcpf(x);
 #else
     return 1.0f / x;
@@ -62,7 +62,7 @@ DGS_HD float fast_rcp(float x)
 
 DGS_HD float fast_exp(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DGS_PRECISE_MATH)
     return __expf(x);
 #else
     return expf(x);
@@ -77,6 +77,12 @@ struct Camera {
     int width, height;
     int tiles_x, tiles_y;
 };
+
+// ---- per-surfel forward: FMA contraction off for this whole section, so that culling / ceil / (int)
+// decisions and the stored records are bit-identical to the CPU oracle (gcc -ffp-contract=off).
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 
 // auxiliary.h:64-74 getRect: tile rectangle [min,max) touched by a disc of integer radius.
 DGS_HD void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1)
@@ -154,7 +160,6 @@ DGS_HD int preprocess_surfel(const Camera& cam, const float* pos, const float* s
                              int deg, const float* sh /*or null*/, const float* color_precomp /*or null*/,
                              SurfelRec& rec, int& tiles)
 {
-#pragma clang fp contract(off)
     tiles = 0;
     const float* vm = cam.view;
     float pv[3];
@@ -211,6 +216,10 @@ DGS_HD int preprocess_surfel(const Camera& cam, const float* pos, const float* s
     tiles = cnt;
     return radius;
 }
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Per-(pixel, surfel) evaluation shared by the forward and backward blend (forward.cu:359-399,

@@ -16,7 +16,7 @@ import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
 LIB_NAME = "libdgs_surfel_rasterizer.so"
-LIB_PATH = os.path.join(_CSRC, LIB_NAME)
+LIB_PATH = os.environ.get("DGS_SURFEL_LIB", os.path.join(_CSRC, LIB_NAME))  # override: development A/B builds only
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 _SOURCES = ["surfel_rasterizer.hip", "kernels_blend.h", "kernels_preprocess.h", "surfel_math.h"]
 

@@ -97,3 +97,20 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def grad_close(a, b, name, tol_trim=2e-4, tol_all=5e-3, trim_frac=1e-3):
+    """Per-surfel gradient parity.  fp32 evaluation of near edge-on surfels (p = k x l cancels) and
+    contributors sitting on the 1/255 / 1e-4 thresholds make a handful of surfels ill-conditioned: the
+    fp32 and fp64 builds of the ORACLE ITSELF differ by rel-L2 ~2.5e-3 on the 200k/800x800 scene with
+    >99% of the squared error on <100 surfels.  So: relative L2 <= tol_trim after discarding the
+    trim_frac of surfels with the largest error, and <= tol_all over everything."""
+    a = np.asarray(a, np.float64).reshape(a.shape[0], -1)
+    b = np.asarray(b, np.float64).reshape(b.shape[0], -1)
+    e = np.linalg.norm(a - b, axis=1)
+    denom = max(np.linalg.norm(b), 1e-30)
+    full = float(np.linalg.norm(e) / denom)
+    k = int(np.ceil(trim_frac * e.shape[0]))
+    trimmed = float(np.linalg.norm(np.sort(e)[:e.shape[0] - k]) / denom) if e.shape[0] > k else 0.0
+    assert trimmed <= tol_trim, "%s: trimmed rel-L2 %.3e" % (name, trimmed)
+    assert full <= tol_all, "%s: rel-L2 %.3e" % (name, full)
