@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): train views/sec (fwd+bwd), 800x800, 200k surfels, at 1/2/4/8 GPUs.
+One "step" = one full training pass of the hot path over one synthetic view per rank:
+  node deformation (PyTorch-ROCm) -> HIP surfel rasterizer forward -> L1 + D-SSIM + normal + distortion loss
+  -> rasterizer backward -> deformation backward -> [N>1] one flat RCCL all-reduce -> Adam (surfels + deform).
+Inputs (scene S(200k,800,800,seed 0)) are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  "roofline"     : achieved algorithmic HBM GB/s of the dominant kernel (the backward blend), timed with HIP
+                   events on the launch stream inside the timed region, against the 8 TB/s HBM3E peak;
+  "roofline_fwd" : the same for the forward blend;
+  "cpu_baseline" : the CPU port (C oracle rasterizer with OpenMP + PyTorch-CPU deformation/loss/Adam) timed on
+                   this box's host cores for a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (surfels, H, W)   -- "metric" is the configuration BASELINE.json's metric is quoted on
+    "metric": (200_000, 800, 800),
+    "c3": (150_000, 800, 800),
+    "c4": (300_000, 800, 800),
+    "c5": (1_000_000, 1600, 1600),
+    "tiny": (5_000, 128, 128),
+}
+
+
+def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None):
+    from dgs_amd.cameras import orbit_cameras
+    from dgs_amd.deform import ControlNodes
+    from dgs_amd.model import SurfelModel
+    from dgs_amd.synthetic import make_scene, target_image
+    from dgs_amd.train import Trainer
+    torch.manual_seed(0)
+    scene = make_scene(P, seed=0)
+    surfels = SurfelModel(scene).to(device)
+    deform = ControlNodes(node_num=1024, K=3, hyper_dim=8, local_frame=True).to(device)
+    deform.init_from_points(surfels.get_xyz.detach(), fps=True)
+    cams = [c.to(device) for c in orbit_cameras(n_views, W, H)]
+    targets = [target_image(H, W, seed=1 + v).to(device) for v in range(n_targets)]
+    bg = torch.zeros(3, device=device)
+    return Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam)
+
+
+def blend_bytes(S_per_launch, ntiles, HW, backward):
+    """Algorithmic bytes per launch of the blend kernels (SURVEY.md section 8d / DESIGN.md):
+    fwd B7 = 76*S + 8*T + 64*H*W ; bwd B8 = B7 + 4*16*N_vis with N_vis bounded by S."""
+    b = 76.0 * S_per_launch + 8.0 * ntiles + 64.0 * HW
+    if backward:
+        b += 64.0 * S_per_launch
+    return b
+
+
+def cpu_baseline(P, H, W, budget_s=25.0):
+    """The oracle-backed CPU port of the same train step, bounded sample (about 10-30 s of CPU work)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_raster_op import OracleRasterizer  # test-only operator: oracle/ is the checker, never shipped
+    from oracle import surfel_oracle
+    ncores = min(os.cpu_count() or 1, 32)  # more threads only add contention on the accumulations
+    torch.set_num_threads(ncores)
+    surfel_oracle.set_threads(ncores)
+    tr = build_trainer(P, H, W, torch.device("cpu"), n_views=8, n_targets=2, rasterizer_cls=OracleRasterizer, fused_adam=False)
+    tr.step()  # untimed: the first call pays one-off BLAS/oneDNN initialisation (tens of seconds on some hosts)
+    t0 = time.time()
+    tr.step()
+    n = 1
+    per = time.time() - t0
+    while n < 3 and (time.time() - t0) + per < budget_s:
+        tr.step()
+        n += 1
+        per = (time.time() - t0) / n
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "views/s", "cores": ncores, "kind": "port",
+            "sample": "%d full train steps (views) of the same %dk-surfel %dx%d workload, %.1f s" % (n, P // 1000, W, H, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the surfel rasterizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+
+    from diff_surfel_rasterization import _C
+    P, H, W = WORKLOADS[args.workload]
+    tr = build_trainer(P, H, W, device)
+    for _ in range(args.warmup):
+        tr.step()
+    _C.profile_enable(True)
+    _C.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = _C.profile_read()
+    _C.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+        def roof(kind):
+            n, ms, S = prof[kind + "_n"], prof[kind + "_ms"], prof[kind + "_S"]
+            if n == 0 or ms <= 0:
+                return None
+            bytes_per = blend_bytes(S / n, ntiles, H * W, backward=(kind == "bwd"))
+            gbs = bytes_per / (ms / n * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "blend_%s_kernel" % kind, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_kernel_ms": round(ms / n, 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S / n)}
+
+        out = {
+            "metric": "train views/sec (fwd+bwd), 800x800, 200k surfels" if args.workload == "metric"
+            else "train views/sec (fwd+bwd), %dx%d, %dk surfels" % (W, H, P // 1000),
+            "value": round(world * args.steps / dt, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: synthetic scene S(%d surfels, %dx%d, seed 0), full train step (node deform + surfel "
+                                   "raster fwd/bwd + L1/D-SSIM/normal/distortion loss + Adam), 1 view per GPU per step" % (args.workload, P, W, H),
+                       "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "control_nodes": 1024,
+                       "views_per_step": world, "parallelism": "dp%d (views sharded, one flat all-reduce)" % world},
+            "roofline": roof("bwd"), "roofline_fwd": roof("fwd"),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del tr
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(P, H, W)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,8 +151,17 @@ struct HostStage {
 HostStage g_stage;
 
 // ---- optional kernel timing (bench.py roofline leg) ------------------------------------------------
+__global__ void sum_tile_last_kernel(const uint32_t* tile_last, int n, unsigned long long* dst)
+{
+    unsigned long long acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += tile_last[i];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, acc);
+}
+
 struct Prof {
     bool on = false;
+    unsigned long long* counters = nullptr;  // device: [0] sum of S over timed fwd launches, [1] over bwd launches
     std::mutex mu;
     struct Pair { hipEvent_t a, b; int kind; };
     std::vector<Pair> pending;
@@ -177,11 +186,17 @@ bool prof_begin(int kind, hipStream_t s, Prof::Pair& p)
     return true;
 }
 
-void prof_end(hipStream_t s, Prof::Pair& p)
+void prof_end(hipStream_t s, Prof::Pair& p, const uint32_t* tile_last, int ntiles)
 {
     (void)hipEventRecord(p.b, s);
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.pending.push_back(p);
+    // S = sum over tiles of the list length actually traversed, for the roofline
+    if (!g_prof.counters) {
+        if (hipMalloc((void**)&g_prof.counters, 16) != hipSuccess) { g_prof.counters = nullptr; return; }
+        (void)hipMemsetAsync(g_prof.counters, 0, 16, s);
+    }
+    hipLaunchKernelGGL(sum_tile_last_kernel, dim3(1), dim3(256), 0, s, tile_last, ntiles, g_prof.counters + p.kind);
 }
 
 int check_common(int P, int W, int H, const void* means3D)
@@ -208,6 +223,7 @@ void dgs_profile_reset(void)
     g_prof.pending.clear();
     g_prof.ms[0] = g_prof.ms[1] = 0;
     g_prof.n[0] = g_prof.n[1] = 0;
+    if (g_prof.counters) (void)hipMemset(g_prof.counters, 0, 16);
 }
 
 int dgs_profile_read(double* out, int cap)
@@ -222,8 +238,10 @@ int dgs_profile_read(double* out, int cap)
         g_prof.pool.push_back(p);
     }
     g_prof.pending.clear();
-    const double v[4] = {g_prof.ms[0], (double)g_prof.n[0], g_prof.ms[1], (double)g_prof.n[1]};
-    int k = cap < 4 ? cap : 4;
+    unsigned long long cnt[2] = {0, 0};
+    if (g_prof.counters) (void)hipMemcpy(cnt, g_prof.counters, 16, hipMemcpyDeviceToHost);
+    const double v[6] = {g_prof.ms[0], (double)g_prof.n[0], g_prof.ms[1], (double)g_prof.n[1], (double)cnt[0], (double)cnt[1]};
+    int k = cap < 6 ? cap : 6;
     for (int i = 0; i < k; i++) out[i] = v[i];
     return k;
 }
@@ -365,7 +383,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     Prof::Pair pp;
     const bool timed = prof_begin(0, stream, pp);
     hipLaunchKernelGGL(dgs::blend_fwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, fa);
-    if (timed) prof_end(stream, pp);
+    if (timed) prof_end(stream, pp, fa.tile_last, il.ntiles);
     DGS_STAGE("blend_fwd", debug, stream);
     return R;
 }
@@ -419,7 +437,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
         Prof::Pair pp;
         const bool timed = prof_begin(1, stream, pp);
         hipLaunchKernelGGL(dgs::blend_bwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
-        if (timed) prof_end(stream, pp);
+        if (timed) prof_end(stream, pp, ba.tile_last, il.ntiles);
         DGS_STAGE("blend_bwd", debug, stream);
     }
 

@@ -1,0 +1,48 @@
+"""Surfel parameters + optimiser groups: the slice of scene/gaussian_model.py the train step touches
+(activations :60-134, Adam groups :181-203, densification statistics :484-486)."""
+import torch
+import torch.nn as nn
+
+from .synthetic import SurfelScene
+
+
+class SurfelModel(nn.Module):
+    def __init__(self, scene: SurfelScene, sh_degree: int = 3, active_sh_degree: int = 3):
+        super().__init__()
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = active_sh_degree
+        self._xyz = nn.Parameter(scene.xyz.clone())
+        self._features_dc = nn.Parameter(scene.f_dc.clone())
+        self._features_rest = nn.Parameter(scene.f_rest.clone())
+        self._scaling = nn.Parameter(scene.log_scale.clone())
+        self._rotation = nn.Parameter(scene.rotation.clone())
+        self._opacity = nn.Parameter(scene.opacity_logit.clone())
+        self.feature = nn.Parameter(scene.feature.clone())
+        P = scene.xyz.shape[0]
+        self.register_buffer("xyz_gradient_accum", torch.zeros(P, 1), persistent=False)
+        self.register_buffer("denom", torch.zeros(P, 1), persistent=False)
+        self.register_buffer("max_radii2D", torch.zeros(P, dtype=torch.int32), persistent=False)
+
+    get_xyz = property(lambda self: self._xyz)
+    get_scaling = property(lambda self: torch.exp(self._scaling))
+    get_opacity = property(lambda self: torch.sigmoid(self._opacity))
+    get_features = property(lambda self: torch.cat((self._features_dc, self._features_rest), dim=1))
+
+    def get_rotation_bias(self, rotation_bias=0.0):
+        return torch.nn.functional.normalize(self._rotation + rotation_bias)
+
+    @property
+    def motion_mask(self):  # with_motion_mask=False (arguments/__init__.py:72)
+        return torch.ones_like(self._xyz[..., :1])
+
+    def optimizer_groups(self, position_lr=0.00016, feature_lr=0.004, opacity_lr=0.05, scaling_lr=0.002, rotation_lr=0.002,
+                         spatial_lr_scale=5.0):
+        return [
+            {'params': [self._xyz], 'lr': position_lr * spatial_lr_scale, "name": "xyz"},
+            {'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
+            {'params': [self._features_rest], 'lr': feature_lr / 20.0, "name": "f_rest"},
+            {'params': [self._opacity], 'lr': opacity_lr, "name": "opacity"},
+            {'params': [self._scaling], 'lr': scaling_lr * spatial_lr_scale, "name": "scaling"},
+            {'params': [self._rotation], 'lr': rotation_lr, "name": "rotation"},
+            {'params': [self.feature], 'lr': feature_lr, 'name': 'feature'},
+        ]

@@ -1,0 +1,96 @@
+"""One training step of the hot path, view/timestamp-parallel over the GPUs of a node.
+
+Compute of the reference's GUI.train_step (train_gui.py:272-313,372,410-432) in the iteration > 20000
+regime (ARAP off, normal + distortion regularisers on): node deformation -> render (HIP rasterizer) ->
+L1 + D-SSIM + normal + distortion loss -> backward -> [DP] one flat all-reduce -> Adam (surfels + deform).
+
+Data parallelism (new design, the reference is single-process): every rank holds a full replica, renders its
+own view of the step's batch, and all gradients live in ONE flat fp32 bucket that is all-reduced once per
+step over RCCL/xGMI (backend "nccl"; "gloo" in the CPU tests).  The bucket tail carries the densification
+statistics (train_gui.py:411, gaussian_model.py:484-486) so replicas stay identical without a second sum.
+"""
+import torch
+import torch.distributed as dist
+
+from .losses import training_loss
+from .render import render
+
+
+class FlatGradBucket:
+    """All gradients as views into one contiguous fp32 buffer (+ a tail of `extra` floats)."""
+
+    def __init__(self, params, extra=0):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n + extra, dtype=torch.float32, device=dev)
+        self.n_grad = n
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.extra = self.flat[n:]
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat[:self.n_grad].mul_(1.0 / dist.get_world_size(group))
+
+
+class Trainer:
+    def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=0.00016 * 5.0, fused_adam=None,
+                 rasterizer_cls=None):
+        self.surfels, self.deform = surfels, deform
+        self.rasterizer_cls = rasterizer_cls  # None = the HIP operator; tests / the CPU baseline inject the oracle op
+        self.cameras, self.targets, self.bg = cameras, targets, bg_color
+        P = surfels.get_xyz.shape[0]
+        self.P = P
+        params = [p for g in surfels.optimizer_groups() for p in g['params']] + list(deform.parameters())
+        self.bucket = FlatGradBucket(params, extra=2 * P)
+        dev = surfels.get_xyz.device
+        if fused_adam is None:
+            fused_adam = dev.type == "cuda"
+        kw = {"fused": True} if fused_adam else {}
+        self.opt_surfels = torch.optim.Adam(surfels.optimizer_groups(), lr=0.0, eps=1e-15, **kw)
+        self.opt_deform = torch.optim.Adam([
+            {'params': list(deform.network.parameters()), 'lr': deform_lr, 'name': 'deform'},
+            {'params': [deform.nodes, deform._node_radius, deform._node_weight], 'lr': deform_lr, 'name': 'nodes'}],
+            lr=0.0, eps=1e-15, **kw)
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.iteration = 0
+
+    def view_for(self, iteration):
+        """Shared deterministic schedule: step i renders views {i*world + rank} mod V."""
+        return (iteration * self.world + self.rank) % len(self.cameras)
+
+    def step(self):
+        cam = self.cameras[self.view_for(self.iteration)]
+        gt = self.targets[self.view_for(self.iteration) % len(self.targets)]
+        s, d = self.surfels, self.deform
+        self.bucket.zero()
+        t = d.expand_time(cam.fid)
+        dv = d(s.get_xyz.detach(), t, s.feature, s.motion_mask)
+        pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls)
+        loss = training_loss(pkg, gt)
+        loss.backward()
+        with torch.no_grad():
+            # densification statistics of this view into the bucket tail (summed over ranks)
+            vis = pkg["visibility_filter"]
+            g2 = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
+            self.bucket.extra[:self.P].copy_(torch.where(vis, g2, torch.zeros_like(g2)))
+            self.bucket.extra[self.P:].copy_(vis.to(torch.float32))
+            self.bucket.all_reduce_mean()
+            s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
+            s.denom.add_(self.bucket.extra[self.P:, None])
+            radii = torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"]))
+            if self.world > 1:
+                dist.all_reduce(radii, op=dist.ReduceOp.MAX)
+            torch.maximum(s.max_radii2D, radii, out=s.max_radii2D)
+            self.opt_surfels.step()
+            self.opt_deform.step()
+        self.iteration += 1
+        return loss.detach()

@@ -240,7 +240,7 @@ def profile_reset():
 
 
 def profile_read():
-    """{'fwd_ms', 'fwd_n', 'bwd_ms', 'bwd_n'} accumulated over timed blend-kernel launches."""
-    out = (ctypes.c_double * 4)()
-    load().dgs_profile_read(out, 4)
-    return {"fwd_ms": out[0], "fwd_n": int(out[1]), "bwd_ms": out[2], "bwd_n": int(out[3])}
+    """{'fwd_ms', 'fwd_n', 'bwd_ms', 'bwd_n', 'fwd_S', 'bwd_S'} accumulated over timed blend-kernel launches."""
+    out = (ctypes.c_double * 6)()
+    load().dgs_profile_read(out, 6)
+    return {"fwd_ms": out[0], "fwd_n": int(out[1]), "bwd_ms": out[2], "bwd_n": int(out[3]), "fwd_S": out[4], "bwd_S": out[5]}

@@ -96,7 +96,9 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
 
 /* Kernel timing hook for bench.py: when enabled, the library brackets the forward and backward blend
  * kernels with HIP events on the launch stream; dgs_profile_read returns accumulated milliseconds and
- * launch counts since the last reset: out[0..1] fwd blend (ms, n), out[2..3] bwd blend (ms, n). */
+ * launch counts since the last reset: out[0..1] fwd blend (ms, n), out[2..3] bwd blend (ms, n),
+ * out[4], out[5] = sum over the timed fwd / bwd launches of S = sum_tiles(entries traversed), the unit
+ * of the algorithmic-bytes formula. */
 void dgs_profile_enable(int on);
 void dgs_profile_reset(void);
 int dgs_profile_read(double* out, int cap);

@@ -413,6 +413,10 @@ static void render_bwd(const OracleState* st, const real* feat, const real* bg, 
     for (int tile = 0; tile < st->tiles_x * st->tiles_y; tile++) {
         const int tx = tile % st->tiles_x, ty = tile / st->tiles_x;
         const uint32_t r0 = st->ranges[2 * tile], r1 = st->ranges[2 * tile + 1];
+        if (r1 == r0) continue;
+        /* tile-local partial sums [entry][18] (dcolor 3, dnormal 3, dT 9, dopac 1, dmean2D 2), flushed once
+         * per (tile, entry) below: same sums, 256x fewer atomics on many-core hosts */
+        double* loc = (double*)calloc((size_t)(r1 - r0) * 18, sizeof(double));
         for (int ly = 0; ly < BLOCK_Y; ly++)
             for (int lx = 0; lx < BLOCK_X; lx++) {
                 const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
@@ -445,6 +449,7 @@ static void render_bwd(const OracleState* st, const real* feat, const real* bg, 
                 for (int contributor = (int)(r1 - r0) - 1; contributor >= 0; contributor--) {
                     if (contributor >= last_contributor) continue;
                     const uint32_t id = st->point_list[r0 + (uint32_t)contributor];
+                    double* la = loc + (size_t)contributor * 18;
                     const real* Tm = st->transMat + 9 * id;
                     const real* Tu = Tm; const real* Tv = Tm + 3; const real* Tw = Tm + 6;
                     real k[3] = {-Tu[0] + pfx * Tw[0], -Tu[1] + pfx * Tw[1], -Tu[2] + pfx * Tw[2]};
@@ -475,7 +480,7 @@ static void render_bwd(const OracleState* st, const real* feat, const real* bg, 
                         accum_rec[ch] = last_alpha * last_color[ch] + (1 - last_alpha) * accum_rec[ch];
                         last_color[ch] = c;
                         dL_dalpha += (c - accum_rec[ch]) * dL_dpixel[ch];
-                        acc_add(&g->dcolor[3 * id + ch], (double)(dchannel_dcolor * dL_dpixel[ch]));
+                        la[ch] += (double)(dchannel_dcolor * dL_dpixel[ch]);
                     }
                     real dL_dz = 0, dL_dweight = 0;
                     const real m_d = mapped_depth(c_d);
@@ -495,7 +500,7 @@ static void render_bwd(const OracleState* st, const real* feat, const real* bg, 
                         accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1 - last_alpha) * accum_normal_rec[ch];
                         last_normal[ch] = no[ch];
                         dL_dalpha += (no[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
-                        acc_add(&g->dnormal[3 * id + ch], (double)(alpha * T * dL_dnormal2D[ch]));
+                        la[3 + ch] += (double)(alpha * T * dL_dnormal2D[ch]);
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
@@ -512,20 +517,30 @@ static void render_bwd(const OracleState* st, const real* feat, const real* bg, 
                         cross3(l, dL_dp, dL_dk);
                         cross3(dL_dp, k, dL_dl);
                         for (int c = 0; c < 3; c++) {
-                            acc_add(&g->dT[9 * id + c], (double)(-dL_dk[c]));
-                            acc_add(&g->dT[9 * id + 3 + c], (double)(-dL_dl[c]));
-                            acc_add(&g->dT[9 * id + 6 + c], (double)(pfx * dL_dk[c] + pfy * dL_dl[c] + dL_dz * dz_dTw[c]));
+                            la[6 + c] += (double)(-dL_dk[c]);
+                            la[9 + c] += (double)(-dL_dl[c]);
+                            la[12 + c] += (double)(pfx * dL_dk[c] + pfy * dL_dl[c] + dL_dz * dz_dTw[c]);
                         }
                     } else {                                      /* :436-443 */
                         const real dG_ddelx = (real)((double)(-G) * FILTER_INV_SQUARE * (double)dx);
                         const real dG_ddely = (real)((double)(-G) * FILTER_INV_SQUARE * (double)dy);
-                        acc_add(&g->dmean2D[2 * id], (double)(dL_dG * dG_ddelx));
-                        acc_add(&g->dmean2D[2 * id + 1], (double)(dL_dG * dG_ddely));
-                        acc_add(&g->dT[9 * id + 8], (double)dL_dz);
+                        la[16] += (double)(dL_dG * dG_ddelx);
+                        la[17] += (double)(dL_dG * dG_ddely);
+                        la[14] += (double)dL_dz;
                     }
-                    acc_add(&g->dopac[id], (double)(G * dL_dalpha)); /* :446 */
+                    la[15] += (double)(G * dL_dalpha); /* :446 */
                 }
             }
+        for (uint32_t e = 0; e < r1 - r0; e++) {
+            const double* la = loc + (size_t)e * 18;
+            const uint32_t id = st->point_list[r0 + e];
+            for (int c = 0; c < 3; c++) { if (la[c] != 0) acc_add(&g->dcolor[3 * id + c], la[c]); if (la[3 + c] != 0) acc_add(&g->dnormal[3 * id + c], la[3 + c]); }
+            for (int c = 0; c < 9; c++) if (la[6 + c] != 0) acc_add(&g->dT[9 * id + c], la[6 + c]);
+            if (la[15] != 0) acc_add(&g->dopac[id], la[15]);
+            if (la[16] != 0) acc_add(&g->dmean2D[2 * id], la[16]);
+            if (la[17] != 0) acc_add(&g->dmean2D[2 * id + 1], la[17]);
+        }
+        free(loc);
     }
 }
 
@@ -761,6 +776,21 @@ void oracle_mark_visible(int P, const real* means3D, const real* vm, unsigned ch
         real z = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
         present[i] = !(z <= (real)0.2);
     }
+}
+
+/* thread count for the OpenMP loops (bench.py cpu_baseline reports it as "cores") */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 /* introspection for stage-by-stage tests */

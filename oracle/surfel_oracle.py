@@ -53,6 +53,8 @@ def _lib(dtype):
         lib.oracle_get_int.argtypes = [vp, ctypes.c_int]
         lib.oracle_get_ptr.restype = vp
         lib.oracle_get_ptr.argtypes = [vp, ctypes.c_int]
+        lib.oracle_set_threads.restype = ctypes.c_int
+        lib.oracle_set_threads.argtypes = [ctypes.c_int]
         lib.oracle_mark_visible.restype = None
         lib.oracle_mark_visible.argtypes = [ctypes.c_int, vp, vp, vp]
         _LIBS[key] = lib
@@ -171,3 +173,8 @@ def mark_visible(means3D, viewmatrix, dtype=np.float32):
     if m.shape[0]:
         lib.oracle_mark_visible(m.shape[0], _p(m), _p(v), out.ctypes.data_as(ctypes.c_void_p))
     return out.astype(bool)
+
+
+def set_threads(n, dtype=np.float32):
+    """Sets the OpenMP thread count of the oracle's tile loops; returns the count in effect."""
+    return int(_lib(dtype).oracle_set_threads(int(n)))

@@ -1,0 +1,131 @@
+"""Host logic on the CPU: render() dict, loss, Trainer step and the world_size-2 gloo data-parallel path.
+The rasterizer call is served by the test-only oracle operator (tests/oracle_raster_op.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import dgs_amd.render as render_mod
+from dgs_amd.cameras import orbit_cameras
+from dgs_amd.deform import ControlNodes
+from dgs_amd.losses import training_loss
+from dgs_amd.model import SurfelModel
+from dgs_amd.synthetic import make_scene, target_image
+from dgs_amd.train import Trainer
+from oracle_raster_op import OracleRasterizer
+
+
+def _build(P=300, S=48, nodes=32, views=4, seed=0):
+    torch.manual_seed(seed)
+    scene = make_scene(P, seed)
+    scene = scene._replace(log_scale=scene.log_scale + 0.9)  # bigger surfels: everything visible at 48x48
+    surfels = SurfelModel(scene)
+    deform = ControlNodes(node_num=nodes)
+    deform.init_from_points(scene.xyz)
+    with torch.no_grad():  # non-trivial deformation (default init is ~1e-5)
+        deform.network.gaussian_warp.weight.mul_(2e3)
+        deform.network.gaussian_rotation.weight.mul_(2e3)
+    cams = orbit_cameras(views, S, S)
+    targets = [target_image(S, S, seed=1 + v) for v in range(views)]
+    return surfels, deform, cams, targets, torch.zeros(3)
+
+
+@pytest.fixture(autouse=True)
+def _oracle_backend(monkeypatch):
+    monkeypatch.setattr(render_mod, "GaussianRasterizer", OracleRasterizer)
+
+
+def test_render_dict_and_loss_backward():
+    surfels, deform, cams, targets, bg = _build()
+    cam = cams[1]
+    dv = deform(surfels.get_xyz.detach(), deform.expand_time(cam.fid), surfels.feature, surfels.motion_mask)
+    pkg = render_mod.render(cam, surfels, bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'])
+    for k in ("render", "viewspace_points", "visibility_filter", "radii", "alpha", "rend_normal", "rend_dist", "depth",
+              "surf_normal", "surf_point", "bg_color"):  # gaussian_renderer/__init__.py:154-217
+        assert k in pkg, k
+    assert pkg["render"].shape == (3, 48, 48) and pkg["alpha"].shape == (1, 48, 48) and pkg["surf_normal"].shape == (3, 48, 48)
+    loss = training_loss(pkg, targets[1])
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert surfels._xyz.grad.abs().sum() > 0 and surfels._features_rest.grad.abs().sum() > 0
+    assert surfels.feature.grad.abs().sum() > 0          # through the KNN distances (hyper coordinates)
+    assert deform.network.linear[0].weight.grad.abs().sum() > 0 and deform.nodes.grad[:, 3:].abs().sum() > 0
+    assert pkg["viewspace_points"].grad[:, :2].abs().sum() > 0 and float(pkg["viewspace_points"].grad[:, 2].abs().sum()) == 0
+
+
+def test_trainer_single_process_updates_everything():
+    surfels, deform, cams, targets, bg = _build()
+    tr = Trainer(surfels, deform, cams, targets, bg)
+    before = [p.detach().clone() for p in tr.bucket.params]
+    l0 = float(tr.step())
+    l1 = float(tr.step())
+    assert l0 == l0 and l1 == l1
+    changed = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, tr.bucket.params))
+    assert changed == len(before)
+    assert float(surfels.denom.sum()) > 0 and int(surfels.max_radii2D.max()) > 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    render_mod.GaussianRasterizer = OracleRasterizer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        surfels, deform, cams, targets, bg = _build()
+        tr = Trainer(surfels, deform, cams, targets, bg)
+        assert tr.view_for(0) == rank
+        tr.step()
+        flat_after = tr.bucket.flat.clone()
+        tr.step()
+        params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params])
+        gathered = [torch.zeros_like(params) for _ in range(world)]
+        dist.all_gather(gathered, params)
+        same = all(torch.equal(gathered[0], g) for g in gathered)
+        stats = torch.cat([surfels.xyz_gradient_accum.reshape(-1), surfels.denom.reshape(-1), surfels.max_radii2D.float()])
+        gs = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gs, stats)
+        same_stats = all(torch.equal(gs[0], g) for g in gs)
+        if rank == 0:
+            q.put((same, same_stats, flat_after))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, same_stats, flat_dp = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert same and same_stats
+    # the all-reduced bucket == mean of the two views' single-process gradients (+ summed statistics)
+    render_mod.GaussianRasterizer = OracleRasterizer
+    flats = []
+    for view in range(world):
+        surfels, deform, cams, targets, bg = _build()
+        tr = Trainer(surfels, deform, cams, targets, bg)
+        tr.view_for = lambda it, v=view: v
+        tr.opt_surfels.step = lambda: None
+        tr.opt_deform.step = lambda: None
+        tr.step()
+        flats.append(tr.bucket.flat.clone())
+    n = tr.bucket.n_grad
+    expect = torch.cat([(flats[0][:n] + flats[1][:n]) / 2, flats[0][n:] + flats[1][n:]])
+    assert torch.allclose(flat_dp, expect, rtol=1e-4, atol=1e-7)
