@@ -81,13 +81,23 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
         __syncthreads();
 
         if (!wave_done) {
+            // Entry j's alpha part (q0..q2) is prefetched into registers one iteration ahead, evaluated
+            // branch-free for all 64 lanes, and a single wave-uniform branch skips the entry when no lane
+            // passes -- the common case.
+            float4 n0 = s_rec[0][0], n1 = s_rec[1][0], n2 = s_rec[2][0];
+            const uint32_t base = (uint32_t)(b * kBatch);
             for (int j = 0; j < n; j++) {
-                if (__ballot(!done) == 0ull) break;  // wave-level early out
-                if (done) continue;
-                st.contributor++;
+                const float4 q0 = n0, q1 = n1, q2 = n2;
+                const int jn = j + 1 < kBatch ? j + 1 : j;
+                n0 = s_rec[0][jn]; n1 = s_rec[1][jn]; n2 = s_rec[2][jn];
                 PairEval e;
-                if (!pair_eval(pfx, pfy, as_quad(s_rec[0][j]), as_quad(s_rec[1][j]), as_quad(s_rec[2][j]), e)) continue;
-                if (!pixfwd_blend(st, e, as_quad(s_rec[3][j]), as_quad(s_rec[4][j]))) done = true;
+                const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), e) && !done;
+                if (__ballot(ok) == 0ull) continue;
+                if (ok) {
+                    st.contributor = base + (uint32_t)j + 1u;  // 1-based list position (forward.cu:356)
+                    if (!pixfwd_blend(st, e, as_quad(s_rec[3][j]), as_quad(s_rec[4][j]))) done = true;
+                }
+                if (__ballot(!done) == 0ull) break;  // wave-level early out (only re-evaluated after a blend)
             }
         }
     }
@@ -247,23 +257,27 @@ __global__ void __launch_bounds__(kTilePix) blend_bwd_kernel(BlendBwdArgs a)
         }
         __syncthreads();
         const int n = (L - b * kBatch) < kBatch ? (L - b * kBatch) : kBatch;
-        for (int j = 0; j < n; j++) {
+        // skip the leading entries no lane of this wave needs (wave-uniform)
+        int j0 = (L - 1 - b * kBatch) - (wave_last - 1);
+        j0 = j0 < 0 ? 0 : j0;
+        if (j0 >= n) continue;
+        float4 n0 = s_rec[0][j0], n1 = s_rec[1][j0], n2 = s_rec[2][j0];
+        for (int j = j0; j < n; j++) {
             const int e = L - 1 - (b * kBatch + j);  // 0-based list index == the reference's `contributor`
-            if (e >= wave_last) continue;            // wave-uniform skip
+            const float4 q0 = n0, q1 = n1, q2 = n2;
+            const int jn = j + 1 < kBatch ? j + 1 : j;
+            n0 = s_rec[0][jn]; n1 = s_rec[1][jn]; n2 = s_rec[2][jn];
+            PairEval ev;
+            const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), ev) && (e < st.last_contributor);
+            if (__ballot(ok) == 0ull) continue;
             float out[kAccFloats];
 #pragma unroll
             for (int c = 0; c < 18; c++) out[c] = 0.f;
-            bool contrib = false, flat = false;
-            if (e < st.last_contributor) {
-                PairEval ev;
-                const Quad q0 = as_quad(s_rec[0][j]), q1 = as_quad(s_rec[1][j]), q2 = as_quad(s_rec[2][j]);
-                if (pair_eval(pfx, pfy, q0, q1, q2, ev)) {
-                    pixbwd_step(st, ev, e, pfx, pfy, q1, q2, as_quad(s_rec[3][j]), as_quad(s_rec[4][j]), out);
-                    contrib = true;
-                    flat = !ev.use3d;
-                }
+            bool flat = false;
+            if (ok) {
+                pixbwd_step(st, ev, e, pfx, pfy, as_quad(q1), as_quad(q2), as_quad(s_rec[3][j]), as_quad(s_rec[4][j]), out);
+                flat = !ev.use3d;
             }
-            if (__ballot(contrib) == 0ull) continue;
             float* dst = a.acc + (size_t)s_id[j] * kAccFloats;
             float v16[16];
 #pragma unroll

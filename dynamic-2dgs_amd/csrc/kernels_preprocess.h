@@ -23,7 +23,9 @@ struct PreprocessArgs {
     Camera cam;
     int* radii;             // [P] out
     float4* rec;            // [P*5] out
+    uint2* rects;           // [P] out: packed (tight) tile rectangle of every surfel
     uint32_t* block_sums;   // [ceil(P/256)] out: sum of tile counts of the block
+    int tight;              // 1: exact opacity-aware rectangles (default), 0: the reference's rectangles
 };
 
 // wave64 inclusive scan with DPP-friendly shuffles
@@ -65,8 +67,10 @@ __global__ void __launch_bounds__(kSurfelBlock) preprocess_fwd_kernel(Preprocess
         float q[4] = {qv.x, qv.y, qv.z, qv.w};
         const float* sh = a.colors_precomp ? nullptr : a.shs + (size_t)idx * a.M * 3;
         const float* cp = a.colors_precomp ? a.colors_precomp + 3 * idx : nullptr;
-        int radius = preprocess_surfel(a.cam, pos, sc, q, a.opacities[idx], a.D, sh, cp, rec, tiles);
+        TileRect tr;
+        int radius = preprocess_surfel(a.cam, pos, sc, q, a.opacities[idx], a.D, sh, cp, rec, tiles, tr, a.tight != 0);
         a.radii[idx] = radius;
+        a.rects[idx] = make_uint2(tr.xs, tr.ys);
         if (radius > 0) {
             const float4* src = reinterpret_cast<const float4*>(&rec);
             float4* dst = a.rec + (size_t)idx * kRecQuads;
@@ -101,6 +105,7 @@ struct EmitArgs {
     int P;
     const int* radii;
     const float4* rec;
+    const uint2* rects;
     const uint32_t* block_offsets;  // exclusive scan of block sums
     uint64_t* keys;                 // [R]
     uint32_t* vals;                 // [R]
@@ -119,10 +124,10 @@ __global__ void __launch_bounds__(kSurfelBlock) emit_keys_kernel(EmitArgs a)
     if (idx < a.P) {
         const int radius = a.radii[idx];
         if (radius > 0) {
-            const float4 q2 = a.rec[(size_t)idx * kRecQuads + 2];
-            const float4 q4 = a.rec[(size_t)idx * kRecQuads + 4];
-            tile_rect(q2.y, q2.z, radius, a.tiles_x, a.tiles_y, x0, y0, x1, y1);
-            depth_bits = __float_as_uint(q4.z);
+            const uint2 r = a.rects[idx];
+            x0 = (int)(r.x & 0xffffu); x1 = (int)(r.x >> 16);
+            y0 = (int)(r.y & 0xffffu); y1 = (int)(r.y >> 16);
+            if (x1 > x0 && y1 > y0) depth_bits = __float_as_uint(a.rec[(size_t)idx * kRecQuads + 4].z);
         }
     }
     const uint32_t cnt = (uint32_t)((x1 - x0) * (y1 - y0));

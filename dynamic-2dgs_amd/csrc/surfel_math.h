@@ -152,15 +152,62 @@ DGS_HD uint32_t sh_to_rgb(int deg, const float* sh, const float* pos, const floa
     return flags;
 }
 
+// Exact, opacity-aware tile rectangle (NOT in the reference): a (surfel, tile) pair can only produce
+// alpha >= 1/255 (forward.cu:397-399) if  rho = min(rho3d, rho2d) <= tau = 2 ln(255 o).  The region
+// {rho3d <= tau} is the projection of the splat-space disc of radius sqrt(tau): its exact screen bounding box
+// follows from the same bounding-box algebra as computeAABB (forward.cu:133-163) applied to T diag(r,r,1);
+// {rho2d <= tau} is the disc of radius sqrt(tau/2) pixels around the projected centre.  Intersecting the
+// union of both boxes with the reference's rectangle drops pairs that cannot touch any pixel -- rendered
+// results are unchanged, only the private lists get shorter.  Evaluated in double (the box is a difference
+// of O(width^2) terms) with a 0.01 px + 1e-4 relative margin; when the disc is not entirely in front of
+// the camera plane (projection not an ellipse) the reference rectangle is kept.
+DGS_HD void tight_tile_rect(const float* Tu, const float* Tv, const float* Tw, float cxy_x, float cxy_y, float opacity,
+                            int& x0, int& y0, int& x1, int& y1)
+{
+    if (!(opacity >= kAlphaMin)) { x1 = x0; y1 = y0; return; }  // alpha <= o * G <= o < 1/255 everywhere
+    const double tau = 2.0 * log(255.0 * (double)opacity) * (1.0 + 1e-6) + 1e-5;
+    const double r2 = tau;
+    const double twx = Tw[0], twy = Tw[1], twz = Tw[2];
+    const double d = r2 * (twx * twx + twy * twy) - twz * twz;
+    if (!(d < -1e-9 * twz * twz) || !(twz > 0.0)) return;   // not a regular ellipse: keep the reference rectangle
+    const double inv = 1.0 / d;
+    const double r2d = sqrt(0.5 * tau);
+    double lo[2], hi[2];
+    const float* Trow[2] = {Tu, Tv};
+    const double cref[2] = {(double)cxy_x, (double)cxy_y};
+    for (int a = 0; a < 2; a++) {
+        const double tx = Trow[a][0], ty = Trow[a][1], tz = Trow[a][2];
+        const double c = (r2 * (tx * twx + ty * twy) - tz * twz) * inv;
+        double h0 = c * c - (r2 * (tx * tx + ty * ty) - tz * tz) * inv;
+        const double e = sqrt(h0 > 0.0 ? h0 : 0.0);
+        double l = c - e, h = c + e;
+        if (cref[a] - r2d < l) l = cref[a] - r2d;
+        if (cref[a] + r2d > h) h = cref[a] + r2d;
+        const double m = 0.01 + 1e-4 * (h - l);
+        lo[a] = l - m; hi[a] = h + m;
+    }
+    // tile t holds pixel centres 16 t + 0.5 ... 16 t + 15.5
+    const double fx0 = ceil((lo[0] - 15.5) / kTileX), fx1 = floor((hi[0] - 0.5) / kTileX) + 1.0;
+    const double fy0 = ceil((lo[1] - 15.5) / kTileY), fy1 = floor((hi[1] - 0.5) / kTileY) + 1.0;
+    if (fx0 > (double)x0) x0 = fx0 < (double)x1 ? (int)fx0 : x1;
+    if (fy0 > (double)y0) y0 = fy0 < (double)y1 ? (int)fy0 : y1;
+    if (fx1 < (double)x1) x1 = fx1 > (double)x0 ? (int)fx1 : x0;
+    if (fy1 < (double)y1) y1 = fy1 > (double)y0 ? (int)fy1 : y0;
+}
+
+// Packed tile rectangle: x0 | x1 << 16, y0 | y1 << 16
+struct TileRect { uint32_t xs, ys; };
+
 // forward.cu:166-260 preprocessCUDA with computeTransMat (:75-128), computeAABB (:133-163) and the
 // near cull of in_frustum (auxiliary.h:160-185).  Returns the integer radius (0 = culled) and the
 // tile count.  Contraction is switched off so that the culling / ceil / (int) decisions are taken on
 // the same IEEE values as the CPU oracle.
 DGS_HD int preprocess_surfel(const Camera& cam, const float* pos, const float* scale, const float* quat, float opacity,
                              int deg, const float* sh /*or null*/, const float* color_precomp /*or null*/,
-                             SurfelRec& rec, int& tiles)
+                             SurfelRec& rec, int& tiles, TileRect& trect, bool tight = true)
 {
     tiles = 0;
+    trect.xs = trect.ys = 0;
     const float* vm = cam.view;
     float pv[3];
     pv[0] = vm[0] * pos[0] + vm[4] * pos[1] + vm[8] * pos[2] + vm[12];
@@ -213,7 +260,10 @@ DGS_HD int preprocess_surfel(const Camera& cam, const float* pos, const float* s
     } else {
         rec.flags = sh_to_rgb(deg, sh, pos, cam.campos, rec.rgb);
     }
-    tiles = cnt;
+    if (tight) tight_tile_rect(Tu, Tv, Tw, px, py, opacity, x0, y0, x1, y1);
+    trect.xs = (uint32_t)x0 | ((uint32_t)x1 << 16);
+    trect.ys = (uint32_t)y0 | ((uint32_t)y1 << 16);
+    tiles = (x1 - x0) * (y1 - y0);   // may be 0: visible (radius > 0) but unable to reach alpha >= 1/255 anywhere
     return radius;
 }
 
@@ -257,6 +307,33 @@ DGS_HD bool pair_eval(float pfx, float pfy, const Quad& q0, const Quad& q1, cons
     float a = q2.w * e.G;
     e.alpha = a < kAlphaMax ? a : kAlphaMax;
     return !(e.alpha < kAlphaMin);
+}
+
+// Branch-free variant used by the kernels: everything is evaluated for every lane (no exec-mask nest,
+// no serialised LDS round trips) and the four skips of forward.cu:369-399 become one predicate.
+// Inf/NaN produced by pz == 0 never pass because pz != 0 is part of the predicate.
+DGS_HD bool pair_eval_bf(float pfx, float pfy, const Quad& q0, const Quad& q1, const Quad& q2, PairEval& e)
+{
+    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y, Twx = q1.z, Twy = q1.w, Twz = q2.x;
+    e.kx = pfx * Twx - Tux; e.ky = pfx * Twy - Tuy; e.kz = pfx * Twz - Tuz;
+    e.lx = pfy * Twx - Tvx; e.ly = pfy * Twy - Tvy; e.lz = pfy * Twz - Tvz;
+    const float ppx = e.ky * e.lz - e.kz * e.ly;
+    const float ppy = e.kz * e.lx - e.kx * e.lz;
+    e.pz = e.kx * e.ly - e.ky * e.lx;
+    const float inv = fast_rcp(e.pz);
+    e.sx = ppx * inv; e.sy = ppy * inv;
+    const float rho3d = e.sx * e.sx + e.sy * e.sy;
+    e.dx = q2.y - pfx; e.dy = q2.z - pfy;
+    const float rho2d = 2.0f * (e.dx * e.dx + e.dy * e.dy);
+    e.use3d = rho3d <= rho2d;
+    const float rho = e.use3d ? rho3d : rho2d;
+    const float d3 = (e.sx * Twx + e.sy * Twy) + Twz;
+    e.depth = e.use3d ? d3 : Twz;
+    const float power = -0.5f * rho;
+    e.G = fast_exp(power);
+    const float a = q2.w * e.G;
+    e.alpha = a < kAlphaMax ? a : kAlphaMax;
+    return (e.pz != 0.0f) & (e.depth >= kNear) & !(power > 0.0f) & (e.alpha >= kAlphaMin);
 }
 
 DGS_HD float mapped_depth(float depth)  // (FAR*d - FAR*NEAR) / ((FAR-NEAR)*d), forward.cu:412

@@ -18,6 +18,7 @@
 namespace {
 
 thread_local std::string g_err;
+bool g_tight_rects = true;  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
 
 int fail(int code, const std::string& msg)
 {
@@ -54,7 +55,7 @@ struct Carver {  // 128-byte aligned sub-allocation, like obtain() in rasterizer
 };
 
 struct GeomLayout {
-    size_t rec, block_sums, total, internal_radii, acc, bytes;
+    size_t rec, block_sums, total, internal_radii, acc, rects, bytes;
     int nblocks;
     explicit GeomLayout(int P)
     {
@@ -65,6 +66,7 @@ struct GeomLayout {
         total = c.take(4);
         internal_radii = c.take((size_t)P * 4);
         acc = c.take((size_t)P * dgs::kAccFloats * 4);
+        rects = c.take((size_t)P * 8);
         bytes = align_up(c.off, 128);
     }
 };
@@ -214,6 +216,8 @@ int dgs_abi_version(void) { return DGS_ABI_VERSION; }
 
 const char* dgs_last_error(void) { return g_err.c_str(); }
 
+void dgs_set_tight_rects(int on) { g_tight_rects = on != 0; }
+
 void dgs_profile_enable(int on) { g_prof.on = on != 0; }
 
 void dgs_profile_reset(void)
@@ -251,7 +255,7 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
     std::vector<size_t> v;
     if (which == 0) {
         GeomLayout g(P);
-        v = {g.rec, g.block_sums, g.total, g.internal_radii, g.acc, g.bytes};
+        v = {g.rec, g.block_sums, g.total, g.internal_radii, g.acc, g.rects, g.bytes};
     } else if (which == 1) {
         ImageLayout m(width, height);
         v = {m.final_T, m.n_contrib, m.ranges, m.tile_last, m.bytes};
@@ -319,6 +323,8 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     pa.radii = radii;
     pa.rec = (float4*)(geom + gl.rec);
     pa.block_sums = (uint32_t*)(geom + gl.block_sums);
+    pa.rects = (uint2*)(geom + gl.rects);
+    pa.tight = g_tight_rects ? 1 : 0;
     hipLaunchKernelGGL(dgs::preprocess_fwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, pa);
     DGS_STAGE("preprocess_fwd", debug, stream);
     // ---- K3 scan of the block sums (replaces cub::DeviceScan::InclusiveSum over P values)
@@ -348,7 +354,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     if (R > 0) {
         // ---- K4 key emission
         dgs::EmitArgs ea;
-        ea.P = P; ea.radii = radii; ea.rec = pa.rec; ea.block_offsets = pa.block_sums;
+        ea.P = P; ea.radii = radii; ea.rec = pa.rec; ea.rects = pa.rects; ea.block_offsets = pa.block_sums;
         ea.keys = (uint64_t*)(bin + bl.keys_unsorted);
         ea.vals = (uint32_t*)(bin + bl.vals_unsorted);
         ea.tiles_x = il.tiles_x; ea.tiles_y = il.tiles_y;

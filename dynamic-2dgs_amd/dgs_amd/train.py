@@ -41,8 +41,17 @@ class FlatGradBucket:
 
 
 class Trainer:
-    def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=0.00016 * 5.0, fused_adam=None,
-                 rasterizer_cls=None):
+    # Learning rates of the reference's exponential schedules at the END of their decay (iteration >= 40000:
+    # xyz 1.6e-6 * spatial_lr_scale, deform 1.6e-6; arguments/__init__.py:103-108, scene/deform_model.py:38,
+    # utils/general_utils.py get_expon_lr_func), the other groups are constant in the reference.  With the
+    # iteration-0 rates a fresh Adam moves every deform-head weight by 8e-4 in its first step, which on the
+    # synthetic noise targets inflates d_scaling to 4x the surfel scale after ONE step (mean radius 20 -> 75 px,
+    # num_rendered x14): the timed workload would no longer be the 200k-surfel scene the metric names.
+    LATE_POSITION_LR = 0.0000016
+    LATE_DEFORM_LR = 0.0000016
+
+    def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=LATE_DEFORM_LR, position_lr=LATE_POSITION_LR,
+                 fused_adam=None, rasterizer_cls=None):
         self.surfels, self.deform = surfels, deform
         self.rasterizer_cls = rasterizer_cls  # None = the HIP operator; tests / the CPU baseline inject the oracle op
         self.cameras, self.targets, self.bg = cameras, targets, bg_color
@@ -54,7 +63,7 @@ class Trainer:
         if fused_adam is None:
             fused_adam = dev.type == "cuda"
         kw = {"fused": True} if fused_adam else {}
-        self.opt_surfels = torch.optim.Adam(surfels.optimizer_groups(), lr=0.0, eps=1e-15, **kw)
+        self.opt_surfels = torch.optim.Adam(surfels.optimizer_groups(position_lr=position_lr), lr=0.0, eps=1e-15, **kw)
         self.opt_deform = torch.optim.Adam([
             {'params': list(deform.network.parameters()), 'lr': deform_lr, 'name': 'deform'},
             {'params': [deform.nodes, deform._node_radius, deform._node_weight], 'lr': deform_lr, 'name': 'nodes'}],

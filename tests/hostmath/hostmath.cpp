@@ -27,18 +27,38 @@ extern "C" {
 
 void hm_preprocess(int P, int D, int M, const float* means3D, const float* scales, const float* rots, const float* opac,
                    const float* shs, const float* colors_precomp, const float* view, const float* campos, int W, int H, float tx,
-                   float ty, int* radii, float* rec /*[P,20]*/, int* tiles)
+                   float ty, int* radii, float* rec /*[P,20]*/, int* tiles, uint32_t* rects /*[P,2]*/, int tight)
 {
     Camera cam = make_cam(view, campos, W, H, tx, ty);
     for (int i = 0; i < P; i++) {
         SurfelRec r;
         std::memset(&r, 0, sizeof(r));
         int t = 0;
+        TileRect tr;
         radii[i] = preprocess_surfel(cam, means3D + 3 * i, scales + 2 * i, rots + 4 * i, opac[i], D,
-                                     colors_precomp ? nullptr : shs + (size_t)i * M * 3, colors_precomp ? colors_precomp + 3 * i : nullptr, r, t);
+                                     colors_precomp ? nullptr : shs + (size_t)i * M * 3, colors_precomp ? colors_precomp + 3 * i : nullptr, r, t, tr,
+                                     tight != 0);
         tiles[i] = t;
+        rects[2 * i] = tr.xs; rects[2 * i + 1] = tr.ys;
         std::memcpy(rec + (size_t)i * kRecFloats, &r, sizeof(r));
     }
+}
+
+// 1 if any pixel of tile (tx,ty) passes the alpha test for this record (branchy and branch-free variants must agree)
+int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
+{
+    int any = 0;
+    for (int ly = 0; ly < 16; ly++)
+        for (int lx = 0; lx < 16; lx++) {
+            const int px = tx * 16 + lx, py = ty * 16 + ly;
+            if (px >= W || py >= H) continue;
+            PairEval a, b;
+            const bool ka = pair_eval((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), a);
+            const bool kb = pair_eval_bf((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), b);
+            if (ka != kb) return -1;
+            any |= ka ? 1 : 0;
+        }
+    return any;
 }
 
 // planar [c,H,W] outputs like the reference's image state
@@ -56,7 +76,7 @@ void hm_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
                 const float* r = rec + (size_t)point_list[e] * kRecFloats;
                 st.contributor++;
                 PairEval ev;
-                if (!pair_eval(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
+                if (!pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
                 if (!pixfwd_blend(st, ev, Q(r, 3), Q(r, 4))) break;
             }
             const int pix = py * W + px;
@@ -90,7 +110,7 @@ void hm_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* p
                 const uint32_t id = point_list[r0 + (uint32_t)e];
                 const float* r = rec + (size_t)id * kRecFloats;
                 PairEval ev;
-                if (!pair_eval(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
+                if (!pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
                 float out[kAccFloats] = {0};
                 pixbwd_step(st, ev, e, pfx, pfy, Q(r, 1), Q(r, 2), Q(r, 3), Q(r, 4), out);
                 for (int c = 0; c < 18; c++) dacc[(size_t)id * kAccFloats + c] += out[c];

@@ -49,8 +49,9 @@ def test_hostmath_pipeline_matches_oracle(hm, cfg):
     radii = np.zeros(P, np.int32)
     rec = np.zeros((P, 20), np.float32)
     tiles = np.zeros(P, np.int32)
+    rects = np.zeros((P, 2), np.uint32)
     hm.hm_preprocess(P, D, M, p(m3), p(sc), p(rot), p(op), p(sh), None, p(vm), p(cp), W, H,
-                     ctypes.c_float(case["tanfovx"]), ctypes.c_float(case["tanfovy"]), p(radii), p(rec), p(tiles))
+                     ctypes.c_float(case["tanfovx"]), ctypes.c_float(case["tanfovy"]), p(radii), p(rec), p(tiles), p(rects), 0)
     # ---- preprocess: bit-exact (same IEEE operations, contraction off on both sides)
     assert np.array_equal(radii, orc.radii)
     assert np.array_equal(tiles.astype(np.uint32), orc.field("tiles_touched"))
@@ -108,3 +109,41 @@ def test_hostmath_pipeline_matches_oracle(hm, cfg):
     close(dsh, og["dL_dsh"], "dL_dsh")
     close(dscale, og["dL_dscales"], "dL_dscales")
     close(drot, og["dL_drotations"], "dL_drotations")
+
+
+@pytest.mark.parametrize("cfg", CASES + [dict(P=600, H=96, W=112, seed=31, view=6, scale_mul=0.6, sh_degree=1),
+                                         dict(P=300, H=64, W=64, seed=32, view=0, scale_mul=5.0, sh_degree=0, radius=1.6)])
+def test_tight_tile_rects_are_conservative(hm, cfg):
+    """The opacity-aware rectangles (surfel_math.h tight_tile_rect) must be sub-rectangles of the reference's and
+    may only drop (surfel, tile) pairs in which NO pixel passes the alpha test -- so rendered results cannot
+    change.  Also checks that the branchy and the branch-free pair evaluation agree on every pixel."""
+    case = small_case(**cfg)
+    P, H, W = case["means3D"].shape[0], case["image_height"], case["image_width"]
+    m3, sc, rot, op, sh = (f32(case[k]) for k in ("means3D", "scales", "rotations", "opacities", "shs"))
+    vm, cp = f32(case["viewmatrix"]).reshape(-1), f32(case["campos"])
+    D, M = case["sh_degree"], sh.shape[1]
+    out = {}
+    for tight in (0, 1):
+        radii = np.zeros(P, np.int32); rec = np.zeros((P, 20), np.float32); tiles = np.zeros(P, np.int32); rects = np.zeros((P, 2), np.uint32)
+        hm.hm_preprocess(P, D, M, p(m3), p(sc), p(rot), p(op), p(sh), None, p(vm), p(cp), W, H,
+                         ctypes.c_float(case["tanfovx"]), ctypes.c_float(case["tanfovy"]), p(radii), p(rec), p(tiles), p(rects), tight)
+        out[tight] = (radii, rec, tiles, rects)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])  # radii / records untouched
+    dropped = kept = 0
+    for i in np.nonzero(out[0][0] > 0)[0]:
+        (xs0, ys0), (xs1, ys1) = out[0][3][i], out[1][3][i]
+        ref = (xs0 & 0xffff, xs0 >> 16, ys0 & 0xffff, ys0 >> 16)
+        tig = (xs1 & 0xffff, xs1 >> 16, ys1 & 0xffff, ys1 >> 16)
+        assert tig[0] >= ref[0] and tig[1] <= ref[1] and tig[2] >= ref[2] and tig[3] <= ref[3]
+        assert out[1][2][i] == max(0, int(tig[1]) - int(tig[0])) * max(0, int(tig[3]) - int(tig[2]))
+        for ty in range(ref[2], ref[3]):
+            for tx in range(ref[0], ref[1]):
+                inside = tig[0] <= tx < tig[1] and tig[2] <= ty < tig[3]
+                r = hm.hm_tile_reachable(W, H, int(tx), int(ty), p(np.ascontiguousarray(out[0][1][i])))
+                assert r >= 0, "pair_eval / pair_eval_bf disagree"
+                if not inside:
+                    assert r == 0, "tight rectangle dropped a reachable tile (surfel %d, tile %d,%d)" % (i, tx, ty)
+                    dropped += 1
+                else:
+                    kept += 1
+    assert dropped > 0 and kept > 0
