@@ -19,9 +19,10 @@ __device__ __forceinline__ Quad as_quad(const float4& v) { return Quad{v.x, v.y,
 
 struct BlendFwdArgs {
     const uint2* ranges;         // [T]
+    const uint32_t* order;       // [T] dispatch order (mode 3) or null
     const uint32_t* point_list;  // [R] sorted surfel ids
     const float4* rec;           // [P*5]
-    int W, H, tiles_x, tiles_y;
+    int W, H, tiles_x, tiles_y, mode;
     const float* bg;             // [3] device
     float* final_T;              // [3][T*256] tile-major: T, dist1, dist2
     uint32_t* n_contrib;         // [2][T*256] tile-major: last contributor, median contributor
@@ -30,15 +31,81 @@ struct BlendFwdArgs {
     float* out_others;           // [8,H,W]
 };
 
-// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md), each
-// XCD has a private 4 MiB L2.  Give every XCD a contiguous run of row-major tiles so that the
-// surfel records shared by neighbouring tiles are fetched into one L2 instead of eight.
-__device__ __forceinline__ int xcd_tile_index(int bid, int ntiles)
+// Tile order.  The dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md) and every XCD has a private
+// 4 MiB L2, so which tiles share an XCD decides how often a surfel record is re-fetched.  Modes (A/B-able at
+// run time through dgs_set_option(DGS_OPT_TILE_ORDER, m)):
+//   0  plain row-major blockIdx (neighbouring tiles land on 8 different L2s),
+//   1  contiguous: XCD x gets tiles [x*T/8, (x+1)*T/8)  (best locality, but whole image bands -- empty sky vs
+//      dense centre -- go to one XCD: load imbalance),
+//   2  row-interleaved: XCD x gets tile rows r with r % 8 == x, walked left to right (horizontal neighbours
+//      share an L2, every XCD samples the whole image height).
+__device__ __forceinline__ int tile_for_block(int bid, int tiles_x, int tiles_y, int mode)
 {
     constexpr int kXcd = 8;
-    const int per = (ntiles + kXcd - 1) / kXcd;
-    const int t = (bid % kXcd) * per + bid / kXcd;
-    return t;  // may be >= ntiles for the padded tail; caller checks
+    const int ntiles = tiles_x * tiles_y;
+    if (mode == 0 || mode == 3) return bid;  // mode 3 indexes the sorted order[] with it
+    const int xcd = bid % kXcd, k = bid / kXcd;
+    if (mode == 1) {
+        const int per = (ntiles + kXcd - 1) / kXcd;
+        return xcd * per + k;  // may be >= ntiles for the padded tail; caller checks
+    }
+    // mode 2: the k-th tile of this XCD is in its (k / tiles_x)-th row
+    const int row = (k / tiles_x) * kXcd + xcd;
+    if (row >= tiles_y) return ntiles;
+    return row * tiles_x + (k % tiles_x);
+}
+
+// Mode 3 (default): longest-processing-time-first.  Tile work varies by >10x (empty corners vs the dense centre)
+// and a workgroup owns its tile to the end, so with ~7 resident workgroups per CU the kernel time is set by
+// whichever SIMD drew the heaviest tiles last.  Dispatching tiles in descending list length (counting sort below)
+// puts the long tiles first and lets the short ones fill the tail.
+constexpr int kOrderBins = 1024;
+
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, const uint32_t* weights, int ntiles, uint32_t* order)
+{
+    __shared__ uint32_t s_hist[kOrderBins];
+    __shared__ uint32_t s_wsum[16];
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    // bin 0 = heaviest.  weight = list length (ranges) or traversed length (weights), 4 entries per bin, saturating
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint32_t w = weights ? weights[t] : (ranges[t].y - ranges[t].x);
+        const uint32_t bin = kOrderBins - 1 - min(w >> 2, (uint32_t)(kOrderBins - 1));
+        atomicAdd(&s_hist[bin], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins (one per thread)
+    const uint32_t v = s_hist[tid];
+    uint32_t inc = v;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += n;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wsum[w];
+    __syncthreads();
+    s_hist[tid] = base + inc - v;
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint32_t w = weights ? weights[t] : (ranges[t].y - ranges[t].x);
+        const uint32_t bin = kOrderBins - 1 - min(w >> 2, (uint32_t)(kOrderBins - 1));
+        const uint32_t pos = atomicAdd(&s_hist[bin], 1u);
+        order[pos] = (uint32_t)t;
+    }
+}
+
+// grid size that covers every tile under `mode`
+inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
+{
+    const int ntiles = tiles_x * tiles_y;
+    if (mode == 0 || mode == 3) return ntiles;
+    if (mode == 1) return ((ntiles + 7) / 8) * 8;
+    return ((tiles_y + 7) / 8) * tiles_x * 8;
 }
 
 __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
@@ -48,8 +115,9 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
     __shared__ uint32_t s_max[4];
 
     const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = xcd_tile_index(blockIdx.x, ntiles);
+    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
     if (tile >= ntiles) return;
+    if (a.mode == 3) tile = (int)a.order[tile];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int px = tx * kTileX + (tid & 15), py = ty * kTileY + (tid >> 4);
@@ -146,9 +214,10 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
 
 struct BlendBwdArgs {
     const uint2* ranges;
+    const uint32_t* order;
     const uint32_t* point_list;
     const float4* rec;
-    int W, H, tiles_x, tiles_y;
+    int W, H, tiles_x, tiles_y, mode;
     const float* bg;
     const float* final_T;
     const uint32_t* n_contrib;
@@ -206,8 +275,9 @@ __global__ void __launch_bounds__(kTilePix) blend_bwd_kernel(BlendBwdArgs a)
     __shared__ uint32_t s_id[kBatch];
 
     const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = xcd_tile_index(blockIdx.x, ntiles);
+    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
     if (tile >= ntiles) return;
+    if (a.mode == 3) tile = (int)a.order[tile];
     const int L = (int)a.tile_last[tile];  // entries [0, L) can contribute to some pixel of the tile
     if (L == 0) return;
     const int tid = threadIdx.x, lane = tid & 63;

@@ -19,6 +19,7 @@ namespace {
 
 thread_local std::string g_err;
 bool g_tight_rects = true;  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
+int g_tile_order = 3;       // kernels_blend.h tile_for_block (3 = longest tile first)
 
 int fail(int code, const std::string& msg)
 {
@@ -72,7 +73,7 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, tile_last, bytes;
+    size_t final_T, n_contrib, ranges, tile_last, order_fwd, order_bwd, bytes;
     int tiles_x, tiles_y, ntiles;
     ImageLayout(int W, int H)
     {
@@ -85,6 +86,8 @@ struct ImageLayout {
         n_contrib = c.take(2 * plane * 4);
         ranges = c.take((size_t)ntiles * 8);
         tile_last = c.take((size_t)ntiles * 4);
+        order_fwd = c.take((size_t)ntiles * 4);
+        order_bwd = c.take((size_t)ntiles * 4);
         bytes = align_up(c.off, 128);
     }
 };
@@ -218,6 +221,13 @@ const char* dgs_last_error(void) { return g_err.c_str(); }
 
 void dgs_set_tight_rects(int on) { g_tight_rects = on != 0; }
 
+int dgs_set_option(int key, int value)
+{
+    if (key == 0) { g_tight_rects = value != 0; return 0; }
+    if (key == 1 && value >= 0 && value <= 3) { g_tile_order = value; return 0; }
+    return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_set_option: unknown key / value");
+}
+
 void dgs_profile_enable(int on) { g_prof.on = on != 0; }
 
 void dgs_profile_reset(void)
@@ -258,7 +268,7 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
         v = {g.rec, g.block_sums, g.total, g.internal_radii, g.acc, g.rects, g.bytes};
     } else if (which == 1) {
         ImageLayout m(width, height);
-        v = {m.final_T, m.n_contrib, m.ranges, m.tile_last, m.bytes};
+        v = {m.final_T, m.n_contrib, m.ranges, m.tile_last, m.order_fwd, m.order_bwd, m.bytes};
     } else if (which == 2) {
         ImageLayout m(width, height);
         BinningLayout b(R, m.ntiles);
@@ -378,14 +388,20 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     fa.ranges = ranges;
     fa.point_list = (const uint32_t*)(bin + bl.point_list);
     fa.rec = pa.rec;
-    fa.W = width; fa.H = height; fa.tiles_x = il.tiles_x; fa.tiles_y = il.tiles_y;
+    fa.W = width; fa.H = height; fa.tiles_x = il.tiles_x; fa.tiles_y = il.tiles_y; fa.mode = g_tile_order;
+    fa.order = (const uint32_t*)(img + il.order_fwd);
+    if (fa.mode == 3) {
+        hipLaunchKernelGGL(dgs::tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint2*)ranges, (const uint32_t*)nullptr,
+                           il.ntiles, (uint32_t*)(img + il.order_fwd));
+        DGS_STAGE("tile_order_fwd", debug, stream);
+    }
     fa.bg = background;
     fa.final_T = (float*)(img + il.final_T);
     fa.n_contrib = (uint32_t*)(img + il.n_contrib);
     fa.tile_last = (uint32_t*)(img + il.tile_last);
     fa.out_color = out_color;
     fa.out_others = out_others;
-    const int grid = ((il.ntiles + 7) / 8) * 8;
+    const int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, fa.mode);
     Prof::Pair pp;
     const bool timed = prof_begin(0, stream, pp);
     hipLaunchKernelGGL(dgs::blend_fwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, fa);
@@ -431,7 +447,13 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
         ba.ranges = (const uint2*)(img_buffer + il.ranges);
         ba.point_list = (const uint32_t*)(binning_buffer + bl.point_list);
         ba.rec = (const float4*)(geom_buffer + gl.rec);
-        ba.W = width; ba.H = height; ba.tiles_x = il.tiles_x; ba.tiles_y = il.tiles_y;
+        ba.W = width; ba.H = height; ba.tiles_x = il.tiles_x; ba.tiles_y = il.tiles_y; ba.mode = g_tile_order;
+        ba.order = (const uint32_t*)(img_buffer + il.order_bwd);
+        if (ba.mode == 3) {  // by the traversed length the forward measured
+            hipLaunchKernelGGL(dgs::tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint2*)nullptr,
+                               (const uint32_t*)(img_buffer + il.tile_last), il.ntiles, (uint32_t*)(img_buffer + il.order_bwd));
+            DGS_STAGE("tile_order_bwd", debug, stream);
+        }
         ba.bg = background;
         ba.final_T = (const float*)(img_buffer + il.final_T);
         ba.n_contrib = (const uint32_t*)(img_buffer + il.n_contrib);
@@ -439,7 +461,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
         ba.dL_dpix = dL_dpix;
         ba.dL_dothers = dL_depths;
         ba.acc = acc;
-        const int grid = ((il.ntiles + 7) / 8) * 8;
+        const int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, ba.mode);
         Prof::Pair pp;
         const bool timed = prof_begin(1, stream, pp);
         hipLaunchKernelGGL(dgs::blend_bwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);

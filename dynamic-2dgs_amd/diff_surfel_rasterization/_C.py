@@ -24,7 +24,7 @@ _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 _lib = None
 
 _EXPORTS = ("dgs_abi_version", "dgs_last_error", "dgs_rasterizer_mark_visible", "dgs_rasterizer_forward",
-            "dgs_rasterizer_backward", "dgs_debug_layout", "dgs_set_tight_rects", "dgs_profile_enable", "dgs_profile_reset",
+            "dgs_rasterizer_backward", "dgs_debug_layout", "dgs_set_tight_rects", "dgs_set_option", "dgs_profile_enable", "dgs_profile_reset",
             "dgs_profile_read")
 
 
@@ -71,6 +71,8 @@ def load():
     lib.dgs_debug_layout.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(sz), ci]
     lib.dgs_set_tight_rects.restype = None
     lib.dgs_set_tight_rects.argtypes = [ci]
+    lib.dgs_set_option.restype = ci
+    lib.dgs_set_option.argtypes = [ci, ci]
     lib.dgs_profile_enable.restype = None
     lib.dgs_profile_enable.argtypes = [ci]
     lib.dgs_profile_reset.restype = None
@@ -237,6 +239,13 @@ def debug_layout(which, P=0, width=1, height=1, R=0):
 def set_tight_rects(on=True):
     """Tile-list policy (see dgs_set_tight_rects): False reproduces the reference's lists entry for entry."""
     load().dgs_set_tight_rects(1 if on else 0)
+
+
+def set_option(key, value):
+    lib = load()
+    rc = lib.dgs_set_option(int(key), int(value))
+    if rc < 0:
+        _raise(lib, rc, "set_option")
 
 
 def profile_enable(on=True):

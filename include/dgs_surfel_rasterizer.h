@@ -90,7 +90,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
  * stage with the oracle.  which: 0 geometry (P), 1 image (W,H), 2 binning (R).  Writes up to `cap`
  * offsets, returns the number of sub-arrays; the last entry written is the total size.
  *   geometry: rec[P*20 f32], block_sums[u32], total[u32], internal_radii[P i32], acc[P*20 f32], rects[P uint2]
- *   image   : final_T[3*T*256 f32], n_contrib[2*T*256 u32], ranges[T uint2], tile_last[T u32]
+ *   image   : final_T[3*T*256 f32], n_contrib[2*T*256 u32], ranges[T uint2], tile_last[T u32], order_fwd[T u32], order_bwd[T u32]
  *   binning : keys_unsorted[R u64], keys[R u64], vals_unsorted[R u32], point_list[R u32], sort temp */
 int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* offsets, int cap);
 
@@ -99,6 +99,10 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
  * (auxiliary.h:64-74), so that the sorted lists are entry-for-entry those of the reference.  Rendered outputs and
  * gradients are the same either way; num_rendered and the private lists differ. */
 void dgs_set_tight_rects(int on);
+
+/* Development knobs for A/B measurements (defaults are the tuned values): key 0 = tight rects (0/1),
+ * key 1 = blend tile order (0 row-major, 1 XCD-contiguous, 2 XCD row-interleaved, 3 longest-list-first [default]). Returns DGS_OK or an error. */
+int dgs_set_option(int key, int value);
 
 /* Kernel timing hook for bench.py: when enabled, the library brackets the forward and backward blend
  * kernels with HIP events on the launch stream; dgs_profile_read returns accumulated milliseconds and

@@ -141,3 +141,41 @@ void hm_surfel_bwd(int P, int D, int M, const float* means3D, const float* scale
 }
 
 }  // extern "C"
+
+// ---- analysis helper (development): how much of the traversed work is useful?
+extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*8*/)
+{
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    double S = 0, strip_pairs = 0, strip_any = 0, pix_pairs = 0, pix_pass = 0, pix_blend = 0, strip_blend_any = 0;
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const int tile = ty * tiles_x + tx;
+            const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            PixFwd st[256]; bool done[256]; bool inside[256];
+            for (int i = 0; i < 256; i++) { pixfwd_init(st[i]); int px = tx * 16 + (i & 15), py = ty * 16 + (i >> 4); inside[i] = px < W && py < H; done[i] = !inside[i]; }
+            uint32_t e;
+            for (e = r0; e < r1; e++) {
+                int alive = 0; for (int i = 0; i < 256; i++) alive += !done[i];
+                if (!alive) break;
+                const float* r = rec + (size_t)point_list[e] * kRecFloats;
+                for (int w = 0; w < 4; w++) {
+                    int wa = 0; for (int i = 64 * w; i < 64 * w + 64; i++) wa += !done[i];
+                    if (!wa) continue;
+                    strip_pairs += 1;
+                    int any = 0, anyb = 0;
+                    for (int i = 64 * w; i < 64 * w + 64; i++) {
+                        if (!inside[i]) continue;
+                        pix_pairs += 1;
+                        PairEval ev;
+                        const float pfx = tx * 16 + (i & 15) + 0.5f, pfy = ty * 16 + (i >> 4) + 0.5f;
+                        bool ok = pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev);
+                        if (ok) { pix_pass += 1; any = 1; }
+                        if (ok && !done[i]) { anyb = 1; pix_blend += 1; st[i].contributor = e - r0 + 1; if (!pixfwd_blend(st[i], ev, Q(r, 3), Q(r, 4))) done[i] = true; }
+                    }
+                    strip_any += any; strip_blend_any += anyb;
+                }
+            }
+            S += (e - r0);
+        }
+    out[0] = S; out[1] = strip_pairs; out[2] = strip_any; out[3] = pix_pairs; out[4] = pix_pass; out[5] = pix_blend; out[6] = strip_blend_any;
+}
