@@ -276,7 +276,7 @@ DGS_HD int preprocess_surfel(const Camera& cam, const float* pos, const float* s
 // backward.cu:283-323).
 struct PairEval {
     float kx, ky, kz, lx, ly, lz;  // the two homogeneous planes
-    float pz;                      // z of their cross product
+    float pz, inv_pz;              // z of their cross product and its reciprocal
     float sx, sy;                  // intersection in splat space
     float dx, dy;                  // projected centre minus pixel centre
     float G, alpha, depth;
@@ -293,6 +293,7 @@ DGS_HD bool pair_eval(float pfx, float pfy, const Quad& q0, const Quad& q1, cons
     e.pz = e.kx * e.ly - e.ky * e.lx;
     if (e.pz == 0.0f) return false;
     float inv = fast_rcp(e.pz);
+    e.inv_pz = inv;
     e.sx = ppx * inv; e.sy = ppy * inv;
     float rho3d = e.sx * e.sx + e.sy * e.sy;
     e.dx = q2.y - pfx; e.dy = q2.z - pfy;
@@ -321,6 +322,7 @@ DGS_HD bool pair_eval_bf(float pfx, float pfy, const Quad& q0, const Quad& q1, c
     const float ppy = e.kz * e.lx - e.kx * e.lz;
     e.pz = e.kx * e.ly - e.ky * e.lx;
     const float inv = fast_rcp(e.pz);
+    e.inv_pz = inv;
     e.sx = ppx * inv; e.sy = ppy * inv;
     const float rho3d = e.sx * e.sx + e.sy * e.sy;
     e.dx = q2.y - pfx; e.dy = q2.z - pfy;
@@ -336,10 +338,14 @@ DGS_HD bool pair_eval_bf(float pfx, float pfy, const Quad& q0, const Quad& q1, c
     return (e.pz != 0.0f) & (e.depth >= kNear) & !(power > 0.0f) & (e.alpha >= kAlphaMin);
 }
 
-DGS_HD float mapped_depth(float depth)  // (FAR*d - FAR*NEAR) / ((FAR-NEAR)*d), forward.cu:412
+// (FAR*d - FAR*NEAR) / ((FAR-NEAR)*d), forward.cu:412, through one reciprocal (v_rcp_f32, 1 ulp) that the
+// backward reuses for d(mapped)/d(depth) = FAR*NEAR / ((FAR-NEAR) d^2), backward.cu:352
+DGS_HD float mapped_depth_r(float depth, float rd /* = fast_rcp(depth) */)
 {
-    return (100.0f * depth - 20.0f) / (99.8f * depth);
+    return (100.0f * depth - 20.0f) * (rd * (1.0f / 99.8f));
 }
+
+DGS_HD float mapped_depth(float depth) { return mapped_depth_r(depth, fast_rcp(depth)); }
 
 // Running per-pixel state of the forward blend (forward.cu:313-329).
 struct PixFwd {
@@ -418,7 +424,8 @@ DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, int contributor, float pfx
 {
     const float alpha = e.alpha, G = e.G;
     const float one_m_a = 1.f - alpha;
-    s.T = s.T / one_m_a;
+    const float inv_1ma = fast_rcp(one_m_a);  // alpha <= 0.99: well conditioned
+    s.T = s.T * inv_1ma;
     const float w = alpha * s.T;
     const float col[3] = {q3.w, q4.x, q4.y};
     const float nrm[3] = {q3.x, q3.y, q3.z};
@@ -431,8 +438,9 @@ DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, int contributor, float pfx
     }
     float dL_dz = 0.f, dL_dweight = 0.f;
     const float c_d = e.depth;
-    const float m_d = mapped_depth(c_d);
-    const float dmd_dd = 20.0f / (99.8f * c_d * c_d);
+    const float r_d = fast_rcp(c_d);
+    const float m_d = mapped_depth_r(c_d, r_d);
+    const float dmd_dd = (20.0f / 99.8f) * (r_d * r_d);
     if (contributor == s.med_c - 1) { dL_dz += s.g_meddepth; dL_dweight += s.g_medw; }
     dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2.f * m_d * s.final_D) * s.g_dist;
     dL_dalpha += dL_dweight - s.last_dL_dT;
@@ -452,7 +460,7 @@ DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, int contributor, float pfx
     }
     dL_dalpha *= s.T;
     s.last_alpha = alpha;
-    dL_dalpha += (-s.T_final / one_m_a) * s.bg_dot;
+    dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot;
     const float dL_dG = q2.w * dL_dalpha;
     dL_dz += w * s.g_depth;
 
@@ -460,8 +468,7 @@ DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, int contributor, float pfx
     if (e.use3d) {
         const float dsx = dL_dG * -G * e.sx + dL_dz * Twx;
         const float dsy = dL_dG * -G * e.sy + dL_dz * Twy;
-        const float inv = 1.0f / e.pz;
-        const float ax = dsx * inv, ay = dsy * inv;
+        const float ax = dsx * e.inv_pz, ay = dsy * e.inv_pz;
         const float dpx = ax, dpy = ay, dpz = -(ax * e.sx + ay * e.sy);
         // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
         const float dkx = e.ly * dpz - e.lz * dpy, dky = e.lz * dpx - e.lx * dpz, dkz = e.lx * dpy - e.ly * dpx;
