@@ -34,7 +34,15 @@ def _blur(x, w1d, channel):
 
 
 def ssim(img1, img2, window_size=11):
-    """Mean SSIM of two [C,H,W] (or [B,C,H,W]) images."""
+    """Mean SSIM of two [C,H,W] (or [B,C,H,W]) images.  HIP tensors go through the fused gfx950 kernel
+    (csrc/train_ops.hip), CPU tensors through the PyTorch formulation below (same arithmetic)."""
+    if img1.is_cuda and img1.dim() == 3 and window_size == 11 and img1.dtype == torch.float32:
+        from . import _ops
+        return _ops.fused_ssim(img1, img2)
+    return ssim_torch(img1, img2, window_size)
+
+
+def ssim_torch(img1, img2, window_size=11):
     if img1.dim() == 3:
         img1, img2 = img1[None], img2[None]
     C = img1.size(-3)

@@ -1,0 +1,45 @@
+/*
+ * dgs_train_ops.h -- C ABI of the two per-step helper kernels next to the rasterizer on the training path
+ * (SURVEY.md section 8 rows f1 and f3).  They are NOT part of the reference's rasterizer FFI; each replaces a
+ * PyTorch / third-party call of the reference's train step:
+ *
+ *   dgs_ssim_forward/backward  <-  utils/loss_utils.py:45-76  ssim() : five 11x11 grouped conv2d + their autograd
+ *   dgs_knn_points             <-  pytorch3d.ops.knn_points (utils/time_utils.py:950), K nearest control nodes
+ *
+ * All pointers are device pointers, fp32 contiguous unless noted; every call is asynchronous on `stream`.
+ * Return value: 0 or a negative status, message through dgs_train_ops_last_error().
+ */
+#ifndef DGS_TRAIN_OPS_H
+#define DGS_TRAIN_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGS_TRAIN_OPS_ABI_VERSION 1
+
+int dgs_train_ops_abi_version(void);
+const char* dgs_train_ops_last_error(void);
+
+/* SSIM with the 11-tap sigma=1.5 Gaussian window, zero padding (loss_utils.py:33-76), separable.
+ * img1, img2: [C,H,W].  ssim_sum: device float, ACCUMULATED into (caller zeroes it): sum over all C*H*W of the
+ * SSIM map, so mean = ssim_sum / (C*H*W).  If dm_dmu1 / dm_dsigma1_sq / dm_dsigma12 ([C,H,W] each) are non-NULL the
+ * per-pixel partial derivatives of the map w.r.t. the three img1-dependent window statistics are stored for
+ * dgs_ssim_backward. */
+int dgs_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_sum, float* dm_dmu1,
+                     float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+
+/* dL/dimg1 [C,H,W] (overwritten) for L = mean(SSIM map) * (*dL_dmean): dL_dmean is a DEVICE scalar. */
+int dgs_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
+                      const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* dL_dmean, float* dL_dimg1,
+                      void* stream);
+
+/* Brute-force K nearest neighbours under squared L2, ascending, ties to the lower index.
+ * x: [N,D], nodes: [M,D], 1 <= D <= 16, 1 <= K <= 4, K <= M.  idx: [N,K] int64.  dist2 (may be NULL): [N,K]. */
+int dgs_knn_points(int N, int M, int D, int K, const float* x, const float* nodes, long long* idx, float* dist2,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGS_TRAIN_OPS_H */
