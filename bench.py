@@ -58,6 +58,8 @@ def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None,
     cams = [c.to(device) for c in orbit_cameras(n_views, W, H)]
     targets = [target_image(H, W, seed=1 + v).to(device) for v in range(n_targets)]
     bg = torch.zeros(3, device=device)
+    if device.type == "cuda" and os.environ.get("DGS_NO_GRAPHS", "0") != "1":
+        deform.enable_graphs(deform.expand_time(cams[0].fid))
     return Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam)
 
 

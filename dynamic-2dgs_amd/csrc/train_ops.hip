@@ -143,16 +143,17 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n
 constexpr int kKnnChunk = 1024;  // nodes staged per pass
 constexpr int kKnnDpad = 16;
 
-template <int K>
+// Q = number of float4 per (zero-padded) node row: D <= 4*Q.  Compile-time so that the distance loop fully
+// unrolls and the wave-uniform node reads become ds_read_b128 broadcasts.
+template <int K, int Q>
 __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
                                                   long long* __restrict__ idx, float* __restrict__ dist2)
 {
-    extern __shared__ float s_nodes[];  // [chunk][Dp], Dp = D rounded up to 4
-    const int Dp = (D + 3) & ~3;
+    __shared__ float4 s_nodes[kKnnChunk * Q];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    float xv[kKnnDpad];
+    float xv[4 * Q];
 #pragma unroll
-    for (int d = 0; d < kKnnDpad; d++) xv[d] = (p < N && d < D) ? x[(size_t)p * D + d] : 0.f;
+    for (int d = 0; d < 4 * Q; d++) xv[d] = (p < N && d < D) ? x[(size_t)p * D + d] : 0.f;
     float bd[K];
     int bi[K];
 #pragma unroll
@@ -160,17 +161,23 @@ __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const flo
     for (int base = 0; base < M; base += kKnnChunk) {
         const int cnt = (M - base) < kKnnChunk ? (M - base) : kKnnChunk;
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt * Dp; i += 256) {
-            const int r = i / Dp, d = i - r * Dp;
-            s_nodes[i] = d < D ? nodes[(size_t)(base + r) * D + d] : 0.f;
+        float* s_flat = reinterpret_cast<float*>(s_nodes);
+        for (int i = threadIdx.x; i < cnt * 4 * Q; i += 256) {
+            const int r = i / (4 * Q), d = i - r * (4 * Q);
+            s_flat[i] = d < D ? nodes[(size_t)(base + r) * D + d] : 0.f;
         }
         __syncthreads();
+#pragma unroll 4
         for (int j = 0; j < cnt; j++) {
-            const float* nd = s_nodes + j * Dp;  // wave-uniform address: LDS broadcast
             float acc = 0.f;
 #pragma unroll
-            for (int d = 0; d < kKnnDpad; d++) {
-                if (d < Dp) { const float t = xv[d] - nd[d]; acc += t * t; }
+            for (int q = 0; q < Q; q++) {
+                const float4 nd = s_nodes[j * Q + q];  // wave-uniform address: LDS broadcast
+                float t;
+                t = xv[4 * q + 0] - nd.x; acc += t * t;
+                t = xv[4 * q + 1] - nd.y; acc += t * t;
+                t = xv[4 * q + 2] - nd.z; acc += t * t;
+                t = xv[4 * q + 3] - nd.w; acc += t * t;
             }
             // insertion into the sorted K best; strict < keeps the lower index on ties
             if (acc < bd[K - 1]) {
@@ -194,15 +201,24 @@ __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const flo
     }
 }
 
-template <int K>
-int launch_knn(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s)
+template <int K, int Q>
+int launch_knn_q(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s)
 {
-    const int Dp = (D + 3) & ~3;
-    const size_t lds = (size_t)(M < kKnnChunk ? M : kKnnChunk) * Dp * sizeof(float);
-    hipLaunchKernelGGL(knn_kernel<K>, dim3((N + 255) / 256), dim3(256), lds, s, N, M, D, x, nodes, idx, dist2);
+    hipLaunchKernelGGL((knn_kernel<K, Q>), dim3((N + 255) / 256), dim3(256), 0, s, N, M, D, x, nodes, idx, dist2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("knn_kernel: ") + hipGetErrorString(e));
     return 0;
+}
+
+template <int K>
+int launch_knn(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s)
+{
+    switch ((D + 3) / 4) {
+    case 1: return launch_knn_q<K, 1>(N, M, D, x, nodes, idx, dist2, s);
+    case 2: return launch_knn_q<K, 2>(N, M, D, x, nodes, idx, dist2, s);
+    case 3: return launch_knn_q<K, 3>(N, M, D, x, nodes, idx, dist2, s);
+    default: return launch_knn_q<K, 4>(N, M, D, x, nodes, idx, dist2, s);
+    }
 }
 
 }  // namespace
