@@ -1,8 +1,14 @@
-// kernels_preprocess.h -- per-surfel kernels (gfx950): forward preprocess + tile count block sums,
-// block-sum scan, key emission, tile ranges, fused per-surfel backward, frustum mark.
-// Replaces preprocessCUDA / InclusiveSum / duplicateWithKeys / identifyTileRanges / computeAABB-bwd /
-// preprocessCUDA-bwd / checkFrustum of the reference (forward.cu:166-260, rasterizer_impl.cu:54-138,278,
-// backward.cu:533-649).  One thread per surfel, 256 threads (4 wave64) per workgroup.
+// kernels_preprocess.h -- per-surfel and binning kernels (gfx950): forward preprocess + per-tile counts, tile scan,
+// key scatter, per-tile sort, fused per-surfel backward, frustum mark.
+// Replaces preprocessCUDA / cub InclusiveSum / duplicateWithKeys / cub DeviceRadixSort / identifyTileRanges /
+// computeAABB-bwd / preprocessCUDA-bwd / checkFrustum of the reference (forward.cu:166-260,
+// rasterizer_impl.cu:54-138,278,304-319, backward.cu:533-649).
+//
+// Binning is a TILE-BUCKETED sort instead of the reference's global 44..46-bit LSD radix sort over
+// (tile << 32 | depth) keys: count entries per tile (atomics), scan the T counts, scatter (depth, index) keys into
+// the tile's bucket, then sort every bucket in LDS with one workgroup.  The global sort moves 12 B x R x ~12 through
+// HBM; here every key is written once and read once, and tile ranges fall out of the scan.  The result is the same
+// list: buckets ordered by tile, entries by (depth bits, surfel index) = the stable radix order.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,137 +30,234 @@ struct PreprocessArgs {
     int* radii;             // [P] out
     float4* rec;            // [P*5] out
     uint2* rects;           // [P] out: packed (tight) tile rectangle of every surfel
-    uint32_t* block_sums;   // [ceil(P/256)] out: sum of tile counts of the block
     int tight;              // 1: exact opacity-aware rectangles (default), 0: the reference's rectangles
 };
 
-// wave64 inclusive scan with DPP-friendly shuffles
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
-    }
-    return v;
-}
-
-// exclusive scan over the 256 threads of a workgroup; returns the exclusive prefix, total in `total`
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t& total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = wave_inclusive_scan(v);
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) base += (w < wave) ? s_wave[w] : 0u;
-    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    return base + inc - v;
-}
-
 __global__ void __launch_bounds__(kSurfelBlock) preprocess_fwd_kernel(PreprocessArgs a)
 {
-    __shared__ uint32_t s_wave[4];
     const int idx = blockIdx.x * kSurfelBlock + threadIdx.x;
-    int tiles = 0;
-    if (idx < a.P) {
-        SurfelRec rec;
-        float pos[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-        float sc[2] = {a.scales[2 * idx], a.scales[2 * idx + 1]};
-        const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
-        float q[4] = {qv.x, qv.y, qv.z, qv.w};
-        const float* sh = a.colors_precomp ? nullptr : a.shs + (size_t)idx * a.M * 3;
-        const float* cp = a.colors_precomp ? a.colors_precomp + 3 * idx : nullptr;
-        TileRect tr;
-        int radius = preprocess_surfel(a.cam, pos, sc, q, a.opacities[idx], a.D, sh, cp, rec, tiles, tr, a.tight != 0);
-        a.radii[idx] = radius;
-        a.rects[idx] = make_uint2(tr.xs, tr.ys);
-        if (radius > 0) {
-            const float4* src = reinterpret_cast<const float4*>(&rec);
-            float4* dst = a.rec + (size_t)idx * kRecQuads;
+    if (idx >= a.P) return;
+    SurfelRec rec;
+    float pos[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    float sc[2] = {a.scales[2 * idx], a.scales[2 * idx + 1]};
+    const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
+    float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    const float* sh = a.colors_precomp ? nullptr : a.shs + (size_t)idx * a.M * 3;
+    const float* cp = a.colors_precomp ? a.colors_precomp + 3 * idx : nullptr;
+    TileRect tr;
+    int tiles;
+    const int radius = preprocess_surfel(a.cam, pos, sc, q, a.opacities[idx], a.D, sh, cp, rec, tiles, tr, a.tight != 0);
+    a.radii[idx] = radius;
+    a.rects[idx] = make_uint2(tr.xs, tr.ys);
+    if (radius > 0) {
+        const float4* src = reinterpret_cast<const float4*>(&rec);
+        float4* dst = a.rec + (size_t)idx * kRecQuads;
 #pragma unroll
-            for (int c = 0; c < kRecQuads; c++) dst[c] = src[c];
-        }
+        for (int c = 0; c < kRecQuads; c++) dst[c] = src[c];
     }
-    uint32_t total;
-    block_exclusive_scan((uint32_t)tiles, s_wave, total);
-    if (threadIdx.x == 0) a.block_sums[blockIdx.x] = total;
 }
 
-// Single-workgroup exclusive scan of the block sums (P/256 values: 782 at 200k surfels, 3907 at 1M).
-// In place; the grand total (num_rendered, rasterizer_impl.cu:281) goes to *total_out.
-__global__ void __launch_bounds__(kSurfelBlock) scan_block_sums_kernel(uint32_t* sums, int n, uint32_t* total_out)
+// ---- binning, step 1: per-tile entry counts -------------------------------------------------------------------
+// kBinGroups workgroups each own a contiguous chunk of surfels and histogram its (surfel, tile) pairs in LDS
+// (T counters: 10 KB at 800x800, 40 KB at 1600x1600); row g of the G x T matrix M receives the histogram.  Global
+// atomics on 2500 hot counters measured 7.5 G/s on MI355X (1.5 M pairs = 200 us); LDS atomics make this ~20 us and
+// the scatter below reuses the same chunking, so bucket positions need no global atomics either.
+constexpr int kBinGroups = 256;
+
+struct BinArgs {
+    int P, ntiles, tiles_x, chunk;   // chunk = surfels per workgroup
+    const int* radii;
+    const uint2* rects;
+    const float4* rec;
+    uint32_t* M;            // [kBinGroups, T] counts, then bucket write cursors
+    uint64_t* keys;         // [R] (scatter only)
+};
+
+__global__ void __launch_bounds__(256) count_tiles_lds_kernel(BinArgs a)
 {
-    __shared__ uint32_t s_wave[4];
-    uint32_t carry = 0;
-    for (int base = 0; base < n; base += kSurfelBlock) {
-        const int i = base + threadIdx.x;
-        uint32_t v = i < n ? sums[i] : 0u;
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan(v, s_wave, total);
-        if (i < n) sums[i] = carry + ex;
-        carry += total;
+    extern __shared__ uint32_t s_hist[];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < a.ntiles; t += 256) s_hist[t] = 0;
+    __syncthreads();
+    const int end = min(a.P, (g + 1) * a.chunk);
+    for (int idx = g * a.chunk + tid; idx < end; idx += 256) {
+        if (!(a.radii[idx] > 0)) continue;
+        const uint2 r = a.rects[idx];
+        const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
+    }
+    __syncthreads();
+    for (int t = tid; t < a.ntiles; t += 256) a.M[(size_t)g * a.ntiles + t] = s_hist[t];
+}
+
+// column totals of M: counts[t] = sum_g M[g][t]
+__global__ void __launch_bounds__(256) column_totals_kernel(const uint32_t* M, int ntiles, uint32_t* counts)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    uint32_t acc = 0;
+    for (int g = 0; g < kBinGroups; g++) acc += M[(size_t)g * ntiles + t];
+    counts[t] = acc;
+}
+
+// M[g][t] <- start[t] + sum_{g' < g} M[g'][t]: where workgroup g writes its first entry of tile t
+__global__ void __launch_bounds__(256) column_prefix_kernel(uint32_t* M, int ntiles, const uint2* ranges)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    uint32_t run = ranges[t].x;
+    for (int g = 0; g < kBinGroups; g++) {
+        const uint32_t c = M[(size_t)g * ntiles + t];
+        M[(size_t)g * ntiles + t] = run;
+        run += c;
+    }
+}
+
+// duplicateWithKeys (rasterizer_impl.cu:70-111) for the tile-bucketed sort: the tile id is implied by the bucket, so
+// the key only carries (depth, surfel index) -- the tie-break order of the reference's stable radix sort.
+__global__ void __launch_bounds__(256) scatter_keys_lds_kernel(BinArgs a)
+{
+    extern __shared__ uint32_t s_cur[];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < a.ntiles; t += 256) s_cur[t] = a.M[(size_t)g * a.ntiles + t];
+    __syncthreads();
+    const int end = min(a.P, (g + 1) * a.chunk);
+    for (int idx = g * a.chunk + tid; idx < end; idx += 256) {
+        if (!(a.radii[idx] > 0)) continue;
+        const uint2 r = a.rects[idx];
+        const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+        if (x1 <= x0 || y1 <= y0) continue;
+        const uint64_t key = ((uint64_t)__float_as_uint(a.rec[(size_t)idx * kRecQuads + 4].z) << 32) | (uint32_t)idx;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) a.keys[atomicAdd(&s_cur[y * a.tiles_x + x], 1u)] = key;
+    }
+}
+
+// Fallback for images with more tiles than fit the LDS histogram (> ~36k tiles): global atomics.
+__global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P, const int* radii, const uint2* rects, int tiles_x,
+                                                                          uint32_t* tile_counts)
+{
+    const int idx = blockIdx.x * kSurfelBlock + threadIdx.x;
+    if (idx >= P || !(radii[idx] > 0)) return;
+    const uint2 r = rects[idx];
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) atomicAdd(&tile_counts[y * tiles_x + x], 1u);
+}
+
+// Exclusive scan of the per-tile counts (T = 2500 at 800x800, 10000 at 1600x1600) by ONE workgroup:
+// ranges[t] = [start, end) (identifyTileRanges, rasterizer_impl.cu:116-138), cursor[t] = start (scatter cursors),
+// *total_out = num_rendered (rasterizer_impl.cu:281).
+__global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
+                                                          uint32_t* total_out /*[2]: num_rendered, longest list*/)
+{
+    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_carry, s_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_carry = 0; s_max = 0; }
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 1024) {
+        const int t = base + tid;
+        const uint32_t v = t < ntiles ? counts[t] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t n = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += n;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int w = 0; w < wave; w++) off += s_wsum[w];
+        const uint32_t start = off + inc - v;
+        if (t < ntiles) { ranges[t] = make_uint2(start, start + v); if (cursor) cursor[t] = start; }
+        atomicMax(&s_max, v);
+        __syncthreads();
+        if (tid == 1023) s_carry = start + v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (tid == 0) { total_out[0] = s_carry; total_out[1] = s_max; }
 }
 
-struct EmitArgs {
+struct ScatterArgs {
     int P;
     const int* radii;
     const float4* rec;
     const uint2* rects;
-    const uint32_t* block_offsets;  // exclusive scan of block sums
-    uint64_t* keys;                 // [R]
-    uint32_t* vals;                 // [R]
-    int tiles_x, tiles_y;
+    uint32_t* cursor;       // [T] running write position of every tile bucket
+    uint64_t* keys;         // [R] out: depth bits << 32 | surfel index, bucketed by tile (unordered inside a bucket)
+    int tiles_x;
 };
 
-// duplicateWithKeys (rasterizer_impl.cu:70-111): key = tile << 32 | depth bits, value = surfel index.
-// The per-surfel offsets are recomputed from the block offset + an in-block scan instead of a
-// materialised inclusive-sum array.
-__global__ void __launch_bounds__(kSurfelBlock) emit_keys_kernel(EmitArgs a)
+// global-atomics variant of scatter_keys_lds_kernel (fallback for very large tile counts)
+__global__ void __launch_bounds__(kSurfelBlock) scatter_keys_kernel(ScatterArgs a)
 {
-    __shared__ uint32_t s_wave[4];
     const int idx = blockIdx.x * kSurfelBlock + threadIdx.x;
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    uint32_t depth_bits = 0;
-    if (idx < a.P) {
-        const int radius = a.radii[idx];
-        if (radius > 0) {
-            const uint2 r = a.rects[idx];
-            x0 = (int)(r.x & 0xffffu); x1 = (int)(r.x >> 16);
-            y0 = (int)(r.y & 0xffffu); y1 = (int)(r.y >> 16);
-            if (x1 > x0 && y1 > y0) depth_bits = __float_as_uint(a.rec[(size_t)idx * kRecQuads + 4].z);
-        }
-    }
-    const uint32_t cnt = (uint32_t)((x1 - x0) * (y1 - y0));
-    uint32_t total;
-    uint32_t off = a.block_offsets[blockIdx.x] + block_exclusive_scan(cnt, s_wave, total);
+    if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    const uint2 r = a.rects[idx];
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    if (x1 <= x0 || y1 <= y0) return;
+    const uint64_t key = ((uint64_t)__float_as_uint(a.rec[(size_t)idx * kRecQuads + 4].z) << 32) | (uint32_t)idx;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
-            uint64_t key = (uint64_t)(uint32_t)(y * a.tiles_x + x);
-            key = (key << 32) | depth_bits;
-            a.keys[off] = key;
-            a.vals[off] = (uint32_t)idx;
-            off++;
+            const uint32_t pos = atomicAdd(&a.cursor[y * a.tiles_x + x], 1u);
+            a.keys[pos] = key;
         }
 }
 
-// identifyTileRanges (rasterizer_impl.cu:116-138) on the sorted keys; `ranges` pre-zeroed.
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int R, const uint64_t* keys, uint2* ranges)
+// Per-tile sort by (depth, index): one workgroup per tile, bitonic network on 64-bit keys.
+//   sort_tiles_lds_kernel<CAP>: buckets with lo < n <= CAP are padded to a power of two and sorted in LDS
+//       (CAP = 4096 -> 32 KB, the common case: a few hundred entries; CAP = 16384 -> 128 KB for crowded tiles);
+//   sort_tiles_global_kernel: buckets longer than that are copied, padded, into scratch [2*start, 2*start + n2)
+//       (disjoint across tiles because n2 < 2n) and sorted there by the same network -- slow, but only reachable
+//       by degenerate views (tens of thousands of surfels over one tile).
+__device__ __forceinline__ void bitonic_network(uint64_t* k, int n2, int tid)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t cur = (uint32_t)(keys[i] >> 32);
-    if (i == 0) ranges[cur].x = 0;
-    else {
-        const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
-        if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
-    }
-    if (i == R - 1) ranges[cur].y = (uint32_t)R;
+    for (int kk = 2; kk <= n2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (n2 >> 1); i += 256) {
+                const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), m = l + j;  // j is a power of two
+                const bool up = (l & kk) == 0;
+                const uint64_t a = k[l], b = k[m];
+                if ((a > b) == up) { k[l] = b; k[m] = a; }
+            }
+            __syncthreads();
+        }
+}
+
+template <int CAP>
+__global__ void __launch_bounds__(256) sort_tiles_lds_kernel(const uint2* ranges, const uint64_t* keys, uint32_t* point_list, int lo)
+{
+    __shared__ uint64_t s_keys[CAP];
+    const uint2 rg = ranges[blockIdx.x];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= lo || n > CAP) return;
+    const uint64_t* gk = keys + rg.x;
+    const int tid = threadIdx.x;
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int i = tid; i < n2; i += 256) s_keys[i] = i < n ? gk[i] : ~0ull;
+    __syncthreads();
+    bitonic_network(s_keys, n2, tid);
+    for (int i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)s_keys[i];
+}
+
+__global__ void __launch_bounds__(256) sort_tiles_global_kernel(const uint2* ranges, const uint64_t* keys, uint64_t* scratch /*[2R]*/,
+                                                                uint32_t* point_list, int lo)
+{
+    const uint2 rg = ranges[blockIdx.x];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= lo) return;
+    const uint64_t* gk = keys + rg.x;
+    uint64_t* sk = scratch + 2 * (size_t)rg.x;
+    const int tid = threadIdx.x;
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int i = tid; i < n2; i += 256) sk[i] = i < n ? gk[i] : ~0ull;
+    __syncthreads();
+    bitonic_network(sk, n2, tid);
+    for (int i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)sk[i];
 }
 
 struct SurfelBwdArgs {

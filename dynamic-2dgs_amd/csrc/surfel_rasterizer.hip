@@ -4,9 +4,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
-
 #include <mutex>
 #include <string>
 #include <vector>
@@ -56,15 +53,14 @@ struct Carver {  // 128-byte aligned sub-allocation, like obtain() in rasterizer
 };
 
 struct GeomLayout {
-    size_t rec, block_sums, total, internal_radii, acc, rects, bytes;
+    size_t rec, total, internal_radii, acc, rects, bytes;
     int nblocks;
     explicit GeomLayout(int P)
     {
         Carver c;
         nblocks = (P + dgs::kSurfelBlock - 1) / dgs::kSurfelBlock;
         rec = c.take((size_t)P * dgs::kRecFloats * 4);
-        block_sums = c.take((size_t)(nblocks > 0 ? nblocks : 1) * 4);
-        total = c.take(4);
+        total = c.take(8);  // num_rendered, longest tile list
         internal_radii = c.take((size_t)P * 4);
         acc = c.take((size_t)P * dgs::kAccFloats * 4);
         rects = c.take((size_t)P * 8);
@@ -73,7 +69,8 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, tile_last, order_fwd, order_bwd, bytes;
+    size_t final_T, n_contrib, ranges, tile_last, order_fwd, order_bwd, tile_counts, cursor, bytes;
+    bool lds_bins;  // per-workgroup LDS histograms fit (T * 4 bytes <= 144 KB)
     int tiles_x, tiles_y, ntiles;
     ImageLayout(int W, int H)
     {
@@ -88,38 +85,25 @@ struct ImageLayout {
         tile_last = c.take((size_t)ntiles * 4);
         order_fwd = c.take((size_t)ntiles * 4);
         order_bwd = c.take((size_t)ntiles * 4);
+        tile_counts = c.take((size_t)ntiles * 4);
+        lds_bins = (size_t)ntiles * 4 <= 144 * 1024;
+        // LDS path: G x T matrix of per-workgroup counts / cursors; fallback: T global cursors
+        cursor = c.take(lds_bins ? (size_t)dgs::kBinGroups * ntiles * 4 : (size_t)ntiles * 4);
         bytes = align_up(c.off, 128);
     }
 };
 
-int sort_end_bit(int ntiles)  // bits needed for tile ids (getHigherMsb, rasterizer_impl.cu:35-50)
-{
-    int bit = 0;
-    while ((1u << bit) < (unsigned)ntiles && bit < 31) bit++;
-    if (bit == 0) bit = 1;
-    return 32 + bit;
-}
-
 struct BinningLayout {
-    size_t keys_unsorted, keys, vals_unsorted, point_list, sort_temp, bytes;
-    size_t temp_bytes;
-    int err = 0;
-    BinningLayout(int R, int ntiles)
+    size_t keys, point_list, scratch, bytes;
+    // `with_scratch`: room for the global-memory fallback of the per-tile sort (2R keys); only allocated when a
+    // tile list exceeds the LDS sorts' capacity.  point_list comes first so that its offset does not depend on it.
+    BinningLayout(int R, bool with_scratch)
     {
         Carver c;
         const size_t n = (size_t)(R > 0 ? R : 1);
-        keys_unsorted = c.take(n * 8);
-        keys = c.take(n * 8);
-        vals_unsorted = c.take(n * 4);
         point_list = c.take(n * 4);
-        temp_bytes = 0;
-        if (R > 0) {
-            hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)R, 0u,
-                                                     (unsigned)sort_end_bit(ntiles), (hipStream_t)0);
-            if (e != hipSuccess) err = 1;
-        }
-        sort_temp = c.take(temp_bytes > 0 ? temp_bytes : 4);
+        keys = c.take(n * 8);
+        scratch = c.take(with_scratch ? 2 * n * 8 : 8);
         bytes = align_up(c.off, 128);
     }
 };
@@ -142,7 +126,7 @@ dgs::Camera make_camera(const float* view_dev, const float* campos_dev, int W, i
 
 // Small pinned staging word for num_rendered (the one device->host read of the forward).
 struct HostStage {
-    uint32_t* u = nullptr;   // num_rendered
+    uint32_t* u = nullptr;   // [2] num_rendered, longest tile list
     std::mutex mu;
     int ensure()
     {
@@ -265,14 +249,14 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
     std::vector<size_t> v;
     if (which == 0) {
         GeomLayout g(P);
-        v = {g.rec, g.block_sums, g.total, g.internal_radii, g.acc, g.rects, g.bytes};
+        v = {g.rec, g.total, g.internal_radii, g.acc, g.rects, g.bytes};
     } else if (which == 1) {
         ImageLayout m(width, height);
-        v = {m.final_T, m.n_contrib, m.ranges, m.tile_last, m.order_fwd, m.order_bwd, m.bytes};
+        v = {m.final_T, m.n_contrib, m.ranges, m.tile_last, m.order_fwd, m.order_bwd, m.tile_counts, m.cursor, m.bytes};
     } else if (which == 2) {
         ImageLayout m(width, height);
-        BinningLayout b(R, m.ntiles);
-        v = {b.keys_unsorted, b.keys, b.vals_unsorted, b.point_list, b.sort_temp, b.bytes};
+        BinningLayout b(R, false);
+        v = {b.point_list, b.keys, b.scratch, b.bytes};
     } else {
         return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_debug_layout: which must be 0, 1 or 2");
     }
@@ -325,62 +309,84 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
 
     const dgs::Camera cam = make_camera(viewmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
 
-    // ---- K2 preprocess + per-block tile counts
+    // ---- K2 preprocess
+    uint32_t* tile_counts = (uint32_t*)(img + il.tile_counts);
+    uint32_t* cursor = (uint32_t*)(img + il.cursor);
+    uint2* ranges = (uint2*)(img + il.ranges);
     dgs::PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = M;
     pa.means3D = means3D; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities;
     pa.shs = shs; pa.colors_precomp = colors_precomp; pa.cam = cam;
     pa.radii = radii;
     pa.rec = (float4*)(geom + gl.rec);
-    pa.block_sums = (uint32_t*)(geom + gl.block_sums);
     pa.rects = (uint2*)(geom + gl.rects);
     pa.tight = g_tight_rects ? 1 : 0;
     hipLaunchKernelGGL(dgs::preprocess_fwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, pa);
     DGS_STAGE("preprocess_fwd", debug, stream);
-    // ---- K3 scan of the block sums (replaces cub::DeviceScan::InclusiveSum over P values)
-    hipLaunchKernelGGL(dgs::scan_block_sums_kernel, dim3(1), dim3(dgs::kSurfelBlock), 0, stream, pa.block_sums, gl.nblocks,
-                       (uint32_t*)(geom + gl.total));
-    DGS_STAGE("scan_block_sums", debug, stream);
+    // ---- K3 per-tile entry counts
+    dgs::BinArgs ba_;
+    ba_.P = P; ba_.ntiles = il.ntiles; ba_.tiles_x = il.tiles_x; ba_.chunk = (P + dgs::kBinGroups - 1) / dgs::kBinGroups;
+    ba_.radii = radii; ba_.rects = pa.rects; ba_.rec = pa.rec; ba_.M = cursor; ba_.keys = nullptr;
+    const size_t hist_bytes = (size_t)il.ntiles * 4;
+    if (il.lds_bins) {
+        hipLaunchKernelGGL(dgs::count_tiles_lds_kernel, dim3(dgs::kBinGroups), dim3(256), hist_bytes, stream, ba_);
+        hipLaunchKernelGGL(dgs::column_totals_kernel, dim3((il.ntiles + 255) / 256), dim3(256), 0, stream, (const uint32_t*)cursor,
+                           il.ntiles, tile_counts);
+    } else {
+        DGS_HIP(hipMemsetAsync(tile_counts, 0, hist_bytes, stream));
+        hipLaunchKernelGGL(dgs::count_tiles_global_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, P, (const int*)radii,
+                           (const uint2*)pa.rects, il.tiles_x, tile_counts);
+    }
+    DGS_STAGE("count_tiles", debug, stream);
+    // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
+    hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
+                       il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total));
+    DGS_STAGE("scan_tiles", debug, stream);
 
     // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285)
-    uint32_t R_u = 0;
+    uint32_t R_u = 0, longest = 0;
     {
         std::lock_guard<std::mutex> lk(g_stage.mu);
         if (g_stage.ensure()) return fail(DGS_ERR_HIP, "hipHostMalloc failed");
-        DGS_HIP(hipMemcpyAsync(g_stage.u, geom + gl.total, 4, hipMemcpyDeviceToHost, stream));
+        DGS_HIP(hipMemcpyAsync(g_stage.u, geom + gl.total, 8, hipMemcpyDeviceToHost, stream));
         DGS_HIP(hipStreamSynchronize(stream));
-        R_u = *g_stage.u;
+        R_u = g_stage.u[0];
+        longest = g_stage.u[1];
     }
     if (R_u > 0x7fffffffu) return fail(DGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
     const int R = (int)R_u;
 
-    BinningLayout bl(R, il.ntiles);
-    if (bl.err) return fail(DGS_ERR_HIP, "rocprim::radix_sort_pairs size query failed");
+    const bool need_global_sort = longest > 16384u;
+    BinningLayout bl(R, need_global_sort);
     char* bin = binning_alloc(binning_ctx, bl.bytes);
     if (!bin) return fail(DGS_ERR_ALLOC, "binning allocator returned NULL");
-
-    uint2* ranges = (uint2*)(img + il.ranges);
-    DGS_HIP(hipMemsetAsync(ranges, 0, (size_t)il.ntiles * 8, stream));  // rasterizer_impl.cu:311
     if (R > 0) {
-        // ---- K4 key emission
-        dgs::EmitArgs ea;
-        ea.P = P; ea.radii = radii; ea.rec = pa.rec; ea.rects = pa.rects; ea.block_offsets = pa.block_sums;
-        ea.keys = (uint64_t*)(bin + bl.keys_unsorted);
-        ea.vals = (uint32_t*)(bin + bl.vals_unsorted);
-        ea.tiles_x = il.tiles_x; ea.tiles_y = il.tiles_y;
-        hipLaunchKernelGGL(dgs::emit_keys_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, ea);
-        DGS_STAGE("emit_keys", debug, stream);
-        // ---- K5 stable LSD radix sort on (tile | depth) keys (rasterizer_impl.cu:304-309)
-        size_t temp_bytes = bl.temp_bytes;
-        DGS_HIP(rocprim::radix_sort_pairs((void*)(bin + bl.sort_temp), temp_bytes, (const uint64_t*)ea.keys,
-                                          (uint64_t*)(bin + bl.keys), (const uint32_t*)ea.vals,
-                                          (uint32_t*)(bin + bl.point_list), (size_t)R, 0u,
-                                          (unsigned)sort_end_bit(il.ntiles), stream));
-        DGS_STAGE("radix_sort", debug, stream);
-        // ---- K6 tile ranges
-        hipLaunchKernelGGL(dgs::tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R,
-                           (const uint64_t*)(bin + bl.keys), ranges);
-        DGS_STAGE("tile_ranges", debug, stream);
+        // ---- K4 scatter (depth, index) keys into the tile buckets
+        uint64_t* keys = (uint64_t*)(bin + bl.keys);
+        if (il.lds_bins) {
+            hipLaunchKernelGGL(dgs::column_prefix_kernel, dim3((il.ntiles + 255) / 256), dim3(256), 0, stream, cursor, il.ntiles,
+                               (const uint2*)ranges);
+            ba_.keys = keys;
+            hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups), dim3(256), hist_bytes, stream, ba_);
+        } else {
+            dgs::ScatterArgs sa;
+            sa.P = P; sa.radii = radii; sa.rec = pa.rec; sa.rects = pa.rects; sa.cursor = cursor;
+            sa.keys = keys;
+            sa.tiles_x = il.tiles_x;
+            hipLaunchKernelGGL(dgs::scatter_keys_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, sa);
+        }
+        DGS_STAGE("scatter_keys", debug, stream);
+        // ---- K5 per-tile sort (stable radix order of rasterizer_impl.cu:304-309 = (tile, depth bits, surfel index))
+        uint32_t* plist = (uint32_t*)(bin + bl.point_list);
+        hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<4096>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                           (const uint64_t*)keys, plist, 0);
+        if (longest > 4096u)
+            hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<16384>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                               (const uint64_t*)keys, plist, 4096);
+        if (need_global_sort)
+            hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                               (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, 16384);
+        DGS_STAGE("sort_tiles", debug, stream);
     }
 
     // ---- K7 forward blend
@@ -433,7 +439,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
 
     GeomLayout gl(P);
     ImageLayout il(width, height);
-    BinningLayout bl(R, il.ntiles);
+    BinningLayout bl(R, false);  // only point_list is needed; its offset does not depend on the scratch
     if (!radii) radii = (const int*)(geom_buffer + gl.internal_radii);
 
     const dgs::Camera cam = make_camera(viewmatrix, campos, width, height, tan_fovx, tan_fovy);

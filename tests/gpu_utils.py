@@ -74,7 +74,7 @@ def run_hip_raw(case, dev="cuda:0"):
         final_T=np.stack([untile(fT[i]) for i in range(3)]), n_contrib=np.stack([untile(nc[i]) for i in range(2)]),
         ranges=ib[i_off[2]:i_off[2] + T * 8].view(np.uint32).reshape(T, 2),
         tile_last=ib[i_off[3]:i_off[3] + T * 4].view(np.uint32),
-        point_list=bb[b_off[3]:b_off[3] + R * 4].view(np.uint32) if R > 0 else np.zeros(0, np.uint32),
+        point_list=bb[b_off[0]:b_off[0] + R * 4].view(np.uint32) if R > 0 else np.zeros(0, np.uint32),
         keys=bb[b_off[1]:b_off[1] + R * 8].view(np.uint64) if R > 0 else np.zeros(0, np.uint64),
     )
     return out
