@@ -91,26 +91,37 @@ __global__ void __launch_bounds__(256) count_tiles_lds_kernel(BinArgs a)
     for (int t = tid; t < a.ntiles; t += 256) a.M[(size_t)g * a.ntiles + t] = s_hist[t];
 }
 
-// column totals of M: counts[t] = sum_g M[g][t]
-__global__ void __launch_bounds__(256) column_totals_kernel(const uint32_t* M, int ntiles, uint32_t* counts)
+// Column pass over M.  Block = 64 tiles x 4 row groups (kBinGroups / 4 = 64 rows per thread, all loads independent
+// and in flight together); the four partial sums of a tile meet in LDS.
+//   counts == nullptr : M[g][t] <- ranges[t].x + sum_{g' < g} M[g'][t]   (where workgroup g starts writing tile t)
+//   counts != nullptr : counts[t] = sum_g M[g][t]
+__global__ void __launch_bounds__(256) column_pass_kernel(uint32_t* M, int ntiles, const uint2* ranges, uint32_t* counts)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    constexpr int kRows = kBinGroups / 4;
+    __shared__ uint32_t s_part[4][64];
+    const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx;
+    uint32_t v[kRows];
+    uint32_t sum = 0;
+    if (t < ntiles) {
+#pragma unroll
+        for (int i = 0; i < kRows; i++) v[i] = M[(size_t)(ry * kRows + i) * ntiles + t];
+#pragma unroll
+        for (int i = 0; i < kRows; i++) sum += v[i];
+    }
+    s_part[ry][tx] = sum;
+    __syncthreads();
     if (t >= ntiles) return;
-    uint32_t acc = 0;
-    for (int g = 0; g < kBinGroups; g++) acc += M[(size_t)g * ntiles + t];
-    counts[t] = acc;
-}
-
-// M[g][t] <- start[t] + sum_{g' < g} M[g'][t]: where workgroup g writes its first entry of tile t
-__global__ void __launch_bounds__(256) column_prefix_kernel(uint32_t* M, int ntiles, const uint2* ranges)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
+    if (counts) {
+        if (ry == 0) counts[t] = s_part[0][tx] + s_part[1][tx] + s_part[2][tx] + s_part[3][tx];
+        return;
+    }
     uint32_t run = ranges[t].x;
-    for (int g = 0; g < kBinGroups; g++) {
-        const uint32_t c = M[(size_t)g * ntiles + t];
-        M[(size_t)g * ntiles + t] = run;
-        run += c;
+    for (int r = 0; r < ry; r++) run += s_part[r][tx];
+#pragma unroll
+    for (int i = 0; i < kRows; i++) {
+        M[(size_t)(ry * kRows + i) * ntiles + t] = run;
+        run += v[i];
     }
 }
 
@@ -149,35 +160,38 @@ __global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P,
 // Exclusive scan of the per-tile counts (T = 2500 at 800x800, 10000 at 1600x1600) by ONE workgroup:
 // ranges[t] = [start, end) (identifyTileRanges, rasterizer_impl.cu:116-138), cursor[t] = start (scatter cursors),
 // *total_out = num_rendered (rasterizer_impl.cu:281).
-__global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
-                                                          uint32_t* total_out /*[2]: num_rendered, longest list*/)
+__global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
+                                                         uint32_t* total_out /*[2]: num_rendered, longest list*/)
 {
-    __shared__ uint32_t s_wsum[16];
-    __shared__ uint32_t s_carry, s_max;
+    __shared__ uint32_t s_wsum[4], s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_carry = 0; s_max = 0; }
-    __syncthreads();
-    for (int base = 0; base < ntiles; base += 1024) {
-        const int t = base + tid;
-        const uint32_t v = t < ntiles ? counts[t] : 0u;
-        uint32_t inc = v;
+    const int per = (ntiles + 255) / 256;
+    const int t0 = tid * per, t1 = min(ntiles, t0 + per);
+    uint32_t sum = 0, mx = 0;
+    for (int t = t0; t < t1; t++) { const uint32_t c = counts[t]; sum += c; mx = max(mx, c); }
+    uint32_t inc = sum;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t n = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += n;
-        }
-        if (lane == 63) s_wsum[wave] = inc;
-        __syncthreads();
-        uint32_t off = s_carry;
-        for (int w = 0; w < wave; w++) off += s_wsum[w];
-        const uint32_t start = off + inc - v;
-        if (t < ntiles) { ranges[t] = make_uint2(start, start + v); if (cursor) cursor[t] = start; }
-        atomicMax(&s_max, v);
-        __syncthreads();
-        if (tid == 1023) s_carry = start + v;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += n;
     }
-    if (tid == 0) { total_out[0] = s_carry; total_out[1] = s_max; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 63) s_wsum[wave] = inc;
+    if (lane == 0) s_wmax[wave] = mx;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wave; w++) run += s_wsum[w];
+    for (int t = t0; t < t1; t++) {
+        const uint32_t c = counts[t];
+        ranges[t] = make_uint2(run, run + c);
+        if (cursor) cursor[t] = run;
+        run += c;
+    }
+    if (tid == 0) {
+        total_out[0] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        total_out[1] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    }
 }
 
 struct ScatterArgs {
@@ -208,21 +222,41 @@ __global__ void __launch_bounds__(kSurfelBlock) scatter_keys_kernel(ScatterArgs 
 
 // Per-tile sort by (depth, index): one workgroup per tile, bitonic network on 64-bit keys.
 //   sort_tiles_lds_kernel<CAP>: buckets with lo < n <= CAP are padded to a power of two and sorted in LDS
-//       (CAP = 4096 -> 32 KB, the common case: a few hundred entries; CAP = 16384 -> 128 KB for crowded tiles);
+//       (CAP = 2048 -> 16 KB and ten resident workgroups per CU, the common case: a few hundred entries;
+//        CAP = 16384 -> 128 KB for crowded tiles);
 //   sort_tiles_global_kernel: buckets longer than that are copied, padded, into scratch [2*start, 2*start + n2)
 //       (disjoint across tiles because n2 < 2n) and sorted there by the same network -- slow, but only reachable
 //       by degenerate views (tens of thousands of surfels over one tile).
-__device__ __forceinline__ void bitonic_network(uint64_t* k, int n2, int tid)
+// Thread i of a pass handles the pair (l, l + j) with l = ((i & ~(j-1)) << 1) | (i & (j-1)).  For j <= 64 the 64 pairs
+// of a wave (i = 64w .. 64w+63, and again every 256) live in the wave's own 128-key window, so consecutive stages with
+// j <= 64 need no workgroup barrier -- only the LDS ordering of a single wave.  A 1024-key sort keeps 9 of its 55 barriers.  (`wave_local` must be false when `k` is global memory.)
+__device__ __forceinline__ void bitonic_network(uint64_t* k, int n2, int tid, bool wave_local)
 {
+    const int half = n2 >> 1;
     for (int kk = 2; kk <= n2; kk <<= 1)
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < (n2 >> 1); i += 256) {
-                const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), m = l + j;  // j is a power of two
-                const bool up = (l & kk) == 0;
-                const uint64_t a = k[l], b = k[m];
-                if ((a > b) == up) { k[l] = b; k[m] = a; }
+            // four independent pairs per thread and trip: all eight loads are in flight before the first compare
+            for (int i0 = tid; i0 < half; i0 += 1024) {
+                int l[4];
+                uint64_t a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + 256 * u;
+                    l[u] = ((i & ~(j - 1)) << 1) | (i & (j - 1));  // j is a power of two
+                    if (i < half) { a[u] = k[l[u]]; b[u] = k[l[u] + j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + 256 * u;
+                    const bool up = (l[u] & kk) == 0;
+                    if (i < half && (a[u] > b[u]) == up) { k[l[u]] = b[u]; k[l[u] + j] = a[u]; }
+                }
             }
-            __syncthreads();
+            // the next stage is (kk, j/2), or (2kk, kk) after j == 1; a workgroup barrier is needed only when this
+            // stage or the next one crosses the 128-key windows (stride > 64)
+            const int j_next = j > 1 ? (j >> 1) : kk;
+            if (wave_local && j <= 64 && j_next <= 64) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            else __syncthreads();
         }
 }
 
@@ -239,7 +273,7 @@ __global__ void __launch_bounds__(256) sort_tiles_lds_kernel(const uint2* ranges
     while (n2 < n) n2 <<= 1;
     for (int i = tid; i < n2; i += 256) s_keys[i] = i < n ? gk[i] : ~0ull;
     __syncthreads();
-    bitonic_network(s_keys, n2, tid);
+    bitonic_network(s_keys, n2, tid, true);
     for (int i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)s_keys[i];
 }
 
@@ -256,7 +290,7 @@ __global__ void __launch_bounds__(256) sort_tiles_global_kernel(const uint2* ran
     while (n2 < n) n2 <<= 1;
     for (int i = tid; i < n2; i += 256) sk[i] = i < n ? gk[i] : ~0ull;
     __syncthreads();
-    bitonic_network(sk, n2, tid);
+    bitonic_network(sk, n2, tid, false);
     for (int i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)sk[i];
 }
 

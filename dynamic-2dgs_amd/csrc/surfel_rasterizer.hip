@@ -330,8 +330,8 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     const size_t hist_bytes = (size_t)il.ntiles * 4;
     if (il.lds_bins) {
         hipLaunchKernelGGL(dgs::count_tiles_lds_kernel, dim3(dgs::kBinGroups), dim3(256), hist_bytes, stream, ba_);
-        hipLaunchKernelGGL(dgs::column_totals_kernel, dim3((il.ntiles + 255) / 256), dim3(256), 0, stream, (const uint32_t*)cursor,
-                           il.ntiles, tile_counts);
+        hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(256), 0, stream, cursor, il.ntiles,
+                           (const uint2*)nullptr, tile_counts);
     } else {
         DGS_HIP(hipMemsetAsync(tile_counts, 0, hist_bytes, stream));
         hipLaunchKernelGGL(dgs::count_tiles_global_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, P, (const int*)radii,
@@ -339,7 +339,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     }
     DGS_STAGE("count_tiles", debug, stream);
     // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
-    hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
+    hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(256), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
                        il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total));
     DGS_STAGE("scan_tiles", debug, stream);
 
@@ -364,8 +364,8 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
         // ---- K4 scatter (depth, index) keys into the tile buckets
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         if (il.lds_bins) {
-            hipLaunchKernelGGL(dgs::column_prefix_kernel, dim3((il.ntiles + 255) / 256), dim3(256), 0, stream, cursor, il.ntiles,
-                               (const uint2*)ranges);
+            hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(256), 0, stream, cursor, il.ntiles,
+                               (const uint2*)ranges, (uint32_t*)nullptr);
             ba_.keys = keys;
             hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups), dim3(256), hist_bytes, stream, ba_);
         } else {
@@ -378,11 +378,11 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
         DGS_STAGE("scatter_keys", debug, stream);
         // ---- K5 per-tile sort (stable radix order of rasterizer_impl.cu:304-309 = (tile, depth bits, surfel index))
         uint32_t* plist = (uint32_t*)(bin + bl.point_list);
-        hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<4096>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+        hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
                            (const uint64_t*)keys, plist, 0);
-        if (longest > 4096u)
+        if (longest > 2048u)
             hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<16384>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
-                               (const uint64_t*)keys, plist, 4096);
+                               (const uint64_t*)keys, plist, 2048);
         if (need_global_sort)
             hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
                                (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, 16384);

@@ -206,7 +206,7 @@ def test_full_size_properties():
 
 
 def test_long_tile_lists_use_all_sort_paths():
-    """Zoomed-in view of big splats: single tiles hold > 4096 and > 16384 entries, which exercises the 128 KB LDS
+    """Zoomed-in view of big splats: single tiles hold > 2048 and > 16384 entries, which exercises the 128 KB LDS
     sort and the global-memory fallback of the tile-bucketed sort; the lists must still equal the reference order."""
     from diff_surfel_rasterization import _C
     from gpu_utils import frac_close, run_hip_raw
