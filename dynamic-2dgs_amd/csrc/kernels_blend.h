@@ -2,9 +2,11 @@
 //
 // One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 16x4 pixel strip
 // rows 4w..4w+3, so all 64 lanes of a wave consume the same staged surfel at the same time.
-// The tile's depth-sorted list is consumed in batches of 256 entries whose packed 80-B records are
-// gathered into LDS as five float4 planes (20 KB); the inner loop reads them with wave-uniform
-// addresses (LDS broadcast, conflict free).  Replaces renderCUDA of forward.cu:265-463 and
+// The tile's depth-sorted list is consumed in batches of 256 entries whose packed 96-B records are gathered
+// into LDS as five float4 planes (20 KB; the sixth quad, the surfel's exact pixel bounding box, is consumed at
+// staging time: each entry is tested against the four 16x4 strips and the four per-strip ballots become 64-bit
+// masks, so a wave only visits the entries whose box touches its strip).  The inner loop reads the planes with
+// wave-uniform addresses (LDS broadcast, conflict free).  Replaces renderCUDA of forward.cu:265-463 and
 // backward.cu:143-449.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -14,8 +16,15 @@
 namespace dgs {
 
 constexpr int kBatch = 256;
+constexpr int kStagedQuads = 5;  // q0..q4 go to LDS, q5 (bounding box) is consumed while staging
 
 __device__ __forceinline__ Quad as_quad(const float4& v) { return Quad{v.x, v.y, v.z, v.w}; }
+
+__device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 struct BlendFwdArgs {
     const uint2* ranges;         // [T]
@@ -110,7 +119,8 @@ inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
 
 __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
 {
-    __shared__ float4 s_rec[kRecQuads][kBatch];
+    __shared__ float4 s_rec[kStagedQuads][kBatch];
+    __shared__ unsigned long long s_bits[4][4];  // [strip][chunk of 64 entries]
     __shared__ int s_flag[4];
     __shared__ uint32_t s_max[4];
 
@@ -123,6 +133,7 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
     const int px = tx * kTileX + (tid & 15), py = ty * kTileY + (tid >> 4);
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+    const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
 
     const uint2 range = a.ranges[tile];
     int todo = (int)(range.y - range.x);
@@ -140,32 +151,49 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
         if (s_flag[0] & s_flag[1] & s_flag[2] & s_flag[3]) break;
 
         const int n = todo < kBatch ? todo : kBatch;
+        uint32_t smask = 0;
         if (tid < n) {
             const uint32_t id = a.point_list[range.x + (uint32_t)(b * kBatch + tid)];
             const float4* src = a.rec + (size_t)id * kRecQuads;
 #pragma unroll
-            for (int c = 0; c < kRecQuads; c++) s_rec[c][tid] = src[c];
+            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = src[c];
+            { const float4 bx = src[5]; smask = strip_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned long long bal = __ballot((smask >> w) & 1u);
+            if (lane == 0) s_bits[w][wave] = bal;  // this wave staged entries 64*wave .. 64*wave+63
         }
         __syncthreads();
 
         if (!wave_done) {
-            // Entry j's alpha part (q0..q2) is prefetched into registers one iteration ahead, evaluated
-            // branch-free for all 64 lanes, and a single wave-uniform branch skips the entry when no lane
-            // passes -- the common case.
-            float4 n0 = s_rec[0][0], n1 = s_rec[1][0], n2 = s_rec[2][0];
+            // Visit, in list order, only the entries whose box touches this wave's strip.  The alpha part (q0..q2) of
+            // the next visited entry is prefetched while the current one is evaluated branch-free for all 64 lanes;
+            // a single wave-uniform branch skips the blend when no lane passes.
             const uint32_t base = (uint32_t)(b * kBatch);
-            for (int j = 0; j < n; j++) {
-                const float4 q0 = n0, q1 = n1, q2 = n2;
-                const int jn = j + 1 < kBatch ? j + 1 : j;
-                n0 = s_rec[0][jn]; n1 = s_rec[1][jn]; n2 = s_rec[2][jn];
-                PairEval e;
-                const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), e) && !done;
-                if (__ballot(ok) == 0ull) continue;
-                if (ok) {
-                    st.contributor = base + (uint32_t)j + 1u;  // 1-based list position (forward.cu:356)
-                    if (!pixfwd_blend(st, e, as_quad(s_rec[3][j]), as_quad(s_rec[4][j]))) done = true;
+            bool stop = false;
+            for (int c = 0; c < 4 && !stop; c++) {
+                unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
+                if (m == 0ull) continue;
+                int j = c * 64 + __builtin_ctzll(m);
+                float4 n0 = s_rec[0][j], n1 = s_rec[1][j], n2 = s_rec[2][j];
+                while (m != 0ull) {
+                    const float4 q0 = n0, q1 = n1, q2 = n2;
+                    const int jc = j;
+                    m &= m - 1ull;
+                    if (m != 0ull) {
+                        j = c * 64 + __builtin_ctzll(m);
+                        n0 = s_rec[0][j]; n1 = s_rec[1][j]; n2 = s_rec[2][j];
+                    }
+                    PairEval e;
+                    const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), e) && !done;
+                    if (__ballot(ok) == 0ull) continue;
+                    if (ok) {
+                        st.contributor = base + (uint32_t)jc + 1u;  // 1-based list position (forward.cu:356)
+                        if (!pixfwd_blend(st, e, as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]))) done = true;
+                    }
+                    if (__ballot(!done) == 0ull) { stop = true; break; }  // wave-level early out
                 }
-                if (__ballot(!done) == 0ull) break;  // wave-level early out (only re-evaluated after a blend)
             }
         }
     }
@@ -271,8 +299,9 @@ __device__ __forceinline__ float wave_sum(float v)
 
 __global__ void __launch_bounds__(kTilePix) blend_bwd_kernel(BlendBwdArgs a)
 {
-    __shared__ float4 s_rec[kRecQuads][kBatch];
+    __shared__ float4 s_rec[kStagedQuads][kBatch];
     __shared__ uint32_t s_id[kBatch];
+    __shared__ unsigned long long s_bits[4][4];
 
     const int ntiles = a.tiles_x * a.tiles_y;
     int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
@@ -280,11 +309,12 @@ __global__ void __launch_bounds__(kTilePix) blend_bwd_kernel(BlendBwdArgs a)
     if (a.mode == 3) tile = (int)a.order[tile];
     const int L = (int)a.tile_last[tile];  // entries [0, L) can contribute to some pixel of the tile
     if (L == 0) return;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int px = tx * kTileX + (tid & 15), py = ty * kTileY + (tid >> 4);
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+    const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
     const uint2 range = a.ranges[tile];
 
     const size_t plane = (size_t)ntiles * kTilePix;
@@ -318,46 +348,62 @@ __global__ void __launch_bounds__(kTilePix) blend_bwd_kernel(BlendBwdArgs a)
         __syncthreads();
         // back to front: batch entry j holds list entry e = L-1 - (b*256 + j)
         const int e_mine = L - 1 - (b * kBatch + tid);
+        uint32_t smask = 0;
         if (e_mine >= 0) {
             const uint32_t id = a.point_list[range.x + (uint32_t)e_mine];
             s_id[tid] = id;
             const float4* src = a.rec + (size_t)id * kRecQuads;
 #pragma unroll
-            for (int c = 0; c < kRecQuads; c++) s_rec[c][tid] = src[c];
+            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = src[c];
+            { const float4 bx = src[5]; smask = strip_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned long long bal = __ballot((smask >> w) & 1u);
+            if (lane == 0) s_bits[w][wave] = bal;
         }
         __syncthreads();
-        const int n = (L - b * kBatch) < kBatch ? (L - b * kBatch) : kBatch;
-        // skip the leading entries no lane of this wave needs (wave-uniform)
+        // entries j < j0 lie behind everything this wave blended (wave-uniform)
         int j0 = (L - 1 - b * kBatch) - (wave_last - 1);
         j0 = j0 < 0 ? 0 : j0;
-        if (j0 >= n) continue;
-        float4 n0 = s_rec[0][j0], n1 = s_rec[1][j0], n2 = s_rec[2][j0];
-        for (int j = j0; j < n; j++) {
-            const int e = L - 1 - (b * kBatch + j);  // 0-based list index == the reference's `contributor`
-            const float4 q0 = n0, q1 = n1, q2 = n2;
-            const int jn = j + 1 < kBatch ? j + 1 : j;
-            n0 = s_rec[0][jn]; n1 = s_rec[1][jn]; n2 = s_rec[2][jn];
-            PairEval ev;
-            const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), ev) && (e < st.last_contributor);
-            if (__ballot(ok) == 0ull) continue;
-            float out[kAccFloats];
+        for (int c = 0; c < 4; c++) {
+            if (c * 64 + 63 < j0) continue;
+            unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
+            if (j0 > c * 64) m &= ~((1ull << (j0 - c * 64)) - 1ull);
+            if (m == 0ull) continue;
+            int j = c * 64 + __builtin_ctzll(m);
+            float4 n0 = s_rec[0][j], n1 = s_rec[1][j], n2 = s_rec[2][j];
+            while (m != 0ull) {
+                const float4 q0 = n0, q1 = n1, q2 = n2;
+                const int jc = j;
+                m &= m - 1ull;
+                if (m != 0ull) {
+                    j = c * 64 + __builtin_ctzll(m);
+                    n0 = s_rec[0][j]; n1 = s_rec[1][j]; n2 = s_rec[2][j];
+                }
+                const int e = L - 1 - (b * kBatch + jc);  // 0-based list index == the reference's `contributor`
+                PairEval ev;
+                const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), ev) && (e < st.last_contributor);
+                if (__ballot(ok) == 0ull) continue;
+                float out[kAccFloats];
 #pragma unroll
-            for (int c = 0; c < 18; c++) out[c] = 0.f;
-            bool flat = false;
-            if (ok) {
-                pixbwd_step(st, ev, e, pfx, pfy, as_quad(q1), as_quad(q2), as_quad(s_rec[3][j]), as_quad(s_rec[4][j]), out);
-                flat = !ev.use3d;
-            }
-            float* dst = a.acc + (size_t)s_id[j] * kAccFloats;
-            float v16[16];
+                for (int k = 0; k < 18; k++) out[k] = 0.f;
+                bool flat = false;
+                if (ok) {
+                    pixbwd_step(st, ev, e, pfx, pfy, as_quad(q1), as_quad(q2), as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]), out);
+                    flat = !ev.use3d;
+                }
+                float* dst = a.acc + (size_t)s_id[jc] * kAccFloats;
+                float v16[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) v16[c] = out[c];
-            const float tot = wave_reduce16(v16, lane);
-            if ((lane & 3) == 0) atomicAdd(dst + (lane >> 2), tot);
-            if (__ballot(flat) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
-                const float mx = wave_sum(out[kAccMean2D + 0]);
-                const float my = wave_sum(out[kAccMean2D + 1]);
-                if (lane == 0) { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                for (int k = 0; k < 16; k++) v16[k] = out[k];
+                const float tot = wave_reduce16(v16, lane);
+                if ((lane & 3) == 0) atomicAdd(dst + (lane >> 2), tot);
+                if (__ballot(flat) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                    const float mx = wave_sum(out[kAccMean2D + 0]);
+                    const float my = wave_sum(out[kAccMean2D + 1]);
+                    if (lane == 0) { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                }
             }
         }
     }

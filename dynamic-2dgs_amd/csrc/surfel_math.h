@@ -28,11 +28,12 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTmin = 0.0001f;
 
 // ---- packed per-surfel record written by the preprocess kernel and gathered by the blend kernels.
-// 20 floats = 80 B = five 16-B chunks, so one surfel is 5 dwordx4 transactions:
+// 24 floats = 96 B = six 16-B chunks, so one surfel is 6 dwordx4 transactions:
 //   q0 = (Tu.x Tu.y Tu.z Tv.x)  q1 = (Tv.y Tv.z Tw.x Tw.y)  q2 = (Tw.z xy.x xy.y opacity)   <- alpha part
 //   q3 = (n.x n.y n.z r)        q4 = (g b depth flags)                                      <- shading part
-constexpr int kRecFloats = 20;
-constexpr int kRecQuads = 5;
+//   q5 = (x_lo x_hi y_lo y_hi)  exact pixel bounding box of {alpha >= 1/255} (see tight_tile_rect) <- culling part
+constexpr int kRecFloats = 24;
+constexpr int kRecQuads = 6;
 
 struct Quad { float x, y, z, w; };
 
@@ -44,8 +45,9 @@ struct SurfelRec {
     float rgb[3];
     float depth;
     uint32_t flags;  // bit c set: colour channel c was clamped at 0 (forward.cu:66-69)
+    float bbox[4];   // x_lo, x_hi, y_lo, y_hi in pixel-centre coordinates; (-inf, +inf) when not applicable
 };
-static_assert(sizeof(SurfelRec) == kRecFloats * 4, "record must be 80 bytes");
+static_assert(sizeof(SurfelRec) == kRecFloats * 4, "record must be 96 bytes");
 
 // ---- per-surfel gradient accumulator slots written by the backward blend (one 80-B row per surfel)
 constexpr int kAccFloats = 20;
@@ -162,8 +164,9 @@ DGS_HD uint32_t sh_to_rgb(int deg, const float* sh, const float* pos, const floa
 // of O(width^2) terms) with a 0.01 px + 1e-4 relative margin; when the disc is not entirely in front of
 // the camera plane (projection not an ellipse) the reference rectangle is kept.
 DGS_HD void tight_tile_rect(const float* Tu, const float* Tv, const float* Tw, float cxy_x, float cxy_y, float opacity,
-                            int& x0, int& y0, int& x1, int& y1)
+                            int& x0, int& y0, int& x1, int& y1, float bbox[4])
 {
+    bbox[0] = bbox[2] = -3.0e38f; bbox[1] = bbox[3] = 3.0e38f;
     if (!(opacity >= kAlphaMin)) { x1 = x0; y1 = y0; return; }  // alpha <= o * G <= o < 1/255 everywhere
     const double tau = 2.0 * log(255.0 * (double)opacity) * (1.0 + 1e-6) + 1e-5;
     const double r2 = tau;
@@ -186,6 +189,9 @@ DGS_HD void tight_tile_rect(const float* Tu, const float* Tv, const float* Tw, f
         const double m = 0.01 + 1e-4 * (h - l);
         lo[a] = l - m; hi[a] = h + m;
     }
+    // float box for the per-strip culling of the blend kernels (rounded outwards; the margin above dwarfs one ulp)
+    bbox[0] = (float)lo[0] - 1e-3f; bbox[1] = (float)hi[0] + 1e-3f;
+    bbox[2] = (float)lo[1] - 1e-3f; bbox[3] = (float)hi[1] + 1e-3f;
     // tile t holds pixel centres 16 t + 0.5 ... 16 t + 15.5
     const double fx0 = ceil((lo[0] - 15.5) / kTileX), fx1 = floor((hi[0] - 0.5) / kTileX) + 1.0;
     const double fy0 = ceil((lo[1] - 15.5) / kTileY), fy1 = floor((hi[1] - 0.5) / kTileY) + 1.0;
@@ -193,6 +199,19 @@ DGS_HD void tight_tile_rect(const float* Tu, const float* Tv, const float* Tw, f
     if (fy0 > (double)y0) y0 = fy0 < (double)y1 ? (int)fy0 : y1;
     if (fx1 < (double)x1) x1 = fx1 > (double)x0 ? (int)fx1 : x0;
     if (fy1 < (double)y1) y1 = fy1 > (double)y0 ? (int)fy1 : y0;
+}
+
+// Bit w set: the box reaches a pixel centre of strip w (pixel rows 4w..4w+3) of the tile whose first pixel is
+// (px0, py0).  Used by the blend kernels while staging: a wave only visits entries whose bit for its strip is set.
+DGS_HD uint32_t strip_mask(float x_lo, float x_hi, float y_lo, float y_hi, float px0, float py0)
+{
+    if (x_hi < px0 + 0.5f || x_lo > px0 + 15.5f) return 0u;
+    uint32_t m = 0;
+    for (int w = 0; w < 4; w++) {
+        const float y_first = py0 + 4.0f * w + 0.5f;
+        m |= (y_hi >= y_first && y_lo <= y_first + 3.0f) ? (1u << w) : 0u;
+    }
+    return m;
 }
 
 // Packed tile rectangle: x0 | x1 << 16, y0 | y1 << 16
@@ -260,7 +279,8 @@ DGS_HD int preprocess_surfel(const Camera& cam, const float* pos, const float* s
     } else {
         rec.flags = sh_to_rgb(deg, sh, pos, cam.campos, rec.rgb);
     }
-    if (tight) tight_tile_rect(Tu, Tv, Tw, px, py, opacity, x0, y0, x1, y1);
+    rec.bbox[0] = rec.bbox[2] = -3.0e38f; rec.bbox[1] = rec.bbox[3] = 3.0e38f;
+    if (tight) tight_tile_rect(Tu, Tv, Tw, px, py, opacity, x0, y0, x1, y1, rec.bbox);
     trect.xs = (uint32_t)x0 | ((uint32_t)x1 << 16);
     trect.ys = (uint32_t)y0 | ((uint32_t)y1 << 16);
     tiles = (x1 - x0) * (y1 - y0);   // may be 0: visible (radius > 0) but unable to reach alpha >= 1/255 anywhere

@@ -89,7 +89,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
 /* Byte offsets of the private sub-arrays inside the three scratch buffers, so tests can compare each
  * stage with the oracle.  which: 0 geometry (P), 1 image (W,H), 2 binning (R).  Writes up to `cap`
  * offsets, returns the number of sub-arrays; the last entry written is the total size.
- *   geometry: rec[P*20 f32], total[2 u32: num_rendered, longest list], internal_radii[P i32], acc[P*20 f32], rects[P uint2]
+ *   geometry: rec[P*24 f32], total[2 u32: num_rendered, longest list], internal_radii[P i32], acc[P*20 f32], rects[P uint2]
  *   image   : final_T[3*T*256 f32], n_contrib[2*T*256 u32], ranges[T uint2], tile_last[T u32], order_fwd[T u32],
  *             order_bwd[T u32], tile_counts[T u32], cursor[T u32]
  *   binning : point_list[R u32], keys[R u64: depth bits << 32 | surfel, bucketed by tile], scratch */

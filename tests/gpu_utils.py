@@ -60,7 +60,7 @@ def run_hip_raw(case, dev="cuda:0"):
     gb, bb, ib = geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()
     tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
     T = tiles_x * tiles_y
-    rec = gb[g_off[0]:g_off[0] + P * 80].view(np.float32).reshape(P, 20)
+    rec = gb[g_off[0]:g_off[0] + P * 96].view(np.float32).reshape(P, 24)
     plane = T * 256
 
     def untile(a):  # [T,256] tile-major -> [H,W]

@@ -44,7 +44,9 @@ void hm_preprocess(int P, int D, int M, const float* means3D, const float* scale
     }
 }
 
-// 1 if any pixel of tile (tx,ty) passes the alpha test for this record (branchy and branch-free variants must agree)
+// Bit w of the result: some pixel of strip w of tile (tx,ty) passes the alpha test for this record.
+// -1: the branchy and branch-free evaluations disagree; -2: a strip is reachable although the record's
+// bounding box (q5) says it is not (strip culling of the blend kernels would be wrong).
 int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
 {
     int any = 0;
@@ -56,8 +58,10 @@ int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
             const bool ka = pair_eval((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), a);
             const bool kb = pair_eval_bf((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), b);
             if (ka != kb) return -1;
-            any |= ka ? 1 : 0;
+            any |= ka ? (1 << (ly >> 2)) : 0;
         }
+    const uint32_t mask = strip_mask(r[20], r[21], r[22], r[23], (float)(tx * 16), (float)(ty * 16));
+    if (any & ~(int)mask) return -2;
     return any;
 }
 
