@@ -66,6 +66,7 @@ constexpr int kBinGroups = 256;
 
 struct BinArgs {
     int P, ntiles, tiles_x, chunk;   // chunk = surfels per workgroup
+    const uint32_t* state;  // [3] num_rendered, longest, overflow (scatter is skipped when overflow is set)
     const int* radii;
     const uint2* rects;
     const float4* rec;
@@ -131,6 +132,7 @@ __global__ void __launch_bounds__(256) scatter_keys_lds_kernel(BinArgs a)
 {
     extern __shared__ uint32_t s_cur[];
     const int g = blockIdx.x, tid = threadIdx.x;
+    if (a.state[2] != 0u) return;  // capacity overflow: nothing may be written
     for (int t = tid; t < a.ntiles; t += 256) s_cur[t] = a.M[(size_t)g * a.ntiles + t];
     __syncthreads();
     const int end = min(a.P, (g + 1) * a.chunk);
@@ -160,8 +162,11 @@ __global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P,
 // Exclusive scan of the per-tile counts (T = 2500 at 800x800, 10000 at 1600x1600) by ONE workgroup:
 // ranges[t] = [start, end) (identifyTileRanges, rasterizer_impl.cu:116-138), cursor[t] = start (scatter cursors),
 // *total_out = num_rendered (rasterizer_impl.cu:281).
+// `cap` > 0 (capacity mode, no host round trip): if the lists do not fit the pre-sized binning buffer every tile is
+// left empty (the frame renders as background) and *overflow is raised instead of writing out of bounds.
 __global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
-                                                         uint32_t* total_out /*[2]: num_rendered, longest list*/)
+                                                         uint32_t* total_out /*[3]: num_rendered, longest list, overflow*/,
+                                                         uint32_t cap, int* overflow)
 {
     __shared__ uint32_t s_wsum[4], s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,17 +185,22 @@ __global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32_t* counts,
     if (lane == 63) s_wsum[wave] = inc;
     if (lane == 0) s_wmax[wave] = mx;
     __syncthreads();
+    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const bool over = cap > 0 && total > cap;
     uint32_t run = inc - sum;
     for (int w = 0; w < wave; w++) run += s_wsum[w];
     for (int t = t0; t < t1; t++) {
-        const uint32_t c = counts[t];
+        const uint32_t c = over ? 0u : counts[t];
+        if (over) run = 0;
         ranges[t] = make_uint2(run, run + c);
         if (cursor) cursor[t] = run;
         run += c;
     }
     if (tid == 0) {
-        total_out[0] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        total_out[0] = total;
         total_out[1] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+        total_out[2] = over ? 1u : 0u;
+        if (over && overflow) atomicOr(overflow, 1);
     }
 }
 
@@ -199,6 +209,7 @@ struct ScatterArgs {
     const int* radii;
     const float4* rec;
     const uint2* rects;
+    const uint32_t* state;  // [3] num_rendered, longest, overflow
     uint32_t* cursor;       // [T] running write position of every tile bucket
     uint64_t* keys;         // [R] out: depth bits << 32 | surfel index, bucketed by tile (unordered inside a bucket)
     int tiles_x;
@@ -208,7 +219,7 @@ struct ScatterArgs {
 __global__ void __launch_bounds__(kSurfelBlock) scatter_keys_kernel(ScatterArgs a)
 {
     const int idx = blockIdx.x * kSurfelBlock + threadIdx.x;
-    if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    if (idx >= a.P || !(a.radii[idx] > 0) || a.state[2] != 0u) return;
     const uint2 r = a.rects[idx];
     const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
     if (x1 <= x0 || y1 <= y0) return;

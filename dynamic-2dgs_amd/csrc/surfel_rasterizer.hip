@@ -17,6 +17,8 @@ namespace {
 thread_local std::string g_err;
 bool g_tight_rects = true;  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
 int g_tile_order = 3;       // kernels_blend.h tile_for_block (3 = longest tile first)
+int g_capacity = 0;         // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
+int* g_overflow = nullptr;  // device flag raised by a capacity overflow
 
 int fail(int code, const std::string& msg)
 {
@@ -60,7 +62,7 @@ struct GeomLayout {
         Carver c;
         nblocks = (P + dgs::kSurfelBlock - 1) / dgs::kSurfelBlock;
         rec = c.take((size_t)P * dgs::kRecFloats * 4);
-        total = c.take(8);  // num_rendered, longest tile list
+        total = c.take(16);  // num_rendered, longest tile list, overflow flag
         internal_radii = c.take((size_t)P * 4);
         acc = c.take((size_t)P * dgs::kAccFloats * 4);
         rects = c.take((size_t)P * 8);
@@ -205,10 +207,27 @@ const char* dgs_last_error(void) { return g_err.c_str(); }
 
 void dgs_set_tight_rects(int on) { g_tight_rects = on != 0; }
 
+int dgs_read_overflow(int reset)
+{
+    if (!g_overflow) return 0;
+    int v = 0;
+    if (hipMemcpy(&v, g_overflow, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(DGS_ERR_HIP, "hipMemcpy failed");
+    if (reset && v) (void)hipMemset(g_overflow, 0, 4);
+    return v;
+}
+
 int dgs_set_option(int key, int value)
 {
     if (key == 0) { g_tight_rects = value != 0; return 0; }
     if (key == 1 && value >= 0 && value <= 3) { g_tile_order = value; return 0; }
+    if (key == 2 && value >= 0) {
+        if (value > 0 && !g_overflow) {
+            if (hipMalloc((void**)&g_overflow, 4) != hipSuccess) return fail(DGS_ERR_HIP, "hipMalloc failed");
+            (void)hipMemset(g_overflow, 0, 4);
+        }
+        g_capacity = value;
+        return 0;
+    }
     return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_set_option: unknown key / value");
 }
 
@@ -327,6 +346,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     dgs::BinArgs ba_;
     ba_.P = P; ba_.ntiles = il.ntiles; ba_.tiles_x = il.tiles_x; ba_.chunk = (P + dgs::kBinGroups - 1) / dgs::kBinGroups;
     ba_.radii = radii; ba_.rects = pa.rects; ba_.rec = pa.rec; ba_.M = cursor; ba_.keys = nullptr;
+    ba_.state = (const uint32_t*)(geom + gl.total);
     const size_t hist_bytes = (size_t)il.ntiles * 4;
     if (il.lds_bins) {
         hipLaunchKernelGGL(dgs::count_tiles_lds_kernel, dim3(dgs::kBinGroups), dim3(256), hist_bytes, stream, ba_);
@@ -340,12 +360,18 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     DGS_STAGE("count_tiles", debug, stream);
     // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
     hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(256), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
-                       il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total));
+                       il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)g_capacity, g_overflow);
     DGS_STAGE("scan_tiles", debug, stream);
 
-    // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285)
+    // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285).
+    // Capacity mode skips the round trip: the buffer is sized for g_capacity entries, every sort variant is
+    // launched (each tile picks its own), and the value returned to the caller is the capacity.
     uint32_t R_u = 0, longest = 0;
-    {
+    const bool capacity_mode = g_capacity > 0;
+    if (capacity_mode) {
+        R_u = (uint32_t)g_capacity;
+        longest = 0xffffffffu;
+    } else {
         std::lock_guard<std::mutex> lk(g_stage.mu);
         if (g_stage.ensure()) return fail(DGS_ERR_HIP, "hipHostMalloc failed");
         DGS_HIP(hipMemcpyAsync(g_stage.u, geom + gl.total, 8, hipMemcpyDeviceToHost, stream));
@@ -371,6 +397,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
         } else {
             dgs::ScatterArgs sa;
             sa.P = P; sa.radii = radii; sa.rec = pa.rec; sa.rects = pa.rects; sa.cursor = cursor;
+            sa.state = (const uint32_t*)(geom + gl.total);
             sa.keys = keys;
             sa.tiles_x = il.tiles_x;
             hipLaunchKernelGGL(dgs::scatter_keys_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, sa);

@@ -13,6 +13,8 @@ _RAYS = {}
 
 def _camera_rays(cam, device):
     """Per-camera constants of utils/point_utils.py:9-25 (cached: the reference rebuilds them per call)."""
+    if getattr(cam, "rays_d", None) is not None:  # static-buffer camera of the graph-captured train step
+        return cam.rays_d, cam.rays_o
     key = (id(cam), str(device))
     hit = _RAYS.get(key)
     if hit is not None and hit[0] is cam:
@@ -30,6 +32,11 @@ def _camera_rays(cam, device):
         _RAYS.clear()
     _RAYS[key] = (cam, rays_d, rays_o)
     return rays_d, rays_o
+
+
+def camera_rays(cam, device):
+    """(rays_d [H*W,3], rays_o [3]) of a camera: the per-view constants of depth_to_normal."""
+    return _camera_rays(cam, device)
 
 
 def depth_to_normal(cam, depth):

@@ -13,7 +13,30 @@ import torch
 import torch.distributed as dist
 
 from .losses import training_loss
-from .render import render
+from .render import camera_rays, render
+
+
+class StaticCamera:
+    """Camera whose tensors are fixed device buffers: the captured step reads them, `load` refills them per view."""
+
+    def __init__(self, cam, device):
+        self.image_height, self.image_width = cam.image_height, cam.image_width
+        self.FoVx, self.FoVy = cam.FoVx, cam.FoVy
+        self.world_view_transform = cam.world_view_transform.to(device).clone()
+        self.full_proj_transform = cam.full_proj_transform.to(device).clone()
+        self.camera_center = cam.camera_center.to(device).clone()
+        self.fid = cam.fid.to(device).clone()
+        rd, ro = camera_rays(cam, device)
+        self.rays_d, self.rays_o = rd.clone(), ro.clone()
+
+    def load(self, packed):
+        wvt, proj, center, fid, rd, ro = packed
+        self.world_view_transform.copy_(wvt, non_blocking=True)
+        self.full_proj_transform.copy_(proj, non_blocking=True)
+        self.camera_center.copy_(center, non_blocking=True)
+        self.fid.copy_(fid, non_blocking=True)
+        self.rays_d.copy_(rd, non_blocking=True)
+        self.rays_o.copy_(ro, non_blocking=True)
 
 
 class FlatGradBucket:
@@ -62,7 +85,8 @@ class Trainer:
         dev = surfels.get_xyz.device
         if fused_adam is None:
             fused_adam = dev.type == "cuda"
-        kw = {"fused": True} if fused_adam else {}
+        # capturable: the step counters live on the device, so the optimiser can be part of a HIP graph
+        kw = {"fused": True, "capturable": True} if fused_adam else {}
         self.opt_surfels = torch.optim.Adam(surfels.optimizer_groups(position_lr=position_lr), lr=0.0, eps=1e-15, **kw)
         self.opt_deform = torch.optim.Adam([
             {'params': list(deform.network.parameters()), 'lr': deform_lr, 'name': 'deform'},
@@ -71,14 +95,48 @@ class Trainer:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.iteration = 0
+        self._graph = None
 
-    def view_for(self, iteration):
-        """Shared deterministic schedule: step i renders views {i*world + rank} mod V."""
-        return (iteration * self.world + self.rank) % len(self.cameras)
+    # ---- whole-step HIP graph ------------------------------------------------------------------------------------
+    def enable_graph(self, capacity):
+        """Capture deform -> render -> loss -> backward (-> Adam when single-GPU) into HIP graphs and replay them per
+        step: the step is ~400 small launches and otherwise bound by the host, not the GPU.  Needs the rasterizer's
+        capacity mode (`capacity` list entries; no device->host read inside the step).  Per-view inputs are copied into
+        static buffers before each replay.  Under data parallelism the all-reduce stays outside the graphs."""
+        from diff_surfel_rasterization import _C
+        assert self.rasterizer_cls is None, "graph capture is for the HIP operator"
+        dev = self.surfels.get_xyz.device
+        _C.set_capacity(int(capacity))
+        self._packed = []
+        for cam in self.cameras:
+            rd, ro = camera_rays(cam, dev)
+            self._packed.append((cam.world_view_transform, cam.full_proj_transform, cam.camera_center, cam.fid, rd, ro))
+        self._scam = StaticCamera(self.cameras[0], dev)
+        self._sgt = self.targets[0].clone()
+        self._sloss = torch.zeros((), device=dev)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up on a side stream (allocations, optimiser state) as torch.cuda.graph requires
+            for _ in range(3):
+                self._fwd_bwd(self._scam, self._sgt)
+                self._finish()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1):
+            self._sloss.copy_(self._fwd_bwd(self._scam, self._sgt))
+            if self.world == 1:
+                self._finish()
+        self._g2 = None
+        if self.world > 1:
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g2):
+                self._finish(reduce=False)
+        self._graph = True
+        if _C.read_overflow():
+            raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
 
-    def step(self):
-        cam = self.cameras[self.view_for(self.iteration)]
-        gt = self.targets[self.view_for(self.iteration) % len(self.targets)]
+    def _fwd_bwd(self, cam, gt):
         s, d = self.surfels, self.deform
         self.bucket.zero()
         t = d.expand_time(cam.fid)
@@ -92,14 +150,42 @@ class Trainer:
             g2 = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
             self.bucket.extra[:self.P].copy_(torch.where(vis, g2, torch.zeros_like(g2)))
             self.bucket.extra[self.P:].copy_(vis.to(torch.float32))
-            self.bucket.all_reduce_mean()
+            if not hasattr(self, "_radii"):
+                self._radii = torch.zeros_like(pkg["radii"])
+            self._radii.copy_(torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"])))
+        return loss.detach()
+
+    def _reduce(self):
+        self.bucket.all_reduce_mean()
+        if self.world > 1:
+            dist.all_reduce(self._radii, op=dist.ReduceOp.MAX)
+
+    def _finish(self, reduce=True):
+        s = self.surfels
+        with torch.no_grad():
+            if reduce:
+                self._reduce()
             s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
             s.denom.add_(self.bucket.extra[self.P:, None])
-            radii = torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"]))
-            if self.world > 1:
-                dist.all_reduce(radii, op=dist.ReduceOp.MAX)
-            torch.maximum(s.max_radii2D, radii, out=s.max_radii2D)
+            torch.maximum(s.max_radii2D, self._radii, out=s.max_radii2D)
             self.opt_surfels.step()
             self.opt_deform.step()
+
+    def view_for(self, iteration):
+        """Shared deterministic schedule: step i renders views {i*world + rank} mod V."""
+        return (iteration * self.world + self.rank) % len(self.cameras)
+
+    def step(self):
+        v = self.view_for(self.iteration)
         self.iteration += 1
-        return loss.detach()
+        if self._graph:
+            self._scam.load(self._packed[v])
+            self._sgt.copy_(self.targets[v % len(self.targets)], non_blocking=True)
+            self._g1.replay()
+            if self._g2 is not None:
+                self._reduce()
+                self._g2.replay()
+            return self._sloss
+        loss = self._fwd_bwd(self.cameras[v], self.targets[v % len(self.targets)])
+        self._finish()
+        return loss

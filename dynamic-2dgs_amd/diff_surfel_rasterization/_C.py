@@ -27,7 +27,7 @@ _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 _lib = None
 
 _EXPORTS = ("dgs_abi_version", "dgs_last_error", "dgs_rasterizer_mark_visible", "dgs_rasterizer_forward",
-            "dgs_rasterizer_backward", "dgs_debug_layout", "dgs_set_tight_rects", "dgs_set_option", "dgs_profile_enable", "dgs_profile_reset",
+            "dgs_rasterizer_backward", "dgs_debug_layout", "dgs_set_tight_rects", "dgs_set_option", "dgs_read_overflow", "dgs_profile_enable", "dgs_profile_reset",
             "dgs_profile_read")
 
 
@@ -76,6 +76,8 @@ def load():
     lib.dgs_set_tight_rects.argtypes = [ci]
     lib.dgs_set_option.restype = ci
     lib.dgs_set_option.argtypes = [ci, ci]
+    lib.dgs_read_overflow.restype = ci
+    lib.dgs_read_overflow.argtypes = [ci]
     lib.dgs_profile_enable.restype = None
     lib.dgs_profile_enable.argtypes = [ci]
     lib.dgs_profile_reset.restype = None
@@ -249,6 +251,15 @@ def set_option(key, value):
     rc = lib.dgs_set_option(int(key), int(value))
     if rc < 0:
         _raise(lib, rc, "set_option")
+
+
+def set_capacity(n_entries):
+    """Capacity mode (dgs_set_option key 2): > 0 makes forward/backward free of host synchronisation, 0 restores it."""
+    set_option(2, int(n_entries))
+
+
+def read_overflow(reset=True):
+    return bool(load().dgs_read_overflow(1 if reset else 0))
 
 
 def profile_enable(on=True):

@@ -89,7 +89,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
 /* Byte offsets of the private sub-arrays inside the three scratch buffers, so tests can compare each
  * stage with the oracle.  which: 0 geometry (P), 1 image (W,H), 2 binning (R).  Writes up to `cap`
  * offsets, returns the number of sub-arrays; the last entry written is the total size.
- *   geometry: rec[P*24 f32], total[2 u32: num_rendered, longest list], internal_radii[P i32], acc[P*20 f32], rects[P uint2]
+ *   geometry: rec[P*24 f32], total[3 u32: num_rendered, longest list, overflow], internal_radii[P i32], acc[P*20 f32], rects[P uint2]
  *   image   : final_T[3*T*256 f32], n_contrib[2*T*256 u32], ranges[T uint2], tile_last[T u32], order_fwd[T u32],
  *             order_bwd[T u32], tile_counts[T u32], cursor[T u32]
  *   binning : point_list[R u32], keys[R u64: depth bits << 32 | surfel, bucketed by tile], scratch */
@@ -102,8 +102,16 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
 void dgs_set_tight_rects(int on);
 
 /* Development knobs for A/B measurements (defaults are the tuned values): key 0 = tight rects (0/1),
- * key 1 = blend tile order (0 row-major, 1 XCD-contiguous, 2 XCD row-interleaved, 3 longest-list-first [default]). Returns DGS_OK or an error. */
+ * key 1 = blend tile order (0 row-major, 1 XCD-contiguous, 2 XCD row-interleaved, 3 longest-list-first [default]),
+ * key 2 = capacity mode: value > 0 sizes the binning buffer for `value` list entries and removes the one
+ *         device->host read of the forward (rasterizer_impl.cu:281-282), which makes forward + backward legal inside
+ *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do
+ *         not fit renders as background and raises a flag readable with dgs_read_overflow(); value 0 restores the
+ *         exact-size mode. Returns DGS_OK or an error. */
 int dgs_set_option(int key, int value);
+
+/* 1 if a capacity overflow happened since the last reset (blocking device read; call it outside hot loops). */
+int dgs_read_overflow(int reset);
 
 /* Kernel timing hook for bench.py: when enabled, the library brackets the forward and backward blend
  * kernels with HIP events on the launch stream; dgs_profile_read returns accumulated milliseconds and

@@ -9,6 +9,8 @@ from dgs_amd.render import render
 dev = torch.device("cuda:0")
 P, H, W = bench.WORKLOADS[os.environ.get("WL", "metric")]
 tr = bench.build_trainer(P, H, W, dev)
+if os.environ.get('MLP_GRAPH', '1') == '1':
+    tr.deform.enable_graphs(tr.deform.expand_time(tr.cameras[0].fid))
 for _ in range(3):
     tr.step()
 torch.cuda.synchronize()
