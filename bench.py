@@ -24,6 +24,12 @@ import os
 import sys
 import time
 
+# ROCm 7.2 replays captured graphs through pre-recorded AQL packets by default; with this train step (memset nodes of
+# PyTorch's multi-block reductions and of the rasterizer between kernel nodes) that path intermittently executes a
+# zero-fill out of order (an L1 term of exactly 0, or 1e18 gradients, depending on host timing).  The runtime knob
+# below selects the regular graph launch path; it must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
     if _p not in sys.path:
@@ -138,8 +144,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    timed_losses = []
     for _ in range(args.steps):
-        tr.step()
+        timed_losses.append(tr.step().clone())  # device-side copy; the reference reads loss.item() every step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -147,6 +154,7 @@ def main():
     dt = time.perf_counter() - t0
     if use_graph and _C.read_overflow():
         raise SystemExit("rasterizer capacity overflow during the timed region: result invalid")
+    timed_losses = [float(x) for x in timed_losses]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -159,11 +167,15 @@ def main():
     _C.set_capacity(0)
     _C.profile_enable(True)
     _C.profile_reset()
-    for _ in range(args.steps):
-        tr.step()
+    eager_losses = [float(tr.step()) for _ in range(args.steps)]
     torch.cuda.synchronize()
     prof = _C.profile_read()
     _C.profile_enable(False)
+    # self-check of the graph replay: the eager steps continue the same training run, so the two loss series must agree
+    ref = sum(eager_losses) / len(eager_losses)
+    if not all(l == l and 0.8 * ref <= l <= 1.25 * ref for l in timed_losses):
+        raise SystemExit("graph-replayed steps disagree with eager steps (losses %s vs eager mean %.5f): result invalid"
+                         % (["%.4f" % l for l in timed_losses], ref))
 
     if rank == 0:
         ntiles = ((W + 15) // 16) * ((H + 15) // 16)

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 _WINDOWS = {}
+DEBUG_TERMS = None
 
 
 def l1_loss(a, b):
@@ -66,4 +67,8 @@ def training_loss(pkg, gt_image, lambda_dssim=0.2, lambda_normal=0.02, lambda_di
     dist_loss = lambda_dist * pkg["rend_dist"].mean()
     ll1 = l1_loss(image, gt_image)
     loss_img = (1.0 - lambda_dssim) * ll1 + lambda_dssim * (1.0 - ssim(image, gt_image))
+    if DEBUG_TERMS is not None:  # development aid: static buffers that receive the individual terms
+        for k, v in (("l1", ll1), ("ssim", loss_img * 0 + (1.0 - (loss_img - (1.0 - lambda_dssim) * ll1) / lambda_dssim)),
+                     ("normal", normal_loss), ("dist", dist_loss), ("img_mean", image.mean()), ("gt_mean", gt_image.mean())):
+            DEBUG_TERMS.setdefault(k, torch.zeros((), device=image.device)).copy_(v.detach())
     return loss_img + normal_loss + dist_loss

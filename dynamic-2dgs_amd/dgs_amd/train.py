@@ -103,8 +103,14 @@ class Trainer:
         step: the step is ~400 small launches and otherwise bound by the host, not the GPU.  Needs the rasterizer's
         capacity mode (`capacity` list entries; no device->host read inside the step).  Per-view inputs are copied into
         static buffers before each replay.  Under data parallelism the all-reduce stays outside the graphs."""
+        import os
         from diff_surfel_rasterization import _C
         assert self.rasterizer_cls is None, "graph capture is for the HIP operator"
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            # ROCm 7.2: the AQL-packet-capture replay path intermittently runs the step's memset nodes out of order
+            # (observed: an L1 loss term of exactly 0, 1e18 gradients).  The knob is read when the HIP runtime starts.
+            raise RuntimeError("set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE importing torch to use "
+                               "Trainer.enable_graph() (see DESIGN.md, 'HIP graphs')")
         dev = self.surfels.get_xyz.device
         _C.set_capacity(int(capacity))
         self._packed = []

@@ -1,5 +1,6 @@
 """Phase-level GPU time breakdown of one train step (development aid, GPU only)."""
 import os, sys, time
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
