@@ -221,6 +221,184 @@ int launch_knn(int N, int M, int D, const float* x, const float* nodes, long lon
     }
 }
 
+// ---- control-node LBS -------------------------------------------------------------------------------------------
+constexpr int kLbsK = 3;
+constexpr int kLbsHmax = 13;
+constexpr int kLbsAttr = 13;       // quaternion 4 | trans 3 | rot 4 | scale 2
+constexpr int kLbsBlocks = 256;    // backward: one partial gradient table per workgroup
+
+struct LbsArgs {
+    int N, M, H, fstride;
+    const float* x; const float* feature; const long long* idx; const float* ntab; const float* attrs; const float* mask;
+};
+
+// quaternion (r,i,j,k), not necessarily unit -> rotation matrix, utils/time_utils.py:115-132
+__device__ __forceinline__ void quat_to_mat(const float* q, float* R, float& two_s)
+{
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    R[0] = 1 - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r); R[4] = 1 - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1 - two_s * (i * i + j * j);
+}
+
+// per-point evaluation shared by forward and backward
+struct LbsPoint {
+    float w[kLbsK], e[kLbsK], dist[kLbsK], Ax[kLbsK][3];
+    float W;
+    int j[kLbsK];
+};
+
+__device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, float* xq /*[3+Hmax]*/)
+{
+    const int T = 3 + a.H + 2;
+    xq[0] = a.x[3 * n]; xq[1] = a.x[3 * n + 1]; xq[2] = a.x[3 * n + 2];
+    for (int h = 0; h < kLbsHmax; h++) xq[3 + h] = h < a.H ? a.feature[(size_t)n * a.fstride + h] : 0.f;
+    p.W = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLbsK; k++) {
+        const int j = (int)a.idx[(size_t)n * kLbsK + k];
+        p.j[k] = j;
+        const float* nd = a.ntab + (size_t)j * T;
+        float dist = 0.f;
+        for (int c = 0; c < 3 + kLbsHmax; c++)
+            if (c < 3 + a.H) { const float t = xq[c] - nd[c]; dist += t * t; }
+        const float r = nd[3 + a.H], wg = nd[3 + a.H + 1];
+        p.dist[k] = dist;
+        p.e[k] = expf(-dist / (2.f * r * r));
+        p.w[k] = p.e[k] * wg + 1e-7f;
+        p.W += p.w[k];
+        const float* at = a.attrs + (size_t)j * kLbsAttr;
+        float R[9], two_s;
+        quat_to_mat(at, R, two_s);
+        const float dx = xq[0] - nd[0], dy = xq[1] - nd[1], dz = xq[2] - nd[2];
+        p.Ax[k][0] = R[0] * dx + R[1] * dy + R[2] * dz + nd[0] + at[4];
+        p.Ax[k][1] = R[3] * dx + R[4] * dy + R[5] * dz + nd[1] + at[5];
+        p.Ax[k][2] = R[6] * dx + R[7] * dy + R[8] * dz + nd[2] + at[6];
+    }
+}
+
+__global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, float* d_rot, float* d_scale)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.N) return;
+    LbsPoint p;
+    float xq[3 + kLbsHmax];
+    lbs_eval(a, n, p, xq);
+    const float inv = 1.0f / p.W, m = a.mask[n];
+    float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0}, s[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < kLbsK; k++) {
+        const float w = p.w[k] * inv;
+        const float* at = a.attrs + (size_t)p.j[k] * kLbsAttr;
+        for (int c = 0; c < 3; c++) t[c] += w * p.Ax[k][c];
+        for (int c = 0; c < 4; c++) q[c] += w * at[7 + c];
+        for (int c = 0; c < 2; c++) s[c] += w * at[11 + c];
+    }
+    for (int c = 0; c < 3; c++) d_xyz[3 * n + c] = (t[c] - xq[c]) * m;
+    for (int c = 0; c < 4; c++) d_rot[4 * n + c] = q[c] * m;
+    for (int c = 0; c < 2; c++) d_scale[2 * n + c] = s[c] * m;
+}
+
+// Backward.  Per-node gradients (13 attribute + H+2 table columns) of the ~782 points of a workgroup are accumulated
+// in an LDS table with ds_add_f32 and written once as that workgroup's partial table; lbs_reduce_kernel sums the
+// kLbsBlocks partials.  (Direct global atomics would be ~7 M adds onto ~24 k hot addresses.)
+__global__ void __launch_bounds__(256) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
+                                                      float* g_feature, float* partial /*[kLbsBlocks][M][G]*/, int chunk)
+{
+    extern __shared__ float s_tab[];  // [M][G], G = 13 + H + 2
+    const int G = kLbsAttr + a.H + 2;
+    const int T = 3 + a.H + 2;
+    for (int i = threadIdx.x; i < a.M * G; i += 256) s_tab[i] = 0.f;
+    __syncthreads();
+    const int end = min(a.N, (int)(blockIdx.x + 1) * chunk);
+    for (int n = blockIdx.x * chunk + threadIdx.x; n < end; n += 256) {
+        LbsPoint p;
+        float xq[3 + kLbsHmax];
+        lbs_eval(a, n, p, xq);
+        const float inv = 1.0f / p.W, m = a.mask[n];
+        const float gx[3] = {g_xyz[3 * n] * m, g_xyz[3 * n + 1] * m, g_xyz[3 * n + 2] * m};
+        const float gq[4] = {g_rot[4 * n] * m, g_rot[4 * n + 1] * m, g_rot[4 * n + 2] * m, g_rot[4 * n + 3] * m};
+        const float gs[2] = {g_scale[2 * n] * m, g_scale[2 * n + 1] * m};
+        float dwh[kLbsK], mean = 0.f;  // d loss / d (normalised weight)
+#pragma unroll
+        for (int k = 0; k < kLbsK; k++) {
+            const float* at = a.attrs + (size_t)p.j[k] * kLbsAttr;
+            float v = p.Ax[k][0] * gx[0] + p.Ax[k][1] * gx[1] + p.Ax[k][2] * gx[2];
+            for (int c = 0; c < 4; c++) v += at[7 + c] * gq[c];
+            for (int c = 0; c < 2; c++) v += at[11 + c] * gs[c];
+            dwh[k] = v;
+            mean += p.w[k] * inv * v;
+        }
+        float gfeat[kLbsHmax];
+        for (int h = 0; h < kLbsHmax; h++) gfeat[h] = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLbsK; k++) {
+            const int j = p.j[k];
+            const float wn = p.w[k] * inv;
+            const float* nd = a.ntab + (size_t)j * T;
+            const float* at = a.attrs + (size_t)j * kLbsAttr;
+            float* acc = s_tab + (size_t)j * G;
+            // ---- attributes: rotation quaternion through R, translation, rotation/scale residuals
+            const float dA[3] = {wn * gx[0], wn * gx[1], wn * gx[2]};
+            const float dl[3] = {xq[0] - nd[0], xq[1] - nd[1], xq[2] - nd[2]};
+            float Gm[9];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Gm[3 * r + c] = dA[r] * dl[c];
+            {
+                const float r = at[0], i = at[1], jq = at[2], kq = at[3];
+                const float n2 = r * r + i * i + jq * jq + kq * kq, two_s = 2.0f / n2;
+                const float B[9] = {-(jq * jq + kq * kq), i * jq - kq * r, i * kq + jq * r, i * jq + kq * r, -(i * i + kq * kq),
+                                    jq * kq - i * r, i * kq - jq * r, jq * kq + i * r, -(i * i + jq * jq)};
+                float BG = 0.f;
+                for (int c = 0; c < 9; c++) BG += B[c] * Gm[c];
+                const float dBr = -kq * Gm[1] + jq * Gm[2] + kq * Gm[3] - i * Gm[5] - jq * Gm[6] + i * Gm[7];
+                const float dBi = jq * (Gm[1] + Gm[3]) + kq * (Gm[2] + Gm[6]) - 2.f * i * (Gm[4] + Gm[8]) + r * (Gm[7] - Gm[5]);
+                const float dBj = -2.f * jq * (Gm[0] + Gm[8]) + i * (Gm[1] + Gm[3]) + r * (Gm[2] - Gm[6]) + kq * (Gm[5] + Gm[7]);
+                const float dBk = -2.f * kq * (Gm[0] + Gm[4]) + r * (Gm[3] - Gm[1]) + i * (Gm[2] + Gm[6]) + jq * (Gm[5] + Gm[7]);
+                const float cs = -4.0f * BG / (n2 * n2);
+                atomicAdd(acc + 0, two_s * dBr + cs * r);
+                atomicAdd(acc + 1, two_s * dBi + cs * i);
+                atomicAdd(acc + 2, two_s * dBj + cs * jq);
+                atomicAdd(acc + 3, two_s * dBk + cs * kq);
+            }
+            for (int c = 0; c < 3; c++) atomicAdd(acc + 4 + c, dA[c]);
+            for (int c = 0; c < 4; c++) atomicAdd(acc + 7 + c, wn * gq[c]);
+            for (int c = 0; c < 2; c++) atomicAdd(acc + 11 + c, wn * gs[c]);
+            // ---- weights: w = e * weight + 1e-7, e = exp(-dist / (2 r^2)), normalised over the K neighbours
+            const float dw = (dwh[k] - mean) * inv;
+            const float rad = nd[3 + a.H], wg = nd[3 + a.H + 1];
+            const float de = dw * wg * p.e[k];
+            const float ddist = -de / (2.f * rad * rad);
+            atomicAdd(acc + kLbsAttr + a.H, de * p.dist[k] / (rad * rad * rad));  // d radius
+            atomicAdd(acc + kLbsAttr + a.H + 1, dw * p.e[k]);                     // d weight
+            for (int h = 0; h < kLbsHmax; h++)
+                if (h < a.H) {
+                    const float gd = 2.f * (xq[3 + h] - nd[3 + h]) * ddist;
+                    gfeat[h] += gd;
+                    atomicAdd(acc + kLbsAttr + h, -gd);                           // d node hyper coordinate
+                }
+        }
+        for (int h = 0; h < kLbsHmax; h++)
+            if (h < a.H) g_feature[(size_t)n * a.H + h] = gfeat[h];
+    }
+    __syncthreads();
+    float* dst = partial + (size_t)blockIdx.x * a.M * G;
+    for (int i = threadIdx.x; i < a.M * G; i += 256) dst[i] = s_tab[i];
+}
+
+__global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, int M, int H, float* g_ntab, float* g_attrs)
+{
+    const int G = kLbsAttr + H + 2, T = 3 + H + 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * G) return;
+    float acc = 0.f;
+    for (int b = 0; b < kLbsBlocks; b++) acc += partial[(size_t)b * M * G + i];
+    const int node = i / G, c = i - node * G;
+    if (c < kLbsAttr) g_attrs[(size_t)node * kLbsAttr + c] = acc;
+    else g_ntab[(size_t)node * T + 3 + (c - kLbsAttr)] = acc;
+    if (c < 3) g_ntab[(size_t)node * T + c] = 0.f;  // node positions are detached in the reference
+}
+
 }  // namespace
 
 extern "C" {
@@ -256,6 +434,47 @@ int dgs_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
                        dm_dsigma12, dL_dmean, dL_dimg1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+size_t dgs_lbs_scratch_bytes(int M, int H) { return (size_t)kLbsBlocks * (size_t)M * (size_t)(kLbsAttr + H + 2) * sizeof(float); }
+
+static int lbs_check(int N, int M, int H)
+{
+    if (N < 0 || M <= 0 || H < 0 || H > kLbsHmax) return fail(-1, "dgs_lbs: bad sizes");
+    return 0;
+}
+
+int dgs_lbs_forward(int N, int M, int H, const float* x, const float* feature, int feature_stride, const long long* idx,
+                    const float* ntab, const float* attrs, const float* mask, float* d_xyz, float* d_rot, float* d_scale,
+                    void* stream)
+{
+    if (int e = lbs_check(N, M, H)) return e;
+    if (N == 0) return 0;
+    LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask};
+    hipLaunchKernelGGL(lbs_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, d_xyz, d_rot, d_scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("lbs_fwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, int feature_stride, const long long* idx,
+                     const float* ntab, const float* attrs, const float* mask, const float* g_xyz, const float* g_rot,
+                     const float* g_scale, float* g_feature, float* g_ntab, float* g_attrs, void* scratch, void* stream)
+{
+    if (int e = lbs_check(N, M, H)) return e;
+    const int G = kLbsAttr + H + 2;
+    const size_t lds = (size_t)M * G * sizeof(float);
+    if (lds > 150 * 1024) return fail(-2, "dgs_lbs_backward: node table does not fit LDS (M * (15 + H) floats > 150 KB)");
+    if (!scratch) return fail(-1, "dgs_lbs_backward: scratch is NULL");
+    LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask};
+    const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
+    hipLaunchKernelGGL(lbs_bwd_kernel, dim3(kLbsBlocks), dim3(256), lds, (hipStream_t)stream, a, g_xyz, g_rot, g_scale, g_feature,
+                       (float*)scratch, chunk > 0 ? chunk : 1);
+    hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
+                       g_ntab, g_attrs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("lbs_bwd_kernel: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -11,7 +11,8 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "libdgs_train_ops.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
 _lib = None
-_EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_forward", "dgs_ssim_backward", "dgs_knn_points")
+_EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_forward", "dgs_ssim_backward", "dgs_knn_points",
+            "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward")
 
 
 def build(force=False, verbose=False):
@@ -45,6 +46,12 @@ def load():
         lib.dgs_ssim_backward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dgs_knn_points.restype = ci
         lib.dgs_knn_points.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp]
+        lib.dgs_lbs_scratch_bytes.restype = ctypes.c_size_t
+        lib.dgs_lbs_scratch_bytes.argtypes = [ci, ci]
+        lib.dgs_lbs_forward.restype = ci
+        lib.dgs_lbs_forward.argtypes = [ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.dgs_lbs_backward.restype = ci
+        lib.dgs_lbs_backward.argtypes = [ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         if lib.dgs_train_ops_abi_version() != 1:
             raise RuntimeError("libdgs_train_ops.so ABI version mismatch")
         _lib = lib
@@ -109,3 +116,55 @@ def knn_indices(x, nodes, K):
         rc = lib.dgs_knn_points(N, nodes.shape[0], D, K, x.data_ptr(), nodes.data_ptr(), idx.data_ptr(), None, _stream(x.device))
     _check(lib, rc, "dgs_knn_points")
     return idx
+
+
+class _FusedLBS(torch.autograd.Function):
+    """Control-node blend skinning (dgs_lbs_forward / dgs_lbs_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, feature, idx, ntab, attrs, mask, H):
+        lib = load()
+        x, feature, idx = x.contiguous(), feature.contiguous(), idx.contiguous()
+        ntab, attrs, mask = ntab.contiguous(), attrs.contiguous(), mask.contiguous().reshape(-1)
+        N, M = x.shape[0], ntab.shape[0]
+        d_xyz = torch.empty((N, 3), dtype=torch.float32, device=x.device)
+        d_rot = torch.empty((N, 4), dtype=torch.float32, device=x.device)
+        d_scale = torch.empty((N, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dgs_lbs_forward(N, M, H, x.data_ptr(), feature.data_ptr(), feature.shape[1], idx.data_ptr(), ntab.data_ptr(),
+                                     attrs.data_ptr(), mask.data_ptr(), d_xyz.data_ptr(), d_rot.data_ptr(), d_scale.data_ptr(),
+                                     _stream(x.device))
+        _check(lib, rc, "dgs_lbs_forward")
+        ctx.save_for_backward(x, feature, idx, ntab, attrs, mask)
+        ctx.H = H
+        return d_xyz, d_rot, d_scale
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_scale):
+        lib = load()
+        x, feature, idx, ntab, attrs, mask = ctx.saved_tensors
+        H, N, M = ctx.H, x.shape[0], ntab.shape[0]
+        dev = x.device
+        z = lambda g, c: torch.zeros((N, c), dtype=torch.float32, device=dev) if g is None else g.contiguous()
+        g_xyz, g_rot, g_scale = z(g_xyz, 3), z(g_rot, 4), z(g_scale, 2)
+        g_feat = torch.zeros_like(feature)
+        g_feat_h = torch.empty((N, H), dtype=torch.float32, device=dev)
+        g_ntab = torch.empty_like(ntab)
+        g_attrs = torch.empty_like(attrs)
+        scratch = torch.empty(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dgs_lbs_backward(N, M, H, x.data_ptr(), feature.data_ptr(), feature.shape[1], idx.data_ptr(), ntab.data_ptr(),
+                                      attrs.data_ptr(), mask.data_ptr(), g_xyz.data_ptr(), g_rot.data_ptr(), g_scale.data_ptr(),
+                                      g_feat_h.data_ptr(), g_ntab.data_ptr(), g_attrs.data_ptr(), scratch.data_ptr(), _stream(dev))
+        _check(lib, rc, "dgs_lbs_backward")
+        g_feat[:, :H] = g_feat_h
+        return None, g_feat, None, g_ntab, g_attrs, None, None
+
+
+def fused_lbs(x, feature, idx, ntab, attrs, mask, H):
+    """(d_xyz, d_rotation, d_scaling) of ControlNodeWarp.forward (local frame, K = 3) from the per-node tables."""
+    return _FusedLBS.apply(x, feature, idx, ntab, attrs, mask, H)
+
+
+def lbs_supported(M, H):
+    return H <= 13 and M * (15 + H) * 4 <= 150 * 1024

@@ -12,6 +12,8 @@
 #ifndef DGS_TRAIN_OPS_H
 #define DGS_TRAIN_OPS_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -38,6 +40,24 @@ int dgs_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
  * x: [N,D], nodes: [M,D], 1 <= D <= 16, 1 <= K <= 4, K <= M.  idx: [N,K] int64.  dist2 (may be NULL): [N,K]. */
 int dgs_knn_points(int N, int M, int D, int K, const float* x, const float* nodes, long long* idx, float* dist2,
                    void* stream);
+
+/* Control-node linear blend skinning: ControlNodeWarp.forward with local frames (utils/time_utils.py:1139-1194) and
+ * cal_nn_weight (:956-962) fused into one kernel per direction.  K = 3 neighbours, H = hyper dims (<= 13).
+ *   x[N,3] surfel centres (no gradient), feature[N,feature_stride] (first H columns used, gradient), idx[N,3] int64,
+ *   ntab[M, 3+H+2]  = per node [xyz(3, no gradient) | hyper(H) | radius | weight]      (radius = exp(_node_radius),
+ *                                                                                       weight = sigmoid(_node_weight))
+ *   attrs[M,13]     = per node [local rotation quaternion r,i,j,k (bias already added) | d_xyz(3) | d_rotation(4) | d_scaling(2)]
+ *   mask[N]         motion mask (no gradient)
+ * forward : d_xyz[N,3], d_rot[N,4], d_scale[N,2]
+ * backward: g_feature[N,H] (overwritten), g_ntab[M,3+H+2], g_attrs[M,13] (overwritten; xyz columns of g_ntab are 0).
+ *           scratch: at least dgs_lbs_scratch_bytes(M, H) bytes. */
+size_t dgs_lbs_scratch_bytes(int M, int H);
+int dgs_lbs_forward(int N, int M, int H, const float* x, const float* feature, int feature_stride, const long long* idx,
+                    const float* ntab, const float* attrs, const float* mask, float* d_xyz, float* d_rot, float* d_scale,
+                    void* stream);
+int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, int feature_stride, const long long* idx,
+                     const float* ntab, const float* attrs, const float* mask, const float* g_xyz, const float* g_rot,
+                     const float* g_scale, float* g_feature, float* g_ntab, float* g_attrs, void* scratch, void* stream);
 
 #ifdef __cplusplus
 }

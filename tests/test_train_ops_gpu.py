@@ -87,3 +87,51 @@ def test_capacity_overflow_is_flagged_not_fatal():
         _C.set_capacity(0)
     out = run_hip(case, debug=False)
     assert abs(out["color"]).max() > 0
+
+
+def test_fused_lbs_matches_torch_autograd():
+    """dgs_lbs_forward/backward against the PyTorch formulation of ControlNodes.forward (itself golden-pinned
+    against the reference on the CPU): outputs and every gradient that leaves the deformation module."""
+    from dgs_amd.deform import ControlNodes
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(3)
+    N, Mn = 5000, 256
+    x = ((torch.rand(N, 3, generator=g) * 2 - 1) * 1.3).cuda()
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(1)
+        m = ControlNodes(node_num=Mn, K=3, hyper_dim=8, local_frame=True).cuda()
+        m.init_from_points(x)
+        with torch.no_grad():
+            m.nodes[:, 3:] += 0.02 * torch.randn(Mn, 8, generator=g).cuda()
+            m._node_weight += 0.5 * torch.randn(Mn, 1, generator=g).cuda()
+            m._node_radius += 0.2 * torch.randn(Mn, generator=g).cuda()
+            for head in (m.network.gaussian_warp, m.network.gaussian_rotation, m.network.gaussian_scaling, m.network.local_rotation):
+                head.weight.mul_(3e3)
+        g = torch.Generator().manual_seed(3)  # same draws for both variants
+        _ = torch.rand(N, 3, generator=g)
+        m.use_fused = fused
+        feature = (0.05 * torch.randn(N, 8, generator=torch.Generator().manual_seed(5))).cuda().requires_grad_(True)
+        mask = torch.sigmoid(torch.randn(N, 1, generator=torch.Generator().manual_seed(6))).cuda()
+        t = torch.full((Mn, 1), 0.37).cuda()
+        out = m(x, t, feature, mask)
+        cot = [torch.randn(N, c, generator=torch.Generator().manual_seed(7 + c)).cuda() for c in (3, 4, 2)]
+        loss = (out['d_xyz'] * cot[0]).sum() + (out['d_rotation'] * cot[1]).sum() + (out['d_scaling'] * cot[2]).sum()
+        loss.backward()
+        res[fused] = dict(out={k: v.detach() for k, v in out.items()}, feature=feature.grad.clone(), nodes=m.nodes.grad.clone(),
+                          radius=m._node_radius.grad.clone(), weight=m._node_weight.grad.clone(),
+                          net={n: p.grad.clone() for n, p in m.network.named_parameters()})
+    a, b = res[False], res[True]
+
+    def close(u, v, name, tol=2e-4):
+        scale = max(float(u.abs().max()), 1e-12)
+        err = float((u - v).abs().max())
+        assert err <= tol * scale, "%s: err %.3e scale %.3e" % (name, err, scale)
+
+    for k in a["out"]:
+        close(a["out"][k], b["out"][k], k, 1e-5)
+    for k in ("feature", "nodes", "radius", "weight"):
+        close(a[k], b[k], "grad " + k)
+    assert float(b["nodes"][:, :3].abs().max()) == 0.0
+    for n in a["net"]:
+        close(a["net"][n], b["net"][n], "grad net." + n, 5e-4)
