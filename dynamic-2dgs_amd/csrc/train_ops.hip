@@ -144,20 +144,28 @@ constexpr int kKnnChunk = 1024;  // nodes staged per pass
 constexpr int kKnnDpad = 16;
 
 // Q = number of float4 per (zero-padded) node row: D <= 4*Q.  Compile-time so that the distance loop fully
-// unrolls and the wave-uniform node reads become ds_read_b128 broadcasts.
+// unrolls and the wave-uniform node reads become ds_read_b128 broadcasts.  Every thread owns kKnnPts query points:
+// one set of LDS reads feeds kKnnPts independent distance chains (the loop is latency-, not throughput-bound).
+constexpr int kKnnPts = 2;
+constexpr int kKnnGrp = 4;
+
 template <int K, int Q>
 __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
                                                   long long* __restrict__ idx, float* __restrict__ dist2)
 {
     __shared__ float4 s_nodes[kKnnChunk * Q];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    float xv[4 * Q];
+    const int p0 = (blockIdx.x * 256 + threadIdx.x) * kKnnPts;
+    float xv[kKnnPts][4 * Q];
 #pragma unroll
-    for (int d = 0; d < 4 * Q; d++) xv[d] = (p < N && d < D) ? x[(size_t)p * D + d] : 0.f;
-    float bd[K];
-    int bi[K];
+    for (int u = 0; u < kKnnPts; u++)
 #pragma unroll
-    for (int k = 0; k < K; k++) { bd[k] = INFINITY; bi[k] = 0; }
+        for (int d = 0; d < 4 * Q; d++) xv[u][d] = (p0 + u < N && d < D) ? x[(size_t)(p0 + u) * D + d] : 0.f;
+    float bd[kKnnPts][K];
+    int bi[kKnnPts][K];
+#pragma unroll
+    for (int u = 0; u < kKnnPts; u++)
+#pragma unroll
+        for (int k = 0; k < K; k++) { bd[u][k] = INFINITY; bi[u][k] = 0; }
     for (int base = 0; base < M; base += kKnnChunk) {
         const int cnt = (M - base) < kKnnChunk ? (M - base) : kKnnChunk;
         __syncthreads();
@@ -167,44 +175,72 @@ __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const flo
             s_flat[i] = d < D ? nodes[(size_t)(base + r) * D + d] : 0.f;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < cnt; j++) {
-            float acc = 0.f;
+        // groups of kKnnGrp nodes: all LDS reads of a group are issued before the first use, the kKnnPts x kKnnGrp
+        // distances are independent FMA chains, and the (rare) insertions come last
+        for (int j0 = 0; j0 < cnt; j0 += kKnnGrp) {
+            float4 nd[kKnnGrp][Q];
 #pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const float4 nd = s_nodes[j * Q + q];  // wave-uniform address: LDS broadcast
-                float t;
-                t = xv[4 * q + 0] - nd.x; acc += t * t;
-                t = xv[4 * q + 1] - nd.y; acc += t * t;
-                t = xv[4 * q + 2] - nd.z; acc += t * t;
-                t = xv[4 * q + 3] - nd.w; acc += t * t;
-            }
-            // insertion into the sorted K best; strict < keeps the lower index on ties
-            if (acc < bd[K - 1]) {
-                bd[K - 1] = acc; bi[K - 1] = base + j;
+            for (int g = 0; g < kKnnGrp; g++)
 #pragma unroll
-                for (int k = K - 1; k > 0; k--) {
-                    if (bd[k] < bd[k - 1]) {
-                        const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
-                        const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+                for (int q = 0; q < Q; q++) nd[g][q] = s_nodes[min(j0 + g, cnt - 1) * Q + q];  // wave-uniform: LDS broadcast
+            // (A v_pk_add_f32 / v_pk_fma_f32 formulation pairing the two points was measured at the same 0.23 ms: packed
+            // fp32 does not issue faster than two scalar ops on gfx950 and needs extra moves to splat the node value.)
+            float acc[kKnnPts][kKnnGrp];
+#pragma unroll
+            for (int u = 0; u < kKnnPts; u++)
+#pragma unroll
+                for (int g = 0; g < kKnnGrp; g++) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        float t;
+                        t = xv[u][4 * q + 0] - nd[g][q].x; a += t * t;
+                        t = xv[u][4 * q + 1] - nd[g][q].y; a += t * t;
+                        t = xv[u][4 * q + 2] - nd[g][q].z; a += t * t;
+                        t = xv[u][4 * q + 3] - nd[g][q].w; a += t * t;
+                    }
+                    acc[u][g] = (j0 + g < cnt) ? a : INFINITY;
+                }
+#pragma unroll
+            for (int u = 0; u < kKnnPts; u++) {
+                float best = acc[u][0];
+#pragma unroll
+                for (int g = 1; g < kKnnGrp; g++) best = fminf(best, acc[u][g]);
+                if (best < bd[u][K - 1]) {
+#pragma unroll
+                    for (int g = 0; g < kKnnGrp; g++) {
+                        // insertion into the sorted K best; strict < keeps the lower index on ties
+                        if (acc[u][g] < bd[u][K - 1]) {
+                            bd[u][K - 1] = acc[u][g]; bi[u][K - 1] = base + j0 + g;
+#pragma unroll
+                            for (int k = K - 1; k > 0; k--) {
+                                if (bd[u][k] < bd[u][k - 1]) {
+                                    const float td = bd[u][k]; bd[u][k] = bd[u][k - 1]; bd[u][k - 1] = td;
+                                    const int ti = bi[u][k]; bi[u][k] = bi[u][k - 1]; bi[u][k - 1] = ti;
+                                }
+                            }
+                        }
                     }
                 }
             }
         }
     }
-    if (p < N) {
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            idx[(size_t)p * K + k] = bi[k];
-            if (dist2) dist2[(size_t)p * K + k] = bd[k];
+    for (int u = 0; u < kKnnPts; u++)
+        if (p0 + u < N) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                idx[(size_t)(p0 + u) * K + k] = bi[u][k];
+                if (dist2) dist2[(size_t)(p0 + u) * K + k] = bd[u][k];
+            }
         }
-    }
 }
 
 template <int K, int Q>
 int launch_knn_q(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s)
 {
-    hipLaunchKernelGGL((knn_kernel<K, Q>), dim3((N + 255) / 256), dim3(256), 0, s, N, M, D, x, nodes, idx, dist2);
+    const int per_block = 256 * kKnnPts;
+    hipLaunchKernelGGL((knn_kernel<K, Q>), dim3((N + per_block - 1) / per_block), dim3(256), 0, s, N, M, D, x, nodes, idx, dist2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("knn_kernel: ") + hipGetErrorString(e));
     return 0;
