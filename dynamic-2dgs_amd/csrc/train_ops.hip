@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <string>
+#include <vector>
 
 #include "../../include/dgs_train_ops.h"
 
@@ -435,6 +436,49 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, i
     if (c < 3) g_ntab[(size_t)node * T + c] = 0.f;  // node positions are detached in the reference
 }
 
+// ---- flat Adam --------------------------------------------------------------------------------------------------
+constexpr int kAdamSeg = 64;
+constexpr int kAdamChunk = 4096;   // elements per workgroup (256 threads x 16)
+
+struct AdamSegs {
+    float* p[kAdamSeg];
+    long long off[kAdamSeg + 1];
+    float lr[kAdamSeg];
+};
+
+__global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step_count,
+                                                   float b1, float b2, float eps)
+{
+    const int2 pl = plan[blockIdx.x];            // (segment, first element of this block inside the segment)
+    const int s = pl.x;
+    const long long seg_len = sg.off[s + 1] - sg.off[s];
+    const float t = step_count[0];
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    const float step_size = sg.lr[s] / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    float* __restrict__ p = sg.p[s];
+    const long long base = sg.off[s];
+#pragma unroll 4
+    for (int k = 0; k < kAdamChunk / 256; k++) {
+        const long long i = (long long)pl.y + k * 256 + threadIdx.x;
+        if (i < seg_len) {
+            const float g = grad[base + i];
+            const float mi = b1 * m[base + i] + (1.0f - b1) * g;
+            const float vi = b2 * v[base + i] + (1.0f - b2) * g * g;
+            m[base + i] = mi;
+            v[base + i] = vi;
+            p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        }
+    }
+}
+
+long long adam_blocks(int nseg, const long long* off)
+{
+    long long nb = 0;
+    for (int s = 0; s < nseg; s++) nb += (off[s + 1] - off[s] + kAdamChunk - 1) / kAdamChunk;
+    return nb;
+}
+
 }  // namespace
 
 extern "C" {
@@ -511,6 +555,38 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
                        g_ntab, g_attrs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("lbs_bwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+size_t dgs_adam_plan_bytes(long long total) { return (size_t)(total / kAdamChunk + kAdamSeg + 1) * sizeof(int2); }
+
+int dgs_adam_plan(int nseg, const long long* offsets, void* plan, void* stream)
+{
+    if (nseg <= 0 || nseg > kAdamSeg || !offsets || !plan) return fail(-1, "dgs_adam_plan: bad argument");
+    std::vector<int2> host;
+    for (int s = 0; s < nseg; s++)
+        for (long long b = 0; b < offsets[s + 1] - offsets[s]; b += kAdamChunk) host.push_back(make_int2(s, (int)b));
+    if (host.empty()) return 0;
+    hipError_t e = hipMemcpyAsync(plan, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);  // `host` dies at return
+    if (e != hipSuccess) return fail(-4, std::string("dgs_adam_plan: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_adam_step(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* grad, float* exp_avg,
+                  float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
+{
+    if (nseg <= 0 || nseg > kAdamSeg || !params || !offsets || !lrs || !grad || !exp_avg || !exp_avg_sq || !step_count || !plan)
+        return fail(-1, "dgs_adam_step: bad argument");
+    AdamSegs sg;
+    for (int s = 0; s < nseg; s++) { sg.p[s] = params[s]; sg.off[s] = offsets[s]; sg.lr[s] = lrs[s]; }
+    sg.off[nseg] = offsets[nseg];
+    const long long nb = adam_blocks(nseg, offsets);
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, grad, exp_avg,
+                       exp_avg_sq, step_count, beta1, beta2, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("adam_kernel: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_CSRC, "libdgs_train_ops.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
 _lib = None
 _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_forward", "dgs_ssim_backward", "dgs_knn_points",
-            "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward")
+            "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step")
 
 
 def build(force=False, verbose=False):
@@ -52,6 +52,12 @@ def load():
         lib.dgs_lbs_forward.argtypes = [ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dgs_lbs_backward.restype = ci
         lib.dgs_lbs_backward.argtypes = [ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.dgs_adam_plan_bytes.restype = ctypes.c_size_t
+        lib.dgs_adam_plan_bytes.argtypes = [ctypes.c_longlong]
+        lib.dgs_adam_plan.restype = ci
+        lib.dgs_adam_plan.argtypes = [ci, vp, vp, vp]
+        lib.dgs_adam_step.restype = ci
+        lib.dgs_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp]
         if lib.dgs_train_ops_abi_version() != 1:
             raise RuntimeError("libdgs_train_ops.so ABI version mismatch")
         _lib = lib
@@ -168,3 +174,43 @@ def fused_lbs(x, feature, idx, ntab, attrs, mask, H):
 
 def lbs_supported(M, H):
     return H <= 13 and M * (15 + H) * 4 <= 150 * 1024
+
+
+class FlatAdam:
+    """torch.optim.Adam (betas, eps, no weight decay) over parameters whose .grad tensors are consecutive views of
+    one flat fp32 buffer (dgs_amd.train.FlatGradBucket): ONE kernel launch per step instead of one multi-tensor
+    launch per parameter group, with the step counter on the device (HIP-graph capturable)."""
+
+    def __init__(self, params, lrs, flat_grad, betas=(0.9, 0.999), eps=1e-15):
+        lib = load()
+        assert len(params) == len(lrs) <= 64
+        self.params, self.lrs, self.betas, self.eps = list(params), [float(l) for l in lrs], betas, float(eps)
+        dev = flat_grad.device
+        n = sum(p.numel() for p in self.params)
+        assert flat_grad.numel() >= n and flat_grad.is_contiguous()
+        off = [0]
+        for p in self.params:
+            assert p.is_contiguous() and p.dtype == torch.float32 and p.grad.data_ptr() == flat_grad.data_ptr() + 4 * off[-1]
+            off.append(off[-1] + p.numel())
+        self.grad = flat_grad
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._n = len(self.params)
+        self._ptrs = (ctypes.c_void_p * self._n)(*[p.data_ptr() for p in self.params])
+        self._off = (ctypes.c_longlong * (self._n + 1))(*off)
+        self._lr = (ctypes.c_float * self._n)(*self.lrs)
+        self.plan = torch.empty(int(lib.dgs_adam_plan_bytes(n)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _check(lib, lib.dgs_adam_plan(self._n, self._off, self.plan.data_ptr(), _stream(dev)), "dgs_adam_plan")
+
+    @torch.no_grad()
+    def step(self):
+        lib = load()
+        dev = self.grad.device
+        self.t.add_(1.0)
+        with torch.cuda.device(dev):
+            rc = lib.dgs_adam_step(self._n, self._ptrs, self._off, self._lr, self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                   self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0], self.betas[1], self.eps,
+                                   self.plan.data_ptr(), _stream(dev))
+        _check(lib, rc, "dgs_adam_step")

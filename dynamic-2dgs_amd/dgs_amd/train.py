@@ -85,13 +85,20 @@ class Trainer:
         dev = surfels.get_xyz.device
         if fused_adam is None:
             fused_adam = dev.type == "cuda"
-        # capturable: the step counters live on the device, so the optimiser can be part of a HIP graph
-        kw = {"fused": True, "capturable": True} if fused_adam else {}
-        self.opt_surfels = torch.optim.Adam(surfels.optimizer_groups(position_lr=position_lr), lr=0.0, eps=1e-15, **kw)
-        self.opt_deform = torch.optim.Adam([
+        groups = surfels.optimizer_groups(position_lr=position_lr)
+        deform_groups = [
             {'params': list(deform.network.parameters()), 'lr': deform_lr, 'name': 'deform'},
-            {'params': [deform.nodes, deform._node_radius, deform._node_weight], 'lr': deform_lr, 'name': 'nodes'}],
-            lr=0.0, eps=1e-15, **kw)
+            {'params': [deform.nodes, deform._node_radius, deform._node_weight], 'lr': deform_lr, 'name': 'nodes'}]
+        if fused_adam:
+            # HIP device: one flat Adam launch for surfels + deformation (csrc/train_ops.hip); step counter on the device
+            from . import _ops
+            lr_of = {id(p): g['lr'] for g in groups + deform_groups for p in g['params']}
+            plist = self.bucket.params  # bucket order == layout of the flat gradient buffer
+            self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat)
+            self.opt_deform = None
+        else:
+            self.opt_surfels = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+            self.opt_deform = torch.optim.Adam(deform_groups, lr=0.0, eps=1e-15)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.iteration = 0
@@ -175,7 +182,8 @@ class Trainer:
             s.denom.add_(self.bucket.extra[self.P:, None])
             torch.maximum(s.max_radii2D, self._radii, out=s.max_radii2D)
             self.opt_surfels.step()
-            self.opt_deform.step()
+            if self.opt_deform is not None:
+                self.opt_deform.step()
 
     def view_for(self, iteration):
         """Shared deterministic schedule: step i renders views {i*world + rank} mod V."""

@@ -59,6 +59,18 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
                      const float* ntab, const float* attrs, const float* mask, const float* g_xyz, const float* g_rot,
                      const float* g_scale, float* g_feature, float* g_ntab, float* g_attrs, void* scratch, void* stream);
 
+/* One-launch Adam over a flat gradient bucket (torch.optim.Adam semantics: no weight decay, no amsgrad), replacing
+ * the per-group multi_tensor_apply launches of gaussians.optimizer.step() + deform.optimizer.step()
+ * (train_gui.py:427-431).  Parameters stay separate allocations: segment s owns elements
+ * [offsets[s], offsets[s+1]) of grad / exp_avg / exp_avg_sq and updates params[s][0 .. len) with learning rate lrs[s].
+ * `plan` is an opaque device buffer of dgs_adam_plan_bytes(total) bytes that dgs_adam_plan() fills once (block -> segment
+ * map); step_count is a DEVICE float holding t (1 for the first step), so the call is stream-capture safe. nseg <= 64. */
+size_t dgs_adam_plan_bytes(long long total);
+int dgs_adam_plan(int nseg, const long long* offsets /*host, nseg+1*/, void* plan, void* stream);
+int dgs_adam_step(int nseg, float* const* params /*host array of device pointers*/, const long long* offsets /*host*/,
+                  const float* lrs /*host*/, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
+                  float beta1, float beta2, float eps, const void* plan, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,25 @@ def test_fused_lbs_matches_torch_autograd():
     assert float(b["nodes"][:, :3].abs().max()) == 0.0
     for n in a["net"]:
         close(a["net"][n], b["net"][n], "grad net." + n, 5e-4)
+
+
+def test_flat_adam_matches_torch_adam():
+    from dgs_amd import _ops
+    from dgs_amd.train import FlatGradBucket
+    torch.manual_seed(0)
+    shapes = [(1000, 3), (1000, 15, 3), (7,), (256, 93), (1, 1), (5000,)]
+    lrs = [8e-6, 2e-4, 0.05, 1.6e-6, 0.01, 0.002]
+    a = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    bucket = FlatGradBucket(a)
+    flat = _ops.FlatAdam(a, lrs, bucket.flat)
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=0.0, eps=1e-15)
+    for it in range(4):
+        g = [torch.randn(*s, generator=torch.Generator().manual_seed(10 * it + i)).cuda() * (10.0 ** (i - 3)) for i, s in enumerate(shapes)]
+        for p, q, gi in zip(a, b, g):
+            p.grad.copy_(gi)
+            q.grad = gi.clone()
+        flat.step()
+        ref.step()
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), float((p - q).abs().max())

@@ -32,4 +32,4 @@ for it in range(8):
         msg.append("%s %.1e" % (n, float(torch.nan_to_num(p.grad, 0, 0, 0).abs().max())))
     print("  ".join(msg), flush=True)
     with torch.no_grad():
-        tr.opt_surfels.step(); tr.opt_deform.step()
+        tr.opt_surfels.step(); (tr.opt_deform.step() if tr.opt_deform is not None else None)

@@ -38,7 +38,7 @@ for it in range(N):
         tr.bucket.extra[tr.P:].copy_(vis.to(torch.float32))
         tr.bucket.all_reduce_mean()
     ev[6].record()
-    tr.opt_surfels.step(); tr.opt_deform.step()
+    tr.opt_surfels.step(); (tr.opt_deform.step() if tr.opt_deform is not None else None)
     ev[7].record()
     torch.cuda.synchronize()
     wall += time.perf_counter() - t0
