@@ -436,6 +436,116 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, i
     if (c < 3) g_ntab[(size_t)node * T + c] = 0.f;  // node positions are detached in the reference
 }
 
+// ---- fused regulariser loss -----------------------------------------------------------------------------------------
+__device__ __forceinline__ float clean_depth(float d)  // torch.nan_to_num(x, 0, 0): nan -> 0, +inf -> 0, -inf -> lowest
+{
+    if (d != d) return 0.f;
+    if (d == INFINITY) return 0.f;
+    if (d == -INFINITY) return -3.4028234663852886e38f;
+    return d;
+}
+
+struct RegArgs {
+    int H, W;
+    const float* allmap; const float* rays_d; const float* rays_o; const float* wvt;
+    float ln, ld;
+};
+
+// back-projected point of pixel (y, x)
+__device__ __forceinline__ void reg_point(const RegArgs& a, int y, int x, float* p)
+{
+    const size_t q = (size_t)y * a.W + x;
+    const float d = clean_depth(a.allmap[5 * (size_t)a.H * a.W + q]);
+    p[0] = d * a.rays_d[3 * q] + a.rays_o[0];
+    p[1] = d * a.rays_d[3 * q + 1] + a.rays_o[1];
+    p[2] = d * a.rays_d[3 * q + 2] + a.rays_o[2];
+}
+
+// un-normalised normal v = dx x dy at an interior pixel, dx = p[y+1] - p[y-1], dy = p[x+1] - p[x-1]
+__device__ __forceinline__ void reg_cross(const RegArgs& a, int y, int x, float* dx, float* dy, float* v)
+{
+    float pu[3], pd[3], pl[3], pr[3];
+    reg_point(a, y + 1, x, pd); reg_point(a, y - 1, x, pu); reg_point(a, y, x + 1, pr); reg_point(a, y, x - 1, pl);
+    for (int c = 0; c < 3; c++) { dx[c] = pd[c] - pu[c]; dy[c] = pr[c] - pl[c]; }
+    v[0] = dx[1] * dy[2] - dx[2] * dy[1];
+    v[1] = dx[2] * dy[0] - dx[0] * dy[2];
+    v[2] = dx[0] * dy[1] - dx[1] * dy[0];
+}
+
+__global__ void __launch_bounds__(256) regloss_fwd_kernel(RegArgs a, float* loss)
+{
+    __shared__ float s_red[4];
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const size_t HW = (size_t)a.H * a.W;
+    float val = 0.f;
+    if (x < a.W && y < a.H) {
+        const size_t q = (size_t)y * a.W + x;
+        float dot = 0.f;
+        if (x >= 1 && y >= 1 && x < a.W - 1 && y < a.H - 1) {
+            float dx[3], dy[3], v[3];
+            reg_cross(a, y, x, dx, dy, v);
+            const float L = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            const float inv = a.allmap[HW + q] / fmaxf(L, 1e-12f);  // normalize(), then * alpha
+            const float nv[3] = {a.allmap[2 * HW + q], a.allmap[3 * HW + q], a.allmap[4 * HW + q]};
+            for (int c = 0; c < 3; c++) {
+                const float nw = nv[0] * a.wvt[4 * c] + nv[1] * a.wvt[4 * c + 1] + nv[2] * a.wvt[4 * c + 2];  // n_view @ wvt[:3,:3].T
+                dot += nw * v[c] * inv;
+            }
+        }
+        val = (a.ln * (1.f - dot) + a.ld * a.allmap[6 * HW + q]) / (float)HW;
+    }
+    for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = val;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+__global__ void __launch_bounds__(256) regloss_bwd_kernel(RegArgs a, const float* g, float* d_allmap)
+{
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= a.W || y >= a.H) return;
+    const size_t HW = (size_t)a.H * a.W, q = (size_t)y * a.W + x;
+    const float gs = g[0] / (float)HW;
+    d_allmap[6 * HW + q] = gs * a.ld;
+    if (!(x >= 1 && y >= 1 && x < a.W - 1 && y < a.H - 1)) return;
+    float dx[3], dy[3], v[3];
+    reg_cross(a, y, x, dx, dy, v);
+    const float L = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float alpha = a.allmap[HW + q];
+    const float denom = fmaxf(L, 1e-12f);
+    const float n[3] = {v[0] / denom, v[1] / denom, v[2] / denom};
+    const float nv[3] = {a.allmap[2 * HW + q], a.allmap[3 * HW + q], a.allmap[4 * HW + q]};
+    float nw[3];
+    for (int c = 0; c < 3; c++) nw[c] = nv[0] * a.wvt[4 * c] + nv[1] * a.wvt[4 * c + 1] + nv[2] * a.wvt[4 * c + 2];
+    const float k = -gs * a.ln;
+    // d / d rend_normal (view space): -lambda/HW * wvt[:3,:3]^T-rotated surf_normal
+    for (int kk = 0; kk < 3; kk++) {
+        float acc = 0.f;
+        for (int c = 0; c < 3; c++) acc += a.wvt[4 * c + kk] * (n[c] * alpha);
+        d_allmap[(2 + kk) * HW + q] = k * acc;
+    }
+    // d / d n (alpha is detached), then through F.normalize and the cross product
+    float dn[3] = {k * nw[0] * alpha, k * nw[1] * alpha, k * nw[2] * alpha}, dv[3];
+    if (L >= 1e-12f) {
+        const float nd = n[0] * dn[0] + n[1] * dn[1] + n[2] * dn[2];
+        for (int c = 0; c < 3; c++) dv[c] = (dn[c] - n[c] * nd) / L;
+    } else {
+        for (int c = 0; c < 3; c++) dv[c] = dn[c] / 1e-12f;
+    }
+    const float ddx[3] = {dy[1] * dv[2] - dy[2] * dv[1], dy[2] * dv[0] - dy[0] * dv[2], dy[0] * dv[1] - dy[1] * dv[0]};  // dy x dv
+    const float ddy[3] = {dv[1] * dx[2] - dv[2] * dx[1], dv[2] * dx[0] - dv[0] * dx[2], dv[0] * dx[1] - dv[1] * dx[0]};  // dv x dx
+    float* dd = d_allmap + 5 * HW;
+    const int ys[4] = {y + 1, y - 1, y, y}, xs[4] = {x, x, x + 1, x - 1};
+    const float sg[4] = {1.f, -1.f, 1.f, -1.f};
+    for (int i = 0; i < 4; i++) {
+        const size_t qq = (size_t)ys[i] * a.W + xs[i];
+        const float raw = a.allmap[5 * HW + qq];
+        if (raw != raw || raw == INFINITY || raw == -INFINITY) continue;  // nan_to_num has zero gradient there
+        const float* gd = i < 2 ? ddx : ddy;
+        atomicAdd(dd + qq, sg[i] * (gd[0] * a.rays_d[3 * qq] + gd[1] * a.rays_d[3 * qq + 1] + gd[2] * a.rays_d[3 * qq + 2]));
+    }
+}
+
 // ---- flat Adam --------------------------------------------------------------------------------------------------
 constexpr int kAdamSeg = 64;
 constexpr int kAdamChunk = 4096;   // elements per workgroup (256 threads x 16)
@@ -555,6 +665,28 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
                        g_ntab, g_attrs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("lbs_bwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_regloss_forward(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                        float lambda_normal, float lambda_dist, float* loss, void* stream)
+{
+    if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !loss) return fail(-1, "dgs_regloss_forward: bad argument");
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist};
+    hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, loss);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("regloss_fwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_regloss_backward(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                         float lambda_normal, float lambda_dist, const float* g, float* d_allmap, void* stream)
+{
+    if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !g || !d_allmap) return fail(-1, "dgs_regloss_backward: bad argument");
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist};
+    hipLaunchKernelGGL(regloss_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, g, d_allmap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("regloss_bwd_kernel: ") + hipGetErrorString(e));
     return 0;
 }
 

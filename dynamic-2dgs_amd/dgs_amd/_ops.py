@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_CSRC, "libdgs_train_ops.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
 _lib = None
 _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_forward", "dgs_ssim_backward", "dgs_knn_points",
-            "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step")
+            "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step",
+            "dgs_regloss_forward", "dgs_regloss_backward")
 
 
 def build(force=False, verbose=False):
@@ -52,6 +53,10 @@ def load():
         lib.dgs_lbs_forward.argtypes = [ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dgs_lbs_backward.restype = ci
         lib.dgs_lbs_backward.argtypes = [ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.dgs_regloss_forward.restype = ci
+        lib.dgs_regloss_forward.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp]
+        lib.dgs_regloss_backward.restype = ci
+        lib.dgs_regloss_backward.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         lib.dgs_adam_plan_bytes.restype = ctypes.c_size_t
         lib.dgs_adam_plan_bytes.argtypes = [ctypes.c_longlong]
         lib.dgs_adam_plan.restype = ci
@@ -214,3 +219,37 @@ class FlatAdam:
                                    self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0], self.betas[1], self.eps,
                                    self.plan.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_adam_step")
+
+
+class _FusedRegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, allmap, rays_d, rays_o, wvt, lam_n, lam_d):
+        lib = load()
+        allmap = allmap.contiguous()
+        H, W = allmap.shape[1:]
+        loss = torch.zeros(1, dtype=torch.float32, device=allmap.device)
+        with torch.cuda.device(allmap.device):
+            rc = lib.dgs_regloss_forward(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), lam_n, lam_d,
+                                         loss.data_ptr(), _stream(allmap.device))
+        _check(lib, rc, "dgs_regloss_forward")
+        ctx.save_for_backward(allmap, rays_d, rays_o, wvt)
+        ctx.lam = (lam_n, lam_d)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        allmap, rays_d, rays_o, wvt = ctx.saved_tensors
+        H, W = allmap.shape[1:]
+        gd = g.reshape(1).to(torch.float32).contiguous()
+        out = torch.zeros_like(allmap)
+        with torch.cuda.device(allmap.device):
+            rc = lib.dgs_regloss_backward(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), ctx.lam[0],
+                                          ctx.lam[1], gd.data_ptr(), out.data_ptr(), _stream(allmap.device))
+        _check(lib, rc, "dgs_regloss_backward")
+        return out, None, None, None, None, None
+
+
+def fused_reg_loss(allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist):
+    """lambda_normal * mean(1 - <rend_normal, surf_normal>) + lambda_dist * mean(rend_dist) straight from the allmap."""
+    return _FusedRegLoss.apply(allmap, rays_d.contiguous(), rays_o.contiguous(), wvt.contiguous(), float(lambda_normal), float(lambda_dist))

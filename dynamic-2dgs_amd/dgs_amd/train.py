@@ -12,7 +12,7 @@ statistics (train_gui.py:411, gaussian_model.py:484-486) so replicas stay identi
 import torch
 import torch.distributed as dist
 
-from .losses import training_loss
+from .losses import training_loss, training_loss_from_allmap
 from .render import camera_rays, render
 
 
@@ -154,8 +154,10 @@ class Trainer:
         self.bucket.zero()
         t = d.expand_time(cam.fid)
         dv = d(s.get_xyz.detach(), t, s.feature, s.motion_mask)
-        pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls)
-        loss = training_loss(pkg, gt)
+        fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
+        pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
+                     postprocess=not fused)
+        loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt) if fused else training_loss(pkg, gt)
         loss.backward()
         with torch.no_grad():
             # densification statistics of this view into the bucket tail (summed over ranks)

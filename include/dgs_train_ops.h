@@ -59,6 +59,19 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
                      const float* ntab, const float* attrs, const float* mask, const float* g_xyz, const float* g_rot,
                      const float* g_scale, float* g_feature, float* g_ntab, float* g_attrs, void* scratch, void* stream);
 
+/* Normal-consistency + depth-distortion regularisers of the train step (train_gui.py:298-301) fused with the allmap
+ * post-processing of render() they need (gaussian_renderer/__init__.py:172-207, utils/point_utils.py:9-38):
+ *   rend_normal = allmap[2:5] rotated to world space, surf_depth = nan_to_num(allmap[5]) (depth_ratio = 1),
+ *   surf_normal = normalize(cross(d/dy, d/dx of the back-projected depth)) * alpha.detach(), 0 on the border,
+ *   loss = lambda_normal * mean(1 - <rend_normal, surf_normal>) + lambda_dist * mean(allmap[6]).
+ * allmap[8,H,W]; rays_d[H*W,3], rays_o[3] as in depths_to_points; wvt = world_view_transform [4,4] (device).
+ * forward ACCUMULATES the scalar into *loss (caller zeroes it).  backward: d_allmap[8,H,W] must be zeroed by the
+ * caller; channels 2-4, 5 (atomically) and 6 receive the gradient scaled by the DEVICE scalar *g. */
+int dgs_regloss_forward(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                        float lambda_normal, float lambda_dist, float* loss, void* stream);
+int dgs_regloss_backward(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                         float lambda_normal, float lambda_dist, const float* g, float* d_allmap, void* stream);
+
 /* One-launch Adam over a flat gradient bucket (torch.optim.Adam semantics: no weight decay, no amsgrad), replacing
  * the per-group multi_tensor_apply launches of gaussians.optimizer.step() + deform.optimizer.step()
  * (train_gui.py:427-431).  Parameters stay separate allocations: segment s owns elements
