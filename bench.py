@@ -180,6 +180,18 @@ def main():
     if rank == 0:
         ntiles = ((W + 15) // 16) * ((H + 15) // 16)
 
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # runs, corrected as MI355X_MICROARCH.md prescribes); only meaningful for the workload they were taken on
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")) as f:
+                pmc = json.load(f)["kernels"]
+            if args.workload == "metric":
+                traffic = {"fwd": pmc["dgs::blend_fwd_kernel"]["hbm_traffic_bytes_per_launch"],
+                           "bwd": pmc["dgs::blend_bwd_kernel"]["hbm_traffic_bytes_per_launch"]}
+        except Exception:
+            traffic = {}
+
         def roof(kind):
             n, ms, S = prof[kind + "_n"], prof[kind + "_ms"], prof[kind + "_S"]
             if n == 0 or ms <= 0:
@@ -187,7 +199,8 @@ def main():
             bytes_per = blend_bytes(S / n, ntiles, H * W, backward=(kind == "bwd"))
             gbs = bytes_per / (ms / n * 1e-3) / 1e9
             return {"bound": "hbm", "kernel": "blend_%s_kernel" % kind, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(kind),
+                    "traffic_source": "profiles/r01_pmc_kernels.json (bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB)" if kind in traffic else None,
                     "timing": "HIP events on the launch stream, eager re-run of the timed steps",
                     "avg_kernel_ms": round(ms / n, 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S / n)}
 
