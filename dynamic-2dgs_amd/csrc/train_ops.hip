@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/dgs_train_ops.h"
+#include "node_mlp.h"
 
 namespace {
 
@@ -719,6 +720,86 @@ int dgs_adam_step(int nseg, float* const* params, const long long* offsets, cons
                        exp_avg_sq, step_count, beta1, beta2, eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("adam_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// ---- control-node MLP (node_mlp.h) ---------------------------------------------------------------------------------
+size_t dgs_mlp_packed_floats(void) { return mlp::kPackedFloats; }
+size_t dgs_mlp_saved_floats(int M) { return mlp::sv_total(M); }
+size_t dgs_mlp_scratch_floats(int M) { return mlp::sc_total(M); }
+
+// params / grads: host arrays of 28 device pointers: (W, b) of T1, T2, L0..L7, local_rotation, warp, rotation, scaling
+static const int kHeadRows[4] = {4, 3, 4, 2};
+
+int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
+                    const float* rot_bias, float* packed, float* saved, float* attrs, void* stream)
+{
+    if (M <= 0 || M % mlp::kRows) return fail(-1, "dgs_mlp_forward: M must be a positive multiple of 16");
+    if (!x || !t || !params || !packed || !saved || !attrs) return fail(-1, "dgs_mlp_forward: null pointer");
+    mlp::Weights w{};
+    for (int l = 0; l < 10; l++) { w.W[l] = params[2 * l]; w.b[l] = params[2 * l + 1]; }
+    int r = 0;
+    for (int h = 0; h < 4; h++)
+        for (int k = 0; k < kHeadRows[h]; k++, r++) { w.hw[r] = params[20 + 2 * h] + (size_t)k * mlp::kW; w.hb[r] = params[21 + 2 * h] + k; }
+    for (; r < 16; r++) { w.hw[r] = w.hw[0]; w.hb[r] = w.hb[0]; }
+    hipStream_t s = (hipStream_t)stream;
+    int nthreads = (mlp::kFwdChunks + mlp::kBwdChunks) * 64;
+    hipLaunchKernelGGL(mlp::mlp_pack_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<float4*>(packed));
+    mlp::FwdArgs a{};
+    a.M = M; a.x = x; a.x_stride = x_stride; a.t = t; a.t_stride = t_stride;
+    a.wp = reinterpret_cast<const float4*>(packed);
+    a.bias = packed + mlp::kBiasOff;
+    a.saved = saved; a.attrs = attrs;
+    for (int i = 0; i < 4; i++) a.rot_bias[i] = rot_bias ? rot_bias[i] : 0.f;
+    hipLaunchKernelGGL(mlp::mlp_fwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, a);
+    if (hipGetLastError() != hipSuccess) return fail(-2, "dgs_mlp_forward: launch failed");
+    return 0;
+}
+
+int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
+                     int accumulate, void* stream)
+{
+    if (M <= 0 || M % mlp::kRows) return fail(-1, "dgs_mlp_backward: M must be a positive multiple of 16");
+    if (!g_attrs || !packed || !saved || !scratch || !grads) return fail(-1, "dgs_mlp_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    mlp::BwdArgs b{};
+    b.M = M; b.g_attrs = g_attrs; b.saved = saved; b.scratch = scratch;
+    b.wq = reinterpret_cast<const float4*>(packed) + (size_t)mlp::kFwdChunks * 64;
+    hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
+
+    mlp::WgArgs g{};
+    g.M = M; g.accumulate = accumulate;
+    int r = 0;
+    for (int h = 0; h < 4; h++)
+        for (int k = 0; k < kHeadRows[h]; k++, r++) { g.hw[r] = grads[20 + 2 * h] + (size_t)k * mlp::kW; g.hb[r] = grads[21 + 2 * h] + k; }
+    for (; r < 16; r++) { g.hw[r] = g.hw[0]; g.hb[r] = g.hb[0]; }
+    int nd = 0, block = 0;
+    auto add = [&](const float* dz, int dzs, int out, const float* x, int xs, int in, float* dw, int dws, float* db) {
+        mlp::WgDesc& d = g.d[nd++];
+        d.dz = dz; d.dz_stride = dzs; d.out = out; d.x = x; d.x_stride = xs; d.in = in; d.dw = dw; d.dw_stride = dws; d.db = db;
+        d.block0 = block; d.iblocks = (in + 31) / 32;
+        block += ((out + 63) / 64) * d.iblocks;
+    };
+    const int W = mlp::kW;
+    auto H = [&](int l) { return saved + mlp::sv_h(M, l); };
+    auto dZ = [&](int l) { return scratch + mlp::sc_dz(M, l); };
+    add(g_attrs, mlp::kHeads, mlp::kHeads, H(7), W, W, nullptr, W, nullptr);                          // heads
+    for (int l = 7; l >= 1; l--) {
+        float* gw = grads[2 * (l + 2)];
+        float* gb = grads[2 * (l + 2) + 1];
+        if (l == 5) {
+            add(dZ(5), W, W, saved + mlp::sv_inp(M), mlp::kInPad, mlp::kIn, gw, mlp::kIn + W, gb);    // [inp | .]
+            add(dZ(5), W, W, H(4), W, W, gw + mlp::kIn, mlp::kIn + W, nullptr);                       // [. | H4]
+        } else {
+            add(dZ(l), W, W, H(l - 1), W, W, gw, W, gb);
+        }
+    }
+    add(dZ(0), W, W, saved + mlp::sv_inp(M), mlp::kInPad, mlp::kIn, grads[4], mlp::kIn, grads[5]);   // L0
+    add(scratch + mlp::sc_dt2(M), 32, mlp::kTOut, saved + mlp::sv_t1(M), W, W, grads[2], W, grads[3]);        // time net 2
+    add(scratch + mlp::sc_dt1(M), W, W, saved + mlp::sv_et(M), mlp::kTPad, mlp::kTCh, grads[0], mlp::kTCh, grads[1]);  // time net 1
+    g.ndesc = nd;
+    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(256), 0, s, g);
+    if (hipGetLastError() != hipSuccess) return fail(-2, "dgs_mlp_backward: launch failed");
     return 0;
 }
 

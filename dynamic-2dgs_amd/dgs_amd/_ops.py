@@ -13,13 +13,15 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 _lib = None
 _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_forward", "dgs_ssim_backward", "dgs_knn_points",
             "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step",
-            "dgs_regloss_forward", "dgs_regloss_backward")
+            "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
+            "dgs_mlp_forward", "dgs_mlp_backward")
 
 
 def build(force=False, verbose=False):
     src = os.path.join(_CSRC, "train_ops.hip")
     hdr = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dgs_train_ops.h")
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [src, hdr, os.path.join(_CSRC, "node_mlp.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc"] + HIPCC_FLAGS + [src, "-o", LIB_PATH]
     if verbose:
@@ -63,6 +65,15 @@ def load():
         lib.dgs_adam_plan.argtypes = [ci, vp, vp, vp]
         lib.dgs_adam_step.restype = ci
         lib.dgs_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp]
+        for f in (lib.dgs_mlp_packed_floats, lib.dgs_mlp_saved_floats, lib.dgs_mlp_scratch_floats):
+            f.restype = ctypes.c_size_t
+        lib.dgs_mlp_packed_floats.argtypes = []
+        lib.dgs_mlp_saved_floats.argtypes = [ci]
+        lib.dgs_mlp_scratch_floats.argtypes = [ci]
+        lib.dgs_mlp_forward.restype = ci
+        lib.dgs_mlp_forward.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
+        lib.dgs_mlp_backward.restype = ci
+        lib.dgs_mlp_backward.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp]
         if lib.dgs_train_ops_abi_version() != 1:
             raise RuntimeError("libdgs_train_ops.so ABI version mismatch")
         _lib = lib
@@ -253,3 +264,90 @@ class _FusedRegLoss(torch.autograd.Function):
 def fused_reg_loss(allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist):
     """lambda_normal * mean(1 - <rend_normal, surf_normal>) + lambda_dist * mean(rend_dist) straight from the allmap."""
     return _FusedRegLoss.apply(allmap, rays_d.contiguous(), rays_o.contiguous(), wvt.contiguous(), float(lambda_normal), float(lambda_dist))
+
+
+def node_mlp_params(net):
+    """The 28 (weight, bias) tensors of a dgs_amd.deform.DeformMLP in the order of dgs_mlp_forward, or None when the
+    module is not the configuration the kernels are written for."""
+    try:
+        ok = (net.D == 8 and net.W == 256 and net.multires == 10 and net.t_multires == 6 and net.local_frame
+              and net.skips == [4] and net.timenet[2].out_features == 30)
+    except AttributeError:
+        return None
+    if not ok:
+        return None
+    mods = [net.timenet[0], net.timenet[2]] + list(net.linear) + [net.local_rotation, net.gaussian_warp, net.gaussian_rotation,
+                                                                 net.gaussian_scaling]
+    out = []
+    for m in mods:
+        out += [m.weight, m.bias]
+    if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in out):
+        return None
+    return out
+
+
+class _FusedNodeMLP(torch.autograd.Function):
+    """attrs[M,13] = [local_rotation + rot_bias | d_xyz | d_rotation | d_scaling] of the control nodes
+    (dgs_mlp_forward / dgs_mlp_backward).  `sink`: None, or the list of 28 gradient tensors (the parameters' .grad
+    views of a FlatGradBucket) the backward adds into directly instead of returning gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, t, rot_bias, sink, *params):
+        lib = load()
+        dev = x.device
+        M = x.shape[0]
+        if x.stride(-1) != 1 or t.dim() != 2 or t.shape[0] != M:
+            raise RuntimeError("fused node MLP: x must be row-major [M,>=3], t [M,1]")
+        packed = torch.empty(int(lib.dgs_mlp_packed_floats()), dtype=torch.float32, device=dev)
+        saved = torch.empty(int(lib.dgs_mlp_saved_floats(M)), dtype=torch.float32, device=dev)
+        attrs = torch.empty((M, 13), dtype=torch.float32, device=dev)
+        ptrs = (ctypes.c_void_p * 28)(*[p.data_ptr() for p in params])
+        rb = (ctypes.c_float * 4)(*rot_bias)
+        with torch.cuda.device(dev):
+            rc = lib.dgs_mlp_forward(M, x.data_ptr(), x.stride(0), t.data_ptr(), t.stride(0), ptrs, rb, packed.data_ptr(),
+                                     saved.data_ptr(), attrs.data_ptr(), _stream(dev))
+        _check(lib, rc, "dgs_mlp_forward")
+        ctx.save_for_backward(packed, saved)
+        ctx.sink = sink
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return attrs
+
+    @staticmethod
+    def backward(ctx, g_attrs):
+        lib = load()
+        packed, saved = ctx.saved_tensors
+        dev = packed.device
+        M = g_attrs.shape[0]
+        g_attrs = g_attrs.contiguous()
+        scratch = torch.empty(int(lib.dgs_mlp_scratch_floats(M)), dtype=torch.float32, device=dev)
+        if ctx.sink is not None:
+            outs, ret = ctx.sink, [None] * 28
+        else:
+            sizes = [int(torch.Size(s).numel()) for s in ctx.shapes]
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            outs, off = [], 0
+            for n, shp in zip(sizes, ctx.shapes):
+                outs.append(flat[off:off + n].view(shp))
+                off += n
+            ret = outs
+        ptrs = (ctypes.c_void_p * 28)(*[o.data_ptr() for o in outs])
+        with torch.cuda.device(dev):
+            rc = lib.dgs_mlp_backward(M, g_attrs.data_ptr(), packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(), ptrs,
+                                      1 if ctx.sink is not None else 0, _stream(dev))
+        _check(lib, rc, "dgs_mlp_backward")
+        return (None, None, None, None) + tuple(ret)
+
+
+def fused_node_mlp(net, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0), grad_sink=False):
+    """Per-node attribute table [M,13] of DeformMLP `net` at positions x[M,>=3] (no gradient) and times t[M,1].
+    grad_sink=True: parameter gradients are ADDED to the existing .grad tensors by the kernel (they must exist, be
+    contiguous fp32) and autograd sees no gradient for them -- for trainers that own a flat gradient buffer."""
+    params = node_mlp_params(net)
+    if params is None or x.shape[0] % 16:
+        raise RuntimeError("fused_node_mlp: unsupported DeformMLP configuration")
+    sink = None
+    if grad_sink and torch.is_grad_enabled():
+        sink = [p.grad for p in params]
+        if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
+            raise RuntimeError("fused_node_mlp(grad_sink=True): every parameter needs a contiguous fp32 .grad")
+    return _FusedNodeMLP.apply(x.detach(), t.detach(), tuple(float(v) for v in rot_bias), sink, *params)

@@ -89,6 +89,8 @@ class Trainer:
         deform_groups = [
             {'params': list(deform.network.parameters()), 'lr': deform_lr, 'name': 'deform'},
             {'params': [deform.nodes, deform._node_radius, deform._node_weight], 'lr': deform_lr, 'name': 'nodes'}]
+        if dev.type == "cuda" and hasattr(deform, "grad_sink"):
+            deform.grad_sink = True  # the fused node MLP adds its weight gradients straight into the bucket views
         if fused_adam:
             # HIP device: one flat Adam launch for surfels + deformation (csrc/train_ops.hip); step counter on the device
             from . import _ops

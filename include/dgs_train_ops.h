@@ -1,5 +1,5 @@
 /*
- * dgs_train_ops.h -- C ABI of the two per-step helper kernels next to the rasterizer on the training path
+ * dgs_train_ops.h -- C ABI of the per-step helper kernels next to the rasterizer on the training path
  * (SURVEY.md section 8 rows f1 and f3).  They are NOT part of the reference's rasterizer FFI; each replaces a
  * PyTorch / third-party call of the reference's train step:
  *
@@ -83,6 +83,25 @@ int dgs_adam_plan(int nseg, const long long* offsets /*host, nseg+1*/, void* pla
 int dgs_adam_step(int nseg, float* const* params /*host array of device pointers*/, const long long* offsets /*host*/,
                   const float* lrs /*host*/, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
                   float beta1, float beta2, float eps, const void* plan, void* stream);
+
+/* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:
+ * posenc(xyz,10) | timenet(posenc(t,6)): 13->256->30, 8 x 256 ReLU layers, skip concat after layer 4, heads
+ * local_rotation 4 / warp 3 / rotation 4 / scaling 2) forward + backward as four kernels on fp32 MFMA.
+ *   params / grads: HOST arrays of 28 device pointers, (weight, bias) of: timenet.0, timenet.2, linear.0 .. linear.7,
+ *                   local_rotation, gaussian_warp, gaussian_rotation, gaussian_scaling  (torch Linear layout [out][in])
+ *   x[M, x_stride] node positions (first 3 columns), t[M * t_stride] time per node (t_stride 0 = one shared value)
+ *   attrs[M,13] = [local_rotation + rot_bias(4, host) | d_xyz 3 | d_rotation 4 | d_scaling 2]  (dgs_lbs_forward's table)
+ *   packed: dgs_mlp_packed_floats() floats, written by forward, read by backward (weights re-laid in MFMA order)
+ *   saved : dgs_mlp_saved_floats(M) floats of activations, written by forward, read by backward
+ *   scratch: dgs_mlp_scratch_floats(M) floats
+ * backward writes (accumulate = 0) or adds to (accumulate = 1) every gradient tensor.  M must be a multiple of 16. */
+size_t dgs_mlp_packed_floats(void);
+size_t dgs_mlp_saved_floats(int M);
+size_t dgs_mlp_scratch_floats(int M);
+int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
+                    const float* rot_bias, float* packed, float* saved, float* attrs, void* stream);
+int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
+                     int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -110,7 +110,7 @@ def test_fused_lbs_matches_torch_autograd():
                 head.weight.mul_(3e3)
         g = torch.Generator().manual_seed(3)  # same draws for both variants
         _ = torch.rand(N, 3, generator=g)
-        m.use_fused = fused
+        m.use_fused, m.use_fused_mlp = fused, False
         feature = (0.05 * torch.randn(N, 8, generator=torch.Generator().manual_seed(5))).cuda().requires_grad_(True)
         mask = torch.sigmoid(torch.randn(N, 1, generator=torch.Generator().manual_seed(6))).cuda()
         t = torch.full((Mn, 1), 0.37).cuda()
@@ -135,6 +135,47 @@ def test_fused_lbs_matches_torch_autograd():
     assert float(b["nodes"][:, :3].abs().max()) == 0.0
     for n in a["net"]:
         close(a["net"][n], b["net"][n], "grad net." + n, 5e-4)
+
+
+@pytest.mark.parametrize("M,per_node_t", [(1024, False), (48, True)])
+def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
+    """dgs_mlp_forward/backward (fp32 MFMA) against DeformMLP.forward + torch.autograd: the attribute table, every
+    weight/bias gradient, in both gradient modes (returned to autograd / added into existing .grad tensors)."""
+    from dgs_amd import _ops
+    from dgs_amd.deform import DeformMLP
+    torch.manual_seed(4)
+    net = DeformMLP().cuda()
+    with torch.no_grad():
+        for head in (net.gaussian_warp, net.gaussian_rotation, net.gaussian_scaling, net.local_rotation):
+            head.weight.normal_(0, 0.05)
+            head.bias.normal_(0, 0.1)
+        for lin in list(net.linear) + [net.timenet[0], net.timenet[2]]:
+            lin.bias.normal_(0, 0.05)
+    nodes = torch.randn(M, 11, device="cuda") * 0.8
+    t = torch.rand(M, 1, device="cuda") if per_node_t else torch.full((1, 1), 0.37, device="cuda").expand(M, 1)
+    cot = torch.randn(M, 13, device="cuda")
+    rot_bias = torch.tensor([1.0, 0.0, 0.0, 0.0], device="cuda")
+
+    o = net(nodes[:, :3], t)
+    ref = torch.cat([o['local_rotation'] + rot_bias, o['d_xyz'], o['d_rotation'], o['d_scaling']], -1)
+    (ref * cot).sum().backward()
+    ref_grads = {n: p.grad.clone() for n, p in net.named_parameters()}
+
+    def close(u, v, name, tol):
+        scale = max(float(u.abs().max()), 1e-12)
+        err = float((u - v).abs().max())
+        assert err <= tol * scale, "%s: err %.3e scale %.3e" % (name, err, scale)
+
+    for sink in (False, True):
+        for p in net.parameters():
+            p.grad = torch.full_like(p, 0.25) if sink else None
+        net_out = _ops.fused_node_mlp(net, nodes, t, grad_sink=sink)
+        close(ref.detach(), net_out.detach(), "attrs", 2e-5)
+        (net_out * cot).sum().backward()
+        for n, p in net.named_parameters():
+            got = p.grad - 0.25 if sink else p.grad
+            assert got is not None, n
+            close(ref_grads[n], got, "grad %s (sink=%s)" % (n, sink), 2e-4)
 
 
 def test_flat_adam_matches_torch_adam():
