@@ -311,6 +311,7 @@ struct SurfelBwdArgs {
     const float* scales;
     const float* rotations;
     const float* shs;            // null when colours were precomputed
+    unsigned row_inv;            // ceil(2^32 / (3 M)): e / (3 M) == __umulhi(e, row_inv) for the element counts of one workgroup
     Camera cam;
     const int* radii;
     const float4* rec;
@@ -330,47 +331,79 @@ struct SurfelBwdArgs {
 // (rasterize_points.cu:194-202); culled surfels are left untouched.
 __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs a)
 {
-    const int idx = blockIdx.x * kSurfelBlock + threadIdx.x;
-    if (idx >= a.P || !(a.radii[idx] > 0)) return;
-    SurfelRec rec;
-    {
-        float4* dst = reinterpret_cast<float4*>(&rec);
-        const float4* src = a.rec + (size_t)idx * kRecQuads;
-#pragma unroll
-        for (int c = 0; c < kRecQuads; c++) dst[c] = src[c];
+    // SH rows (192 B per surfel at degree 3) are the bulk of this kernel's traffic and one-thread-per-surfel access to
+    // them is a 64-way scatter per instruction: the workgroup's rows are staged through LDS with coalesced transfers in
+    // both directions (coefficients in, dL_dsh out through the same rows); row stride M*3 + 1 keeps the per-thread row
+    // accesses bank-conflict free.
+    extern __shared__ float s_sh[];
+    const int base = blockIdx.x * kSurfelBlock;
+    const int idx = base + threadIdx.x;
+    const bool active = idx < a.P && a.radii[idx] > 0;
+    const int row = a.M * 3, stride = row + 1;
+    const int rows_here = min(kSurfelBlock, a.P - base);
+    if (a.shs) {
+        const float* src = a.shs + (size_t)base * row;
+        for (int e = threadIdx.x; e < rows_here * row; e += kSurfelBlock) {
+            const int r = (int)__umulhi((unsigned)e, a.row_inv);
+            s_sh[r * stride + (e - r * row)] = src[e];
+        }
+        __syncthreads();
     }
-    float acc[kAccFloats];
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.acc + (size_t)idx * kAccFloats);
+    if (active) {
+        SurfelRec rec;
+        {
+            float4* dst = reinterpret_cast<float4*>(&rec);
+            const float4* src = a.rec + (size_t)idx * kRecQuads;
 #pragma unroll
-        for (int c = 0; c < kAccFloats / 4; c++) {
-            float4 v = src[c];
-            acc[4 * c] = v.x; acc[4 * c + 1] = v.y; acc[4 * c + 2] = v.z; acc[4 * c + 3] = v.w;
+            for (int c = 0; c < kRecQuads; c++) dst[c] = src[c];
+        }
+        float acc[kAccFloats];
+        {
+            const float4* src = reinterpret_cast<const float4*>(a.acc + (size_t)idx * kAccFloats);
+#pragma unroll
+            for (int c = 0; c < kAccFloats / 4; c++) {
+                float4 v = src[c];
+                acc[4 * c] = v.x; acc[4 * c + 1] = v.y; acc[4 * c + 2] = v.z; acc[4 * c + 3] = v.w;
+            }
+        }
+        float pos[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+        float sc[2] = {a.scales[2 * idx], a.scales[2 * idx + 1]};
+        const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
+        float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        SurfelGrads g;
+        surfel_backward(a.cam, pos, sc, q, rec, acc, g);
+        if (a.shs) {
+            // coefficients to registers first: sh_backward overwrites the LDS row with dL_dsh while it still reads sh
+            float* my = s_sh + threadIdx.x * stride;
+            float shr[48];
+#pragma unroll
+            for (int c = 0; c < 48; c++) shr[c] = c < row ? my[c] : 0.f;
+            sh_backward(a.D, shr, pos, a.cam.campos, rec.flags, acc + kAccColor, my, g.dmean3D);
+        }
+        for (int c = 0; c < 3; c++) {
+            a.dL_dmean3D[3 * idx + c] = g.dmean3D[c];
+            a.dL_dcolor[3 * idx + c] = acc[kAccColor + c];
+            a.dL_dnormal[3 * idx + c] = acc[kAccNormal + c];
+        }
+        a.dL_dmean2D[3 * idx] = g.dmean2D[0];
+        a.dL_dmean2D[3 * idx + 1] = g.dmean2D[1];
+        a.dL_dopacity[idx] = acc[kAccOpacity];
+        for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = g.dT[c];
+        a.dL_dscale[2 * idx] = g.dscale[0];
+        a.dL_dscale[2 * idx + 1] = g.dscale[1];
+        reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(g.drot[0], g.drot[1], g.drot[2], g.drot[3]);
+    }
+    if (a.shs) {
+        // only visible surfels and only the first (D+1)^2 coefficients are written, as in the reference
+        __syncthreads();
+        const int touched = 3 * (a.D + 1) * (a.D + 1);
+        float* dst = a.dL_dsh + (size_t)base * row;
+        for (int e = threadIdx.x; e < rows_here * row; e += kSurfelBlock) {
+            const int r = (int)__umulhi((unsigned)e, a.row_inv);
+            const int c = e - r * row;
+            if (c < touched && a.radii[base + r] > 0) dst[e] = s_sh[r * stride + c];
         }
     }
-    float pos[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    float sc[2] = {a.scales[2 * idx], a.scales[2 * idx + 1]};
-    const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
-    float q[4] = {qv.x, qv.y, qv.z, qv.w};
-    SurfelGrads g;
-    surfel_backward(a.cam, pos, sc, q, rec, acc, g);
-    if (a.shs) {
-        // written straight to global memory: only the first (D+1)^2 coefficients are touched
-        sh_backward(a.D, a.shs + (size_t)idx * a.M * 3, pos, a.cam.campos, rec.flags, acc + kAccColor,
-                    a.dL_dsh + (size_t)idx * a.M * 3, g.dmean3D);
-    }
-    for (int c = 0; c < 3; c++) {
-        a.dL_dmean3D[3 * idx + c] = g.dmean3D[c];
-        a.dL_dcolor[3 * idx + c] = acc[kAccColor + c];
-        a.dL_dnormal[3 * idx + c] = acc[kAccNormal + c];
-    }
-    a.dL_dmean2D[3 * idx] = g.dmean2D[0];
-    a.dL_dmean2D[3 * idx + 1] = g.dmean2D[1];
-    a.dL_dopacity[idx] = acc[kAccOpacity];
-    for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = g.dT[c];
-    a.dL_dscale[2 * idx] = g.dscale[0];
-    a.dL_dscale[2 * idx + 1] = g.dscale[1];
-    reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(g.drot[0], g.drot[1], g.drot[2], g.drot[3]);
 }
 
 // checkFrustum (rasterizer_impl.cu:54-66): present = view.z > 0.2

@@ -6,7 +6,7 @@
 //
 //   mlp_pack_kernel   re-lays the 0.52 M weights into MFMA fragment order (once per step; the weights change every
 //                     Adam step), one copy for Z = X W^T and one for dX = dZ W.
-//   mlp_fwd_kernel    one workgroup = 16 nodes through ALL layers; activations stay in LDS, weights stream from L2 as
+//   mlp_fwd_kernel    one workgroup (16 waves) = 16 nodes through ALL layers; activations stay in LDS, weights stream from L2 as
 //                     coalesced 1-KB fragments, v_mfma_f32_16x16x4_f32 (exact fp32).  Post-ReLU activations are saved.
 //   mlp_bwd_kernel    the same tiling backwards: dZ_l = (dZ_{l+1} W_{l+1}) * [H_l > 0], every dZ_l saved.
 //   mlp_wgrad_kernel  all weight/bias gradients in ONE launch: dW_l = dZ_l^T X_l as 64x32 tiles over a descriptor
@@ -31,7 +31,7 @@ constexpr int kTCh = 13;       // posenc t, 6 bands
 constexpr int kTPad = 16;
 constexpr int kHeads = 13;     // local_rotation 4 | d_xyz 3 | d_rotation 4 | d_scaling 2
 constexpr int kRows = 16;      // nodes per workgroup
-constexpr int kThreads = 512;  // 8 waves, two 16-column tiles each per 256-wide layer
+constexpr int kThreads = 1024; // 16 waves, one 16-column tile each per 256-wide layer (4 waves/SIMD hide the L2 latency of the weights)
 constexpr int kNL = 11;        // layer ids: 0 = T1, 1 = T2, 2..9 = L0..L7, 10 = heads
 
 // layer meta ------------------------------------------------------------------------------------------------------
@@ -179,20 +179,17 @@ __device__ __forceinline__ float band(float v, int q)   // q = 2 * band + is_cos
     return (q & 1) ? cosf(a) : sinf(a);
 }
 
-// one 256-wide hidden layer: two tiles per wave, bias + ReLU, result to LDS and to the saved activations
-__device__ __forceinline__ void hidden_store(const f32x4 (&acc)[2], int wave, int lane, float* __restrict__ sdst,
+// one 256-wide hidden layer: one tile per wave, ReLU, result to LDS and to the saved activations
+__device__ __forceinline__ void hidden_store(const f32x4 (&acc)[1], int wave, int lane, float* __restrict__ sdst,
                                              float* __restrict__ gdst /* [M][256] + row0*256 */)
 {
+    int col = wave * 16 + (lane & 15);
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        int col = (2 * wave + u) * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int row = 4 * (lane >> 4) + r;
-            float v = fmaxf(acc[u][r], 0.f);
-            sdst[row * kSH + col] = v;
-            gdst[row * kW + col] = v;
-        }
+    for (int r = 0; r < 4; r++) {
+        int row = 4 * (lane >> 4) + r;
+        float v = fmaxf(acc[0][r], 0.f);
+        sdst[row * kSH + col] = v;
+        gdst[row * kW + col] = v;
     }
 }
 
@@ -223,17 +220,14 @@ __global__ void __launch_bounds__(kThreads) mlp_fwd_kernel(FwdArgs a)
     }
     __syncthreads();
 
-    f32x4 acc[2];
-    auto init_bias = [&](int l, int tile0) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            float bv = a.bias[l * kW + (tile0 + u) * 16 + (lane & 15)];
-            acc[u] = f32x4{bv, bv, bv, bv};
-        }
+    f32x4 acc[1];
+    auto init_bias = [&](int l, int tile) {
+        float bv = a.bias[l * kW + tile * 16 + (lane & 15)];
+        acc[0] = f32x4{bv, bv, bv, bv};
     };
     // time net layer 1: [16 x 16] -> 256, ReLU
-    init_bias(0, 2 * wave);
-    mma_run<2>(sT, kST, 1, a.wp + ((size_t)(fwd_off(0) + 2 * wave * fwd_kc(0)) * 64 + lane), fwd_kc(0) * 64, acc, lane);
+    init_bias(0, wave);
+    mma_run<1>(sT, kST, 1, a.wp + ((size_t)(fwd_off(0) + wave * fwd_kc(0)) * 64 + lane), 0, acc, lane);
     hidden_store(acc, wave, lane, sA, a.saved + sv_t1(M) + (size_t)row0 * kW);
     __syncthreads();
     // time net layer 2: 256 -> 30 (two tiles, waves 0 and 1), no activation; lands in columns 63..92 of the MLP input
@@ -253,8 +247,8 @@ __global__ void __launch_bounds__(kThreads) mlp_fwd_kernel(FwdArgs a)
         a.saved[sv_inp(M) + (size_t)(row0 + r) * kInPad + c] = sIn[r * kSIn + c];
     }
     // L0: 96 -> 256
-    init_bias(2, 2 * wave);
-    mma_run<2>(sIn, kSIn, fwd_kc(2), a.wp + ((size_t)(fwd_off(2) + 2 * wave * fwd_kc(2)) * 64 + lane), fwd_kc(2) * 64, acc, lane);
+    init_bias(2, wave);
+    mma_run<1>(sIn, kSIn, fwd_kc(2), a.wp + ((size_t)(fwd_off(2) + wave * fwd_kc(2)) * 64 + lane), 0, acc, lane);
     hidden_store(acc, wave, lane, sB, a.saved + sv_h(M, 0) + (size_t)row0 * kW);
     __syncthreads();
     float* cur = sB;
@@ -262,13 +256,13 @@ __global__ void __launch_bounds__(kThreads) mlp_fwd_kernel(FwdArgs a)
 #pragma unroll 1
     for (int li = 1; li < 8; li++) {
         const int l = li + 2;
-        init_bias(l, 2 * wave);
+        init_bias(l, wave);
         if (li == 5) {   // input = [inp | H4]
-            const float4* wp = a.wp + ((size_t)(fwd_off(7) + 2 * wave * fwd_kc(7)) * 64 + lane);
-            mma_run<2>(sIn, kSIn, kInPad / 16, wp, fwd_kc(7) * 64, acc, lane);
-            mma_run<2>(cur, kSH, kW / 16, wp + (kInPad / 16) * 64, fwd_kc(7) * 64, acc, lane);
+            const float4* wp = a.wp + ((size_t)(fwd_off(7) + wave * fwd_kc(7)) * 64 + lane);
+            mma_run<1>(sIn, kSIn, kInPad / 16, wp, 0, acc, lane);
+            mma_run<1>(cur, kSH, kW / 16, wp + (kInPad / 16) * 64, 0, acc, lane);
         } else {
-            mma_run<2>(cur, kSH, kW / 16, a.wp + ((size_t)(fwd_off(l) + 2 * wave * (kW / 16)) * 64 + lane), (kW / 16) * 64, acc, lane);
+            mma_run<1>(cur, kSH, kW / 16, a.wp + ((size_t)(fwd_off(l) + wave * (kW / 16)) * 64 + lane), 0, acc, lane);
         }
         hidden_store(acc, wave, lane, nxt, a.saved + sv_h(M, li) + (size_t)row0 * kW);
         __syncthreads();
@@ -297,20 +291,17 @@ struct BwdArgs {
     float* scratch;            // sc_* layout
 };
 
-// dH tile pair -> mask with the saved post-ReLU activation -> dZ to LDS and scratch
-__device__ __forceinline__ void dz_store(const f32x4 (&acc)[2], int tile0, int lane, const float* __restrict__ hsaved /* + row0*256 */,
+// dH tile -> mask with the saved post-ReLU activation -> dZ to LDS and scratch
+__device__ __forceinline__ void dz_store(const f32x4 (&acc)[1], int tile, int lane, const float* __restrict__ hsaved /* + row0*256 */,
                                          float* __restrict__ sdst, float* __restrict__ gdst /* + row0*256 */)
 {
+    int col = tile * 16 + (lane & 15);
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        int col = (tile0 + u) * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int row = 4 * (lane >> 4) + r;
-            float v = hsaved[row * kW + col] > 0.f ? acc[u][r] : 0.f;
-            sdst[row * kSH + col] = v;
-            gdst[row * kW + col] = v;
-        }
+    for (int r = 0; r < 4; r++) {
+        int row = 4 * (lane >> 4) + r;
+        float v = hsaved[row * kW + col] > 0.f ? acc[0][r] : 0.f;
+        sdst[row * kSH + col] = v;
+        gdst[row * kW + col] = v;
     }
 }
 
@@ -328,22 +319,22 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
         sG[r * kSG + c] = c < kHeads ? a.g_attrs[(size_t)(row0 + r) * kHeads + c] : 0.f;
     }
     __syncthreads();
-    f32x4 acc[2];
+    f32x4 acc[1];
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     // heads: dH7 = g_attrs[16 x 16] * Wh
-    acc[0] = zero; acc[1] = zero;
-    mma_run<2>(sG, kSG, 1, a.wq + ((size_t)(bwd_off(10) + 2 * wave * bwd_kc(10)) * 64 + lane), bwd_kc(10) * 64, acc, lane);
-    dz_store(acc, 2 * wave, lane, a.saved + sv_h(M, 7) + (size_t)row0 * kW, sA, a.scratch + sc_dz(M, 7) + (size_t)row0 * kW);
+    acc[0] = zero;
+    mma_run<1>(sG, kSG, 1, a.wq + ((size_t)(bwd_off(10) + wave * bwd_kc(10)) * 64 + lane), 0, acc, lane);
+    dz_store(acc, wave, lane, a.saved + sv_h(M, 7) + (size_t)row0 * kW, sA, a.scratch + sc_dz(M, 7) + (size_t)row0 * kW);
     __syncthreads();
     float* cur = sA;
     float* nxt = sB;
 #pragma unroll 1
     for (int li = 7; li >= 1; li--) {   // dZ_li (cur) -> dZ_{li-1} (nxt)
         const int l = li + 2;
-        acc[0] = zero; acc[1] = zero;
+        acc[0] = zero;
         if (li == 5) {   // tiles 0..5 belong to the MLP input (only 3..5 carry time-net gradient), 6..21 to H4
             const float4* wq = a.wq + ((size_t)bwd_off(7) * 64 + lane);
-            mma_run<2>(cur, kSH, kW / 16, wq + (size_t)(6 + 2 * wave) * bwd_kc(7) * 64, bwd_kc(7) * 64, acc, lane);
+            mma_run<1>(cur, kSH, kW / 16, wq + (size_t)(6 + wave) * bwd_kc(7) * 64, 0, acc, lane);
             if (wave < 3) {
                 f32x4 c1[1] = {zero};
                 mma_run<1>(cur, kSH, kW / 16, wq + (size_t)(3 + wave) * bwd_kc(7) * 64, 0, c1, lane);
@@ -351,9 +342,9 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
                 for (int r = 0; r < 4; r++) sDin[(4 * (lane >> 4) + r) * kSIn + (3 + wave) * 16 + (lane & 15)] = c1[0][r];
             }
         } else {
-            mma_run<2>(cur, kSH, kW / 16, a.wq + ((size_t)(bwd_off(l) + 2 * wave * (kW / 16)) * 64 + lane), (kW / 16) * 64, acc, lane);
+            mma_run<1>(cur, kSH, kW / 16, a.wq + ((size_t)(bwd_off(l) + wave * (kW / 16)) * 64 + lane), 0, acc, lane);
         }
-        dz_store(acc, 2 * wave, lane, a.saved + sv_h(M, li - 1) + (size_t)row0 * kW, nxt,
+        dz_store(acc, wave, lane, a.saved + sv_h(M, li - 1) + (size_t)row0 * kW, nxt,
                  a.scratch + sc_dz(M, li - 1) + (size_t)row0 * kW);
         __syncthreads();
         float* tmp = cur; cur = nxt; nxt = tmp;
@@ -375,9 +366,9 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
     }
     __syncthreads();
     // dT1 = (dT2 * Wt2) * [T1 > 0]
-    acc[0] = zero; acc[1] = zero;
-    mma_run<2>(sG, kSG, bwd_kc(1), a.wq + ((size_t)(bwd_off(1) + 2 * wave * bwd_kc(1)) * 64 + lane), bwd_kc(1) * 64, acc, lane);
-    dz_store(acc, 2 * wave, lane, a.saved + sv_t1(M) + (size_t)row0 * kW, nxt, a.scratch + sc_dt1(M) + (size_t)row0 * kW);
+    acc[0] = zero;
+    mma_run<1>(sG, kSG, bwd_kc(1), a.wq + ((size_t)(bwd_off(1) + wave * bwd_kc(1)) * 64 + lane), 0, acc, lane);
+    dz_store(acc, wave, lane, a.saved + sv_t1(M) + (size_t)row0 * kW, nxt, a.scratch + sc_dt1(M) + (size_t)row0 * kW);
 }
 
 // ---- weight gradients -------------------------------------------------------------------------------------------
@@ -397,8 +388,11 @@ struct WgArgs {
     float* hb[16];
 };
 
-__global__ void __launch_bounds__(256) mlp_wgrad_kernel(WgArgs a)
+constexpr int kWgThreads = 1024;   // 16 waves: 4 output-feature tiles x 4 quarters of the node rows (latency hiding), LDS reduce
+
+__global__ void __launch_bounds__(kWgThreads) mlp_wgrad_kernel(WgArgs a)
 {
+    __shared__ float sRed[3][4][64][9];   // partial sums of row quarters 1..3: 8 accumulators + bias per lane
     int di = 0;
 #pragma unroll
     for (int i = 1; i < kWgDescs; i++)
@@ -407,17 +401,19 @@ __global__ void __launch_bounds__(256) mlp_wgrad_kernel(WgArgs a)
     const int local = blockIdx.x - d.block0;
     const int jb = local / d.iblocks, ib = local - jb * d.iblocks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jt = wave & 3, part = wave >> 2;
     const int jl = lane & 15, mq = lane >> 4;
-    const int j = jb * 64 + wave * 16 + jl;          // this lane's A row (output feature)
+    const int j = jb * 64 + jt * 16 + jl;            // this lane's A row (output feature)
     const int i0 = ib * 32 + jl;                     // this lane's B column (input feature) of tile 0; tile 1 = +16
     const bool jv = j < d.out, iv0 = i0 < d.in, iv1 = i0 + 16 < d.in;
-    const float* pz = d.dz + (size_t)(4 * mq) * d.dz_stride + (jv ? j : 0);
-    const float* px = d.x + (size_t)(4 * mq) * d.x_stride + (iv0 ? i0 : 0);
+    const int rows = a.M >> 2;                       // rows per quarter (M is a multiple of 64)
+    const float* pz = d.dz + (size_t)(part * rows + 4 * mq) * d.dz_stride + (jv ? j : 0);
+    const float* px = d.x + (size_t)(part * rows + 4 * mq) * d.x_stride + (iv0 ? i0 : 0);
     const int x1 = iv1 ? 16 : 0;
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     float bsum = 0.f;
 #pragma unroll 2
-    for (int m0 = 0; m0 < a.M; m0 += 16) {
+    for (int m0 = 0; m0 < rows; m0 += 16) {
         float av[4], b0[4], b1[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -433,10 +429,25 @@ __global__ void __launch_bounds__(256) mlp_wgrad_kernel(WgArgs a)
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as, iv1 ? b1[s] : 0.f, acc1, 0, 0, 0);
         }
     }
+    if (part > 0) {
+        float* r = sRed[part - 1][jt][lane];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { r[c] = acc0[c]; r[4 + c] = acc1[c]; }
+        r[8] = bsum;
+    }
+    __syncthreads();
+    if (part > 0) return;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        const float* r = sRed[p][jt][lane];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { acc0[c] += r[c]; acc1[c] += r[4 + c]; }
+        bsum += r[8];
+    }
     // D[row = 4*mq + r -> output feature][col = jl -> input feature]
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        int jo = jb * 64 + wave * 16 + 4 * mq + r;
+        int jo = jb * 64 + jt * 16 + 4 * mq + r;
         if (jo >= d.out) continue;
         float* row = d.dw ? d.dw + (size_t)jo * d.dw_stride : a.hw[jo];
         if (iv0) row[i0] = a.accumulate ? row[i0] + acc0[r] : acc0[r];

@@ -513,7 +513,13 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
     sa.acc = acc;
     sa.dL_dmean2D = dL_dmean2D; sa.dL_dnormal = dL_dnormal; sa.dL_dopacity = dL_dopacity; sa.dL_dcolor = dL_dcolor;
     sa.dL_dmean3D = dL_dmean3D; sa.dL_dtransMat = dL_dtransMat; sa.dL_dsh = dL_dsh; sa.dL_dscale = dL_dscale; sa.dL_drot = dL_drot;
-    hipLaunchKernelGGL(dgs::surfel_bwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, sa);
+    size_t sh_lds = 0;
+    if (sa.shs) {
+        if (M * 3 > 48) return fail(DGS_ERR_INVALID_ARGUMENT, "backward: more than 16 SH coefficients per channel");
+        sa.row_inv = (unsigned)(0xFFFFFFFFu / (unsigned)(M * 3)) + 1u;
+        sh_lds = (size_t)dgs::kSurfelBlock * (M * 3 + 1) * sizeof(float);
+    }
+    hipLaunchKernelGGL(dgs::surfel_bwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), sh_lds, stream, sa);
     DGS_STAGE("surfel_bwd", debug, stream);
     return DGS_OK;
 }

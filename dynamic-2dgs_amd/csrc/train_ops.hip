@@ -40,11 +40,12 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                        Gauss g, float* __restrict__ ssim_sum, float* __restrict__ dm_dmu1,
-                                                       float* __restrict__ dm_ds11, float* __restrict__ dm_ds12)
+                                                       float* __restrict__ dm_ds11, float* __restrict__ dm_ds12,
+                                                       float* __restrict__ l1_sum, float* __restrict__ partial)
 {
     __shared__ float s_a[kIn][kIn + 1], s_b[kIn][kIn + 1];
     __shared__ float s_h[5][kIn][kT + 1];
-    __shared__ float s_red[4];
+    __shared__ float s_red[8];
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -75,8 +76,9 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float
         s11 += w * s_h[2][ly + k][lx]; s22 += w * s_h[3][ly + k][lx]; s12 += w * s_h[4][ly + k][lx];
     }
     const int x = x0 + lx, y = y0 + ly;
-    float val = 0.f;
+    float val = 0.f, l1 = 0.f;
     if (x < W && y < H) {
+        l1 = fabsf(s_a[ly + kR][lx + kR] - s_b[ly + kR][lx + kR]);
         const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
         const float sg1 = s11 - mu1_sq, sg2 = s22 - mu2_sq, sg12 = s12 - mu12;
         const float A = 2.f * mu12 + kC1, B = 2.f * sg12 + kC2, Cc = mu1_sq + mu2_sq + kC1, D = sg1 + sg2 + kC2;
@@ -90,13 +92,26 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float
             dm_ds12[o] = 2.f * A * inv_cd;
         }
     }
-    for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
-    if ((tid & 63) == 0) s_red[tid >> 6] = val;
+    for (int d = 32; d >= 1; d >>= 1) { val += __shfl_xor(val, d, 64); l1 += __shfl_xor(l1, d, 64); }
+    if ((tid & 63) == 0) { s_red[tid >> 6] = val; s_red[4 + (tid >> 6)] = l1; }
     __syncthreads();
-    if (tid == 0) atomicAdd(ssim_sum, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    if (tid == 0) {
+        const float vs = s_red[0] + s_red[1] + s_red[2] + s_red[3], vl = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+        if (partial) {
+            // one slot per workgroup, summed by loss_combine_kernel: thousands of atomics on ONE address serialise in a
+            // single L2 channel (~13 ns each) and were most of this kernel's run time
+            const int nb = gridDim.x * gridDim.y * gridDim.z;
+            const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            partial[b] = vs;
+            partial[nb + b] = vl;
+        } else {
+            atomicAdd(ssim_sum, vs);
+            if (l1_sum) atomicAdd(l1_sum, vl);
+        }
+    }
 }
 
-__global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n, const float* __restrict__ img1,
+__global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n, float l1_coef, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, Gauss g, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_ds11, const float* __restrict__ dm_ds12,
                                                        const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1)
@@ -137,7 +152,10 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n
     if (x < W && y < H) {
         const size_t o = plane + (size_t)y * W + x;
         // the zero-padded symmetric window is its own adjoint
-        dL_dimg1[o] = (a + 2.f * img1[o] * b + img2[o] * d) * (inv_n * dL_dmean[0]);
+        // inv_n scales the SSIM-map adjoint, l1_coef the sign(img1 - img2) of an optional mean-|.| term
+        const float df = img1[o] - img2[o];
+        const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        dL_dimg1[o] = ((a + 2.f * img1[o] * b + img2[o] * d) * inv_n + l1_coef * sg) * dL_dmean[0];
     }
 }
 
@@ -153,7 +171,8 @@ constexpr int kKnnGrp = 4;
 
 template <int K, int Q>
 __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
-                                                  long long* __restrict__ idx, float* __restrict__ dist2)
+                                                  long long* __restrict__ idx, float* __restrict__ dist2,
+                                                  const float* __restrict__ x2, int D1, int stride2)
 {
     __shared__ float4 s_nodes[kKnnChunk * Q];
     const int p0 = (blockIdx.x * 256 + threadIdx.x) * kKnnPts;
@@ -161,7 +180,12 @@ __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const flo
 #pragma unroll
     for (int u = 0; u < kKnnPts; u++)
 #pragma unroll
-        for (int d = 0; d < 4 * Q; d++) xv[u][d] = (p0 + u < N && d < D) ? x[(size_t)(p0 + u) * D + d] : 0.f;
+        for (int d = 0; d < 4 * Q; d++) {
+            // coordinates [0, D1) come from x (row stride D1), [D1, D) from x2 (row stride stride2); x2 == nullptr: D1 = D
+            float v = 0.f;
+            if (p0 + u < N && d < D) v = d < D1 ? x[(size_t)(p0 + u) * D1 + d] : x2[(size_t)(p0 + u) * stride2 + d - D1];
+            xv[u][d] = v;
+        }
     float bd[kKnnPts][K];
     int bi[kKnnPts][K];
 #pragma unroll
@@ -239,23 +263,187 @@ __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const flo
 }
 
 template <int K, int Q>
-int launch_knn_q(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s)
+int launch_knn_q(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s,
+                 const float* x2, int D1, int stride2)
 {
     const int per_block = 256 * kKnnPts;
-    hipLaunchKernelGGL((knn_kernel<K, Q>), dim3((N + per_block - 1) / per_block), dim3(256), 0, s, N, M, D, x, nodes, idx, dist2);
+    hipLaunchKernelGGL((knn_kernel<K, Q>), dim3((N + per_block - 1) / per_block), dim3(256), 0, s, N, M, D, x, nodes, idx, dist2,
+                       x2, D1, stride2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("knn_kernel: ") + hipGetErrorString(e));
     return 0;
 }
 
 template <int K>
-int launch_knn(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s)
+int launch_knn(int N, int M, int D, const float* x, const float* nodes, long long* idx, float* dist2, hipStream_t s,
+               const float* x2 = nullptr, int D1 = -1, int stride2 = 0)
 {
+    if (!x2) D1 = D;
     switch ((D + 3) / 4) {
-    case 1: return launch_knn_q<K, 1>(N, M, D, x, nodes, idx, dist2, s);
-    case 2: return launch_knn_q<K, 2>(N, M, D, x, nodes, idx, dist2, s);
-    case 3: return launch_knn_q<K, 3>(N, M, D, x, nodes, idx, dist2, s);
-    default: return launch_knn_q<K, 4>(N, M, D, x, nodes, idx, dist2, s);
+    case 1: return launch_knn_q<K, 1>(N, M, D, x, nodes, idx, dist2, s, x2, D1, stride2);
+    case 2: return launch_knn_q<K, 2>(N, M, D, x, nodes, idx, dist2, s, x2, D1, stride2);
+    case 3: return launch_knn_q<K, 3>(N, M, D, x, nodes, idx, dist2, s, x2, D1, stride2);
+    default: return launch_knn_q<K, 4>(N, M, D, x, nodes, idx, dist2, s, x2, D1, stride2);
+    }
+}
+
+// ---- KNN refinement -----------------------------------------------------------------------------------------------
+// Exact K nearest neighbours again, but seeded with a previous answer (last step's indices: surfels and nodes move by
+// ~1e-6 per step).  The K seed nodes give an upper bound T on the K-th smallest distance; the 3-D part of the distance
+// (coordinates 0..2 of D) is a lower bound of the full one, so only nodes with d3 <= T can be in the answer.  The scan
+// over all M nodes therefore needs 3 of the D coordinates (7 instead of 2*D VALU operations per node) and just records
+// the few candidates; full distances are evaluated for those only.  Any seed (stale, random, duplicated) gives the exact
+// result: a bad seed only makes T large, a full candidate list falls back to the plain scan for that point.
+constexpr int kKnnCap = 12;
+
+template <int K, int Q>
+__global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
+                                                         long long* __restrict__ idx, const float* __restrict__ x2, int D1, int stride2)
+{
+    extern __shared__ float4 s_dyn[];
+    const int Mp = (M + 31) & ~31;                                        // rows padded to the 32-node scan blocks (zeros, masked)
+    float4* s_nodes = s_dyn;                                              // [Mp][Q]
+    int* s_list = reinterpret_cast<int*>(s_dyn + (size_t)Mp * Q);         // [256 * kKnnPts][kKnnCap]
+    float* s_flat = reinterpret_cast<float*>(s_nodes);
+    for (int i = threadIdx.x; i < Mp * 4 * Q; i += 256) {
+        const int r = i / (4 * Q), d = i - r * (4 * Q);
+        s_flat[i] = (r < M && d < D) ? nodes[(size_t)r * D + d] : 0.f;
+    }
+    __syncthreads();
+    const int p0 = (blockIdx.x * 256 + threadIdx.x) * kKnnPts;
+    float xv[kKnnPts][4 * Q];
+    float T[kKnnPts];
+    int cnt[kKnnPts];
+    auto full_dist = [&](int u, int j) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const float4 nd = s_nodes[j * Q + q];
+            float t;
+            t = xv[u][4 * q + 0] - nd.x; a += t * t;
+            t = xv[u][4 * q + 1] - nd.y; a += t * t;
+            t = xv[u][4 * q + 2] - nd.z; a += t * t;
+            t = xv[u][4 * q + 3] - nd.w; a += t * t;
+        }
+        return a;
+    };
+#pragma unroll
+    for (int u = 0; u < kKnnPts; u++) {
+        const bool in = p0 + u < N;
+#pragma unroll
+        for (int d = 0; d < 4 * Q; d++) {
+            float v = 0.f;
+            if (in && d < D) v = d < D1 ? x[(size_t)(p0 + u) * D1 + d] : x2[(size_t)(p0 + u) * stride2 + d - D1];
+            xv[u][d] = v;
+        }
+        // bound from the seed (K distinct valid nodes), slightly inflated never hurts: it is only a filter
+        int sj[K];
+        bool ok = in;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const long long j = in ? idx[(size_t)(p0 + u) * K + k] : 0;
+            ok = ok && j >= 0 && j < M;
+            sj[k] = (int)(j < 0 ? 0 : (j >= M ? M - 1 : j));
+        }
+#pragma unroll
+        for (int k = 1; k < K; k++)
+#pragma unroll
+            for (int k2 = 0; k2 < k; k2++) ok = ok && sj[k] != sj[k2];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) t = fmaxf(t, full_dist(u, sj[k]));
+        T[u] = in ? (ok ? t : INFINITY) : -1.f;
+        cnt[u] = 0;
+    }
+    // ---- scan: 3-D lower bound only.  Branch-free inner loop: the sign of d3 - T' is shifted into a 32-node hit word
+    // (v_alignbit), 7 VALU operations per (node, point); the words are drained once per 32 nodes.
+    float Tn[kKnnPts];
+#pragma unroll
+    for (int u = 0; u < kKnnPts; u++) Tn[u] = -(T[u] * (1.0f + 1e-6f) + 1e-30f);   // inflated: d3 == T must stay a hit
+    for (int j0 = 0; j0 < M; j0 += 32) {
+        unsigned w[kKnnPts];
+#pragma unroll
+        for (int u = 0; u < kKnnPts; u++) w[u] = 0u;
+#pragma unroll
+        for (int g0 = 0; g0 < 32; g0 += kKnnGrp) {
+            float4 nd[kKnnGrp];
+#pragma unroll
+            for (int g = 0; g < kKnnGrp; g++) nd[g] = s_nodes[(j0 + g0 + g) * Q];   // wave-uniform: LDS broadcast
+#pragma unroll
+            for (int g = 0; g < kKnnGrp; g++)
+#pragma unroll
+                for (int u = 0; u < kKnnPts; u++) {
+                    float t, a;
+                    t = xv[u][0] - nd[g].x; a = fmaf(t, t, Tn[u]);
+                    t = xv[u][1] - nd[g].y; a = fmaf(t, t, a);
+                    t = xv[u][2] - nd[g].z; a = fmaf(t, t, a);
+                    w[u] = __builtin_amdgcn_alignbit(w[u], __float_as_uint(a), 31);   // (w << 1) | sign(a)
+                }
+        }
+        const unsigned valid = (M - j0) >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (M - j0));   // node j0 + g <-> bit 31 - g
+#pragma unroll
+        for (int u = 0; u < kKnnPts; u++) {
+            unsigned ww = w[u] & valid;
+            while (ww) {
+                const int lz = __clz(ww);
+                ww &= ~(0x80000000u >> lz);
+                if (cnt[u] < kKnnCap) s_list[(threadIdx.x * kKnnPts + u) * kKnnCap + cnt[u]] = j0 + lz;
+                cnt[u]++;
+            }
+        }
+    }
+    // ---- candidates (ascending index, strict < on insertion: ties keep the lower index like the plain scan)
+#pragma unroll
+    for (int u = 0; u < kKnnPts; u++) {
+        if (p0 + u >= N) continue;
+        float bd[K];
+        int bi[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { bd[k] = INFINITY; bi[k] = 0; }
+        const bool listed = cnt[u] <= kKnnCap;
+        const int n = listed ? cnt[u] : M;
+        for (int c = 0; c < n; c++) {
+            const int j = listed ? s_list[(threadIdx.x * kKnnPts + u) * kKnnCap + c] : c;
+            const float dj = full_dist(u, j);
+            if (dj < bd[K - 1]) {
+                bd[K - 1] = dj; bi[K - 1] = j;
+#pragma unroll
+                for (int k = K - 1; k > 0; k--) {
+                    if (bd[k] < bd[k - 1]) {
+                        const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+                        const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) idx[(size_t)(p0 + u) * K + k] = bi[k];
+    }
+}
+
+template <int K, int Q>
+int launch_knn_refine_q(int N, int M, int D, const float* x, const float* nodes, long long* idx, hipStream_t s, const float* x2, int D1,
+                        int stride2)
+{
+    const int per_block = 256 * kKnnPts;
+    const size_t lds = (size_t)((M + 31) & ~31) * Q * sizeof(float4) + (size_t)256 * kKnnPts * kKnnCap * sizeof(int);
+    hipLaunchKernelGGL((knn_refine_kernel<K, Q>), dim3((N + per_block - 1) / per_block), dim3(256), lds, s, N, M, D, x, nodes, idx, x2, D1,
+                       stride2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("knn_refine_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+template <int K>
+int launch_knn_refine(int N, int M, int D, const float* x, const float* nodes, long long* idx, hipStream_t s, const float* x2, int D1,
+                      int stride2)
+{
+    if (!x2) D1 = D;
+    switch ((D + 3) / 4) {
+    case 1: return launch_knn_refine_q<K, 1>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
+    case 2: return launch_knn_refine_q<K, 2>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
+    case 3: return launch_knn_refine_q<K, 3>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
+    default: return launch_knn_refine_q<K, 4>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
     }
 }
 
@@ -268,6 +456,21 @@ constexpr int kLbsBlocks = 256;    // backward: one partial gradient table per w
 struct LbsArgs {
     int N, M, H, fstride;
     const float* x; const float* feature; const long long* idx; const float* ntab; const float* attrs; const float* mask;
+    // node table rows are tstride floats apart.  rad_raw / w_raw non-null: the table holds only [xyz | hyper] and the
+    // kernel radius / weight are exp(rad_raw[j]) / sigmoid(w_raw[j]) (ControlNodeWarp.node_radius / node_weight)
+    int tstride; const float* rad_raw; const float* w_raw;
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// activations of the surfel parameters that render() applies around the deformation
+// (gaussian_renderer/__init__.py:60-75: means3D = xyz + d_xyz, scales = exp(_scaling) + d_scaling,
+//  rotations = normalize(_rotation + d_rotation), opacity = sigmoid(_opacity); scene/gaussian_model.py:60-78)
+struct AsmArgs {
+    const float* scaling_raw; const float* rotation_raw; const float* opacity_raw;
+    float* means3D; float* scales; float* rotations; float* opacity;                                   // forward out
+    const float* g_means3D; const float* g_scales; const float* g_rotations; const float* g_opacity;   // backward in
+    float* g_xyz; float* g_scaling_raw; float* g_rotation_raw; float* g_opacity_raw;                   // backward out
 };
 
 // quaternion (r,i,j,k), not necessarily unit -> rotation matrix, utils/time_utils.py:115-132
@@ -282,14 +485,14 @@ __device__ __forceinline__ void quat_to_mat(const float* q, float* R, float& two
 
 // per-point evaluation shared by forward and backward
 struct LbsPoint {
-    float w[kLbsK], e[kLbsK], dist[kLbsK], Ax[kLbsK][3];
+    float w[kLbsK], e[kLbsK], dist[kLbsK], Ax[kLbsK][3], rad[kLbsK], wg[kLbsK];
     float W;
     int j[kLbsK];
 };
 
 __device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, float* xq /*[3+Hmax]*/)
 {
-    const int T = 3 + a.H + 2;
+    const int T = a.tstride;
     xq[0] = a.x[3 * n]; xq[1] = a.x[3 * n + 1]; xq[2] = a.x[3 * n + 2];
     for (int h = 0; h < kLbsHmax; h++) xq[3 + h] = h < a.H ? a.feature[(size_t)n * a.fstride + h] : 0.f;
     p.W = 0.f;
@@ -301,7 +504,9 @@ __device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, f
         float dist = 0.f;
         for (int c = 0; c < 3 + kLbsHmax; c++)
             if (c < 3 + a.H) { const float t = xq[c] - nd[c]; dist += t * t; }
-        const float r = nd[3 + a.H], wg = nd[3 + a.H + 1];
+        const float r = a.rad_raw ? expf(a.rad_raw[j]) : nd[3 + a.H];
+        const float wg = a.w_raw ? sigmoidf_(a.w_raw[j]) : nd[3 + a.H + 1];
+        p.rad[k] = r; p.wg[k] = wg;
         p.dist[k] = dist;
         p.e[k] = expf(-dist / (2.f * r * r));
         p.w[k] = p.e[k] * wg + 1e-7f;
@@ -316,14 +521,15 @@ __device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, f
     }
 }
 
-__global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, float* d_rot, float* d_scale)
+template <bool ASM>
+__global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, float* d_rot, float* d_scale, AsmArgs s_)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= a.N) return;
     LbsPoint p;
     float xq[3 + kLbsHmax];
     lbs_eval(a, n, p, xq);
-    const float inv = 1.0f / p.W, m = a.mask[n];
+    const float inv = 1.0f / p.W, m = a.mask ? a.mask[n] : 1.0f;
     float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0}, s[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < kLbsK; k++) {
@@ -333,20 +539,32 @@ __global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, f
         for (int c = 0; c < 4; c++) q[c] += w * at[7 + c];
         for (int c = 0; c < 2; c++) s[c] += w * at[11 + c];
     }
-    for (int c = 0; c < 3; c++) d_xyz[3 * n + c] = (t[c] - xq[c]) * m;
-    for (int c = 0; c < 4; c++) d_rot[4 * n + c] = q[c] * m;
-    for (int c = 0; c < 2; c++) d_scale[2 * n + c] = s[c] * m;
+    if (!ASM) {
+        for (int c = 0; c < 3; c++) d_xyz[3 * n + c] = (t[c] - xq[c]) * m;
+        for (int c = 0; c < 4; c++) d_rot[4 * n + c] = q[c] * m;
+        for (int c = 0; c < 2; c++) d_scale[2 * n + c] = s[c] * m;
+    } else {
+        for (int c = 0; c < 3; c++) s_.means3D[3 * n + c] = xq[c] + (t[c] - xq[c]) * m;
+        for (int c = 0; c < 2; c++) s_.scales[2 * n + c] = expf(s_.scaling_raw[2 * n + c]) + s[c] * m;
+        float v[4], n2 = 0.f;
+        for (int c = 0; c < 4; c++) { v[c] = s_.rotation_raw[4 * n + c] + q[c] * m; n2 += v[c] * v[c]; }
+        const float invn = 1.0f / fmaxf(sqrtf(n2), 1e-12f);   // F.normalize
+        for (int c = 0; c < 4; c++) s_.rotations[4 * n + c] = v[c] * invn;
+        s_.opacity[n] = sigmoidf_(s_.opacity_raw[n]);
+    }
 }
 
 // Backward.  Per-node gradients (13 attribute + H+2 table columns) of the ~782 points of a workgroup are accumulated
 // in an LDS table with ds_add_f32 and written once as that workgroup's partial table; lbs_reduce_kernel sums the
 // kLbsBlocks partials.  (Direct global atomics would be ~7 M adds onto ~24 k hot addresses.)
+template <bool ASM>
 __global__ void __launch_bounds__(256) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
-                                                      float* g_feature, float* partial /*[kLbsBlocks][M][G]*/, int chunk)
+                                                      float* g_feature, int gf_stride, int accumulate,
+                                                      float* partial /*[kLbsBlocks][M][G]*/, int chunk, AsmArgs s_)
 {
     extern __shared__ float s_tab[];  // [M][G], G = 13 + H + 2
     const int G = kLbsAttr + a.H + 2;
-    const int T = 3 + a.H + 2;
+    const int T = a.tstride;
     for (int i = threadIdx.x; i < a.M * G; i += 256) s_tab[i] = 0.f;
     __syncthreads();
     const int end = min(a.N, (int)(blockIdx.x + 1) * chunk);
@@ -354,10 +572,47 @@ __global__ void __launch_bounds__(256) lbs_bwd_kernel(LbsArgs a, const float* g_
         LbsPoint p;
         float xq[3 + kLbsHmax];
         lbs_eval(a, n, p, xq);
-        const float inv = 1.0f / p.W, m = a.mask[n];
-        const float gx[3] = {g_xyz[3 * n] * m, g_xyz[3 * n + 1] * m, g_xyz[3 * n + 2] * m};
-        const float gq[4] = {g_rot[4 * n] * m, g_rot[4 * n + 1] * m, g_rot[4 * n + 2] * m, g_rot[4 * n + 3] * m};
-        const float gs[2] = {g_scale[2 * n] * m, g_scale[2 * n + 1] * m};
+        const float inv = 1.0f / p.W, m = a.mask ? a.mask[n] : 1.0f;
+        float gx[3], gq[4], gs[2];
+        if (!ASM) {
+            for (int c = 0; c < 3; c++) gx[c] = g_xyz[3 * n + c] * m;
+            for (int c = 0; c < 4; c++) gq[c] = g_rot[4 * n + c] * m;
+            for (int c = 0; c < 2; c++) gs[c] = g_scale[2 * n + c] * m;
+        } else {
+            // adjoint of the activations (see AsmArgs); the deformation sees the detached centre, so the centre's own
+            // gradient is just the incoming one
+            for (int c = 0; c < 3; c++) {
+                const float g = s_.g_means3D[3 * n + c];
+                gx[c] = g * m;
+                s_.g_xyz[3 * n + c] = accumulate ? s_.g_xyz[3 * n + c] + g : g;
+            }
+            for (int c = 0; c < 2; c++) {
+                const float g = s_.g_scales[2 * n + c];
+                gs[c] = g * m;
+                const float v = g * expf(s_.scaling_raw[2 * n + c]);
+                s_.g_scaling_raw[2 * n + c] = accumulate ? s_.g_scaling_raw[2 * n + c] + v : v;
+            }
+            float q[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < kLbsK; k++) {
+                const float* at = a.attrs + (size_t)p.j[k] * kLbsAttr;
+                for (int c = 0; c < 4; c++) q[c] += p.w[k] * inv * at[7 + c];
+            }
+            float v[4], n2 = 0.f, dot = 0.f;
+            for (int c = 0; c < 4; c++) { v[c] = s_.rotation_raw[4 * n + c] + q[c] * m; n2 += v[c] * v[c]; }
+            const float nrm = sqrtf(n2);
+            const bool tiny = nrm < 1e-12f;
+            const float invn = 1.0f / fmaxf(nrm, 1e-12f);
+            for (int c = 0; c < 4; c++) dot += v[c] * invn * s_.g_rotations[4 * n + c];
+            for (int c = 0; c < 4; c++) {
+                const float g = tiny ? s_.g_rotations[4 * n + c] * invn : (s_.g_rotations[4 * n + c] - v[c] * invn * dot) * invn;
+                gq[c] = g * m;
+                s_.g_rotation_raw[4 * n + c] = accumulate ? s_.g_rotation_raw[4 * n + c] + g : g;
+            }
+            const float o = sigmoidf_(s_.opacity_raw[n]);
+            const float go = s_.g_opacity[n] * o * (1.0f - o);
+            s_.g_opacity_raw[n] = accumulate ? s_.g_opacity_raw[n] + go : go;
+        }
         float dwh[kLbsK], mean = 0.f;  // d loss / d (normalised weight)
 #pragma unroll
         for (int k = 0; k < kLbsK; k++) {
@@ -404,7 +659,7 @@ __global__ void __launch_bounds__(256) lbs_bwd_kernel(LbsArgs a, const float* g_
             for (int c = 0; c < 2; c++) atomicAdd(acc + 11 + c, wn * gs[c]);
             // ---- weights: w = e * weight + 1e-7, e = exp(-dist / (2 r^2)), normalised over the K neighbours
             const float dw = (dwh[k] - mean) * inv;
-            const float rad = nd[3 + a.H], wg = nd[3 + a.H + 1];
+            const float rad = p.rad[k], wg = p.wg[k];
             const float de = dw * wg * p.e[k];
             const float ddist = -de / (2.f * rad * rad);
             atomicAdd(acc + kLbsAttr + a.H, de * p.dist[k] / (rad * rad * rad));  // d radius
@@ -417,7 +672,10 @@ __global__ void __launch_bounds__(256) lbs_bwd_kernel(LbsArgs a, const float* g_
                 }
         }
         for (int h = 0; h < kLbsHmax; h++)
-            if (h < a.H) g_feature[(size_t)n * a.H + h] = gfeat[h];
+            if (h < a.H) {
+                float* dst = g_feature + (size_t)n * gf_stride + h;
+                *dst = accumulate ? *dst + gfeat[h] : gfeat[h];
+            }
     }
     __syncthreads();
     float* dst = partial + (size_t)blockIdx.x * a.M * G;
@@ -435,6 +693,78 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, i
     if (c < kLbsAttr) g_attrs[(size_t)node * kLbsAttr + c] = acc;
     else g_ntab[(size_t)node * T + 3 + (c - kLbsAttr)] = acc;
     if (c < 3) g_ntab[(size_t)node * T + c] = 0.f;  // node positions are detached in the reference
+}
+
+// raw-parameter variant: gradients of nodes[M, 3+H] (hyper columns), _node_radius (through exp) and _node_weight
+// (through sigmoid), written or added in place; the attribute gradients are always written (the node MLP consumes them)
+__global__ void __launch_bounds__(256) lbs_reduce_raw_kernel(const float* partial, int M, int H, const float* rad_raw,
+                                                             const float* w_raw, float* g_nodes, float* g_rad_raw, float* g_w_raw,
+                                                             float* g_attrs, int accumulate)
+{
+    const int G = kLbsAttr + H + 2, T = 3 + H;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * G) return;
+    float acc = 0.f;
+    for (int b = 0; b < kLbsBlocks; b++) acc += partial[(size_t)b * M * G + i];
+    const int node = i / G, c = i - node * G;
+    if (c < kLbsAttr) { g_attrs[(size_t)node * kLbsAttr + c] = acc; }
+    else if (c < kLbsAttr + H) {
+        float* d = g_nodes + (size_t)node * T + 3 + (c - kLbsAttr);
+        *d = accumulate ? *d + acc : acc;
+    } else if (c == kLbsAttr + H) {
+        const float v = acc * expf(rad_raw[node]);
+        g_rad_raw[node] = accumulate ? g_rad_raw[node] + v : v;
+    } else {
+        const float w = sigmoidf_(w_raw[node]);
+        const float v = acc * w * (1.0f - w);
+        g_w_raw[node] = accumulate ? g_w_raw[node] + v : v;
+    }
+    if (c < 3 && !accumulate) g_nodes[(size_t)node * T + c] = 0.f;
+}
+
+// ---- densification statistics (train_gui.py:411, gaussian_model.py:484-486) ----------------------------------------
+// one view: visible = radii > 0; grad_norm = |dL/dmeans2D[:, :2]| where visible
+__global__ void __launch_bounds__(256) densify_view_kernel(int P, const int* radii, const float* g_means2D, float* grad_norm,
+                                                           float* visible, int* radii_vis)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    const bool v = r > 0;
+    const float gx = g_means2D[3 * i], gy = g_means2D[3 * i + 1];
+    grad_norm[i] = v ? sqrtf(gx * gx + gy * gy) : 0.f;
+    visible[i] = v ? 1.f : 0.f;
+    radii_vis[i] = v ? r : 0;
+}
+// running statistics: xyz_gradient_accum += grad_norm, denom += visible, max_radii2D = max(max_radii2D, radii_vis)
+__global__ void __launch_bounds__(256) densify_accum_kernel(int P, const float* grad_norm, const float* visible, const int* radii_vis,
+                                                            float* accum, float* denom, int* max_radii)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    accum[i] += grad_norm[i];
+    denom[i] += visible[i];
+    max_radii[i] = max(max_radii[i], radii_vis[i]);
+}
+
+// loss = (1 - lambda) * sum(l1 partials) / n + lambda * (1 - sum(ssim partials) / n) + sum(regulariser partials)
+// photo = [ssim partial per workgroup (nphoto) | l1 partial per workgroup (nphoto)], reg = [nreg]; one workgroup
+__global__ void __launch_bounds__(256) loss_combine_kernel(const float* photo, int nphoto, const float* reg, int nreg, float inv_n,
+                                                           float lambda_dssim, float* out)
+{
+    __shared__ float s_red[3][4];
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < nphoto; i += 256) { a += photo[i]; b += photo[nphoto + i]; }
+    for (int i = threadIdx.x; i < nreg; i += 256) c += reg[i];
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); c += __shfl_xor(c, d, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = a; s_red[1][threadIdx.x >> 6] = b; s_red[2][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        b = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        c = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+        out[0] = (1.0f - lambda_dssim) * b * inv_n + lambda_dssim * (1.0f - a * inv_n) + c;
+    }
 }
 
 // ---- fused regulariser loss -----------------------------------------------------------------------------------------
@@ -473,7 +803,7 @@ __device__ __forceinline__ void reg_cross(const RegArgs& a, int y, int x, float*
     v[2] = dx[0] * dy[1] - dx[1] * dy[0];
 }
 
-__global__ void __launch_bounds__(256) regloss_fwd_kernel(RegArgs a, float* loss)
+__global__ void __launch_bounds__(256) regloss_fwd_kernel(RegArgs a, float* loss, float* partial)
 {
     __shared__ float s_red[4];
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -498,7 +828,11 @@ __global__ void __launch_bounds__(256) regloss_fwd_kernel(RegArgs a, float* loss
     for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = val;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    if (threadIdx.x == 0) {
+        const float v = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        if (partial) partial[blockIdx.y * gridDim.x + blockIdx.x] = v;   // see ssim_fwd_kernel
+        else atomicAdd(loss, v);
+    }
 }
 
 __global__ void __launch_bounds__(256) regloss_bwd_kernel(RegArgs a, const float* g, float* d_allmap)
@@ -606,7 +940,7 @@ int dgs_ssim_forward(int C, int H, int W, const float* img1, const float* img2, 
     static const Gauss g = make_gauss();
     dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img1, img2, g, ssim_sum, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12);
+                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_fwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -621,7 +955,7 @@ int dgs_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
     static const Gauss g = make_gauss();
     dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, inv_n, img1, img2, g, dm_dmu1, dm_dsigma1_sq,
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, inv_n, 0.f, img1, img2, g, dm_dmu1, dm_dsigma1_sq,
                        dm_dsigma12, dL_dmean, dL_dimg1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
@@ -642,8 +976,9 @@ int dgs_lbs_forward(int N, int M, int H, const float* x, const float* feature, i
 {
     if (int e = lbs_check(N, M, H)) return e;
     if (N == 0) return 0;
-    LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask};
-    hipLaunchKernelGGL(lbs_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, d_xyz, d_rot, d_scale);
+    LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask, 3 + H + 2, nullptr, nullptr};
+    hipLaunchKernelGGL(lbs_fwd_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, d_xyz, d_rot, d_scale,
+                       AsmArgs{});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("lbs_fwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -658,10 +993,10 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
     const size_t lds = (size_t)M * G * sizeof(float);
     if (lds > 150 * 1024) return fail(-2, "dgs_lbs_backward: node table does not fit LDS (M * (15 + H) floats > 150 KB)");
     if (!scratch) return fail(-1, "dgs_lbs_backward: scratch is NULL");
-    LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask};
+    LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask, 3 + H + 2, nullptr, nullptr};
     const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
-    hipLaunchKernelGGL(lbs_bwd_kernel, dim3(kLbsBlocks), dim3(256), lds, (hipStream_t)stream, a, g_xyz, g_rot, g_scale, g_feature,
-                       (float*)scratch, chunk > 0 ? chunk : 1);
+    hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(kLbsBlocks), dim3(256), lds, (hipStream_t)stream, a, g_xyz, g_rot, g_scale,
+                       g_feature, H, 0, (float*)scratch, chunk > 0 ? chunk : 1, AsmArgs{});
     hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
                        g_ntab, g_attrs);
     hipError_t e = hipGetLastError();
@@ -674,7 +1009,7 @@ int dgs_regloss_forward(int H, int W, const float* allmap, const float* rays_d, 
 {
     if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !loss) return fail(-1, "dgs_regloss_forward: bad argument");
     RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist};
-    hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, loss);
+    hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, loss, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_fwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -734,7 +1069,7 @@ static const int kHeadRows[4] = {4, 3, 4, 2};
 int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
                     const float* rot_bias, float* packed, float* saved, float* attrs, void* stream)
 {
-    if (M <= 0 || M % mlp::kRows) return fail(-1, "dgs_mlp_forward: M must be a positive multiple of 16");
+    if (M <= 0 || M % 64) return fail(-1, "dgs_mlp_forward: M must be a positive multiple of 64");
     if (!x || !t || !params || !packed || !saved || !attrs) return fail(-1, "dgs_mlp_forward: null pointer");
     mlp::Weights w{};
     for (int l = 0; l < 10; l++) { w.W[l] = params[2 * l]; w.b[l] = params[2 * l + 1]; }
@@ -759,7 +1094,7 @@ int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_s
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream)
 {
-    if (M <= 0 || M % mlp::kRows) return fail(-1, "dgs_mlp_backward: M must be a positive multiple of 16");
+    if (M <= 0 || M % 64) return fail(-1, "dgs_mlp_backward: M must be a positive multiple of 64");
     if (!g_attrs || !packed || !saved || !scratch || !grads) return fail(-1, "dgs_mlp_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     mlp::BwdArgs b{};
@@ -798,7 +1133,7 @@ int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const flo
     add(scratch + mlp::sc_dt2(M), 32, mlp::kTOut, saved + mlp::sv_t1(M), W, W, grads[2], W, grads[3]);        // time net 2
     add(scratch + mlp::sc_dt1(M), W, W, saved + mlp::sv_et(M), mlp::kTPad, mlp::kTCh, grads[0], mlp::kTCh, grads[1]);  // time net 1
     g.ndesc = nd;
-    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, s, g);
     if (hipGetLastError() != hipSuccess) return fail(-2, "dgs_mlp_backward: launch failed");
     return 0;
 }
@@ -815,6 +1150,168 @@ int dgs_knn_points(int N, int M, int D, int K, const float* x, const float* node
     case 2: return launch_knn<2>(N, M, D, x, nodes, idx, dist2, s);
     case 3: return launch_knn<3>(N, M, D, x, nodes, idx, dist2, s);
     default: return launch_knn<4>(N, M, D, x, nodes, idx, dist2, s);
+    }
+}
+
+// ---- deformation + activations in one pass (dgs_deform_*) ------------------------------------------------------------
+int dgs_deform_forward(int N, int M, int H, const float* xyz, const float* feature, int feature_stride, const long long* idx,
+                       const float* nodes, const float* node_radius_raw, const float* node_weight_raw, const float* attrs,
+                       const float* mask, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                       float* means3D, float* scales, float* rotations, float* opacity, void* stream)
+{
+    if (int e = lbs_check(N, M, H)) return e;
+    if (N == 0) return 0;
+    if (!xyz || !feature || !idx || !nodes || !node_radius_raw || !node_weight_raw || !attrs || !scaling_raw || !rotation_raw ||
+        !opacity_raw || !means3D || !scales || !rotations || !opacity)
+        return fail(-1, "dgs_deform_forward: NULL pointer");
+    LbsArgs a{N, M, H, feature_stride, xyz, feature, idx, nodes, attrs, mask, 3 + H, node_radius_raw, node_weight_raw};
+    AsmArgs s{};
+    s.scaling_raw = scaling_raw; s.rotation_raw = rotation_raw; s.opacity_raw = opacity_raw;
+    s.means3D = means3D; s.scales = scales; s.rotations = rotations; s.opacity = opacity;
+    hipLaunchKernelGGL(lbs_fwd_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("lbs_fwd_kernel<asm>: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feature, int feature_stride, const long long* idx,
+                        const float* nodes, const float* node_radius_raw, const float* node_weight_raw, const float* attrs,
+                        const float* mask, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                        const float* g_means3D, const float* g_scales, const float* g_rotations, const float* g_opacity,
+                        float* g_xyz, float* g_scaling_raw, float* g_rotation_raw, float* g_opacity_raw, float* g_feature,
+                        float* g_nodes, float* g_radius_raw, float* g_weight_raw, float* g_attrs, int accumulate, void* scratch,
+                        void* stream)
+{
+    if (int e = lbs_check(N, M, H)) return e;
+    const int G = kLbsAttr + H + 2;
+    const size_t lds = (size_t)M * G * sizeof(float);
+    if (lds > 150 * 1024) return fail(-2, "dgs_deform_backward: node table does not fit LDS (M * (15 + H) floats > 150 KB)");
+    if (!scratch || !g_means3D || !g_scales || !g_rotations || !g_opacity || !g_xyz || !g_scaling_raw || !g_rotation_raw ||
+        !g_opacity_raw || !g_feature || !g_nodes || !g_radius_raw || !g_weight_raw || !g_attrs)
+        return fail(-1, "dgs_deform_backward: NULL pointer");
+    LbsArgs a{N, M, H, feature_stride, xyz, feature, idx, nodes, attrs, mask, 3 + H, node_radius_raw, node_weight_raw};
+    AsmArgs s{};
+    s.scaling_raw = scaling_raw; s.rotation_raw = rotation_raw; s.opacity_raw = opacity_raw;
+    s.g_means3D = g_means3D; s.g_scales = g_scales; s.g_rotations = g_rotations; s.g_opacity = g_opacity;
+    s.g_xyz = g_xyz; s.g_scaling_raw = g_scaling_raw; s.g_rotation_raw = g_rotation_raw; s.g_opacity_raw = g_opacity_raw;
+    const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
+    hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(kLbsBlocks), dim3(256), lds, (hipStream_t)stream, a, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate, (float*)scratch,
+                       chunk > 0 ? chunk : 1, s);
+    hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
+                       node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("lbs_bwd_kernel<asm>: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// ---- photometric loss: (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM) (train_gui.py:292-296) ---------------------
+size_t dgs_photo_blocks(int C, int H, int W) { return (size_t)((W + kT - 1) / kT) * ((H + kT - 1) / kT) * (size_t)C; }
+size_t dgs_regloss_blocks(int H, int W) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
+
+int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, float* partials, float* dm_dmu1, float* dm_dsigma1_sq,
+                      float* dm_dsigma12, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !partials || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)
+        return fail(-1, "dgs_photo_forward: bad argument");
+    static const Gauss g = make_gauss();
+    dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img, gt, g, (float*)nullptr, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("ssim_fwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                                 float lambda_normal, float lambda_dist, float* partials, void* stream)
+{
+    if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !partials) return fail(-1, "dgs_regloss_forward_partials: bad argument");
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist};
+    hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, (float*)nullptr,
+                       partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("regloss_fwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                       const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !g_loss || !dL_dimg)
+        return fail(-1, "dgs_photo_backward: bad argument");
+    static const Gauss g = make_gauss();
+    dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
+    const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, -lambda_dssim * inv_n,
+                       (1.0f - lambda_dssim) * inv_n, img, gt, g, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, g_loss, dL_dimg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
+                     float lambda_dssim, float* out, void* stream)
+{
+    if (!photo_partials || !reg_partials || !out || n <= 0 || nphoto < 0 || nreg < 0) return fail(-1, "dgs_loss_combine: bad argument");
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, photo_partials, (int)nphoto, reg_partials,
+                       (int)nreg, 1.0f / (float)n, lambda_dssim, out);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-4, "loss_combine_kernel: launch failed");
+}
+
+// ---- densification statistics ----------------------------------------------------------------------------------------
+int dgs_densify_view(int P, const int* radii, const float* g_means2D, float* grad_norm, float* visible, int* radii_vis, void* stream)
+{
+    if (P < 0 || (P > 0 && (!radii || !g_means2D || !grad_norm || !visible || !radii_vis))) return fail(-1, "dgs_densify_view: bad argument");
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(densify_view_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, radii, g_means2D, grad_norm,
+                       visible, radii_vis);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-4, "densify_view_kernel: launch failed");
+}
+
+int dgs_densify_accumulate(int P, const float* grad_norm, const float* visible, const int* radii_vis, float* accum, float* denom,
+                           int* max_radii, void* stream)
+{
+    if (P < 0 || (P > 0 && (!grad_norm || !visible || !radii_vis || !accum || !denom || !max_radii)))
+        return fail(-1, "dgs_densify_accumulate: bad argument");
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(densify_accum_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, grad_norm, visible, radii_vis,
+                       accum, denom, max_radii);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-4, "densify_accum_kernel: launch failed");
+}
+
+int dgs_knn_points2(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
+                    long long* idx, float* dist2, void* stream)
+{
+    const int D = D1 + D2;
+    if (N < 0 || M <= 0 || D1 < 1 || D2 < 1 || D > kKnnDpad || K < 1 || K > 4 || K > M) return fail(-1, "dgs_knn_points2: bad argument");
+    if (N == 0) return 0;
+    if (!x1 || !x2 || !nodes || !idx) return fail(-1, "dgs_knn_points2: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+    case 1: return launch_knn<1>(N, M, D, x1, nodes, idx, dist2, s, x2, D1, x2_stride);
+    case 2: return launch_knn<2>(N, M, D, x1, nodes, idx, dist2, s, x2, D1, x2_stride);
+    case 3: return launch_knn<3>(N, M, D, x1, nodes, idx, dist2, s, x2, D1, x2_stride);
+    default: return launch_knn<4>(N, M, D, x1, nodes, idx, dist2, s, x2, D1, x2_stride);
+    }
+}
+
+int dgs_knn_refine(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
+                   long long* idx, void* stream)
+{
+    const int D = D1 + D2;
+    if (N < 0 || M <= 0 || D1 < 3 || D2 < 0 || D > kKnnDpad || K < 1 || K > 4 || K > M) return fail(-1, "dgs_knn_refine: bad argument");
+    if (M > 2048) return fail(-2, "dgs_knn_refine: more than 2048 nodes (use dgs_knn_points)");
+    if (N == 0) return 0;
+    if (!x1 || (D2 > 0 && !x2) || !nodes || !idx) return fail(-1, "dgs_knn_refine: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const float* xb = D2 > 0 ? x2 : nullptr;
+    switch (K) {
+    case 1: return launch_knn_refine<1>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
+    case 2: return launch_knn_refine<2>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
+    case 3: return launch_knn_refine<3>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
+    default: return launch_knn_refine<4>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
     }
 }
 

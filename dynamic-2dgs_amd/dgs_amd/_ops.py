@@ -9,12 +9,13 @@ import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libdgs_train_ops.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-munsafe-fp-atomics"]
 _lib = None
 _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_forward", "dgs_ssim_backward", "dgs_knn_points",
             "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step",
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
-            "dgs_mlp_forward", "dgs_mlp_backward")
+            "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
+            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials")
 
 
 def build(force=False, verbose=False):
@@ -74,6 +75,30 @@ def load():
         lib.dgs_mlp_forward.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
         lib.dgs_mlp_backward.restype = ci
         lib.dgs_mlp_backward.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp]
+        lib.dgs_knn_points2.restype = ci
+        lib.dgs_knn_points2.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
+        lib.dgs_knn_refine.restype = ci
+        lib.dgs_knn_refine.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]
+        lib.dgs_deform_forward.restype = ci
+        lib.dgs_deform_forward.argtypes = [ci, ci, ci, vp, vp, ci] + [vp] * 14
+        lib.dgs_deform_backward.restype = ci
+        lib.dgs_deform_backward.argtypes = [ci, ci, ci, vp, vp, ci] + [vp] * 22 + [ci, vp, vp]
+        lib.dgs_photo_forward.restype = ci
+        lib.dgs_photo_forward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+        lib.dgs_photo_backward.restype = ci
+        lib.dgs_photo_backward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp]
+        lib.dgs_loss_combine.restype = ci
+        lib.dgs_loss_combine.argtypes = [vp, ctypes.c_longlong, vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_float, vp, vp]
+        lib.dgs_photo_blocks.restype = ctypes.c_size_t
+        lib.dgs_photo_blocks.argtypes = [ci, ci, ci]
+        lib.dgs_regloss_blocks.restype = ctypes.c_size_t
+        lib.dgs_regloss_blocks.argtypes = [ci, ci]
+        lib.dgs_regloss_forward_partials.restype = ci
+        lib.dgs_regloss_forward_partials.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp]
+        lib.dgs_densify_view.restype = ci
+        lib.dgs_densify_view.argtypes = [ci, vp, vp, vp, vp, vp, vp]
+        lib.dgs_densify_accumulate.restype = ci
+        lib.dgs_densify_accumulate.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp]
         if lib.dgs_train_ops_abi_version() != 1:
             raise RuntimeError("libdgs_train_ops.so ABI version mismatch")
         _lib = lib
@@ -343,7 +368,7 @@ def fused_node_mlp(net, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0), grad_sink=False):
     grad_sink=True: parameter gradients are ADDED to the existing .grad tensors by the kernel (they must exist, be
     contiguous fp32) and autograd sees no gradient for them -- for trainers that own a flat gradient buffer."""
     params = node_mlp_params(net)
-    if params is None or x.shape[0] % 16:
+    if params is None or x.shape[0] % 64:
         raise RuntimeError("fused_node_mlp: unsupported DeformMLP configuration")
     sink = None
     if grad_sink and torch.is_grad_enabled():
@@ -351,3 +376,175 @@ def fused_node_mlp(net, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0), grad_sink=False):
         if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
             raise RuntimeError("fused_node_mlp(grad_sink=True): every parameter needs a contiguous fp32 .grad")
     return _FusedNodeMLP.apply(x.detach(), t.detach(), tuple(float(v) for v in rot_bias), sink, *params)
+
+
+def knn_indices2(x1, x2, nodes, K, seed=None):
+    """knn_indices(cat([x1, x2], 1), nodes, K) without materialising the concatenation (x2 may be a column slice).
+    seed: an int64 [N,K] tensor holding an earlier answer (e.g. last step's); it is refined IN PLACE to the exact
+    current answer and returned (dgs_knn_refine: ~3x cheaper than the plain scan, exact for any seed content)."""
+    lib = load()
+    if seed is not None:
+        N = x1.shape[0]
+        if not (seed.shape == (N, K) and seed.dtype == torch.int64 and seed.is_contiguous() and x1.shape[1] >= 3
+                and nodes.shape[0] <= 2048):
+            raise RuntimeError("knn_indices2: seed must be a contiguous int64 [N,K] tensor (and <= 2048 nodes)")
+        x1d, x2d, nd = x1.detach(), x2.detach(), nodes.detach()
+        with torch.cuda.device(x1.device):
+            rc = lib.dgs_knn_refine(N, nd.shape[0], x1d.shape[1], x2d.shape[1], K, x1d.data_ptr(), x2d.data_ptr(), x2d.stride(0),
+                                    nd.data_ptr(), seed.data_ptr(), _stream(x1.device))
+        _check(lib, rc, "dgs_knn_refine")
+        return seed
+    x1, nodes = x1.detach(), nodes.detach()
+    x2 = x2.detach()
+    if not (x1.is_contiguous() and nodes.is_contiguous() and x2.stride(1) == 1 and x1.dtype == x2.dtype == nodes.dtype == torch.float32):
+        raise RuntimeError("knn_indices2: fp32 row-major inputs expected")
+    N = x1.shape[0]
+    idx = torch.empty((N, K), dtype=torch.int64, device=x1.device)
+    with torch.cuda.device(x1.device):
+        rc = lib.dgs_knn_points2(N, nodes.shape[0], x1.shape[1], x2.shape[1], K, x1.data_ptr(), x2.data_ptr(), x2.stride(0),
+                                 nodes.data_ptr(), idx.data_ptr(), None, _stream(x1.device))
+    _check(lib, rc, "dgs_knn_points2")
+    return idx
+
+
+class _FusedDeform(torch.autograd.Function):
+    """(means3D, scales, rotations, opacity) of the deformed surfels from the raw surfel parameters, the node tables
+    and the node attribute table (dgs_deform_forward / dgs_deform_backward).  sink: None or the list of the eight
+    gradient tensors [xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight] to add into."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink):
+        lib = load()
+        dev = xyz.device
+        N, M = xyz.shape[0], nodes.shape[0]
+        tens = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
+        if not all(t.is_contiguous() and t.dtype == torch.float32 for t in tens) or nodes.shape[1] != 3 + H:
+            raise RuntimeError("fused deform: contiguous fp32 parameters expected, nodes [M, 3 + hyper_dim]")
+        attrs, idx = attrs.contiguous(), idx.contiguous()
+        mask = None if mask is None else mask.contiguous().reshape(-1)
+        # four separate row-major outputs carved from one allocation
+        r = lambda n: (n + 63) // 64 * 64  # segment starts stay 256-byte aligned
+        o1, o2, o3 = r(3 * N), r(3 * N) + r(2 * N), r(3 * N) + r(2 * N) + r(4 * N)
+        buf = torch.empty(o3 + N, dtype=torch.float32, device=dev)
+        means3D, scales = buf[:3 * N].view(N, 3), buf[o1:o1 + 2 * N].view(N, 2)
+        rots, opac = buf[o2:o2 + 4 * N].view(N, 4), buf[o3:o3 + N].view(N, 1)
+        with torch.cuda.device(dev):
+            rc = lib.dgs_deform_forward(N, M, H, xyz.data_ptr(), feature.data_ptr(), feature.shape[1], idx.data_ptr(), nodes.data_ptr(),
+                                        node_radius.data_ptr(), node_weight.data_ptr(), attrs.data_ptr(),
+                                        None if mask is None else mask.data_ptr(), scaling.data_ptr(), rotation.data_ptr(),
+                                        opacity.data_ptr(), means3D.data_ptr(), scales.data_ptr(), rots.data_ptr(), opac.data_ptr(),
+                                        _stream(dev))
+        _check(lib, rc, "dgs_deform_forward")
+        ctx.save_for_backward(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx)
+        ctx.mask, ctx.H, ctx.sink = mask, H, sink
+        return means3D, scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, g_means, g_scales, g_rots, g_opac):
+        lib = load()
+        xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx = ctx.saved_tensors
+        dev = xyz.device
+        N, M, H = xyz.shape[0], nodes.shape[0], ctx.H
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()
+        g_means, g_scales, g_rots, g_opac = z(g_means, xyz), z(g_scales, scaling), z(g_rots, rotation), z(g_opac, opacity)
+        g_attrs = torch.empty_like(attrs)
+        scratch = torch.empty(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
+        tens = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
+        if ctx.sink is not None:
+            outs, ret, acc = ctx.sink, [None] * 8, 1
+        else:
+            outs = [torch.empty_like(t) for t in tens]
+            if feature.shape[1] > H:
+                outs[4].zero_()
+            ret, acc = outs, 0
+        mask = ctx.mask
+        with torch.cuda.device(dev):
+            rc = lib.dgs_deform_backward(
+                N, M, H, xyz.data_ptr(), feature.data_ptr(), feature.shape[1], idx.data_ptr(), nodes.data_ptr(), node_radius.data_ptr(),
+                node_weight.data_ptr(), attrs.data_ptr(), None if mask is None else mask.data_ptr(), scaling.data_ptr(),
+                rotation.data_ptr(), opacity.data_ptr(), g_means.data_ptr(), g_scales.data_ptr(), g_rots.data_ptr(), g_opac.data_ptr(),
+                outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), outs[5].data_ptr(),
+                outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), acc, scratch.data_ptr(), _stream(dev))
+        _check(lib, rc, "dgs_deform_backward")
+        return tuple(ret) + (g_attrs, None, None, None, None)
+
+
+def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False):
+    """Raw surfel parameters + node tables + node attributes -> (means3D, scales, rotations, opacity) for the rasterizer.
+    grad_sink=True: gradients of the eight parameters are ADDED to their existing .grad tensors by the kernels."""
+    params = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
+    sink = None
+    if grad_sink and torch.is_grad_enabled():
+        sink = [p.grad for p in params]
+        if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
+            raise RuntimeError("fused_deform(grad_sink=True): every parameter needs a contiguous fp32 .grad")
+    return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink)
+
+
+class _FusedTrainLoss(torch.autograd.Function):
+    """(1 - l) * L1(image, gt) + l * (1 - SSIM(image, gt)) + lambda_normal * normal consistency + lambda_dist * distortion
+    from the rasterizer outputs: 4 launches forward, 3 backward."""
+
+    @staticmethod
+    def forward(ctx, image, allmap, gt, rays_d, rays_o, wvt, lam_dssim, lam_n, lam_d):
+        lib = load()
+        dev = image.device
+        image, allmap, gt = image.contiguous(), allmap.contiguous(), gt.contiguous()
+        C, H, W = image.shape
+        nb, nr = int(lib.dgs_photo_blocks(C, H, W)), int(lib.dgs_regloss_blocks(H, W))
+        part = torch.empty(2 * nb + nr, dtype=torch.float32, device=dev)  # per-workgroup partial sums, no zero fill needed
+        maps = torch.empty((3, C, H, W), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            _check(lib, lib.dgs_photo_forward(C, H, W, image.data_ptr(), gt.data_ptr(), part.data_ptr(), maps[0].data_ptr(),
+                                              maps[1].data_ptr(), maps[2].data_ptr(), st), "dgs_photo_forward")
+            _check(lib, lib.dgs_regloss_forward_partials(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
+                                                         lam_n, lam_d, part.data_ptr() + 8 * nb, st), "dgs_regloss_forward_partials")
+            _check(lib, lib.dgs_loss_combine(part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, C * H * W, lam_dssim, loss.data_ptr(), st),
+                   "dgs_loss_combine")
+        ctx.save_for_backward(image, allmap, gt, rays_d, rays_o, wvt, maps)
+        ctx.lam = (lam_dssim, lam_n, lam_d)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        image, allmap, gt, rays_d, rays_o, wvt, maps = ctx.saved_tensors
+        dev = image.device
+        C, H, W = image.shape
+        gd = g.reshape(1).to(torch.float32).contiguous()
+        g_image = torch.empty_like(image)
+        g_allmap = torch.zeros_like(allmap)
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            _check(lib, lib.dgs_photo_backward(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
+                                               maps[2].data_ptr(), ctx.lam[0], gd.data_ptr(), g_image.data_ptr(), st), "dgs_photo_backward")
+            _check(lib, lib.dgs_regloss_backward(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), ctx.lam[1],
+                                                 ctx.lam[2], gd.data_ptr(), g_allmap.data_ptr(), st), "dgs_regloss_backward")
+        return g_image, g_allmap, None, None, None, None, None, None, None
+
+
+def fused_train_loss(image, allmap, gt, rays_d, rays_o, wvt, lambda_dssim, lambda_normal, lambda_dist):
+    return _FusedTrainLoss.apply(image, allmap, gt.detach(), rays_d.contiguous(), rays_o.contiguous(), wvt.contiguous(),
+                                 float(lambda_dssim), float(lambda_normal), float(lambda_dist))
+
+
+def densify_view(radii, g_means2D, grad_norm, visible, radii_vis):
+    """Per-view densification statistics into the given [P] output tensors (see dgs_densify_view)."""
+    lib = load()
+    P = radii.shape[0]
+    g = g_means2D.contiguous()
+    with torch.cuda.device(radii.device):
+        rc = lib.dgs_densify_view(P, radii.data_ptr(), g.data_ptr(), grad_norm.data_ptr(), visible.data_ptr(), radii_vis.data_ptr(),
+                                  _stream(radii.device))
+    _check(lib, rc, "dgs_densify_view")
+
+
+def densify_accumulate(grad_norm, visible, radii_vis, accum, denom, max_radii):
+    lib = load()
+    P = radii_vis.shape[0]
+    with torch.cuda.device(radii_vis.device):
+        rc = lib.dgs_densify_accumulate(P, grad_norm.data_ptr(), visible.data_ptr(), radii_vis.data_ptr(), accum.data_ptr(),
+                                        denom.data_ptr(), max_radii.data_ptr(), _stream(radii_vis.device))
+    _check(lib, rc, "dgs_densify_accumulate")

@@ -50,8 +50,10 @@ def depth_to_normal(cam, depth):
     return output, points
 
 
-def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=False, rasterizer_cls=None, postprocess=True):
-    """pc: dgs_amd.model.SurfelModel.  d_*: outputs of the deformation (or 0.0)."""
+def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=False, rasterizer_cls=None, postprocess=True,
+           assembled=None):
+    """pc: dgs_amd.model.SurfelModel.  d_*: outputs of the deformation (or 0.0).  assembled: (means3D, scales, rotations,
+    opacity) already computed by ControlNodes.forward_assembled (then d_* are ignored)."""
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, requires_grad=True)
     cfg = GaussianRasterizationSettings(
@@ -60,11 +62,15 @@ def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=Fa
         viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=cam.camera_center, prefiltered=False, debug=debug)
     rasterizer = (rasterizer_cls or GaussianRasterizer)(raster_settings=cfg)
-    means3D = xyz + d_xyz
-    scales = pc.get_scaling + d_scaling
-    rotations = pc.get_rotation_bias(d_rotation)
+    if assembled is not None:
+        means3D, scales, rotations, opacity = assembled
+    else:
+        means3D = xyz + d_xyz
+        scales = pc.get_scaling + d_scaling
+        rotations = pc.get_rotation_bias(d_rotation)
+        opacity = pc.get_opacity
     rendered_image, radii, allmap = rasterizer(
-        means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=pc.get_opacity,
+        means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=None)
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "allmap": allmap}

@@ -105,6 +105,7 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.iteration = 0
         self._graph = None
+        self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
 
     # ---- whole-step HIP graph ------------------------------------------------------------------------------------
     def enable_graph(self, capacity):
@@ -155,21 +156,30 @@ class Trainer:
         s, d = self.surfels, self.deform
         self.bucket.zero()
         t = d.expand_time(cam.fid)
-        dv = d(s.get_xyz.detach(), t, s.feature, s.motion_mask)
         fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
-        pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
-                     postprocess=not fused)
+        if fused and self.fuse_deform and d.can_assemble(s):
+            asm = d.forward_assembled(s, t)
+            pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
+        else:
+            dv = d(s.get_xyz.detach(), t, s.feature, s.motion_mask)
+            pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
+                         postprocess=not fused)
         loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt) if fused else training_loss(pkg, gt)
         loss.backward()
         with torch.no_grad():
             # densification statistics of this view into the bucket tail (summed over ranks)
-            vis = pkg["visibility_filter"]
-            g2 = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
-            self.bucket.extra[:self.P].copy_(torch.where(vis, g2, torch.zeros_like(g2)))
-            self.bucket.extra[self.P:].copy_(vis.to(torch.float32))
             if not hasattr(self, "_radii"):
                 self._radii = torch.zeros_like(pkg["radii"])
-            self._radii.copy_(torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"])))
+            if fused:
+                from . import _ops
+                _ops.densify_view(pkg["radii"], pkg["viewspace_points"].grad, self.bucket.extra[:self.P], self.bucket.extra[self.P:],
+                                  self._radii)
+            else:
+                vis = pkg["visibility_filter"]
+                g2 = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
+                self.bucket.extra[:self.P].copy_(torch.where(vis, g2, torch.zeros_like(g2)))
+                self.bucket.extra[self.P:].copy_(vis.to(torch.float32))
+                self._radii.copy_(torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"])))
         return loss.detach()
 
     def _reduce(self):
@@ -182,9 +192,14 @@ class Trainer:
         with torch.no_grad():
             if reduce:
                 self._reduce()
-            s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
-            s.denom.add_(self.bucket.extra[self.P:, None])
-            torch.maximum(s.max_radii2D, self._radii, out=s.max_radii2D)
+            if self.rasterizer_cls is None and s.get_xyz.is_cuda:
+                from . import _ops
+                _ops.densify_accumulate(self.bucket.extra[:self.P], self.bucket.extra[self.P:], self._radii, s.xyz_gradient_accum,
+                                        s.denom, s.max_radii2D)
+            else:
+                s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
+                s.denom.add_(self.bucket.extra[self.P:, None])
+                torch.maximum(s.max_radii2D, self._radii, out=s.max_radii2D)
             self.opt_surfels.step()
             if self.opt_deform is not None:
                 self.opt_deform.step()

@@ -152,8 +152,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                  transMat_precomp=transMat_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, sh=sh, campos=campos)
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-    out_others = torch.zeros((8, H, W), dtype=torch.float32, device=dev)
+    planes = torch.zeros((11, H, W), dtype=torch.float32, device=dev)  # one fill for both images
+    out_color, out_others = planes[:3], planes[3:]
     radii = torch.zeros((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
     rendered = 0
@@ -187,15 +187,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
     opts = dict(dtype=torch.float32, device=dev)
-    dL_dmeans3D = torch.zeros((P, 3), **opts)
-    dL_dmeans2D = torch.zeros((P, 3), **opts)
-    dL_dcolors = torch.zeros((P, 3), **opts)
-    dL_dnormal = torch.zeros((P, 3), **opts)
-    dL_dopacity = torch.zeros((P, 1), **opts)
-    dL_dtransMat = torch.zeros((P, 9), **opts)
-    dL_dsh = torch.zeros((P, M, 3), **opts)
-    dL_dscales = torch.zeros((P, 2), **opts)
-    dL_drotations = torch.zeros((P, 4), **opts)
+    # all nine gradient arrays from ONE zero-filled allocation (one fill launch instead of nine)
+    cols = (3, 3, 3, 3, 1, 9, 3 * M, 2, 4)
+    seg = [(P * c + 63) // 64 * 64 for c in cols]  # segment starts stay 256-byte aligned
+    flat = torch.zeros(sum(seg), **opts)
+    views, off = [], 0
+    for c, n in zip(cols, seg):
+        views.append(flat[off:off + P * c].view(P, c))
+        off += n
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal, dL_dopacity, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = views
+    dL_dsh = dL_dsh.view(P, M, 3)
     if P != 0:
         bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
         sc, rot, tm = _f32c(scales), _f32c(rotations), _f32c(transMat_precomp)

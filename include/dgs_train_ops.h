@@ -94,7 +94,7 @@ int dgs_adam_step(int nseg, float* const* params /*host array of device pointers
  *   packed: dgs_mlp_packed_floats() floats, written by forward, read by backward (weights re-laid in MFMA order)
  *   saved : dgs_mlp_saved_floats(M) floats of activations, written by forward, read by backward
  *   scratch: dgs_mlp_scratch_floats(M) floats
- * backward writes (accumulate = 0) or adds to (accumulate = 1) every gradient tensor.  M must be a multiple of 16. */
+ * backward writes (accumulate = 0) or adds to (accumulate = 1) every gradient tensor.  M must be a multiple of 64. */
 size_t dgs_mlp_packed_floats(void);
 size_t dgs_mlp_saved_floats(int M);
 size_t dgs_mlp_scratch_floats(int M);
@@ -102,6 +102,64 @@ int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_s
                     const float* rot_bias, float* packed, float* saved, float* attrs, void* stream);
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream);
+
+/* dgs_knn_points with the query coordinates split over two arrays: [0,D1) from x1[N,D1], [D1,D1+D2) from
+ * x2[N, x2_stride] (avoids materialising cat([xyz, feature[:, :hyper]]) every step). */
+int dgs_knn_points2(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
+                    long long* idx, float* dist2, void* stream);
+
+/* Control-node skinning of dgs_lbs_* fused with (a) the node-table activations node_radius = exp(_node_radius),
+ * node_weight = sigmoid(_node_weight) (utils/time_utils.py:812-818) and (b) the surfel activations render() applies
+ * around the deformation (gaussian_renderer/__init__.py:60-75, scene/gaussian_model.py:60-78):
+ *   means3D = xyz + d_xyz, scales = exp(_scaling) + d_scaling, rotations = normalize(_rotation + d_rotation),
+ *   opacity = sigmoid(_opacity).
+ * nodes[M,3+H] = [xyz (detached) | hyper]; mask may be NULL (= 1).  backward: g_attrs[M,13] is always overwritten; all
+ * other gradient arrays are overwritten (accumulate = 0; the xyz columns of g_nodes are zeroed) or added to
+ * (accumulate = 1, e.g. the .grad views of a flat gradient bucket).  g_feature has the row stride of feature.
+ * scratch: dgs_lbs_scratch_bytes(M, H) bytes. */
+int dgs_deform_forward(int N, int M, int H, const float* xyz, const float* feature, int feature_stride, const long long* idx,
+                       const float* nodes, const float* node_radius_raw, const float* node_weight_raw, const float* attrs,
+                       const float* mask, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                       float* means3D, float* scales, float* rotations, float* opacity, void* stream);
+int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feature, int feature_stride, const long long* idx,
+                        const float* nodes, const float* node_radius_raw, const float* node_weight_raw, const float* attrs,
+                        const float* mask, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                        const float* g_means3D, const float* g_scales, const float* g_rotations, const float* g_opacity,
+                        float* g_xyz, float* g_scaling_raw, float* g_rotation_raw, float* g_opacity_raw, float* g_feature,
+                        float* g_nodes, float* g_radius_raw, float* g_weight_raw, float* g_attrs, int accumulate, void* scratch,
+                        void* stream);
+
+/* Photometric loss of the train step, (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM(img, gt)) (train_gui.py:292-296),
+ * on the SSIM kernels, with the regularisers of dgs_regloss_*.  Reductions go through per-workgroup partial sums (no
+ * atomics: thousands of atomics on one address serialise in a single L2 channel and dominated these kernels):
+ *   dgs_photo_forward            partials[0 .. B)  = SSIM-map sums, partials[B .. 2B) = |img - gt| sums, B = dgs_photo_blocks()
+ *   dgs_regloss_forward_partials partials[0 .. R)  = regulariser sums (already scaled and divided by H*W), R = dgs_regloss_blocks()
+ *   dgs_loss_combine             out[0] = (1 - lambda) * sum(l1) / n + lambda * (1 - sum(ssim) / n) + sum(reg),  n = C*H*W
+ *   dgs_photo_backward           dL/dimg for the DEVICE scalar *g_loss. */
+size_t dgs_photo_blocks(int C, int H, int W);
+size_t dgs_regloss_blocks(int H, int W);
+int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, float* partials, float* dm_dmu1, float* dm_dsigma1_sq,
+                      float* dm_dsigma12, void* stream);
+int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                                 float lambda_normal, float lambda_dist, float* partials, void* stream);
+int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
+                     float lambda_dssim, float* out, void* stream);
+int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                       const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, void* stream);
+
+/* Densification statistics (train_gui.py:411, scene/gaussian_model.py:484-486).  dgs_densify_view, per rendered view:
+ * visible = radii > 0, grad_norm = |dL/dmeans2D[:, :2]| where visible (else 0), radii_vis = radii where visible.
+ * dgs_densify_accumulate: xyz_gradient_accum += grad_norm, denom += visible, max_radii2D = max(max_radii2D, radii_vis). */
+int dgs_densify_view(int P, const int* radii, const float* g_means2D, float* grad_norm, float* visible, int* radii_vis, void* stream);
+int dgs_densify_accumulate(int P, const float* grad_norm, const float* visible, const int* radii_vis, float* accum, float* denom,
+                           int* max_radii, void* stream);
+
+/* Exact K nearest neighbours seeded with a previous answer: idx[N,K] holds any earlier result on entry (typically last
+ * step's; stale, random or invalid entries only cost time) and the exact answer of dgs_knn_points2 on exit.  The scan over
+ * the M <= 2048 nodes uses only coordinates 0..2 (D1 >= 3: a lower bound of the full squared distance) against the bound
+ * the seed gives; full distances are evaluated for the few survivors.  D2 may be 0 (x2 unused). */
+int dgs_knn_refine(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
+                   long long* idx, void* stream);
 
 #ifdef __cplusplus
 }

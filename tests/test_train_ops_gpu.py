@@ -36,6 +36,27 @@ def test_knn_kernel_matches_bruteforce(N, M, D, K):
     assert bool((dsel[:, 1:] >= dsel[:, :-1] - 1e-6).all())
 
 
+def test_knn_refine_is_exact_for_any_seed():
+    """dgs_knn_refine == plain scan whatever the seed holds: last step's answer, random indices, duplicates, garbage."""
+    from dgs_amd import _ops
+    g = torch.Generator().manual_seed(9)
+    N, M = 30001, 1000
+    x = (torch.rand(N, 3, generator=g) * 2 - 1).cuda()
+    f = (0.05 * torch.randn(N, 8, generator=g)).cuda()
+    nodes = torch.cat([torch.rand(M, 3, generator=g) * 2 - 1, 0.05 * torch.randn(M, 8, generator=g)], 1).cuda()
+    want = _ops.knn_indices2(x, f, nodes, 3)
+    assert torch.equal(want, _ops.knn_indices(torch.cat([x, f], 1), nodes, 3))
+    moved = _ops.knn_indices2(x + 0.01 * torch.randn(N, 3, generator=g).cuda(), f, nodes, 3)
+    seeds = {"previous": moved.clone(), "exact": want.clone(),
+             "random": torch.randint(0, M, (N, 3), generator=g).cuda(),
+             "duplicates": want[:, :1].repeat(1, 3).contiguous(),
+             "garbage": torch.randint(-5, 3 * M, (N, 3), generator=g).cuda()}
+    for name, seed in seeds.items():
+        got = _ops.knn_indices2(x, f, nodes, 3, seed=seed)
+        assert got.data_ptr() == seed.data_ptr()
+        assert torch.equal(got, want), name
+
+
 def test_graph_captured_step_matches_eager():
     """The whole-step HIP graph (rasterizer in capacity mode, no host synchronisation) must train like the eager
     step: same loss trajectory.  enable_graph() runs three warm-up steps on view 0 before capturing, so the eager run
@@ -137,7 +158,7 @@ def test_fused_lbs_matches_torch_autograd():
         close(a["net"][n], b["net"][n], "grad net." + n, 5e-4)
 
 
-@pytest.mark.parametrize("M,per_node_t", [(1024, False), (48, True)])
+@pytest.mark.parametrize("M,per_node_t", [(1024, False), (64, True)])
 def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
     """dgs_mlp_forward/backward (fp32 MFMA) against DeformMLP.forward + torch.autograd: the attribute table, every
     weight/bias gradient, in both gradient modes (returned to autograd / added into existing .grad tensors)."""
@@ -176,6 +197,117 @@ def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
             got = p.grad - 0.25 if sink else p.grad
             assert got is not None, n
             close(ref_grads[n], got, "grad %s (sink=%s)" % (n, sink), 2e-4)
+
+
+def test_fused_deform_assembled_matches_torch_autograd():
+    """ControlNodes.forward_assembled (KNN on split inputs, MFMA node MLP, skinning + surfel activations in one kernel
+    per direction, gradients written or added in place) against the PyTorch formulation feeding render()."""
+    from dgs_amd.deform import ControlNodes
+    from dgs_amd.model import SurfelModel
+    from dgs_amd.synthetic import make_scene
+    N, Mn = 6001, 256
+    cot_g = torch.Generator().manual_seed(11)
+    cot = [torch.randn(N, c, generator=cot_g).cuda() for c in (3, 2, 4, 1)]
+    res = {}
+    for mode in ("torch", "fused", "sink"):
+        torch.manual_seed(1)
+        pc = SurfelModel(make_scene(N, seed=3)).cuda()
+        m = ControlNodes(node_num=Mn, K=3, hyper_dim=8, local_frame=True).cuda()
+        m.init_from_points(pc._xyz.detach())
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            m.nodes[:, 3:] += 0.02 * torch.randn(Mn, 8, generator=g).cuda()
+            m._node_weight += 0.5 * torch.randn(Mn, 1, generator=g).cuda()
+            m._node_radius += 0.2 * torch.randn(Mn, generator=g).cuda()
+            pc.feature += 0.05 * torch.randn(N, 8, generator=g).cuda()
+            for head in (m.network.gaussian_warp, m.network.gaussian_rotation, m.network.gaussian_scaling, m.network.local_rotation):
+                head.weight.mul_(3e3)
+        params = dict(list(pc.named_parameters()) + [("deform." + n, p) for n, p in m.named_parameters()])
+        t = torch.full((1,), 0.37).cuda()
+        if mode == "torch":
+            m.use_fused = m.use_fused_mlp = False
+            dv = m(pc.get_xyz.detach(), t, pc.feature, pc.motion_mask)
+            out = (pc.get_xyz + dv['d_xyz'], pc.get_scaling + dv['d_scaling'], pc.get_rotation_bias(dv['d_rotation']), pc.get_opacity)
+        else:
+            assert m.can_assemble(pc)
+            m.grad_sink = mode == "sink"
+            if m.grad_sink:
+                for p in params.values():
+                    p.grad = torch.full_like(p, 0.5)
+            out = m.forward_assembled(pc, t)
+        sum((o * c).sum() for o, c in zip(out, cot)).backward()
+        grads = {}
+        for n, p in params.items():
+            if p.grad is None:
+                assert n.startswith("_features"), n
+                continue
+            grads[n] = (p.grad - 0.5) if mode == "sink" and not n.startswith("_features") else p.grad.clone()
+        res[mode] = ([o.detach() for o in out], grads)
+
+    def close(u, v, name, tol):
+        scale = max(float(u.abs().max()), 1e-12)
+        err = float((u - v).abs().max())
+        assert err <= tol * scale, "%s: err %.3e scale %.3e" % (name, err, scale)
+
+    for mode in ("fused", "sink"):
+        for i, (a, b) in enumerate(zip(res["torch"][0], res[mode][0])):
+            close(a, b, "%s out %d" % (mode, i), 2e-5)
+        for n, ga in res["torch"][1].items():
+            if n.startswith("_features"):
+                continue
+            close(ga, res[mode][1][n], "%s grad %s" % (mode, n), 5e-4)
+
+
+def test_fused_train_loss_matches_separate_terms():
+    """dgs_photo_* + dgs_regloss_* + dgs_loss_combine as one autograd node == L1 + D-SSIM + regulariser ops."""
+    from dgs_amd import losses
+    from dgs_amd.cameras import orbit_cameras
+    torch.manual_seed(2)
+    H, W = 96, 144
+    cam = orbit_cameras(1, W, H)[0].to("cuda")
+    gt = torch.rand(3, H, W, device="cuda")
+    vals = {}
+    for fused in (False, True):
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        image = (0.6 * torch.rand(3, H, W, device="cuda", generator=gen) + 0.4 * gt).requires_grad_(True)
+        allmap = torch.rand(8, H, W, device="cuda", generator=gen)
+        allmap[5] += 2.0
+        allmap.requires_grad_(True)
+        losses.FUSE_PHOTOMETRIC = fused
+        try:
+            loss = losses.training_loss_from_allmap(image, allmap, cam, gt)
+        finally:
+            losses.FUSE_PHOTOMETRIC = True
+        loss.backward()
+        vals[fused] = (float(loss), image.grad.clone(), allmap.grad.clone())
+    assert abs(vals[0][0] - vals[1][0]) <= 1e-5 * abs(vals[0][0])
+    for a, b in ((vals[0][1], vals[1][1]), (vals[0][2], vals[1][2])):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
+
+
+def test_fused_step_matches_unfused_step():
+    """Trainer with every fused stage (assembled deformation, MFMA node MLP with gradient sinks, fused loss, fused
+    statistics) against the same Trainer on the PyTorch formulations: loss trajectory and statistics."""
+    import bench
+    from dgs_amd import losses
+    dev = torch.device("cuda:0")
+    res = {}
+    for fused in (False, True):
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=4, n_targets=2)
+        tr.fuse_deform = fused
+        tr.deform.use_fused_mlp = fused
+        losses.FUSE_PHOTOMETRIC = fused
+        try:
+            ls = [float(tr.step()) for _ in range(4)]
+        finally:
+            losses.FUSE_PHOTOMETRIC = True
+        res[fused] = (ls, tr.surfels.xyz_gradient_accum.clone(), tr.surfels.denom.clone(), tr.surfels.max_radii2D.clone())
+    for a, b in zip(res[False][0], res[True][0]):
+        assert abs(a - b) <= 2e-4 * abs(a), (res[False][0], res[True][0])
+    assert torch.equal(res[False][2], res[True][2])
+    # four Adam steps on fp32-atomics gradients: trajectories agree statistically, not element by element
+    assert float((res[False][1] - res[True][1]).abs().median()) <= 1e-2 * float(res[False][1].abs().median())
+    assert int((res[False][3] != res[True][3]).sum()) <= 20
 
 
 def test_flat_adam_matches_torch_adam():
