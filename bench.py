@@ -50,7 +50,7 @@ WORKLOADS = {
 }
 
 
-def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None):
+def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None, packed_sh=None):
     from dgs_amd.cameras import orbit_cameras
     from dgs_amd.deform import ControlNodes
     from dgs_amd.model import SurfelModel
@@ -58,7 +58,9 @@ def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None,
     from dgs_amd.train import Trainer
     torch.manual_seed(0)
     scene = make_scene(P, seed=0)
-    surfels = SurfelModel(scene).to(device)
+    if packed_sh is None:  # HIP product path: SH coefficients as one parameter (no per-render concatenation)
+        packed_sh = torch.device(device).type == "cuda" and rasterizer_cls is None and fused_adam is not False
+    surfels = SurfelModel(scene, packed_sh=packed_sh).to(device)
     deform = ControlNodes(node_num=1024, K=3, hyper_dim=8, local_frame=True).to(device)
     deform.init_from_points(surfels.get_xyz.detach(), fps=True)
     cams = [c.to(device) for c in orbit_cameras(n_views, W, H)]

@@ -343,6 +343,7 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
         int o = __shfl_xor(wave_last, d, 64);
         wave_last = o > wave_last ? o : wave_last;
     }
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);  // uniform by construction: keeps the entry masks below in SGPRs
 
     const int rounds = (L + kBatch - 1) / kBatch;
     for (int b = 0; b < rounds; b++) {

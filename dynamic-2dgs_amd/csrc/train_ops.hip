@@ -195,10 +195,23 @@ __global__ void __launch_bounds__(256) knn_kernel(int N, int M, int D, const flo
     for (int base = 0; base < M; base += kKnnChunk) {
         const int cnt = (M - base) < kKnnChunk ? (M - base) : kKnnChunk;
         __syncthreads();
-        float* s_flat = reinterpret_cast<float*>(s_nodes);
-        for (int i = threadIdx.x; i < cnt * 4 * Q; i += 256) {
-            const int r = i / (4 * Q), d = i - r * (4 * Q);
-            s_flat[i] = d < D ? nodes[(size_t)(base + r) * D + d] : 0.f;
+        // one node row per thread and pass, every load of the pass issued before the first LDS store (a flat
+        // element-wise copy is a chain of dependent global-load latencies and used to cost more than the scan)
+        for (int r0 = 0; r0 < cnt; r0 += 1024) {
+            float v[4][4 * Q];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + i * 256 + threadIdx.x;
+#pragma unroll
+                for (int d = 0; d < 4 * Q; d++) v[i][d] = (r < cnt && d < D) ? nodes[(size_t)(base + r) * D + d] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + i * 256 + threadIdx.x;
+                if (r < cnt)
+#pragma unroll
+                    for (int q = 0; q < Q; q++) s_nodes[r * Q + q] = make_float4(v[i][4 * q], v[i][4 * q + 1], v[i][4 * q + 2], v[i][4 * q + 3]);
+            }
         }
         __syncthreads();
         // groups of kKnnGrp nodes: all LDS reads of a group are issued before the first use, the kKnnPts x kKnnGrp
@@ -304,10 +317,21 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
     const int Mp = (M + 31) & ~31;                                        // rows padded to the 32-node scan blocks (zeros, masked)
     float4* s_nodes = s_dyn;                                              // [Mp][Q]
     int* s_list = reinterpret_cast<int*>(s_dyn + (size_t)Mp * Q);         // [256 * kKnnPts][kKnnCap]
-    float* s_flat = reinterpret_cast<float*>(s_nodes);
-    for (int i = threadIdx.x; i < Mp * 4 * Q; i += 256) {
-        const int r = i / (4 * Q), d = i - r * (4 * Q);
-        s_flat[i] = (r < M && d < D) ? nodes[(size_t)r * D + d] : 0.f;
+    for (int r0 = 0; r0 < Mp; r0 += 1024) {   // see knn_kernel: all loads of a pass in flight before the LDS stores
+        float v[4][4 * Q];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + i * 256 + threadIdx.x;
+#pragma unroll
+            for (int d = 0; d < 4 * Q; d++) v[i][d] = (r < M && d < D) ? nodes[(size_t)r * D + d] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + i * 256 + threadIdx.x;
+            if (r < Mp)
+#pragma unroll
+                for (int q = 0; q < Q; q++) s_nodes[r * Q + q] = make_float4(v[i][4 * q], v[i][4 * q + 1], v[i][4 * q + 2], v[i][4 * q + 3]);
+        }
     }
     __syncthreads();
     const int p0 = (blockIdx.x * 256 + threadIdx.x) * kKnnPts;
@@ -557,18 +581,20 @@ __global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, f
 // Backward.  Per-node gradients (13 attribute + H+2 table columns) of the ~782 points of a workgroup are accumulated
 // in an LDS table with ds_add_f32 and written once as that workgroup's partial table; lbs_reduce_kernel sums the
 // kLbsBlocks partials.  (Direct global atomics would be ~7 M adds onto ~24 k hot addresses.)
+constexpr int kLbsBwdThreads = 1024;   // one workgroup per CU (the LDS table is ~94 KB): 16 waves hide the gather latency
+
 template <bool ASM>
-__global__ void __launch_bounds__(256) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
+__global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
                                                       float* g_feature, int gf_stride, int accumulate,
                                                       float* partial /*[kLbsBlocks][M][G]*/, int chunk, AsmArgs s_)
 {
     extern __shared__ float s_tab[];  // [M][G], G = 13 + H + 2
     const int G = kLbsAttr + a.H + 2;
     const int T = a.tstride;
-    for (int i = threadIdx.x; i < a.M * G; i += 256) s_tab[i] = 0.f;
+    for (int i = threadIdx.x; i < a.M * G; i += kLbsBwdThreads) s_tab[i] = 0.f;
     __syncthreads();
     const int end = min(a.N, (int)(blockIdx.x + 1) * chunk);
-    for (int n = blockIdx.x * chunk + threadIdx.x; n < end; n += 256) {
+    for (int n = blockIdx.x * chunk + threadIdx.x; n < end; n += kLbsBwdThreads) {
         LbsPoint p;
         float xq[3 + kLbsHmax];
         lbs_eval(a, n, p, xq);
@@ -679,7 +705,7 @@ __global__ void __launch_bounds__(256) lbs_bwd_kernel(LbsArgs a, const float* g_
     }
     __syncthreads();
     float* dst = partial + (size_t)blockIdx.x * a.M * G;
-    for (int i = threadIdx.x; i < a.M * G; i += 256) dst[i] = s_tab[i];
+    for (int i = threadIdx.x; i < a.M * G; i += kLbsBwdThreads) dst[i] = s_tab[i];
 }
 
 __global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, int M, int H, float* g_ntab, float* g_attrs)
@@ -754,8 +780,20 @@ __global__ void __launch_bounds__(256) loss_combine_kernel(const float* photo, i
 {
     __shared__ float s_red[3][4];
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int i = threadIdx.x; i < nphoto; i += 256) { a += photo[i]; b += photo[nphoto + i]; }
-    for (int i = threadIdx.x; i < nreg; i += 256) c += reg[i];
+    {
+        float a4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0}, c4[4] = {0, 0, 0, 0};
+        for (int i = threadIdx.x; i < nphoto; i += 1024)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = i + 256 * u;
+                a4[u] += k < nphoto ? photo[k] : 0.f;
+                b4[u] += k < nphoto ? photo[nphoto + k] : 0.f;
+            }
+        for (int i = threadIdx.x; i < nreg; i += 1024)
+#pragma unroll
+            for (int u = 0; u < 4; u++) c4[u] += i + 256 * u < nreg ? reg[i + 256 * u] : 0.f;
+        a = (a4[0] + a4[1]) + (a4[2] + a4[3]); b = (b4[0] + b4[1]) + (b4[2] + b4[3]); c = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+    }
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); c += __shfl_xor(c, d, 64); }
     if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = a; s_red[1][threadIdx.x >> 6] = b; s_red[2][threadIdx.x >> 6] = c; }
     __syncthreads();
@@ -889,6 +927,11 @@ struct AdamSegs {
     float* p[kAdamSeg];
     long long off[kAdamSeg + 1];
     float lr[kAdamSeg];
+    // optional periodic learning-rate pattern inside a segment: element i uses lr2 when (i % period) >= split
+    // (e.g. SH coefficients stored [P,16,3]: the DC term and the higher bands have different rates); period 0 = off
+    float lr2[kAdamSeg];
+    int period[kAdamSeg];
+    int split[kAdamSeg];
 };
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, const float* __restrict__ grad,
@@ -900,7 +943,8 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
     const long long seg_len = sg.off[s + 1] - sg.off[s];
     const float t = step_count[0];
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    const float step_size = sg.lr[s] / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const float step_size = sg.lr[s] / bc1, step_size2 = sg.lr2[s] / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const unsigned period = (unsigned)sg.period[s], split = (unsigned)sg.split[s];
     float* __restrict__ p = sg.p[s];
     const long long base = sg.off[s];
 #pragma unroll 4
@@ -912,7 +956,8 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
             const float vi = b2 * v[base + i] + (1.0f - b2) * g * g;
             m[base + i] = mi;
             v[base + i] = vi;
-            p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+            const float ss = (period && (unsigned)(i % period) >= split) ? step_size2 : step_size;
+            p[i] -= ss * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
         }
     }
 }
@@ -995,7 +1040,7 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
     if (!scratch) return fail(-1, "dgs_lbs_backward: scratch is NULL");
     LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask, 3 + H + 2, nullptr, nullptr};
     const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
-    hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(kLbsBlocks), dim3(256), lds, (hipStream_t)stream, a, g_xyz, g_rot, g_scale,
+    hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, g_xyz, g_rot, g_scale,
                        g_feature, H, 0, (float*)scratch, chunk > 0 ? chunk : 1, AsmArgs{});
     hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
                        g_ntab, g_attrs);
@@ -1041,13 +1086,33 @@ int dgs_adam_plan(int nseg, const long long* offsets, void* plan, void* stream)
     return 0;
 }
 
+int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                          const int* periods, const int* splits, const float* grad, float* exp_avg, float* exp_avg_sq,
+                          const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream);
+
 int dgs_adam_step(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* grad, float* exp_avg,
                   float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
 {
+    return dgs_adam_step_pattern(nseg, params, offsets, lrs, nullptr, nullptr, nullptr, grad, exp_avg, exp_avg_sq, step_count, beta1,
+                                 beta2, eps, plan, stream);
+}
+
+int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                          const int* periods, const int* splits, const float* grad, float* exp_avg, float* exp_avg_sq,
+                          const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
+{
     if (nseg <= 0 || nseg > kAdamSeg || !params || !offsets || !lrs || !grad || !exp_avg || !exp_avg_sq || !step_count || !plan)
         return fail(-1, "dgs_adam_step: bad argument");
+    if ((lrs2 != nullptr) != (periods != nullptr) || (lrs2 != nullptr) != (splits != nullptr))
+        return fail(-1, "dgs_adam_step_pattern: pass lrs2, periods and splits together");
     AdamSegs sg;
-    for (int s = 0; s < nseg; s++) { sg.p[s] = params[s]; sg.off[s] = offsets[s]; sg.lr[s] = lrs[s]; }
+    for (int s = 0; s < nseg; s++) {
+        sg.p[s] = params[s]; sg.off[s] = offsets[s]; sg.lr[s] = lrs[s];
+        sg.lr2[s] = lrs2 ? lrs2[s] : lrs[s];
+        sg.period[s] = periods ? periods[s] : 0;
+        sg.split[s] = splits ? splits[s] : 0;
+        if (sg.period[s] < 0 || sg.split[s] < 0) return fail(-1, "dgs_adam_step_pattern: negative period / split");
+    }
     sg.off[nseg] = offsets[nseg];
     const long long nb = adam_blocks(nseg, offsets);
     if (nb == 0) return 0;
@@ -1196,7 +1261,7 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
     s.g_means3D = g_means3D; s.g_scales = g_scales; s.g_rotations = g_rotations; s.g_opacity = g_opacity;
     s.g_xyz = g_xyz; s.g_scaling_raw = g_scaling_raw; s.g_rotation_raw = g_rotation_raw; s.g_opacity_raw = g_opacity_raw;
     const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
-    hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(kLbsBlocks), dim3(256), lds, (hipStream_t)stream, a, (const float*)nullptr,
+    hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate, (float*)scratch,
                        chunk > 0 ? chunk : 1, s);
     hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,

@@ -7,13 +7,21 @@ from .synthetic import SurfelScene
 
 
 class SurfelModel(nn.Module):
-    def __init__(self, scene: SurfelScene, sh_degree: int = 3, active_sh_degree: int = 3):
+    def __init__(self, scene: SurfelScene, sh_degree: int = 3, active_sh_degree: int = 3, packed_sh: bool = False):
+        """packed_sh: keep the SH coefficients as ONE [P,16,3] parameter `_features` (what the rasterizer reads) instead of
+        the reference's `_features_dc` / `_features_rest` pair that is concatenated on every render (gaussian_model.py:103-107);
+        the two learning rates then become a periodic pattern of the flat Adam kernel.  `_features_dc` / `_features_rest`
+        stay readable as views."""
         super().__init__()
         self.max_sh_degree = sh_degree
         self.active_sh_degree = active_sh_degree
+        self.packed_sh = packed_sh
         self._xyz = nn.Parameter(scene.xyz.clone())
-        self._features_dc = nn.Parameter(scene.f_dc.clone())
-        self._features_rest = nn.Parameter(scene.f_rest.clone())
+        if packed_sh:
+            self._features = nn.Parameter(torch.cat((scene.f_dc, scene.f_rest), dim=1).contiguous())
+        else:
+            self._features_dc = nn.Parameter(scene.f_dc.clone())
+            self._features_rest = nn.Parameter(scene.f_rest.clone())
         self._scaling = nn.Parameter(scene.log_scale.clone())
         self._rotation = nn.Parameter(scene.rotation.clone())
         self._opacity = nn.Parameter(scene.opacity_logit.clone())
@@ -26,7 +34,17 @@ class SurfelModel(nn.Module):
     get_xyz = property(lambda self: self._xyz)
     get_scaling = property(lambda self: torch.exp(self._scaling))
     get_opacity = property(lambda self: torch.sigmoid(self._opacity))
-    get_features = property(lambda self: torch.cat((self._features_dc, self._features_rest), dim=1))
+    @property
+    def get_features(self):
+        if self.packed_sh:
+            return self._features
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def __getattr__(self, name):
+        if name in ("_features_dc", "_features_rest") and self.__dict__.get("packed_sh"):
+            f = self._parameters["_features"]
+            return f[:, :1] if name == "_features_dc" else f[:, 1:]
+        return super().__getattr__(name)
 
     def get_rotation_bias(self, rotation_bias=0.0):
         return torch.nn.functional.normalize(self._rotation + rotation_bias)
@@ -37,10 +55,16 @@ class SurfelModel(nn.Module):
 
     def optimizer_groups(self, position_lr=0.00016, feature_lr=0.004, opacity_lr=0.05, scaling_lr=0.002, rotation_lr=0.002,
                          spatial_lr_scale=5.0):
+        if self.packed_sh:
+            # one parameter, two rates: elements (i % 48) < 3 are the DC term (dgs_adam_step_pattern)
+            sh = [{'params': [self._features], 'lr': feature_lr, "name": "f_all",
+                   'pattern': (3 * self._features.shape[1], 3, feature_lr / 20.0)}]
+        else:
+            sh = [{'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
+                  {'params': [self._features_rest], 'lr': feature_lr / 20.0, "name": "f_rest"}]
         return [
             {'params': [self._xyz], 'lr': position_lr * spatial_lr_scale, "name": "xyz"},
-            {'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
-            {'params': [self._features_rest], 'lr': feature_lr / 20.0, "name": "f_rest"},
+            *sh,
             {'params': [self._opacity], 'lr': opacity_lr, "name": "opacity"},
             {'params': [self._scaling], 'lr': scaling_lr * spatial_lr_scale, "name": "scaling"},
             {'params': [self._rotation], 'lr': rotation_lr, "name": "rotation"},

@@ -95,16 +95,20 @@ class Trainer:
             # HIP device: one flat Adam launch for surfels + deformation (csrc/train_ops.hip); step counter on the device
             from . import _ops
             lr_of = {id(p): g['lr'] for g in groups + deform_groups for p in g['params']}
+            pat_of = {id(p): g['pattern'] for g in groups for p in g['params'] if 'pattern' in g}
             plist = self.bucket.params  # bucket order == layout of the flat gradient buffer
-            self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat)
+            patterns = {i: pat_of[id(p)] for i, p in enumerate(plist) if id(p) in pat_of}
+            self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat, patterns=patterns)
             self.opt_deform = None
         else:
+            assert not getattr(surfels, "packed_sh", False), "packed SH needs the flat Adam kernel (two rates inside one parameter)"
             self.opt_surfels = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
             self.opt_deform = torch.optim.Adam(deform_groups, lr=0.0, eps=1e-15)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.iteration = 0
         self._graph = None
+        self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
         self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
 
     # ---- whole-step HIP graph ------------------------------------------------------------------------------------
@@ -165,7 +169,16 @@ class Trainer:
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
                          postprocess=not fused)
         loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt) if fused else training_loss(pkg, gt)
-        loss.backward()
+        if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink:
+            # the rasterizer's backward writes dL/dSH straight into the bucket view of the packed parameter
+            import diff_surfel_rasterization as dsr
+            dsr.set_sh_grad_sink(s._features.grad)
+            try:
+                loss.backward()
+            finally:
+                dsr.set_sh_grad_sink(None)
+        else:
+            loss.backward()
         with torch.no_grad():
             # densification statistics of this view into the bucket tail (summed over ranks)
             if not hasattr(self, "_radii"):

@@ -175,7 +175,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, dL_dsh_out=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
     dL_dscales[P,2], dL_drotations[P,4])  -- rasterize_points.cu:239"""
     lib = load()
@@ -188,7 +188,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     M = sh.size(1) if sh.numel() != 0 else 0
     opts = dict(dtype=torch.float32, device=dev)
     # all nine gradient arrays from ONE zero-filled allocation (one fill launch instead of nine)
-    cols = (3, 3, 3, 3, 1, 9, 3 * M, 2, 4)
+    cols = (3, 3, 3, 3, 1, 9, 0 if dL_dsh_out is not None else 3 * M, 2, 4)
     seg = [(P * c + 63) // 64 * 64 for c in cols]  # segment starts stay 256-byte aligned
     flat = torch.zeros(sum(seg), **opts)
     views, off = [], 0
@@ -196,7 +196,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         views.append(flat[off:off + P * c].view(P, c))
         off += n
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal, dL_dopacity, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = views
-    dL_dsh = dL_dsh.view(P, M, 3)
+    dL_dsh = dL_dsh_out if dL_dsh_out is not None else dL_dsh.view(P, M, 3)  # caller-provided: written in place (extension)
     if P != 0:
         bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
         sc, rot, tm = _f32c(scales), _f32c(rotations), _f32c(transMat_precomp)

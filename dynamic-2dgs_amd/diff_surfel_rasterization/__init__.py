@@ -60,6 +60,18 @@ def _guarded(fn, args, debug, dump_name, what):
         raise
 
 
+_SH_GRAD_SINK = None
+
+
+def set_sh_grad_sink(tensor):
+    """Extension (not in the reference): while set to a contiguous fp32 [P,M,3] tensor, backward passes write dL/dSH of
+    the visible surfels directly into it (the kernel stores, it does not accumulate; rows of culled surfels are left as
+    they are) and return no gradient for `shs`.  For trainers that keep gradients in one pre-zeroed flat buffer; pass
+    None to restore the reference behaviour."""
+    global _SH_GRAD_SINK
+    _SH_GRAD_SINK = tensor
+
+
 class _SurfelRasterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cfg):
@@ -85,8 +97,17 @@ class _SurfelRasterFn(torch.autograd.Function):
         call = (cfg.bg, means3D, radii, colors_precomp, scales, rotations, cfg.scale_modifier, cov3Ds_precomp,
                 cfg.viewmatrix, cfg.projmatrix, cfg.tanfovx, cfg.tanfovy, g_color, g_allmap, sh, cfg.sh_degree, cfg.campos,
                 geom, ctx.n_rendered, binning, img, cfg.debug)
-        (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
-            _C.rasterize_gaussians_backward, call, cfg.debug, "snapshot_bw.dump", "backward")
+        sink = _SH_GRAD_SINK
+        if sink is not None and not (sink.shape == sh.shape and sink.dtype == torch.float32 and sink.is_contiguous()
+                                     and sink.device == sh.device):
+            raise RuntimeError("set_sh_grad_sink: the sink must be a contiguous fp32 tensor of the shape of shs")
+        if sink is not None:
+            (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _C.rasterize_gaussians_backward(
+                *call, dL_dsh_out=sink)
+            g_sh = None
+        else:
+            (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
+                _C.rasterize_gaussians_backward, call, cfg.debug, "snapshot_bw.dump", "backward")
         return (g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_transMat, None)
 
 

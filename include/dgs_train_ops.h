@@ -83,6 +83,13 @@ int dgs_adam_plan(int nseg, const long long* offsets /*host, nseg+1*/, void* pla
 int dgs_adam_step(int nseg, float* const* params /*host array of device pointers*/, const long long* offsets /*host*/,
                   const float* lrs /*host*/, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
                   float beta1, float beta2, float eps, const void* plan, void* stream);
+/* Same with an optional periodic learning-rate pattern per segment (host arrays of nseg entries, or all three NULL):
+ * element i of segment s uses lrs2[s] when periods[s] > 0 and (i % periods[s]) >= splits[s], else lrs[s].  For the SH
+ * coefficients kept as ONE [P,16,3] parameter: period 48, split 3 gives the DC term feature_lr and the higher bands
+ * feature_lr / 20 (scene/gaussian_model.py:181-203 keeps them as two parameters and concatenates them every render). */
+int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                          const int* periods, const int* splits, const float* grad, float* exp_avg, float* exp_avg_sq,
+                          const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream);
 
 /* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:
  * posenc(xyz,10) | timenet(posenc(t,6)): 13->256->30, 8 x 256 ReLU layers, skip concat after layer 4, heads

@@ -13,7 +13,7 @@ def settings_from_case(case, dev, debug=False):
         sh_degree=case["sh_degree"], campos=case["campos"].to(dev), prefiltered=False, debug=debug)
 
 
-def run_hip(case, gc=None, go=None, colors_precomp=None, dev="cuda:0", debug=True):
+def run_hip(case, gc=None, go=None, colors_precomp=None, dev="cuda:0", debug=True, allow_missing_sh_grad=False):
     """Forward (+ backward when cotangents are given). Returns dict of numpy arrays."""
     cfg = settings_from_case(case, dev, debug)
     rast = GaussianRasterizer(cfg)
@@ -39,7 +39,9 @@ def run_hip(case, gc=None, go=None, colors_precomp=None, dev="cuda:0", debug=Tru
         if colors_precomp is not None:
             out["dL_dcolors"] = kw["colors_precomp"].grad.cpu().numpy()
         else:
-            out["dL_dsh"] = leaves["shs"].grad.cpu().numpy()
+            g_sh = leaves["shs"].grad
+            assert g_sh is not None or allow_missing_sh_grad
+            out["dL_dsh"] = None if g_sh is None else g_sh.cpu().numpy()
     torch.cuda.synchronize()
     return out
 

@@ -147,10 +147,28 @@ void hm_surfel_bwd(int P, int D, int M, const float* means3D, const float* scale
 }  // extern "C"
 
 // ---- analysis helper (development): how much of the traversed work is useful?
-extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*8*/)
+static int g_shape = 0;   // wave shape for hm_blend_stats: 0 = 16x4 strips, 1 = 8x8 blocks, 2 = 32x2 strips
+extern "C" void hm_set_shape(int s) { g_shape = s; }
+static inline int lane_of(int w, int k)   // pixel index (y*16 + x) of lane k of wave w
 {
+    if (g_shape == 1) { const int x = 8 * (w & 1) + (k & 7), y = 8 * (w >> 1) + (k >> 3); return y * 16 + x; }
+    return 64 * w + k;
+}
+static inline bool wave_sees(int w, const float* r, float px0, float py0)
+{
+    if (g_shape == 1) {
+        const float xf = px0 + 8.0f * (w & 1) + 0.5f, yf = py0 + 8.0f * (w >> 1) + 0.5f;
+        return r[21] >= xf && r[20] <= xf + 7.0f && r[23] >= yf && r[22] <= yf + 7.0f;
+    }
+    return (strip_mask(r[20], r[21], r[22], r[23], px0, py0) >> w) & 1u;
+}
+extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*12*/)
+{
+    // per (tile, entry, 16x4 strip) with the wave still alive: visited = the entry's pixel box touches the strip (what the
+    // kernels evaluate); any = some pixel passes the alpha test; blend = some live pixel blends it
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     double S = 0, strip_pairs = 0, strip_any = 0, pix_pairs = 0, pix_pass = 0, pix_blend = 0, strip_blend_any = 0;
+    double visited = 0, visited_any = 0, visited_blend = 0, visited_pix_blend = 0, missed = 0;
     for (int ty = 0; ty < tiles_y; ty++)
         for (int tx = 0; tx < tiles_x; tx++) {
             const int tile = ty * tiles_x + tx;
@@ -163,23 +181,28 @@ extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint3
                 if (!alive) break;
                 const float* r = rec + (size_t)point_list[e] * kRecFloats;
                 for (int w = 0; w < 4; w++) {
-                    int wa = 0; for (int i = 64 * w; i < 64 * w + 64; i++) wa += !done[i];
+                    int wa = 0; for (int k = 0; k < 64; k++) wa += !done[lane_of(w, k)];
                     if (!wa) continue;
                     strip_pairs += 1;
-                    int any = 0, anyb = 0;
-                    for (int i = 64 * w; i < 64 * w + 64; i++) {
+                    const bool vis = wave_sees(w, r, (float)(tx * 16), (float)(ty * 16));
+                    int any = 0, anyb = 0, nb = 0;
+                    for (int k = 0; k < 64; k++) {
+                        const int i = lane_of(w, k);
                         if (!inside[i]) continue;
                         pix_pairs += 1;
                         PairEval ev;
                         const float pfx = tx * 16 + (i & 15) + 0.5f, pfy = ty * 16 + (i >> 4) + 0.5f;
                         bool ok = pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev);
                         if (ok) { pix_pass += 1; any = 1; }
-                        if (ok && !done[i]) { anyb = 1; pix_blend += 1; st[i].contributor = e - r0 + 1; if (!pixfwd_blend(st[i], ev, Q(r, 3), Q(r, 4))) done[i] = true; }
+                        if (ok && !done[i]) { anyb = 1; nb++; pix_blend += 1; st[i].contributor = e - r0 + 1; if (!pixfwd_blend(st[i], ev, Q(r, 3), Q(r, 4))) done[i] = true; }
                     }
                     strip_any += any; strip_blend_any += anyb;
+                    if (vis) { visited += 1; visited_any += any; visited_blend += anyb; visited_pix_blend += nb; }
+                    else if (anyb) missed += 1;
                 }
             }
             S += (e - r0);
         }
     out[0] = S; out[1] = strip_pairs; out[2] = strip_any; out[3] = pix_pairs; out[4] = pix_pass; out[5] = pix_blend; out[6] = strip_blend_any;
+    out[7] = visited; out[8] = visited_any; out[9] = visited_blend; out[10] = visited_pix_blend; out[11] = missed;
 }

@@ -1,5 +1,6 @@
 """-m gpu: the fused SSIM and KNN kernels (csrc/train_ops.hip) against the PyTorch formulations they replace
 (which tests/ verify on the CPU against the reference's formula / brute force)."""
+import numpy as np
 import pytest
 import torch
 
@@ -158,6 +159,56 @@ def test_fused_lbs_matches_torch_autograd():
         close(a["net"][n], b["net"][n], "grad net." + n, 5e-4)
 
 
+def test_flat_adam_rate_pattern_matches_two_parameters():
+    """One [P,16,3] SH parameter with the periodic two-rate pattern == the reference's (_features_dc, _features_rest) pair
+    under torch.optim.Adam with their two rates."""
+    from dgs_amd import _ops
+    from dgs_amd.train import FlatGradBucket
+    torch.manual_seed(3)
+    P = 3001
+    full = torch.randn(P, 16, 3, device="cuda")
+    packed = torch.nn.Parameter(full.clone())
+    other = torch.nn.Parameter(torch.randn(777, device="cuda"))
+    dc, rest = torch.nn.Parameter(full[:, :1].clone()), torch.nn.Parameter(full[:, 1:].clone())
+    other_ref = torch.nn.Parameter(other.detach().clone())
+    ref = torch.optim.Adam([{'params': [dc], 'lr': 4e-3}, {'params': [rest], 'lr': 2e-4}, {'params': [other_ref], 'lr': 1e-2}], eps=1e-15)
+    bucket = FlatGradBucket([other, packed])
+    opt = _ops.FlatAdam(bucket.params, [1e-2, 4e-3], bucket.flat, patterns={1: (48, 3, 2e-4)})
+    for it in range(4):
+        g = torch.randn(P, 16, 3, device="cuda") * (0.1 + it)
+        go = torch.randn(777, device="cuda")
+        bucket.zero()
+        packed.grad.copy_(g); other.grad.copy_(go)
+        dc.grad, rest.grad, other_ref.grad = g[:, :1].clone(), g[:, 1:].clone(), go.clone()
+        opt.step(); ref.step()
+    assert torch.allclose(packed[:, :1], dc, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(packed[:, 1:], rest, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(other, other_ref, rtol=1e-5, atol=1e-7)
+
+
+def test_sh_gradient_sink_matches_returned_gradient():
+    """set_sh_grad_sink: dL/dSH written in place == the gradient autograd would have accumulated; culled rows untouched."""
+    import diff_surfel_rasterization as dsr
+    from gpu_utils import run_hip
+    from scene_utils import small_case
+    case = small_case(P=3000, H=80, W=96, seed=5, view=2, scale_mul=1.5, radius=3.0)
+    g = np.random.default_rng(1)
+    gc = g.standard_normal((3, 80, 96)).astype(np.float32)
+    go = g.standard_normal((8, 80, 96)).astype(np.float32)
+    ref = run_hip(case, gc, go)
+    sink = torch.full((3000, 16, 3), 7.0, device="cuda")
+    dsr.set_sh_grad_sink(sink)
+    try:
+        got = run_hip(case, gc, go, allow_missing_sh_grad=True)
+    finally:
+        dsr.set_sh_grad_sink(None)
+    vis = torch.from_numpy(ref["radii"] > 0).cuda()
+    assert bool((sink[~vis] == 7.0).all()) and int((~vis).sum()) > 0
+    a, b = torch.from_numpy(ref["dL_dsh"]).cuda()[vis], sink[vis]
+    assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+    assert got["dL_dsh"] is None
+
+
 @pytest.mark.parametrize("M,per_node_t", [(1024, False), (64, True)])
 def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
     """dgs_mlp_forward/backward (fp32 MFMA) against DeformMLP.forward + torch.autograd: the attribute table, every
@@ -293,7 +344,7 @@ def test_fused_step_matches_unfused_step():
     dev = torch.device("cuda:0")
     res = {}
     for fused in (False, True):
-        tr = bench.build_trainer(20000, 256, 256, dev, n_views=4, n_targets=2)
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=4, n_targets=2, packed_sh=fused)
         tr.fuse_deform = fused
         tr.deform.use_fused_mlp = fused
         losses.FUSE_PHOTOMETRIC = fused
