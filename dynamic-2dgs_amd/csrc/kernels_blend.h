@@ -175,24 +175,36 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
             for (int c = 0; c < 4 && !stop; c++) {
                 unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
                 if (m == 0ull) continue;
-                int j = c * 64 + __builtin_ctzll(m);
-                float4 n0 = s_rec[0][j], n1 = s_rec[1][j], n2 = s_rec[2][j];
-                while (m != 0ull) {
-                    const float4 q0 = n0, q1 = n1, q2 = n2;
-                    const int jc = j;
-                    m &= m - 1ull;
-                    if (m != 0ull) {
-                        j = c * 64 + __builtin_ctzll(m);
-                        n0 = s_rec[0][j]; n1 = s_rec[1][j]; n2 = s_rec[2][j];
-                    }
+                // Two register sets (a*, b*) alternate as "current" and "prefetched": a single set would be rotated with
+                // six 64-bit moves per entry (8 % of the loop's VALU work).
+                auto visit = [&](const float4& q0, const float4& q1, const float4& q2, int jc) -> bool {
                     PairEval e;
                     const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), e) && !done;
-                    if (__ballot(ok) == 0ull) continue;
+                    if (__ballot(ok) == 0ull) return false;
                     if (ok) {
                         st.contributor = base + (uint32_t)jc + 1u;  // 1-based list position (forward.cu:356)
                         if (!pixfwd_blend(st, e, as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]))) done = true;
                     }
-                    if (__ballot(!done) == 0ull) { stop = true; break; }  // wave-level early out
+                    return __ballot(!done) == 0ull;  // wave-level early out
+                };
+                int ja = c * 64 + __builtin_ctzll(m), jb = 0;
+                float4 a0 = s_rec[0][ja], a1 = s_rec[1][ja], a2 = s_rec[2][ja], b0, b1, b2;
+                b0 = b1 = b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                while (true) {
+                    m &= m - 1ull;
+                    if (m != 0ull) {
+                        jb = c * 64 + __builtin_ctzll(m);
+                        b0 = s_rec[0][jb]; b1 = s_rec[1][jb]; b2 = s_rec[2][jb];
+                    }
+                    if (visit(a0, a1, a2, ja)) { stop = true; break; }
+                    if (m == 0ull) break;
+                    m &= m - 1ull;
+                    if (m != 0ull) {
+                        ja = c * 64 + __builtin_ctzll(m);
+                        a0 = s_rec[0][ja]; a1 = s_rec[1][ja]; a2 = s_rec[2][ja];
+                    }
+                    if (visit(b0, b1, b2, jb)) { stop = true; break; }
+                    if (m == 0ull) break;
                 }
             }
         }
@@ -373,20 +385,12 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
             unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
             if (j0 > c * 64) m &= ~((1ull << (j0 - c * 64)) - 1ull);
             if (m == 0ull) continue;
-            int j = c * 64 + __builtin_ctzll(m);
-            float4 n0 = s_rec[0][j], n1 = s_rec[1][j], n2 = s_rec[2][j];
-            while (m != 0ull) {
-                const float4 q0 = n0, q1 = n1, q2 = n2;
-                const int jc = j;
-                m &= m - 1ull;
-                if (m != 0ull) {
-                    j = c * 64 + __builtin_ctzll(m);
-                    n0 = s_rec[0][j]; n1 = s_rec[1][j]; n2 = s_rec[2][j];
-                }
+            // two alternating register sets for the current / prefetched entry (see blend_fwd_kernel)
+            auto visit = [&](const float4& q0, const float4& q1, const float4& q2, int jc) {
                 const int e = L - 1 - (b * kBatch + jc);  // 0-based list index == the reference's `contributor`
                 PairEval ev;
                 const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), ev) && (e < st.last_contributor);
-                if (__ballot(ok) == 0ull) continue;
+                if (__ballot(ok) == 0ull) return;
                 float out[kAccFloats];
 #pragma unroll
                 for (int k = 0; k < 18; k++) out[k] = 0.f;
@@ -406,6 +410,25 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
                     const float my = wave_sum(out[kAccMean2D + 1]);
                     if (lane == 0) { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
                 }
+            };
+            int ja = c * 64 + __builtin_ctzll(m), jb = 0;
+            float4 a0 = s_rec[0][ja], a1 = s_rec[1][ja], a2 = s_rec[2][ja], b0, b1, b2;
+            b0 = b1 = b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            while (true) {
+                m &= m - 1ull;
+                if (m != 0ull) {
+                    jb = c * 64 + __builtin_ctzll(m);
+                    b0 = s_rec[0][jb]; b1 = s_rec[1][jb]; b2 = s_rec[2][jb];
+                }
+                visit(a0, a1, a2, ja);
+                if (m == 0ull) break;
+                m &= m - 1ull;
+                if (m != 0ull) {
+                    ja = c * 64 + __builtin_ctzll(m);
+                    a0 = s_rec[0][ja]; a1 = s_rec[1][ja]; a2 = s_rec[2][ja];
+                }
+                visit(b0, b1, b2, jb);
+                if (m == 0ull) break;
             }
         }
     }

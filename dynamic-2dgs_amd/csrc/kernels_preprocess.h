@@ -31,18 +31,33 @@ struct PreprocessArgs {
     float4* rec;            // [P*5] out
     uint2* rects;           // [P] out: packed (tight) tile rectangle of every surfel
     int tight;              // 1: exact opacity-aware rectangles (default), 0: the reference's rectangles
+    unsigned row_inv;       // ceil(2^32 / (3 M)) (see surfel_bwd_kernel)
 };
 
 __global__ void __launch_bounds__(kSurfelBlock) preprocess_fwd_kernel(PreprocessArgs a)
 {
-    const int idx = blockIdx.x * kSurfelBlock + threadIdx.x;
+    // SH rows reach the threads through LDS with coalesced loads (see surfel_bwd_kernel)
+    extern __shared__ float s_sh[];
+    const int base = blockIdx.x * kSurfelBlock;
+    const int idx = base + threadIdx.x;
+    const int row = a.M * 3, stride = row + 1;
+    const bool use_sh = !a.colors_precomp && a.shs;
+    if (use_sh) {
+        const int rows_here = min(kSurfelBlock, a.P - base);
+        const float* src = a.shs + (size_t)base * row;
+        for (int e = threadIdx.x; e < rows_here * row; e += kSurfelBlock) {
+            const int r = (int)__umulhi((unsigned)e, a.row_inv);
+            s_sh[r * stride + (e - r * row)] = src[e];
+        }
+        __syncthreads();
+    }
     if (idx >= a.P) return;
     SurfelRec rec;
     float pos[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
     float sc[2] = {a.scales[2 * idx], a.scales[2 * idx + 1]};
     const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
     float q[4] = {qv.x, qv.y, qv.z, qv.w};
-    const float* sh = a.colors_precomp ? nullptr : a.shs + (size_t)idx * a.M * 3;
+    const float* sh = use_sh ? s_sh + threadIdx.x * stride : nullptr;
     const float* cp = a.colors_precomp ? a.colors_precomp + 3 * idx : nullptr;
     TileRect tr;
     int tiles;

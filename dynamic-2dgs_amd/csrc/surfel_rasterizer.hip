@@ -340,7 +340,14 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     pa.rec = (float4*)(geom + gl.rec);
     pa.rects = (uint2*)(geom + gl.rects);
     pa.tight = g_tight_rects ? 1 : 0;
-    hipLaunchKernelGGL(dgs::preprocess_fwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, pa);
+    pa.row_inv = 0;
+    size_t sh_lds = 0;
+    if (!colors_precomp && shs) {
+        if (M * 3 > 48 || M <= 0) return fail(DGS_ERR_INVALID_ARGUMENT, "forward: 1..16 SH coefficients per channel expected");
+        pa.row_inv = (unsigned)(0xFFFFFFFFu / (unsigned)(M * 3)) + 1u;
+        sh_lds = (size_t)dgs::kSurfelBlock * (M * 3 + 1) * sizeof(float);
+    }
+    hipLaunchKernelGGL(dgs::preprocess_fwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), sh_lds, stream, pa);
     DGS_STAGE("preprocess_fwd", debug, stream);
     // ---- K3 per-tile entry counts
     dgs::BinArgs ba_;
