@@ -1,11 +1,11 @@
 // kernels_blend.h -- per-tile forward and backward alpha blend for gfx950.
 //
-// One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 16x4 pixel strip
+// One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 8x8 pixel quadrant (see lane_pixel)
 // rows 4w..4w+3, so all 64 lanes of a wave consume the same staged surfel at the same time.
 // The tile's depth-sorted list is consumed in batches of 256 entries whose packed 96-B records are gathered
 // into LDS as five float4 planes (20 KB; the sixth quad, the surfel's exact pixel bounding box, is consumed at
-// staging time: each entry is tested against the four 16x4 strips and the four per-strip ballots become 64-bit
-// masks, so a wave only visits the entries whose box touches its strip).  The inner loop reads the planes with
+// staging time: each entry is tested against the four 8x8 quadrants and the four per-quadrant ballots become 64-bit
+// masks, so a wave only visits the entries whose box touches its quadrant).  The inner loop reads the planes with
 // wave-uniform addresses (LDS broadcast, conflict free).  Replaces renderCUDA of forward.cu:265-463 and
 // backward.cu:143-449.
 #pragma once
@@ -120,7 +120,7 @@ inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
 __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
 {
     __shared__ float4 s_rec[kStagedQuads][kBatch];
-    __shared__ unsigned long long s_bits[4][4];  // [strip][chunk of 64 entries]
+    __shared__ unsigned long long s_bits[4][4];  // [quadrant][chunk of 64 entries]
     __shared__ int s_flag[4];
     __shared__ uint32_t s_max[4];
 
@@ -130,7 +130,9 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
     if (a.mode == 3) tile = (int)a.order[tile];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int px = tx * kTileX + (tid & 15), py = ty * kTileY + (tid >> 4);
+    int lx_, ly_;
+    lane_pixel(tid, lx_, ly_);
+    const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
     const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
             const float4* src = a.rec + (size_t)id * kRecQuads;
 #pragma unroll
             for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = src[c];
-            { const float4 bx = src[5]; smask = strip_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
+            { const float4 bx = src[5]; smask = quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
         __syncthreads();
 
         if (!wave_done) {
-            // Visit, in list order, only the entries whose box touches this wave's strip.  The alpha part (q0..q2) of
+            // Visit, in list order, only the entries whose box touches this wave's quadrant.  The alpha part (q0..q2) of
             // the next visited entry is prefetched while the current one is evaluated branch-free for all 64 lanes;
             // a single wave-uniform branch skips the blend when no lane passes.
             const uint32_t base = (uint32_t)(b * kBatch);
@@ -324,7 +326,9 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
     if (L == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int px = tx * kTileX + (tid & 15), py = ty * kTileY + (tid >> 4);
+    int lx_, ly_;
+    lane_pixel(tid, lx_, ly_);
+    const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
     const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
@@ -369,7 +373,7 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
             const float4* src = a.rec + (size_t)id * kRecQuads;
 #pragma unroll
             for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = src[c];
-            { const float4 bx = src[5]; smask = strip_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
+            { const float4 bx = src[5]; smask = quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {

@@ -65,9 +65,15 @@ def run_hip_raw(case, dev="cuda:0"):
     rec = gb[g_off[0]:g_off[0] + P * 96].view(np.float32).reshape(P, 24)
     plane = T * 256
 
-    def untile(a):  # [T,256] tile-major -> [H,W]
-        a = a.reshape(tiles_y, tiles_x, 16, 16).transpose(0, 2, 1, 3).reshape(tiles_y * 16, tiles_x * 16)
-        return a[:H, :W]
+    tid = np.arange(256)
+    lane, wave = tid & 63, tid >> 6
+    lx, ly = 8 * (wave & 1) + (lane & 7), 8 * (wave >> 1) + (lane >> 3)   # surfel_math.h lane_pixel
+
+    def untile(a):  # [T,256] tile-major (slot = thread id) -> [H,W]
+        a = a.reshape(tiles_y, tiles_x, 256)
+        img = np.zeros((tiles_y, tiles_x, 16, 16), a.dtype)
+        img[:, :, ly, lx] = a
+        return img.transpose(0, 2, 1, 3).reshape(tiles_y * 16, tiles_x * 16)[:H, :W]
 
     fT = ib[i_off[0]:i_off[0] + 3 * plane * 4].view(np.float32).reshape(3, plane)
     nc = ib[i_off[1]:i_off[1] + 2 * plane * 4].view(np.uint32).reshape(2, plane)

@@ -44,9 +44,9 @@ void hm_preprocess(int P, int D, int M, const float* means3D, const float* scale
     }
 }
 
-// Bit w of the result: some pixel of strip w of tile (tx,ty) passes the alpha test for this record.
-// -1: the branchy and branch-free evaluations disagree; -2: a strip is reachable although the record's
-// bounding box (q5) says it is not (strip culling of the blend kernels would be wrong).
+// Bit w of the result: some pixel of quadrant w (8x8, lane_pixel) of tile (tx,ty) passes the alpha test for this record.
+// -1: the branchy and branch-free evaluations disagree; -2: a quadrant is reachable although the record's
+// bounding box (q5) says it is not (quadrant culling of the blend kernels would be wrong).
 int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
 {
     int any = 0;
@@ -58,9 +58,9 @@ int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
             const bool ka = pair_eval((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), a);
             const bool kb = pair_eval_bf((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), b);
             if (ka != kb) return -1;
-            any |= ka ? (1 << (ly >> 2)) : 0;
+            any |= ka ? (1 << ((ly >> 3) * 2 + (lx >> 3))) : 0;
         }
-    const uint32_t mask = strip_mask(r[20], r[21], r[22], r[23], (float)(tx * 16), (float)(ty * 16));
+    const uint32_t mask = quad_mask(r[20], r[21], r[22], r[23], (float)(tx * 16), (float)(ty * 16));
     if (any & ~(int)mask) return -2;
     return any;
 }
@@ -147,7 +147,7 @@ void hm_surfel_bwd(int P, int D, int M, const float* means3D, const float* scale
 }  // extern "C"
 
 // ---- analysis helper (development): how much of the traversed work is useful?
-static int g_shape = 0;   // wave shape for hm_blend_stats: 0 = 16x4 strips, 1 = 8x8 blocks, 2 = 32x2 strips
+static int g_shape = 1;   // wave shape for hm_blend_stats: 0 = 16x4 strips (round-1 layout), 1 = 8x8 quadrants (the kernels' layout)
 extern "C" void hm_set_shape(int s) { g_shape = s; }
 static inline int lane_of(int w, int k)   // pixel index (y*16 + x) of lane k of wave w
 {
@@ -160,7 +160,8 @@ static inline bool wave_sees(int w, const float* r, float px0, float py0)
         const float xf = px0 + 8.0f * (w & 1) + 0.5f, yf = py0 + 8.0f * (w >> 1) + 0.5f;
         return r[21] >= xf && r[20] <= xf + 7.0f && r[23] >= yf && r[22] <= yf + 7.0f;
     }
-    return (strip_mask(r[20], r[21], r[22], r[23], px0, py0) >> w) & 1u;
+    const float yf = py0 + 4.0f * w + 0.5f;
+    return r[21] >= px0 + 0.5f && r[20] <= px0 + 15.5f && r[23] >= yf && r[22] <= yf + 3.0f;
 }
 extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*12*/)
 {

@@ -141,7 +141,7 @@ def test_tight_tile_rects_are_conservative(hm, cfg):
                 inside = tig[0] <= tx < tig[1] and tig[2] <= ty < tig[3]
                 r = hm.hm_tile_reachable(W, H, int(tx), int(ty), p(np.ascontiguousarray(out[1][1][i])))
                 assert r != -1, "pair_eval / pair_eval_bf disagree"
-                assert r != -2, "bounding box culls a reachable 16x4 strip (surfel %d, tile %d,%d)" % (i, tx, ty)
+                assert r != -2, "bounding box culls a reachable 8x8 quadrant (surfel %d, tile %d,%d)" % (i, tx, ty)
                 if not inside:
                     assert r == 0, "tight rectangle dropped a reachable tile (surfel %d, tile %d,%d)" % (i, tx, ty)
                     dropped += 1
