@@ -251,19 +251,40 @@ class FlatAdam:
         self._ptrs = (ctypes.c_void_p * self._n)(*[p.data_ptr() for p in self.params])
         self._off = (ctypes.c_longlong * (self._n + 1))(*off)
         self._lr = (ctypes.c_float * self._n)(*self.lrs)
-        self.plan = torch.empty(int(lib.dgs_adam_plan_bytes(n)), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            _check(lib, lib.dgs_adam_plan(self._n, self._off, self.plan.data_ptr(), _stream(dev)), "dgs_adam_plan")
+        self._offsets = off
+        self._plans = {}
+        self._range(0, self._n)
+
+    def _range(self, first, last):
+        """ctypes argument slices + block plan of the parameter range [first, last) (built once per range)."""
+        key = (first, last)
+        if key not in self._plans:
+            lib = load()
+            dev = self.grad.device
+            k = last - first
+            off = (ctypes.c_longlong * (k + 1))(*self._offsets[first:last + 1])
+            plan = torch.empty(int(lib.dgs_adam_plan_bytes(self._offsets[last] - self._offsets[first])), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _check(lib, lib.dgs_adam_plan(k, off, plan.data_ptr(), _stream(dev)), "dgs_adam_plan")
+            sl = lambda arr, typ: (typ * k)(*list(arr)[first:last])
+            self._plans[key] = (k, sl(self._ptrs, ctypes.c_void_p), off, sl(self._lr, ctypes.c_float), sl(self._lr2, ctypes.c_float),
+                                sl(self._period, ctypes.c_int), sl(self._split, ctypes.c_int), plan)
+        return self._plans[key]
 
     @torch.no_grad()
-    def step(self):
+    def step(self, first=0, last=None, advance=True):
+        """Adam update of parameters [first, last) (default: all).  advance=False reuses the step count of the previous
+        call: a step split over several launches advances the counter on its first launch only."""
         lib = load()
         dev = self.grad.device
-        self.t.add_(1.0)
+        last = self._n if last is None else last
+        k, ptrs, off, lr, lr2, period, split, plan = self._range(first, last)
+        if advance:
+            self.t.add_(1.0)
         with torch.cuda.device(dev):
-            rc = lib.dgs_adam_step_pattern(self._n, self._ptrs, self._off, self._lr, self._lr2, self._period, self._split,
-                                           self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(),
-                                           self.betas[0], self.betas[1], self.eps, self.plan.data_ptr(), _stream(dev))
+            rc = lib.dgs_adam_step_pattern(k, ptrs, off, lr, lr2, period, split, self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                           self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0], self.betas[1], self.eps,
+                                           plan.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_adam_step")
 
 
@@ -321,6 +342,36 @@ def node_mlp_params(net):
     return out
 
 
+def _mlp_forward_raw(x, t, rot_bias, params):
+    lib = load()
+    dev = x.device
+    M = x.shape[0]
+    if x.stride(-1) != 1 or t.dim() != 2 or t.shape[0] != M:
+        raise RuntimeError("fused node MLP: x must be row-major [M,>=3], t [M,1]")
+    packed = torch.empty(int(lib.dgs_mlp_packed_floats()), dtype=torch.float32, device=dev)
+    saved = torch.empty(int(lib.dgs_mlp_saved_floats(M)), dtype=torch.float32, device=dev)
+    attrs = torch.empty((M, 13), dtype=torch.float32, device=dev)
+    ptrs = (ctypes.c_void_p * 28)(*[p.data_ptr() for p in params])
+    rb = (ctypes.c_float * 4)(*rot_bias)
+    with torch.cuda.device(dev):
+        rc = lib.dgs_mlp_forward(M, x.data_ptr(), x.stride(0), t.data_ptr(), t.stride(0), ptrs, rb, packed.data_ptr(),
+                                 saved.data_ptr(), attrs.data_ptr(), _stream(dev))
+    _check(lib, rc, "dgs_mlp_forward")
+    return attrs, packed, saved
+
+
+def _mlp_backward_raw(g_attrs, packed, saved, outs, accumulate):
+    lib = load()
+    dev = packed.device
+    M = g_attrs.shape[0]
+    scratch = torch.empty(int(lib.dgs_mlp_scratch_floats(M)), dtype=torch.float32, device=dev)
+    ptrs = (ctypes.c_void_p * 28)(*[o.data_ptr() for o in outs])
+    with torch.cuda.device(dev):
+        rc = lib.dgs_mlp_backward(M, g_attrs.data_ptr(), packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(), ptrs,
+                                  1 if accumulate else 0, _stream(dev))
+    _check(lib, rc, "dgs_mlp_backward")
+
+
 class _FusedNodeMLP(torch.autograd.Function):
     """attrs[M,13] = [local_rotation + rot_bias | d_xyz | d_rotation | d_scaling] of the control nodes
     (dgs_mlp_forward / dgs_mlp_backward).  `sink`: None, or the list of 28 gradient tensors (the parameters' .grad
@@ -328,20 +379,7 @@ class _FusedNodeMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, t, rot_bias, sink, *params):
-        lib = load()
-        dev = x.device
-        M = x.shape[0]
-        if x.stride(-1) != 1 or t.dim() != 2 or t.shape[0] != M:
-            raise RuntimeError("fused node MLP: x must be row-major [M,>=3], t [M,1]")
-        packed = torch.empty(int(lib.dgs_mlp_packed_floats()), dtype=torch.float32, device=dev)
-        saved = torch.empty(int(lib.dgs_mlp_saved_floats(M)), dtype=torch.float32, device=dev)
-        attrs = torch.empty((M, 13), dtype=torch.float32, device=dev)
-        ptrs = (ctypes.c_void_p * 28)(*[p.data_ptr() for p in params])
-        rb = (ctypes.c_float * 4)(*rot_bias)
-        with torch.cuda.device(dev):
-            rc = lib.dgs_mlp_forward(M, x.data_ptr(), x.stride(0), t.data_ptr(), t.stride(0), ptrs, rb, packed.data_ptr(),
-                                     saved.data_ptr(), attrs.data_ptr(), _stream(dev))
-        _check(lib, rc, "dgs_mlp_forward")
+        attrs, packed, saved = _mlp_forward_raw(x, t, rot_bias, params)
         ctx.save_for_backward(packed, saved)
         ctx.sink = sink
         ctx.shapes = [tuple(p.shape) for p in params]
@@ -349,12 +387,9 @@ class _FusedNodeMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_attrs):
-        lib = load()
         packed, saved = ctx.saved_tensors
         dev = packed.device
-        M = g_attrs.shape[0]
         g_attrs = g_attrs.contiguous()
-        scratch = torch.empty(int(lib.dgs_mlp_scratch_floats(M)), dtype=torch.float32, device=dev)
         if ctx.sink is not None:
             outs, ret = ctx.sink, [None] * 28
         else:
@@ -365,11 +400,7 @@ class _FusedNodeMLP(torch.autograd.Function):
                 outs.append(flat[off:off + n].view(shp))
                 off += n
             ret = outs
-        ptrs = (ctypes.c_void_p * 28)(*[o.data_ptr() for o in outs])
-        with torch.cuda.device(dev):
-            rc = lib.dgs_mlp_backward(M, g_attrs.data_ptr(), packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(), ptrs,
-                                      1 if ctx.sink is not None else 0, _stream(dev))
-        _check(lib, rc, "dgs_mlp_backward")
+        _mlp_backward_raw(g_attrs, packed, saved, outs, ctx.sink is not None)
         return (None, None, None, None) + tuple(ret)
 
 
@@ -417,13 +448,41 @@ def knn_indices2(x1, x2, nodes, K, seed=None):
     return idx
 
 
+class DeferredNodeMLP:
+    """The node MLP outside autograd, for trainers that own the gradient buffers: forward() returns the attribute table
+    (no graph), backward(g_attrs) ADDS the 28 parameter gradients into the parameters' .grad tensors whenever the caller
+    launches it (e.g. on a side stream, next to the Adam update of the parameters that do not depend on it)."""
+
+    def __init__(self, net):
+        self.params = node_mlp_params(net)
+        if self.params is None:
+            raise RuntimeError("DeferredNodeMLP: unsupported DeformMLP configuration")
+        self.state = None
+
+    @torch.no_grad()
+    def forward(self, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0)):
+        attrs, packed, saved = _mlp_forward_raw(x.detach(), t.detach(), tuple(float(v) for v in rot_bias), self.params)
+        self.state = (packed, saved)
+        return attrs
+
+    @torch.no_grad()
+    def backward(self, g_attrs):
+        packed, saved = self.state
+        sink = [p.grad for p in self.params]
+        if any(g is None or not g.is_contiguous() for g in sink):
+            raise RuntimeError("DeferredNodeMLP.backward: every parameter needs a contiguous .grad")
+        _mlp_backward_raw(g_attrs, packed, saved, sink, True)
+        self.state = None
+
+
 class _FusedDeform(torch.autograd.Function):
     """(means3D, scales, rotations, opacity) of the deformed surfels from the raw surfel parameters, the node tables
     and the node attribute table (dgs_deform_forward / dgs_deform_backward).  sink: None or the list of the eight
     gradient tensors [xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight] to add into."""
 
     @staticmethod
-    def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink):
+    def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
+                g_attrs_out=None):
         lib = load()
         dev = xyz.device
         N, M = xyz.shape[0], nodes.shape[0]
@@ -446,7 +505,7 @@ class _FusedDeform(torch.autograd.Function):
                                         _stream(dev))
         _check(lib, rc, "dgs_deform_forward")
         ctx.save_for_backward(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx)
-        ctx.mask, ctx.H, ctx.sink = mask, H, sink
+        ctx.mask, ctx.H, ctx.sink, ctx.g_attrs_out = mask, H, sink, g_attrs_out
         return means3D, scales, rots, opac
 
     @staticmethod
@@ -457,7 +516,7 @@ class _FusedDeform(torch.autograd.Function):
         N, M, H = xyz.shape[0], nodes.shape[0], ctx.H
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()
         g_means, g_scales, g_rots, g_opac = z(g_means, xyz), z(g_scales, scaling), z(g_rots, rotation), z(g_opac, opacity)
-        g_attrs = torch.empty_like(attrs)
+        g_attrs = torch.empty_like(attrs) if ctx.g_attrs_out is None else ctx.g_attrs_out  # deferred node MLP: caller's buffer
         scratch = torch.empty(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
         tens = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
         if ctx.sink is not None:
@@ -476,10 +535,11 @@ class _FusedDeform(torch.autograd.Function):
                 outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), outs[5].data_ptr(),
                 outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), acc, scratch.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_deform_backward")
-        return tuple(ret) + (g_attrs, None, None, None, None)
+        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None)
 
 
-def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False):
+def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False,
+                 g_attrs_out=None):
     """Raw surfel parameters + node tables + node attributes -> (means3D, scales, rotations, opacity) for the rasterizer.
     grad_sink=True: gradients of the eight parameters are ADDED to their existing .grad tensors by the kernels."""
     params = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
@@ -488,7 +548,8 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
         sink = [p.grad for p in params]
         if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
             raise RuntimeError("fused_deform(grad_sink=True): every parameter needs a contiguous fp32 .grad")
-    return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink)
+    return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
+                              g_attrs_out)
 
 
 class _FusedTrainLoss(torch.autograd.Function):

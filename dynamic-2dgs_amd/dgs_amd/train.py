@@ -89,8 +89,11 @@ class Trainer:
         deform_groups = [
             {'params': list(deform.network.parameters()), 'lr': deform_lr, 'name': 'deform'},
             {'params': [deform.nodes, deform._node_radius, deform._node_weight], 'lr': deform_lr, 'name': 'nodes'}]
+        self.n_surfel_params = sum(len(g['params']) for g in surfels.optimizer_groups())
         if dev.type == "cuda" and hasattr(deform, "grad_sink"):
             deform.grad_sink = True  # the fused node MLP adds its weight gradients straight into the bucket views
+            # ... and its backward is launched by _fwd_bwd on a side stream, next to the surfels' Adam update
+            deform.defer_mlp_backward = fused_adam
         if fused_adam:
             # HIP device: one flat Adam launch for surfels + deformation (csrc/train_ops.hip); step counter on the device
             from . import _ops
@@ -179,6 +182,8 @@ class Trainer:
                 dsr.set_sh_grad_sink(None)
         else:
             loss.backward()
+        if hasattr(d, "finish_backward"):
+            d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
         with torch.no_grad():
             # densification statistics of this view into the bucket tail (summed over ranks)
             if not hasattr(self, "_radii"):
@@ -213,9 +218,17 @@ class Trainer:
                 s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
                 s.denom.add_(self.bucket.extra[self.P:, None])
                 torch.maximum(s.max_radii2D, self._radii, out=s.max_radii2D)
-            self.opt_surfels.step()
             if self.opt_deform is not None:
+                self.opt_surfels.step()
                 self.opt_deform.step()
+            elif getattr(self.deform, "_join_pending", False):
+                # the node-MLP backward is still running on the side stream (64 workgroups): update the surfels, which do
+                # not depend on it, meanwhile; then join and update the deformation parameters
+                self.opt_surfels.step(0, self.n_surfel_params)
+                self.deform.join_backward()
+                self.opt_surfels.step(self.n_surfel_params, None, advance=False)
+            else:
+                self.opt_surfels.step()
 
     def view_for(self, iteration):
         """Shared deterministic schedule: step i renders views {i*world + rank} mod V."""

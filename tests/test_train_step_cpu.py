@@ -97,7 +97,7 @@ def _dp_worker(rank, world, port, q):
         dist.all_gather(gs, stats)
         same_stats = all(torch.equal(gs[0], g) for g in gs)
         if rank == 0:
-            q.put((same, same_stats, flat_after))
+            q.put((same, same_stats, flat_after.numpy().copy()))  # by value: a tensor would be shared through an fd of this process, which may exit first
     finally:
         dist.destroy_process_group()
 
@@ -111,6 +111,7 @@ def test_data_parallel_two_ranks_gloo():
     for p in procs:
         p.start()
     same, same_stats, flat_dp = q.get()
+    flat_dp = torch.from_numpy(flat_dp)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
