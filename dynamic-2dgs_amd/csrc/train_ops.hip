@@ -507,6 +507,23 @@ __device__ __forceinline__ void quat_to_mat(const float* q, float* R, float& two
     R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1 - two_s * (i * i + j * j);
 }
 
+// Table rows are gathered per lane (every lane another row): 4-byte aligned 16-byte loads fetch a row in 3-4 instructions
+// instead of 11-13 scalar ones; the texture path spends its time per instruction and per cache line touched, not per byte.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void load_row(const float* __restrict__ src, int n, float* __restrict__ out /*[16]*/)
+{
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+        if (c + 4 <= n) {
+            const f4u v = *reinterpret_cast<const f4u*>(src + c);
+            out[c] = v.x; out[c + 1] = v.y; out[c + 2] = v.z; out[c + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int d = c; d < c + 4; d++) out[d] = d < n ? src[d] : 0.f;
+        }
+    }
+}
+
 // per-point evaluation shared by forward and backward
 struct LbsPoint {
     float w[kLbsK], e[kLbsK], dist[kLbsK], Ax[kLbsK][3], rad[kLbsK], wg[kLbsK];
@@ -518,24 +535,29 @@ __device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, f
 {
     const int T = a.tstride;
     xq[0] = a.x[3 * n]; xq[1] = a.x[3 * n + 1]; xq[2] = a.x[3 * n + 2];
-    for (int h = 0; h < kLbsHmax; h++) xq[3 + h] = h < a.H ? a.feature[(size_t)n * a.fstride + h] : 0.f;
+    {
+        float fr[16];
+        load_row(a.feature + (size_t)n * a.fstride, a.H < 16 ? a.H : 16, fr);
+        for (int h = 0; h < kLbsHmax; h++) xq[3 + h] = fr[h];
+    }
     p.W = 0.f;
 #pragma unroll
     for (int k = 0; k < kLbsK; k++) {
         const int j = (int)a.idx[(size_t)n * kLbsK + k];
         p.j[k] = j;
-        const float* nd = a.ntab + (size_t)j * T;
+        float nd[16], at[16];
+        load_row(a.ntab + (size_t)j * T, T < 16 ? T : 16, nd);
+        load_row(a.attrs + (size_t)j * kLbsAttr, kLbsAttr, at);
         float dist = 0.f;
         for (int c = 0; c < 3 + kLbsHmax; c++)
             if (c < 3 + a.H) { const float t = xq[c] - nd[c]; dist += t * t; }
-        const float r = a.rad_raw ? expf(a.rad_raw[j]) : nd[3 + a.H];
-        const float wg = a.w_raw ? sigmoidf_(a.w_raw[j]) : nd[3 + a.H + 1];
+        const float r = a.rad_raw ? expf(a.rad_raw[j]) : a.ntab[(size_t)j * T + 3 + a.H];
+        const float wg = a.w_raw ? sigmoidf_(a.w_raw[j]) : a.ntab[(size_t)j * T + 3 + a.H + 1];
         p.rad[k] = r; p.wg[k] = wg;
         p.dist[k] = dist;
         p.e[k] = expf(-dist / (2.f * r * r));
         p.w[k] = p.e[k] * wg + 1e-7f;
         p.W += p.w[k];
-        const float* at = a.attrs + (size_t)j * kLbsAttr;
         float R[9], two_s;
         quat_to_mat(at, R, two_s);
         const float dx = xq[0] - nd[0], dy = xq[1] - nd[1], dz = xq[2] - nd[2];
@@ -558,7 +580,8 @@ __global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, f
 #pragma unroll
     for (int k = 0; k < kLbsK; k++) {
         const float w = p.w[k] * inv;
-        const float* at = a.attrs + (size_t)p.j[k] * kLbsAttr;
+        float at[16];
+        load_row(a.attrs + (size_t)p.j[k] * kLbsAttr, kLbsAttr, at);
         for (int c = 0; c < 3; c++) t[c] += w * p.Ax[k][c];
         for (int c = 0; c < 4; c++) q[c] += w * at[7 + c];
         for (int c = 0; c < 2; c++) s[c] += w * at[11 + c];
@@ -581,7 +604,7 @@ __global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, f
 // Backward.  Per-node gradients (13 attribute + H+2 table columns) of the ~782 points of a workgroup are accumulated
 // in an LDS table with ds_add_f32 and written once as that workgroup's partial table; lbs_reduce_kernel sums the
 // kLbsBlocks partials.  (Direct global atomics would be ~7 M adds onto ~24 k hot addresses.)
-constexpr int kLbsBwdThreads = 1024;   // one workgroup per CU (the LDS table is ~94 KB): 16 waves hide the gather latency
+constexpr int kLbsBwdThreads = 512;    // one workgroup per CU (the LDS table is ~94 KB); 8 waves keep 256 VGPRs per lane (no spills)
 
 template <bool ASM>
 __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
@@ -621,8 +644,9 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
             float q[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < kLbsK; k++) {
-                const float* at = a.attrs + (size_t)p.j[k] * kLbsAttr;
-                for (int c = 0; c < 4; c++) q[c] += p.w[k] * inv * at[7 + c];
+                const f4u r4 = *reinterpret_cast<const f4u*>(a.attrs + (size_t)p.j[k] * kLbsAttr + 7);
+                const float wn = p.w[k] * inv;
+                q[0] += wn * r4.x; q[1] += wn * r4.y; q[2] += wn * r4.z; q[3] += wn * r4.w;
             }
             float v[4], n2 = 0.f, dot = 0.f;
             for (int c = 0; c < 4; c++) { v[c] = s_.rotation_raw[4 * n + c] + q[c] * m; n2 += v[c] * v[c]; }
@@ -642,7 +666,8 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
         float dwh[kLbsK], mean = 0.f;  // d loss / d (normalised weight)
 #pragma unroll
         for (int k = 0; k < kLbsK; k++) {
-            const float* at = a.attrs + (size_t)p.j[k] * kLbsAttr;
+            float at[16];
+            load_row(a.attrs + (size_t)p.j[k] * kLbsAttr, kLbsAttr, at);
             float v = p.Ax[k][0] * gx[0] + p.Ax[k][1] * gx[1] + p.Ax[k][2] * gx[2];
             for (int c = 0; c < 4; c++) v += at[7 + c] * gq[c];
             for (int c = 0; c < 2; c++) v += at[11 + c] * gs[c];
@@ -655,8 +680,9 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
         for (int k = 0; k < kLbsK; k++) {
             const int j = p.j[k];
             const float wn = p.w[k] * inv;
-            const float* nd = a.ntab + (size_t)j * T;
-            const float* at = a.attrs + (size_t)j * kLbsAttr;
+            float nd[16], at[16];
+            load_row(a.ntab + (size_t)j * T, T < 16 ? T : 16, nd);
+            load_row(a.attrs + (size_t)j * kLbsAttr, 4, at);   // only the local-frame quaternion is needed here
             float* acc = s_tab + (size_t)j * G;
             // ---- attributes: rotation quaternion through R, translation, rotation/scale residuals
             const float dA[3] = {wn * gx[0], wn * gx[1], wn * gx[2]};

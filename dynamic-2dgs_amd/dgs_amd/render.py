@@ -72,10 +72,10 @@ def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=Fa
     rendered_image, radii, allmap = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=None)
-    rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "allmap": allmap}
-    if not postprocess:  # the fused loss (losses.training_loss_from_allmap) works on the allmap directly
+    rets = {"render": rendered_image, "viewspace_points": screenspace_points, "radii": radii, "allmap": allmap}
+    if not postprocess:  # the fused loss / statistics kernels work on the rasterizer outputs directly (radii > 0 is the filter)
         return rets
+    rets["visibility_filter"] = radii > 0
     render_alpha = allmap[1:2]
     render_normal = allmap[2:5]
     render_normal = (render_normal.permute(1, 2, 0) @ (cam.world_view_transform[:3, :3].T)).permute(2, 0, 1)
