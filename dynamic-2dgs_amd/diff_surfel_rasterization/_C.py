@@ -152,9 +152,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                  transMat_precomp=transMat_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, sh=sh, campos=campos)
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    planes = torch.zeros((11, H, W), dtype=torch.float32, device=dev)  # one fill for both images
+    # P > 0: the preprocess kernel writes every radius and the forward blend every pixel of all eleven planes (background
+    # included), so the buffers need no fill; P == 0 returns zeros like the reference (rasterize_points.cu:60-106)
+    alloc = torch.empty if P != 0 else torch.zeros
+    planes = alloc((11, H, W), dtype=torch.float32, device=dev)
     out_color, out_others = planes[:3], planes[3:]
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    radii = alloc((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
     rendered = 0
     if P != 0:
