@@ -606,23 +606,102 @@ __global__ void __launch_bounds__(256) lbs_fwd_kernel(LbsArgs a, float* d_xyz, f
 // kLbsBlocks partials.  (Direct global atomics would be ~7 M adds onto ~24 k hot addresses.)
 constexpr int kLbsBwdThreads = 512;    // one workgroup per CU (the LDS table is ~94 KB); 8 waves keep 256 VGPRs per lane (no spills)
 
+// LDS float atomics are the wrong tool here: ds_add_f32 retires ~1 lane per 2.4 clocks on gfx950 (measured: 13.8 M lane
+// adds = 55 of this kernel's 104 us; the same pattern with ds_add_u32 takes 8 us, tools/micro/lds_atomic_bench.hip; the
+// bucketed delivery below costs ~40 us, LDS-instruction bound, and makes the sums deterministic).
+// The per-node sums are therefore built without float atomics: for each of the K neighbour slots the workgroup's threads
+// park their G contributions in an LDS exchange buffer and take a slot in the target node's small bucket with an integer
+// atomic (fast); after one barrier the thread that OWNS a node adds the parked rows into the node's table row with plain
+// read-modify-writes.  Buckets hold kLbsSlots rows; the rare excess is added with float atomics in a second, guarded phase.
+constexpr int kLbsSlots = 4;   // parked rows per node and delivery round; the rare excess goes through float atomics afterwards
+
+__device__ __forceinline__ void lbs_deliver(bool valid, int j, const float* cv, int G, int GS, int M, float* s_tab, float* s_exch,
+                                            int* s_cnt, unsigned short* s_slot, int* s_over)
+{
+    // on entry: s_cnt[] == 0, *s_over == 0 (left that way by the previous round)
+    const int tid = threadIdx.x;
+    int pos = 0;
+    if (valid) {
+        pos = atomicAdd(&s_cnt[j], 1);                       // integer LDS atomic: fast
+        if (pos < kLbsSlots) {
+            s_slot[j * kLbsSlots + pos] = (unsigned short)tid;
+#pragma unroll
+            for (int c = 0; c < kLbsAttr + kLbsHmax + 2; c++)
+                if (c < G) s_exch[tid * GS + c] = cv[c];
+        } else {
+            *s_over = 1;
+        }
+    }
+    __syncthreads();
+    for (int node = tid; node < M; node += kLbsBwdThreads) {
+        const int cn = min(s_cnt[node], kLbsSlots);
+        if (cn == 0) continue;
+        s_cnt[node] = 0;
+        float* row = s_tab + (size_t)node * G;
+        // all reads of a row are independent (static unroll): one LDS latency per row instead of one per element
+        float accv[kLbsAttr + kLbsHmax + 2];
+#pragma unroll
+        for (int c = 0; c < kLbsAttr + kLbsHmax + 2; c++) accv[c] = c < G ? row[c] : 0.f;
+        for (int e = 0; e < cn; e++) {
+            const float* src = s_exch + (int)s_slot[node * kLbsSlots + e] * GS;
+#pragma unroll
+            for (int c = 0; c < kLbsAttr + kLbsHmax + 2; c++) accv[c] += c < G ? src[c] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < kLbsAttr + kLbsHmax + 2; c++)
+            if (c < G) row[c] = accv[c];
+    }
+    __syncthreads();
+    if (*s_over) {   // workgroup-uniform; ~1 round in 6 on the metric scene has a node with more than kLbsSlots rows
+        if (valid && pos >= kLbsSlots) {
+            float* row = s_tab + (size_t)j * G;
+#pragma unroll
+            for (int c = 0; c < kLbsAttr + kLbsHmax + 2; c++)
+                if (c < G) atomicAdd(row + c, cv[c]);
+        }
+        __syncthreads();
+        if (tid == 0) *s_over = 0;
+        // the owners above zero only the counters they served; counters of overfull nodes were zeroed too (cn > 0)
+        __syncthreads();
+    }
+}
+
+__host__ __device__ inline int lbs_exch_stride(int G) { return G | 1; }   // odd row stride: conflict-free row writes
+inline size_t lbs_bwd_lds_bytes(int M, int H)
+{
+    const int G = kLbsAttr + H + 2;
+    return ((size_t)M * G + (size_t)kLbsBwdThreads * lbs_exch_stride(G)) * sizeof(float) + (size_t)M * sizeof(int) +
+           (size_t)M * kLbsSlots * sizeof(unsigned short) + 16;
+}
+
 template <bool ASM>
 __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
                                                       float* g_feature, int gf_stride, int accumulate,
                                                       float* partial /*[kLbsBlocks][M][G]*/, int chunk, AsmArgs s_)
 {
-    extern __shared__ float s_tab[];  // [M][G], G = 13 + H + 2
-    const int G = kLbsAttr + a.H + 2;
+    extern __shared__ float s_tab[];  // [M][G], G = 13 + H + 2, then the exchange buffer and the integer arrays of lbs_deliver
+    const int G = kLbsAttr + a.H + 2, GS = lbs_exch_stride(G);
     const int T = a.tstride;
+    float* s_exch = s_tab + (size_t)a.M * G;
+    int* s_cnt = reinterpret_cast<int*>(s_exch + (size_t)kLbsBwdThreads * GS);
+    int* s_over = s_cnt + a.M;
+    unsigned short* s_slot = reinterpret_cast<unsigned short*>(s_over + 2);
     for (int i = threadIdx.x; i < a.M * G; i += kLbsBwdThreads) s_tab[i] = 0.f;
+    for (int i = threadIdx.x; i < a.M; i += kLbsBwdThreads) s_cnt[i] = 0;
+    if (threadIdx.x == 0) *s_over = 0;
     __syncthreads();
-    const int end = min(a.N, (int)(blockIdx.x + 1) * chunk);
-    for (int n = blockIdx.x * chunk + threadIdx.x; n < end; n += kLbsBwdThreads) {
+    const int begin = blockIdx.x * chunk, end = min(a.N, (int)(blockIdx.x + 1) * chunk);
+    for (int n0 = begin; n0 < end; n0 += kLbsBwdThreads) {   // uniform trip count: lbs_deliver synchronises the workgroup
+        const int n = n0 + threadIdx.x;
+        const bool valid = n < end;
         LbsPoint p;
         float xq[3 + kLbsHmax];
-        lbs_eval(a, n, p, xq);
-        const float inv = 1.0f / p.W, m = a.mask ? a.mask[n] : 1.0f;
-        float gx[3], gq[4], gs[2];
+        float gx[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gs[2] = {0, 0};
+        float inv = 0.f, m = 0.f;
+        if (valid) {
+            lbs_eval(a, n, p, xq);
+            inv = 1.0f / p.W;
+            m = a.mask ? a.mask[n] : 1.0f;
         if (!ASM) {
             for (int c = 0; c < 3; c++) gx[c] = g_xyz[3 * n + c] * m;
             for (int c = 0; c < 4; c++) gq[c] = g_rot[4 * n + c] * m;
@@ -663,7 +742,9 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
             const float go = s_.g_opacity[n] * o * (1.0f - o);
             s_.g_opacity_raw[n] = accumulate ? s_.g_opacity_raw[n] + go : go;
         }
-        float dwh[kLbsK], mean = 0.f;  // d loss / d (normalised weight)
+        }
+        float dwh[kLbsK] = {0, 0, 0}, mean = 0.f;  // d loss / d (normalised weight)
+        if (valid) {
 #pragma unroll
         for (int k = 0; k < kLbsK; k++) {
             float at[16];
@@ -674,16 +755,19 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
             dwh[k] = v;
             mean += p.w[k] * inv * v;
         }
+        }
         float gfeat[kLbsHmax];
         for (int h = 0; h < kLbsHmax; h++) gfeat[h] = 0.f;
 #pragma unroll
         for (int k = 0; k < kLbsK; k++) {
-            const int j = p.j[k];
+            float cv[kLbsAttr + kLbsHmax + 2];   // this point's contribution to node p.j[k]: [attrs 13 | hyper H | radius | weight]
+            int j = 0;
+            if (valid) {
+            j = p.j[k];
             const float wn = p.w[k] * inv;
             float nd[16], at[16];
             load_row(a.ntab + (size_t)j * T, T < 16 ? T : 16, nd);
             load_row(a.attrs + (size_t)j * kLbsAttr, 4, at);   // only the local-frame quaternion is needed here
-            float* acc = s_tab + (size_t)j * G;
             // ---- attributes: rotation quaternion through R, translation, rotation/scale residuals
             const float dA[3] = {wn * gx[0], wn * gx[1], wn * gx[2]};
             const float dl[3] = {xq[0] - nd[0], xq[1] - nd[1], xq[2] - nd[2]};
@@ -701,28 +785,33 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
                 const float dBj = -2.f * jq * (Gm[0] + Gm[8]) + i * (Gm[1] + Gm[3]) + r * (Gm[2] - Gm[6]) + kq * (Gm[5] + Gm[7]);
                 const float dBk = -2.f * kq * (Gm[0] + Gm[4]) + r * (Gm[3] - Gm[1]) + i * (Gm[2] + Gm[6]) + jq * (Gm[5] + Gm[7]);
                 const float cs = -4.0f * BG / (n2 * n2);
-                atomicAdd(acc + 0, two_s * dBr + cs * r);
-                atomicAdd(acc + 1, two_s * dBi + cs * i);
-                atomicAdd(acc + 2, two_s * dBj + cs * jq);
-                atomicAdd(acc + 3, two_s * dBk + cs * kq);
+                cv[0] = two_s * dBr + cs * r;
+                cv[1] = two_s * dBi + cs * i;
+                cv[2] = two_s * dBj + cs * jq;
+                cv[3] = two_s * dBk + cs * kq;
             }
-            for (int c = 0; c < 3; c++) atomicAdd(acc + 4 + c, dA[c]);
-            for (int c = 0; c < 4; c++) atomicAdd(acc + 7 + c, wn * gq[c]);
-            for (int c = 0; c < 2; c++) atomicAdd(acc + 11 + c, wn * gs[c]);
+            for (int c = 0; c < 3; c++) cv[4 + c] = dA[c];
+            for (int c = 0; c < 4; c++) cv[7 + c] = wn * gq[c];
+            for (int c = 0; c < 2; c++) cv[11 + c] = wn * gs[c];
             // ---- weights: w = e * weight + 1e-7, e = exp(-dist / (2 r^2)), normalised over the K neighbours
             const float dw = (dwh[k] - mean) * inv;
             const float rad = p.rad[k], wg = p.wg[k];
             const float de = dw * wg * p.e[k];
             const float ddist = -de / (2.f * rad * rad);
-            atomicAdd(acc + kLbsAttr + a.H, de * p.dist[k] / (rad * rad * rad));  // d radius
-            atomicAdd(acc + kLbsAttr + a.H + 1, dw * p.e[k]);                     // d weight
-            for (int h = 0; h < kLbsHmax; h++)
-                if (h < a.H) {
-                    const float gd = 2.f * (xq[3 + h] - nd[3 + h]) * ddist;
-                    gfeat[h] += gd;
-                    atomicAdd(acc + kLbsAttr + h, -gd);                           // d node hyper coordinate
-                }
+            const float d_rad = de * p.dist[k] / (rad * rad * rad), d_w = dw * p.e[k];
+#pragma unroll
+            for (int h = 0; h < kLbsHmax; h++) {
+                const float gd = h < a.H ? 2.f * (xq[3 + h] - nd[3 + h]) * ddist : 0.f;
+                gfeat[h] += gd;
+                // columns 13 .. 13+H-1: node hyper coordinates, then radius, weight (static register indices only)
+                cv[kLbsAttr + h] = h < a.H ? -gd : (h == a.H ? d_rad : (h == a.H + 1 ? d_w : 0.f));
+            }
+#pragma unroll
+            for (int h = kLbsHmax; h < kLbsHmax + 2; h++) cv[kLbsAttr + h] = h == a.H ? d_rad : (h == a.H + 1 ? d_w : 0.f);
+            }
+            lbs_deliver(valid, j, cv, G, GS, a.M, s_tab, s_exch, s_cnt, s_slot, s_over);
         }
+        if (valid)
         for (int h = 0; h < kLbsHmax; h++)
             if (h < a.H) {
                 float* dst = g_feature + (size_t)n * gf_stride + h;
@@ -1033,6 +1122,7 @@ int dgs_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
     return 0;
 }
 
+int dgs_lbs_supported(int M, int H) { return H >= 0 && H <= kLbsHmax && M > 0 && M <= 4 * kLbsBwdThreads && lbs_bwd_lds_bytes(M, H) <= 160 * 1024; }
 size_t dgs_lbs_scratch_bytes(int M, int H) { return (size_t)kLbsBlocks * (size_t)M * (size_t)(kLbsAttr + H + 2) * sizeof(float); }
 
 static int lbs_check(int N, int M, int H)
@@ -1061,8 +1151,8 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
 {
     if (int e = lbs_check(N, M, H)) return e;
     const int G = kLbsAttr + H + 2;
-    const size_t lds = (size_t)M * G * sizeof(float);
-    if (lds > 150 * 1024) return fail(-2, "dgs_lbs_backward: node table does not fit LDS (M * (15 + H) floats > 150 KB)");
+    const size_t lds = lbs_bwd_lds_bytes(M, H);
+    if (lds > 160 * 1024 || M > 4 * kLbsBwdThreads) return fail(-2, "dgs_lbs_backward: node tables do not fit the 160 KB of LDS");
     if (!scratch) return fail(-1, "dgs_lbs_backward: scratch is NULL");
     LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask, 3 + H + 2, nullptr, nullptr};
     const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
@@ -1276,8 +1366,8 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
 {
     if (int e = lbs_check(N, M, H)) return e;
     const int G = kLbsAttr + H + 2;
-    const size_t lds = (size_t)M * G * sizeof(float);
-    if (lds > 150 * 1024) return fail(-2, "dgs_deform_backward: node table does not fit LDS (M * (15 + H) floats > 150 KB)");
+    const size_t lds = lbs_bwd_lds_bytes(M, H);
+    if (lds > 160 * 1024 || M > 4 * kLbsBwdThreads) return fail(-2, "dgs_deform_backward: node tables do not fit the 160 KB of LDS");
     if (!scratch || !g_means3D || !g_scales || !g_rotations || !g_opacity || !g_xyz || !g_scaling_raw || !g_rotation_raw ||
         !g_opacity_raw || !g_feature || !g_nodes || !g_radius_raw || !g_weight_raw || !g_attrs)
         return fail(-1, "dgs_deform_backward: NULL pointer");

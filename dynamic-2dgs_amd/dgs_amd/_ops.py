@@ -15,7 +15,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step",
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
-            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern")
+            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_lbs_supported")
 
 
 def build(force=False, verbose=False):
@@ -217,7 +217,10 @@ def fused_lbs(x, feature, idx, ntab, attrs, mask, H):
 
 
 def lbs_supported(M, H):
-    return H <= 13 and M * (15 + H) * 4 <= 150 * 1024
+    lib = load()
+    lib.dgs_lbs_supported.restype = ctypes.c_int
+    lib.dgs_lbs_supported.argtypes = [ctypes.c_int, ctypes.c_int]
+    return bool(lib.dgs_lbs_supported(int(M), int(H)))
 
 
 class FlatAdam:

@@ -52,6 +52,7 @@ int dgs_knn_points(int N, int M, int D, int K, const float* x, const float* node
  * backward: g_feature[N,H] (overwritten), g_ntab[M,3+H+2], g_attrs[M,13] (overwritten; xyz columns of g_ntab are 0).
  *           scratch: at least dgs_lbs_scratch_bytes(M, H) bytes. */
 size_t dgs_lbs_scratch_bytes(int M, int H);
+int dgs_lbs_supported(int M, int H);   /* 1 when the backward's tables for M nodes / H hyper dims fit the 160 KB of LDS */
 int dgs_lbs_forward(int N, int M, int H, const float* x, const float* feature, int feature_stride, const long long* idx,
                     const float* ntab, const float* attrs, const float* mask, float* d_xyz, float* d_rot, float* d_scale,
                     void* stream);
