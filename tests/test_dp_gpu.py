@@ -1,0 +1,83 @@
+"""-m gpu: the data-parallel step on the HIP path (fused kernels, in-place gradient sinks, one flat all-reduce), two ranks
+sharing the one GPU of the test box over gloo (the collective's transport is irrelevant to what is checked: replicas stay
+identical, and the reduced bucket is the mean of the two views' single-process gradients)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
+        assert tr.world == world and tr.view_for(0) == rank
+        tr.step()
+        flat_after = tr.bucket.flat.detach().cpu().numpy().copy()
+        tr.step()
+        torch.cuda.synchronize()
+        params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
+        stats = torch.cat([tr.surfels.xyz_gradient_accum.reshape(-1), tr.surfels.denom.reshape(-1), tr.surfels.max_radii2D.float()]).cpu()
+        gp = [torch.zeros_like(params) for _ in range(world)]
+        gs = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gp, params)
+        dist.all_gather(gs, stats)
+        if rank == 0:
+            q.put((all(torch.equal(gp[0], g) for g in gp), all(torch.equal(gs[0], g) for g in gs), flat_after))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_on_the_hip_path():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, same_stats, flat_dp = q.get()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert same and same_stats
+    # single-process gradients of the two views
+    import bench
+    dev = torch.device("cuda:0")
+    flats = []
+    for view in range(world):
+        tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
+        tr.view_for = lambda it, v=view: v
+        tr.opt_surfels.step = lambda *a, **k: None
+        tr.step()
+        flats.append(tr.bucket.flat.detach().cpu().clone())
+    n = tr.bucket.n_grad
+    expect = torch.cat([(flats[0][:n] + flats[1][:n]) / 2, flats[0][n:] + flats[1][n:]])
+    got = torch.from_numpy(flat_dp)
+    # fp32 atomics in the rasterizer backward: compare robustly
+    err = (got - expect).abs()
+    scale = expect.abs().max()
+    assert float(err.max()) <= 2e-3 * float(scale), (float(err.max()), float(scale))
+    assert float(err.median()) <= 1e-6 * float(scale)
