@@ -22,6 +22,46 @@ def _free_port():
     return p
 
 
+def _graph_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from diff_surfel_rasterization import _C
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
+        tr.enable_graph(capacity=24 * 20000)   # graph 1 = forward + backward, eager all-reduce, graph 2 = statistics + Adam
+        losses = [float(tr.step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert not _C.read_overflow()
+        params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
+        gp = [torch.zeros_like(params) for _ in range(world)]
+        dist.all_gather(gp, params)
+        if rank == 0:
+            q.put((all(torch.equal(gp[0], g) for g in gp), bool(torch.isfinite(params).all()), losses))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_graph_replay_keeps_replicas_identical():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, finite, losses = q.get()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert same and finite and all(0.0 < l < 10.0 for l in losses), losses
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
