@@ -41,8 +41,10 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                        Gauss g, float* __restrict__ ssim_sum, float* __restrict__ dm_dmu1,
                                                        float* __restrict__ dm_ds11, float* __restrict__ dm_ds12,
-                                                       float* __restrict__ l1_sum, float* __restrict__ partial)
+                                                       float* __restrict__ l1_sum, float* __restrict__ partial,
+                                                       const float* const* __restrict__ img2_slot)
 {
+    if (img2_slot) img2 = *img2_slot;   // indirection: the comparison image is chosen per graph replay by rewriting one pointer
     __shared__ float s_a[kIn][kIn + 1], s_b[kIn][kIn + 1];
     __shared__ float s_h[5][kIn][kT + 1];
     __shared__ float s_red[8];
@@ -114,8 +116,10 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float
 __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n, float l1_coef, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, Gauss g, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_ds11, const float* __restrict__ dm_ds12,
-                                                       const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1)
+                                                       const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1,
+                                                       const float* const* __restrict__ img2_slot)
 {
+    if (img2_slot) img2 = *img2_slot;
     __shared__ float s_in[3][kIn][kIn + 1];
     __shared__ float s_h[3][kIn][kT + 1];
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
@@ -933,6 +937,7 @@ struct RegArgs {
     int H, W;
     const float* allmap; const float* rays_d; const float* rays_o; const float* wvt;
     float ln, ld;
+    const float* const* rays_slot;   // non-null: rays_d = *rays_slot (chosen per graph replay by rewriting one pointer)
 };
 
 // back-projected point of pixel (y, x)
@@ -958,6 +963,7 @@ __device__ __forceinline__ void reg_cross(const RegArgs& a, int y, int x, float*
 
 __global__ void __launch_bounds__(256) regloss_fwd_kernel(RegArgs a, float* loss, float* partial)
 {
+    if (a.rays_slot) a.rays_d = *a.rays_slot;
     __shared__ float s_red[4];
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     const size_t HW = (size_t)a.H * a.W;
@@ -990,6 +996,7 @@ __global__ void __launch_bounds__(256) regloss_fwd_kernel(RegArgs a, float* loss
 
 __global__ void __launch_bounds__(256) regloss_bwd_kernel(RegArgs a, const float* g, float* d_allmap)
 {
+    if (a.rays_slot) a.rays_d = *a.rays_slot;
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= a.W || y >= a.H) return;
     const size_t HW = (size_t)a.H * a.W, q = (size_t)y * a.W + x;
@@ -1100,7 +1107,7 @@ int dgs_ssim_forward(int C, int H, int W, const float* img1, const float* img2, 
     static const Gauss g = make_gauss();
     dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img1, img2, g, ssim_sum, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr);
+                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr, (const float* const*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_fwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -1116,7 +1123,7 @@ int dgs_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
     dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, inv_n, 0.f, img1, img2, g, dm_dmu1, dm_dsigma1_sq,
-                       dm_dsigma12, dL_dmean, dL_dimg1);
+                       dm_dsigma12, dL_dmean, dL_dimg1, (const float* const*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -1169,7 +1176,7 @@ int dgs_regloss_forward(int H, int W, const float* allmap, const float* rays_d, 
                         float lambda_normal, float lambda_dist, float* loss, void* stream)
 {
     if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !loss) return fail(-1, "dgs_regloss_forward: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr};
     hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, loss, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_fwd_kernel: ") + hipGetErrorString(e));
@@ -1180,7 +1187,20 @@ int dgs_regloss_backward(int H, int W, const float* allmap, const float* rays_d,
                          float lambda_normal, float lambda_dist, const float* g, float* d_allmap, void* stream)
 {
     if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !g || !d_allmap) return fail(-1, "dgs_regloss_backward: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr};
+    hipLaunchKernelGGL(regloss_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, g, d_allmap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("regloss_bwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                              float lambda_normal, float lambda_dist, const float* g, float* d_allmap, const float* const* rays_slot,
+                              void* stream)
+{
+    if (H <= 0 || W <= 0 || !allmap || (!rays_d && !rays_slot) || !rays_o || !wvt || !g || !d_allmap)
+        return fail(-1, "dgs_regloss_backward_slot: bad argument");
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot};
     hipLaunchKernelGGL(regloss_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, g, d_allmap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_bwd_kernel: ") + hipGetErrorString(e));
@@ -1392,24 +1412,25 @@ size_t dgs_photo_blocks(int C, int H, int W) { return (size_t)((W + kT - 1) / kT
 size_t dgs_regloss_blocks(int H, int W) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
 
 int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, float* partials, float* dm_dmu1, float* dm_dsigma1_sq,
-                      float* dm_dsigma12, void* stream)
+                      float* dm_dsigma12, const float* const* gt_slot, void* stream)
 {
     if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !partials || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)
         return fail(-1, "dgs_photo_forward: bad argument");
     static const Gauss g = make_gauss();
     dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img, gt, g, (float*)nullptr, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials);
+                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials, gt_slot);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_fwd_kernel: ") + hipGetErrorString(e));
     return 0;
 }
 
 int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
-                                 float lambda_normal, float lambda_dist, float* partials, void* stream)
+                                 float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot, void* stream)
 {
-    if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !partials) return fail(-1, "dgs_regloss_forward_partials: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist};
+    if (H <= 0 || W <= 0 || !allmap || (!rays_d && !rays_slot) || !rays_o || !wvt || !partials)
+        return fail(-1, "dgs_regloss_forward_partials: bad argument");
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot};
     hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, (float*)nullptr,
                        partials);
     hipError_t e = hipGetLastError();
@@ -1418,7 +1439,8 @@ int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float*
 }
 
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
-                       const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, void* stream)
+                       const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
+                       void* stream)
 {
     if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !g_loss || !dL_dimg)
         return fail(-1, "dgs_photo_backward: bad argument");
@@ -1426,7 +1448,7 @@ int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, c
     dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, -lambda_dssim * inv_n,
-                       (1.0f - lambda_dssim) * inv_n, img, gt, g, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, g_loss, dL_dimg);
+                       (1.0f - lambda_dssim) * inv_n, img, gt, g, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, g_loss, dL_dimg, gt_slot);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
     return 0;

@@ -15,7 +15,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step",
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
-            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_lbs_supported")
+            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_lbs_supported", "dgs_regloss_backward_slot")
 
 
 def build(force=False, verbose=False):
@@ -87,9 +87,11 @@ def load():
         lib.dgs_deform_backward.restype = ci
         lib.dgs_deform_backward.argtypes = [ci, ci, ci, vp, vp, ci] + [vp] * 22 + [ci, vp, vp]
         lib.dgs_photo_forward.restype = ci
-        lib.dgs_photo_forward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+        lib.dgs_photo_forward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dgs_photo_backward.restype = ci
-        lib.dgs_photo_backward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp]
+        lib.dgs_photo_backward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp]
+        lib.dgs_regloss_backward_slot.restype = ci
+        lib.dgs_regloss_backward_slot.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         lib.dgs_loss_combine.restype = ci
         lib.dgs_loss_combine.argtypes = [vp, ctypes.c_longlong, vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_float, vp, vp]
         lib.dgs_photo_blocks.restype = ctypes.c_size_t
@@ -97,7 +99,7 @@ def load():
         lib.dgs_regloss_blocks.restype = ctypes.c_size_t
         lib.dgs_regloss_blocks.argtypes = [ci, ci]
         lib.dgs_regloss_forward_partials.restype = ci
-        lib.dgs_regloss_forward_partials.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp]
+        lib.dgs_regloss_forward_partials.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         lib.dgs_densify_view.restype = ci
         lib.dgs_densify_view.argtypes = [ci, vp, vp, vp, vp, vp, vp]
         lib.dgs_densify_accumulate.restype = ci
@@ -560,8 +562,12 @@ class _FusedTrainLoss(torch.autograd.Function):
     from the rasterizer outputs: 4 launches forward, 3 backward."""
 
     @staticmethod
-    def forward(ctx, image, allmap, gt, rays_d, rays_o, wvt, lam_dssim, lam_n, lam_d):
+    def forward(ctx, image, allmap, gt, rays_d, rays_o, wvt, lam_dssim, lam_n, lam_d, slots=None):
+        """slots: None, or an int64 device tensor [2] holding the pointers of the target image and the ray table to use
+        (read by the kernels at run time: a captured graph switches views by rewriting them)."""
         lib = load()
+        gslot = None if slots is None else ctypes.c_void_p(slots.data_ptr())
+        rslot = None if slots is None else ctypes.c_void_p(slots.data_ptr() + 8)
         dev = image.device
         image, allmap, gt = image.contiguous(), allmap.contiguous(), gt.contiguous()
         C, H, W = image.shape
@@ -572,19 +578,22 @@ class _FusedTrainLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(dev)
             _check(lib, lib.dgs_photo_forward(C, H, W, image.data_ptr(), gt.data_ptr(), part.data_ptr(), maps[0].data_ptr(),
-                                              maps[1].data_ptr(), maps[2].data_ptr(), st), "dgs_photo_forward")
+                                              maps[1].data_ptr(), maps[2].data_ptr(), gslot, st), "dgs_photo_forward")
             _check(lib, lib.dgs_regloss_forward_partials(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
-                                                         lam_n, lam_d, part.data_ptr() + 8 * nb, st), "dgs_regloss_forward_partials")
+                                                         lam_n, lam_d, part.data_ptr() + 8 * nb, rslot, st), "dgs_regloss_forward_partials")
             _check(lib, lib.dgs_loss_combine(part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, C * H * W, lam_dssim, loss.data_ptr(), st),
                    "dgs_loss_combine")
         ctx.save_for_backward(image, allmap, gt, rays_d, rays_o, wvt, maps)
         ctx.lam = (lam_dssim, lam_n, lam_d)
+        ctx.slots = slots
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         lib = load()
         image, allmap, gt, rays_d, rays_o, wvt, maps = ctx.saved_tensors
+        gslot = None if ctx.slots is None else ctypes.c_void_p(ctx.slots.data_ptr())
+        rslot = None if ctx.slots is None else ctypes.c_void_p(ctx.slots.data_ptr() + 8)
         dev = image.device
         C, H, W = image.shape
         gd = g.reshape(1).to(torch.float32).contiguous()
@@ -593,15 +602,16 @@ class _FusedTrainLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(dev)
             _check(lib, lib.dgs_photo_backward(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
-                                               maps[2].data_ptr(), ctx.lam[0], gd.data_ptr(), g_image.data_ptr(), st), "dgs_photo_backward")
-            _check(lib, lib.dgs_regloss_backward(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), ctx.lam[1],
-                                                 ctx.lam[2], gd.data_ptr(), g_allmap.data_ptr(), st), "dgs_regloss_backward")
-        return g_image, g_allmap, None, None, None, None, None, None, None
+                                               maps[2].data_ptr(), ctx.lam[0], gd.data_ptr(), g_image.data_ptr(), gslot, st), "dgs_photo_backward")
+            _check(lib, lib.dgs_regloss_backward_slot(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
+                                                      ctx.lam[1], ctx.lam[2], gd.data_ptr(), g_allmap.data_ptr(), rslot, st),
+                   "dgs_regloss_backward")
+        return g_image, g_allmap, None, None, None, None, None, None, None, None
 
 
-def fused_train_loss(image, allmap, gt, rays_d, rays_o, wvt, lambda_dssim, lambda_normal, lambda_dist):
+def fused_train_loss(image, allmap, gt, rays_d, rays_o, wvt, lambda_dssim, lambda_normal, lambda_dist, slots=None):
     return _FusedTrainLoss.apply(image, allmap, gt.detach(), rays_d.contiguous(), rays_o.contiguous(), wvt.contiguous(),
-                                 float(lambda_dssim), float(lambda_normal), float(lambda_dist))
+                                 float(lambda_dssim), float(lambda_normal), float(lambda_dist), slots)
 
 
 def densify_view(radii, g_means2D, grad_norm, visible, radii_vis):

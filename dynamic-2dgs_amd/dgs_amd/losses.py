@@ -86,7 +86,7 @@ def training_loss_from_allmap(image, allmap, cam, gt_image, lambda_dssim=0.2, la
     rays_d, rays_o = camera_rays(cam, image.device)
     if FUSE_PHOTOMETRIC:
         return _ops.fused_train_loss(image, allmap, gt_image, rays_d, rays_o, cam.world_view_transform, lambda_dssim, lambda_normal,
-                                     lambda_dist)
+                                     lambda_dist, slots=getattr(cam, "slots", None))
     reg = _ops.fused_reg_loss(allmap, rays_d, rays_o, cam.world_view_transform, lambda_normal, lambda_dist)
     ll1 = l1_loss(image, gt_image)
     return (1.0 - lambda_dssim) * ll1 + lambda_dssim * (1.0 - ssim(image, gt_image)) + reg

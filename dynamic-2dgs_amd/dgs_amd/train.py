@@ -17,26 +17,41 @@ from .render import camera_rays, render
 
 
 class StaticCamera:
-    """Camera whose tensors are fixed device buffers: the captured step reads them, `load` refills them per view."""
+    """Camera whose tensors are views of ONE fixed 64-float device row: the captured step reads them, `load` refills the
+    row with a single 256-byte copy per view (nine separate copies -- two of them 7.7 MB: the ray table and the target
+    image -- cost 56 us of a 1.4 ms step).  The row also carries two POINTERS (`slots`: target image, ray table) that the
+    loss kernels dereference at run time, so the big per-view arrays stay where they are.
+    row layout (floats): world_view 0:16 | full_proj 16:32 | camera_center 32:35 | fid 35 | rays_o 36:39 | slots 40:44 (2 x int64)"""
+    ROW = 64
 
-    def __init__(self, cam, device):
+    def __init__(self, cam, device, rays_d, target):
         self.image_height, self.image_width = cam.image_height, cam.image_width
         self.FoVx, self.FoVy = cam.FoVx, cam.FoVy
-        self.world_view_transform = cam.world_view_transform.to(device).clone()
-        self.full_proj_transform = cam.full_proj_transform.to(device).clone()
-        self.camera_center = cam.camera_center.to(device).clone()
-        self.fid = cam.fid.to(device).clone()
-        rd, ro = camera_rays(cam, device)
-        self.rays_d, self.rays_o = rd.clone(), ro.clone()
+        self.row = torch.zeros(self.ROW, dtype=torch.float32, device=device)
+        self.world_view_transform = self.row[0:16].view(4, 4)
+        self.full_proj_transform = self.row[16:32].view(4, 4)
+        self.camera_center = self.row[32:35]
+        self.fid = self.row[35:36]
+        self.rays_o = self.row[36:39]
+        self.slots = self.row[40:44].view(torch.int64)
+        self.rays_d = rays_d      # placeholders of the right shape: the kernels follow `slots`
+        self.target = target
 
-    def load(self, packed):
-        wvt, proj, center, fid, rd, ro = packed
-        self.world_view_transform.copy_(wvt, non_blocking=True)
-        self.full_proj_transform.copy_(proj, non_blocking=True)
-        self.camera_center.copy_(center, non_blocking=True)
-        self.fid.copy_(fid, non_blocking=True)
-        self.rays_d.copy_(rd, non_blocking=True)
-        self.rays_o.copy_(ro, non_blocking=True)
+    @staticmethod
+    def pack(cam, rays_d, rays_o, target):
+        """One table row (CPU float32 tensor) for this view; the tensors it points to must stay alive."""
+        import numpy as np
+        row = np.zeros(StaticCamera.ROW, np.float32)
+        row[0:16] = cam.world_view_transform.detach().cpu().numpy().reshape(-1)
+        row[16:32] = cam.full_proj_transform.detach().cpu().numpy().reshape(-1)
+        row[32:35] = cam.camera_center.detach().cpu().numpy().reshape(-1)
+        row[35] = float(cam.fid.detach().cpu().reshape(-1)[0])
+        row[36:39] = rays_o.detach().cpu().numpy().reshape(-1)
+        row.view(np.int64)[20:22] = [target.data_ptr(), rays_d.data_ptr()]
+        return torch.from_numpy(row)
+
+    def load(self, table_row):
+        self.row.copy_(table_row, non_blocking=True)
 
 
 class FlatGradBucket:
@@ -118,8 +133,9 @@ class Trainer:
     def enable_graph(self, capacity):
         """Capture deform -> render -> loss -> backward (-> Adam when single-GPU) into HIP graphs and replay them per
         step: the step is ~400 small launches and otherwise bound by the host, not the GPU.  Needs the rasterizer's
-        capacity mode (`capacity` list entries; no device->host read inside the step).  Per-view inputs are copied into
-        static buffers before each replay.  Under data parallelism the all-reduce stays outside the graphs."""
+        capacity mode (`capacity` list entries; no device->host read inside the step).  Per view, one 256-byte row (camera,
+        time, pointers of target image and ray table) is copied into a static buffer before each replay.  Under data
+        parallelism the all-reduce stays outside the graphs."""
         import os
         from diff_surfel_rasterization import _C
         assert self.rasterizer_cls is None, "graph capture is for the HIP operator"
@@ -130,13 +146,15 @@ class Trainer:
                                "Trainer.enable_graph() (see DESIGN.md, 'HIP graphs')")
         dev = self.surfels.get_xyz.device
         _C.set_capacity(int(capacity))
-        self._packed = []
-        for cam in self.cameras:
-            rd, ro = camera_rays(cam, dev)
-            self._packed.append((cam.world_view_transform, cam.full_proj_transform, cam.camera_center, cam.fid, rd, ro))
-        self._scam = StaticCamera(self.cameras[0], dev)
-        self._sgt = self.targets[0].clone()
-        self._sloss = torch.zeros((), device=dev)
+        # (rays_d [H*W,3], rays_o [3]) per view and the targets stay resident: the table rows point at them
+        self._rays = [tuple(t.contiguous() for t in camera_rays(cam, dev)) for cam in self.cameras]
+        self._targets_c = [t.contiguous() for t in self.targets]
+        rows = [StaticCamera.pack(cam, self._rays[v][0], self._rays[v][1], self._targets_c[v % len(self._targets_c)])
+                for v, cam in enumerate(self.cameras)]
+        self._vtab = torch.stack(rows).to(dev)
+        self._scam = StaticCamera(self.cameras[0], dev, self._rays[0][0], self._targets_c[0])
+        self._scam.load(self._vtab[0])
+        self._sgt = self._scam.target
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up on a side stream (allocations, optimiser state) as torch.cuda.graph requires
@@ -147,7 +165,7 @@ class Trainer:
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):
-            self._sloss.copy_(self._fwd_bwd(self._scam, self._sgt))
+            self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
             if self.world == 1:
                 self._finish()
         self._g2 = None
@@ -238,8 +256,7 @@ class Trainer:
         v = self.view_for(self.iteration)
         self.iteration += 1
         if self._graph:
-            self._scam.load(self._packed[v])
-            self._sgt.copy_(self.targets[v % len(self.targets)], non_blocking=True)
+            self._scam.load(self._vtab[v])   # one 256-byte copy: camera matrices, time, and the pointers of target / ray table
             self._g1.replay()
             if self._g2 is not None:
                 self._reduce()

@@ -143,17 +143,23 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
  *   dgs_photo_forward            partials[0 .. B)  = SSIM-map sums, partials[B .. 2B) = |img - gt| sums, B = dgs_photo_blocks()
  *   dgs_regloss_forward_partials partials[0 .. R)  = regulariser sums (already scaled and divided by H*W), R = dgs_regloss_blocks()
  *   dgs_loss_combine             out[0] = (1 - lambda) * sum(l1) / n + lambda * (1 - sum(ssim) / n) + sum(reg),  n = C*H*W
- *   dgs_photo_backward           dL/dimg for the DEVICE scalar *g_loss. */
+ *   dgs_photo_backward           dL/dimg for the DEVICE scalar *g_loss.
+ * gt_slot / rays_slot (may be NULL): DEVICE locations holding the pointer to use instead of gt / rays_d -- a captured HIP
+ * graph then switches target image and ray table per replay by rewriting 8 bytes instead of copying 7.7 MB each. */
 size_t dgs_photo_blocks(int C, int H, int W);
 size_t dgs_regloss_blocks(int H, int W);
 int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, float* partials, float* dm_dmu1, float* dm_dsigma1_sq,
-                      float* dm_dsigma12, void* stream);
+                      float* dm_dsigma12, const float* const* gt_slot, void* stream);
 int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
-                                 float lambda_normal, float lambda_dist, float* partials, void* stream);
+                                 float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot, void* stream);
+int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                              float lambda_normal, float lambda_dist, const float* g, float* d_allmap, const float* const* rays_slot,
+                              void* stream);
 int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
                      float lambda_dssim, float* out, void* stream);
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
-                       const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, void* stream);
+                       const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
+                       void* stream);
 
 /* Densification statistics (train_gui.py:411, scene/gaussian_model.py:484-486).  dgs_densify_view, per rendered view:
  * visible = radii > 0, grad_norm = |dL/dmeans2D[:, :2]| where visible (else 0), radii_vis = radii where visible.
