@@ -414,12 +414,14 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
         uint32_t* plist = (uint32_t*)(bin + bl.point_list);
         hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
                            (const uint64_t*)keys, plist, 0);
-        if (longest > 2048u)
+        // capacity mode does not know the longest list on the host: ONE fallback launch (global scratch) covers every tile
+        // above 2048 entries instead of two mostly empty ones
+        if (longest > 2048u && !capacity_mode)
             hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<16384>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
                                (const uint64_t*)keys, plist, 2048);
         if (need_global_sort)
             hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
-                               (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, 16384);
+                               (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, capacity_mode ? 2048 : 16384);
         DGS_STAGE("sort_tiles", debug, stream);
     }
 

@@ -938,6 +938,7 @@ struct RegArgs {
     const float* allmap; const float* rays_d; const float* rays_o; const float* wvt;
     float ln, ld;
     const float* const* rays_slot;   // non-null: rays_d = *rays_slot (chosen per graph replay by rewriting one pointer)
+    int write_all;                   // backward: also store the zeros of planes 0, 1, 7 and of the border (caller zero-fills plane 5 only)
 };
 
 // back-projected point of pixel (y, x)
@@ -1002,7 +1003,12 @@ __global__ void __launch_bounds__(256) regloss_bwd_kernel(RegArgs a, const float
     const size_t HW = (size_t)a.H * a.W, q = (size_t)y * a.W + x;
     const float gs = g[0] / (float)HW;
     d_allmap[6 * HW + q] = gs * a.ld;
-    if (!(x >= 1 && y >= 1 && x < a.W - 1 && y < a.H - 1)) return;
+    const bool interior = x >= 1 && y >= 1 && x < a.W - 1 && y < a.H - 1;
+    if (a.write_all) {
+        d_allmap[q] = 0.f; d_allmap[HW + q] = 0.f; d_allmap[7 * HW + q] = 0.f;
+        if (!interior) { d_allmap[2 * HW + q] = 0.f; d_allmap[3 * HW + q] = 0.f; d_allmap[4 * HW + q] = 0.f; }
+    }
+    if (!interior) return;
     float dx[3], dy[3], v[3];
     reg_cross(a, y, x, dx, dy, v);
     const float L = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -1176,7 +1182,7 @@ int dgs_regloss_forward(int H, int W, const float* allmap, const float* rays_d, 
                         float lambda_normal, float lambda_dist, float* loss, void* stream)
 {
     if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !loss) return fail(-1, "dgs_regloss_forward: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr, 0};
     hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, loss, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_fwd_kernel: ") + hipGetErrorString(e));
@@ -1187,7 +1193,7 @@ int dgs_regloss_backward(int H, int W, const float* allmap, const float* rays_d,
                          float lambda_normal, float lambda_dist, const float* g, float* d_allmap, void* stream)
 {
     if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !g || !d_allmap) return fail(-1, "dgs_regloss_backward: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr, 0};
     hipLaunchKernelGGL(regloss_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, g, d_allmap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_bwd_kernel: ") + hipGetErrorString(e));
@@ -1196,11 +1202,11 @@ int dgs_regloss_backward(int H, int W, const float* allmap, const float* rays_d,
 
 int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
                               float lambda_normal, float lambda_dist, const float* g, float* d_allmap, const float* const* rays_slot,
-                              void* stream)
+                              int write_all, void* stream)
 {
     if (H <= 0 || W <= 0 || !allmap || (!rays_d && !rays_slot) || !rays_o || !wvt || !g || !d_allmap)
         return fail(-1, "dgs_regloss_backward_slot: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, write_all};
     hipLaunchKernelGGL(regloss_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, g, d_allmap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_bwd_kernel: ") + hipGetErrorString(e));
@@ -1430,7 +1436,7 @@ int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float*
 {
     if (H <= 0 || W <= 0 || !allmap || (!rays_d && !rays_slot) || !rays_o || !wvt || !partials)
         return fail(-1, "dgs_regloss_forward_partials: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, 0};
     hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, (float*)nullptr,
                        partials);
     hipError_t e = hipGetLastError();

@@ -91,7 +91,7 @@ def load():
         lib.dgs_photo_backward.restype = ci
         lib.dgs_photo_backward.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp]
         lib.dgs_regloss_backward_slot.restype = ci
-        lib.dgs_regloss_backward_slot.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+        lib.dgs_regloss_backward_slot.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, ci, vp]
         lib.dgs_loss_combine.restype = ci
         lib.dgs_loss_combine.argtypes = [vp, ctypes.c_longlong, vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_float, vp, vp]
         lib.dgs_photo_blocks.restype = ctypes.c_size_t
@@ -598,13 +598,14 @@ class _FusedTrainLoss(torch.autograd.Function):
         C, H, W = image.shape
         gd = g.reshape(1).to(torch.float32).contiguous()
         g_image = torch.empty_like(image)
-        g_allmap = torch.zeros_like(allmap)
+        g_allmap = torch.empty_like(allmap)   # the kernel stores everything but plane 5, which collects atomics
+        g_allmap[5].zero_()
         with torch.cuda.device(dev):
             st = _stream(dev)
             _check(lib, lib.dgs_photo_backward(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
                                                maps[2].data_ptr(), ctx.lam[0], gd.data_ptr(), g_image.data_ptr(), gslot, st), "dgs_photo_backward")
             _check(lib, lib.dgs_regloss_backward_slot(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
-                                                      ctx.lam[1], ctx.lam[2], gd.data_ptr(), g_allmap.data_ptr(), rslot, st),
+                                                      ctx.lam[1], ctx.lam[2], gd.data_ptr(), g_allmap.data_ptr(), rslot, 1, st),
                    "dgs_regloss_backward")
         return g_image, g_allmap, None, None, None, None, None, None, None, None
 

@@ -55,7 +55,16 @@ def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=Fa
     """pc: dgs_amd.model.SurfelModel.  d_*: outputs of the deformation (or 0.0).  assembled: (means3D, scales, rotations,
     opacity) already computed by ControlNodes.forward_assembled (then d_* are ignored)."""
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    # leaf that only receives dL/dmeans2D (its values are never read): one persistent tensor per model instead of a
+    # zero-filled [P,3] allocation per render
+    screenspace_points = getattr(pc, "_screenspace_leaf", None)
+    if screenspace_points is None or screenspace_points.shape != xyz.shape or screenspace_points.device != xyz.device:
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+        try:
+            object.__setattr__(pc, "_screenspace_leaf", screenspace_points)
+        except Exception:
+            pass
+    screenspace_points.grad = None
     cfg = GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width),
         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color, scale_modifier=1.0,

@@ -190,16 +190,22 @@ class Trainer:
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
                          postprocess=not fused)
         loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt) if fused else training_loss(pkg, gt)
+        if fused:
+            if getattr(self, "_unit", None) is None:
+                self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
+            seed_grad = self._unit   # explicit unit gradient: loss.backward() alone launches a fill for it every step
+        else:
+            seed_grad = None
         if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink:
             # the rasterizer's backward writes dL/dSH straight into the bucket view of the packed parameter
             import diff_surfel_rasterization as dsr
             dsr.set_sh_grad_sink(s._features.grad)
             try:
-                loss.backward()
+                loss.backward(seed_grad)
             finally:
                 dsr.set_sh_grad_sink(None)
         else:
-            loss.backward()
+            loss.backward(seed_grad)
         if hasattr(d, "finish_backward"):
             d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
         with torch.no_grad():

@@ -84,6 +84,7 @@ class _SurfelRasterFn(torch.autograd.Function):
         ctx.n_rendered = n_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # otherwise autograd zero-fills a [P] int32 "gradient" of radii on every backward
         return color, radii, allmap
 
     @staticmethod

@@ -145,7 +145,9 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
  *   dgs_loss_combine             out[0] = (1 - lambda) * sum(l1) / n + lambda * (1 - sum(ssim) / n) + sum(reg),  n = C*H*W
  *   dgs_photo_backward           dL/dimg for the DEVICE scalar *g_loss.
  * gt_slot / rays_slot (may be NULL): DEVICE locations holding the pointer to use instead of gt / rays_d -- a captured HIP
- * graph then switches target image and ray table per replay by rewriting 8 bytes instead of copying 7.7 MB each. */
+ * graph then switches target image and ray table per replay by rewriting 8 bytes instead of copying 7.7 MB each.
+ * dgs_regloss_backward_slot with write_all = 1 stores every element of d_allmap except plane 5 (the depth gradient, added
+ * atomically): the caller zero-fills that plane only instead of all eight. */
 size_t dgs_photo_blocks(int C, int H, int W);
 size_t dgs_regloss_blocks(int H, int W);
 int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, float* partials, float* dm_dmu1, float* dm_dsigma1_sq,
@@ -154,7 +156,7 @@ int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float*
                                  float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot, void* stream);
 int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
                               float lambda_normal, float lambda_dist, const float* g, float* d_allmap, const float* const* rays_slot,
-                              void* stream);
+                              int write_all, void* stream);
 int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
                      float lambda_dssim, float* out, void* stream);
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
