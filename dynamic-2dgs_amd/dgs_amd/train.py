@@ -95,8 +95,14 @@ class Trainer:
         self.cameras, self.targets, self.bg = cameras, targets, bg_color
         P = surfels.get_xyz.shape[0]
         self.P = P
-        params = [p for g in surfels.optimizer_groups() for p in g['params']] + list(deform.parameters())
+        surf_params = [p for g in surfels.optimizer_groups() for p in g['params']]
+        if getattr(surfels, "packed_sh", False):
+            # the SH gradient (2/3 of the bucket) first: under data parallelism it is final right after the rasterizer's
+            # backward and is all-reduced while the rest of the backward still runs (see step())
+            surf_params = [surfels._features] + [p for p in surf_params if p is not surfels._features]
+        params = surf_params + list(deform.parameters())
         self.bucket = FlatGradBucket(params, extra=2 * P)
+        self.n_sh = surfels._features.numel() if getattr(surfels, "packed_sh", False) else 0
         dev = surfels.get_xyz.device
         if fused_adam is None:
             fused_adam = dev.type == "cuda"
@@ -126,6 +132,7 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.iteration = 0
         self._graph = None
+        self.overlap_allreduce = True  # DP: all-reduce the SH gradients while the deformation backward runs
         self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
         self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
 
@@ -164,24 +171,36 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1):
-            self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
-            if self.world == 1:
-                self._finish()
+        self._g1b = None
+        self._split = self._split_ok()
+        if self._split:
+            # data parallel: graph 1a = forward + backward down to the rasterizer inputs (SH gradients final), eager async
+            # all-reduce of the SH segment, graph 1b = rest of the backward, eager all-reduce of the rest, graph 2 = update
+            with torch.cuda.graph(self._g1):
+                self._sloss = self._fwd_bwd_a(self._scam, self._sgt)
+            self._g1b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g1b, pool=self._g1.pool()):
+                self._fwd_bwd_b()
+        else:
+            with torch.cuda.graph(self._g1):
+                self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
+                if self.world == 1:
+                    self._finish()
         self._g2 = None
         if self.world > 1:
             self._g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g2):
+            with torch.cuda.graph(self._g2, pool=self._g1.pool()):
                 self._finish(reduce=False)
         self._graph = True
         if _C.read_overflow():
             raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
 
-    def _fwd_bwd(self, cam, gt):
+    def _forward(self, cam, gt):
         s, d = self.surfels, self.deform
         self.bucket.zero()
         t = d.expand_time(cam.fid)
         fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
+        asm = None
         if fused and self.fuse_deform and d.can_assemble(s):
             asm = d.forward_assembled(s, t)
             pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
@@ -190,24 +209,24 @@ class Trainer:
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
                          postprocess=not fused)
         loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt) if fused else training_loss(pkg, gt)
-        if fused:
-            if getattr(self, "_unit", None) is None:
-                self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
-            seed_grad = self._unit   # explicit unit gradient: loss.backward() alone launches a fill for it every step
-        else:
-            seed_grad = None
+        if fused and getattr(self, "_unit", None) is None:
+            self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return loss, pkg, asm, fused
+
+    def _run_backward(self, fn, fused):
+        """fn() under the SH gradient sink when it applies (the rasterizer's backward then writes dL/dSH straight into the
+        bucket view of the packed parameter)."""
+        s = self.surfels
         if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink:
-            # the rasterizer's backward writes dL/dSH straight into the bucket view of the packed parameter
             import diff_surfel_rasterization as dsr
             dsr.set_sh_grad_sink(s._features.grad)
             try:
-                loss.backward(seed_grad)
+                return fn()
             finally:
                 dsr.set_sh_grad_sink(None)
-        else:
-            loss.backward(seed_grad)
-        if hasattr(d, "finish_backward"):
-            d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
+        return fn()
+
+    def _statistics(self, pkg, fused):
         with torch.no_grad():
             # densification statistics of this view into the bucket tail (summed over ranks)
             if not hasattr(self, "_radii"):
@@ -222,7 +241,49 @@ class Trainer:
                 self.bucket.extra[:self.P].copy_(torch.where(vis, g2, torch.zeros_like(g2)))
                 self.bucket.extra[self.P:].copy_(vis.to(torch.float32))
                 self._radii.copy_(torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"])))
+
+    def _fwd_bwd(self, cam, gt):
+        d = self.deform
+        loss, pkg, asm, fused = self._forward(cam, gt)
+        # explicit unit gradient: loss.backward() alone launches a fill for it every step
+        self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
+        if hasattr(d, "finish_backward"):
+            d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
+        self._statistics(pkg, fused)
         return loss.detach()
+
+    # ---- data parallel: the backward in two halves with the SH all-reduce in between ---------------------------------
+    def _split_ok(self):
+        s = self.surfels
+        return (self.world > 1 and self.overlap_allreduce and self.rasterizer_cls is None and s.get_xyz.is_cuda and self.fuse_deform
+                and getattr(s, "packed_sh", False) and self.sh_grad_sink and self.n_sh > 0 and self.deform.can_assemble(s))
+
+    def _fwd_bwd_a(self, cam, gt):
+        """Forward, loss and the backward down to the rasterizer's inputs: afterwards the SH segment of the bucket is final."""
+        loss, pkg, asm, fused = self._forward(cam, gt)
+        leaf = pkg["viewspace_points"]
+        grads = self._run_backward(lambda: torch.autograd.grad(loss, list(asm) + [leaf], grad_outputs=self._unit, allow_unused=True), fused)
+        leaf.grad = grads[4]
+        self._half = (asm, grads[:4], pkg)
+        return loss.detach()
+
+    def _fwd_bwd_b(self):
+        """The rest of the backward: skinning / activations, node MLP, statistics."""
+        asm, g_asm, pkg = self._half
+        keep = [(a, g) for a, g in zip(asm, g_asm) if g is not None]
+        torch.autograd.backward([a for a, _ in keep], [g for _, g in keep])
+        self.deform.finish_backward(join=True)
+        self._statistics(pkg, True)
+        self._half = None
+
+    def _reduce_sh_start(self):
+        return dist.all_reduce(self.bucket.flat[:self.n_sh], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _reduce_rest(self, work_sh):
+        dist.all_reduce(self.bucket.flat[self.n_sh:], op=dist.ReduceOp.SUM)
+        dist.all_reduce(self._radii, op=dist.ReduceOp.MAX)
+        work_sh.wait()
+        self.bucket.flat[:self.bucket.n_grad].mul_(1.0 / self.world)
 
     def _reduce(self):
         self.bucket.all_reduce_mean()
@@ -264,10 +325,24 @@ class Trainer:
         if self._graph:
             self._scam.load(self._vtab[v])   # one 256-byte copy: camera matrices, time, and the pointers of target / ray table
             self._g1.replay()
-            if self._g2 is not None:
+            if self._g1b is not None:
+                work = self._reduce_sh_start()   # runs on the collective's stream while graph 1b replays
+                self._g1b.replay()
+                self._reduce_rest(work)
+                self._g2.replay()
+            elif self._g2 is not None:
                 self._reduce()
                 self._g2.replay()
             return self._sloss
-        loss = self._fwd_bwd(self.cameras[v], self.targets[v % len(self.targets)])
+        cam, gt = self.cameras[v], self.targets[v % len(self.targets)]
+        if self._split_ok():
+            loss = self._fwd_bwd_a(cam, gt)
+            work = self._reduce_sh_start()
+            self._fwd_bwd_b()
+            with torch.no_grad():
+                self._reduce_rest(work)
+            self._finish(reduce=False)
+            return loss
+        loss = self._fwd_bwd(cam, gt)
         self._finish()
         return loss
