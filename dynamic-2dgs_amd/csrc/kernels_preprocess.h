@@ -45,9 +45,18 @@ __global__ void __launch_bounds__(kSurfelBlock) preprocess_fwd_kernel(Preprocess
     if (use_sh) {
         const int rows_here = min(kSurfelBlock, a.P - base);
         const float* src = a.shs + (size_t)base * row;
-        for (int e = threadIdx.x; e < rows_here * row; e += kSurfelBlock) {
-            const int r = (int)__umulhi((unsigned)e, a.row_inv);
-            s_sh[r * stride + (e - r * row)] = src[e];
+        // batches of 12 elements per thread: all loads of a batch are in flight before the first LDS store (an
+        // element-wise copy loop is a chain of dependent global-load latencies)
+        const int total = rows_here * row;
+        for (int e0 = threadIdx.x; e0 < total; e0 += 12 * kSurfelBlock) {
+            float v[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const int e = e0 + i * kSurfelBlock; v[i] = e < total ? src[e] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const int e = e0 + i * kSurfelBlock;
+                if (e < total) { const int r = (int)__umulhi((unsigned)e, a.row_inv); s_sh[r * stride + (e - r * row)] = v[i]; }
+            }
         }
         __syncthreads();
     }
@@ -358,9 +367,18 @@ __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs 
     const int rows_here = min(kSurfelBlock, a.P - base);
     if (a.shs) {
         const float* src = a.shs + (size_t)base * row;
-        for (int e = threadIdx.x; e < rows_here * row; e += kSurfelBlock) {
-            const int r = (int)__umulhi((unsigned)e, a.row_inv);
-            s_sh[r * stride + (e - r * row)] = src[e];
+        // batches of 12 elements per thread: all loads of a batch are in flight before the first LDS store (an
+        // element-wise copy loop is a chain of dependent global-load latencies)
+        const int total = rows_here * row;
+        for (int e0 = threadIdx.x; e0 < total; e0 += 12 * kSurfelBlock) {
+            float v[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const int e = e0 + i * kSurfelBlock; v[i] = e < total ? src[e] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const int e = e0 + i * kSurfelBlock;
+                if (e < total) { const int r = (int)__umulhi((unsigned)e, a.row_inv); s_sh[r * stride + (e - r * row)] = v[i]; }
+            }
         }
         __syncthreads();
     }
