@@ -8,9 +8,12 @@
  * PARITY UNPINNED against the reference's own tests: hustvl/Dynamic-2DGS ships no tests,
  * golden vectors or fixtures for this path, and its CUDA sources cannot be
  * built in this image (no nvcc / CUB / cooperative_groups).  The oracle is instead pinned by
- *   (i)  fp64 torch.autograd of an independent dense re-derivation of the forward
- *        (tests/dense_torch_ref.py) against the ORACLE_F64 build of this file, and
- *   (ii) the committed fixtures under tests/golden/ generated from it.
+ *   (i)   fp64 torch.autograd of an independent dense re-derivation of the forward
+ *         (tests/dense_torch_ref.py) against the ORACLE_F64 build of this file, and
+ *   (ii)  for the one part of this path the reference also has in Python -- the SH colour evaluation, utils/sh_utils.py
+ *         eval_sh -- golden vectors produced by importing that module (tests/golden/make_aux_golden.py,
+ *         tests/test_aux_golden.py); the geometry / blending / backward parts exist in the reference only as CUDA and
+ *         stay unpinned.
  *
  * Every function cites the reference file:line whose behaviour it restates; paths are relative
  * to /root/reference/submodules/diff-surfel-rasterization/.
