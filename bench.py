@@ -50,7 +50,7 @@ WORKLOADS = {
 }
 
 
-def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None, packed_sh=None):
+def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None, packed_sh=None, slots=None):
     from dgs_amd.cameras import orbit_cameras
     from dgs_amd.deform import ControlNodes
     from dgs_amd.model import SurfelModel
@@ -60,9 +60,9 @@ def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None,
     scene = make_scene(P, seed=0)
     if packed_sh is None:  # HIP product path: SH coefficients as one parameter (no per-render concatenation)
         packed_sh = torch.device(device).type == "cuda" and rasterizer_cls is None and fused_adam is not False
-    surfels = SurfelModel(scene, packed_sh=packed_sh).to(device)
+    surfels = SurfelModel(scene, packed_sh=packed_sh, capacity=slots).to(device)   # slots > P: room for densification
     deform = ControlNodes(node_num=1024, K=3, hyper_dim=8, local_frame=True).to(device)
-    deform.init_from_points(surfels.get_xyz.detach(), fps=True)
+    deform.init_from_points(surfels.get_xyz.detach()[surfels.alive], fps=True)
     cams = [c.to(device) for c in orbit_cameras(n_views, W, H)]
     targets = [target_image(H, W, seed=1 + v).to(device) for v in range(n_targets)]
     bg = torch.zeros(3, device=device)

@@ -276,6 +276,14 @@ class FlatAdam:
                                 sl(self._period, ctypes.c_int), sl(self._split, ctypes.c_int), plan)
         return self._plans[key]
 
+    def moments(self, p):
+        """(exp_avg, exp_avg_sq) of parameter p as views shaped like p (state surgery of dgs_amd/densify.py)."""
+        for i, q in enumerate(self.params):
+            if q is p:
+                a, b = self._offsets[i], self._offsets[i + 1]
+                return self.exp_avg[a:b].view_as(p), self.exp_avg_sq[a:b].view_as(p)
+        return None, None
+
     @torch.no_grad()
     def step(self, first=0, last=None, advance=True):
         """Adam update of parameters [first, last) (default: all).  advance=False reuses the step count of the previous

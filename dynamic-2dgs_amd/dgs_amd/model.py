@@ -6,13 +6,32 @@ import torch.nn as nn
 from .synthetic import SurfelScene
 
 
+def pad_scene(scene: SurfelScene, capacity: int) -> SurfelScene:
+    """Append dead slots: opacity logit DEAD_LOGIT (sigmoid == 0), identity rotation, everything else zero."""
+    from .densify import DEAD_LOGIT
+    n = capacity - scene.xyz.shape[0]
+
+    def pad(t, fill=0.0):
+        return torch.cat((t, torch.full((n,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)))
+    rot = torch.zeros(n, 4, dtype=scene.rotation.dtype, device=scene.rotation.device)
+    rot[:, 0] = 1
+    return SurfelScene(pad(scene.xyz), pad(scene.log_scale, -6.0), torch.cat((scene.rotation, rot)), pad(scene.opacity_logit, DEAD_LOGIT),
+                       pad(scene.f_dc), pad(scene.f_rest), pad(scene.feature, -1e-2))
+
+
 class SurfelModel(nn.Module):
-    def __init__(self, scene: SurfelScene, sh_degree: int = 3, active_sh_degree: int = 3, packed_sh: bool = False):
-        """packed_sh: keep the SH coefficients as ONE [P,16,3] parameter `_features` (what the rasterizer reads) instead of
+    def __init__(self, scene: SurfelScene, sh_degree: int = 3, active_sh_degree: int = 3, packed_sh: bool = False,
+                 capacity: int = None):
+        """capacity: number of surfel SLOTS (>= the scene's surfel count); the extra slots start dead and are filled by
+        densification without re-allocating anything (dgs_amd/densify.py).  `alive` marks the slots in use.
+        packed_sh: keep the SH coefficients as ONE [P,16,3] parameter `_features` (what the rasterizer reads) instead of
         the reference's `_features_dc` / `_features_rest` pair that is concatenated on every render (gaussian_model.py:103-107);
         the two learning rates then become a periodic pattern of the flat Adam kernel.  `_features_dc` / `_features_rest`
         stay readable as views."""
         super().__init__()
+        n_alive = scene.xyz.shape[0]
+        if capacity is not None and capacity > n_alive:
+            scene = pad_scene(scene, capacity)
         self.max_sh_degree = sh_degree
         self.active_sh_degree = active_sh_degree
         self.packed_sh = packed_sh
@@ -30,6 +49,11 @@ class SurfelModel(nn.Module):
         self.register_buffer("xyz_gradient_accum", torch.zeros(P, 1), persistent=False)
         self.register_buffer("denom", torch.zeros(P, 1), persistent=False)
         self.register_buffer("max_radii2D", torch.zeros(P, dtype=torch.int32), persistent=False)
+        self.register_buffer("alive", torch.arange(P) < n_alive, persistent=False)
+
+    @property
+    def num_surfels(self):
+        return int(self.alive.sum())
 
     get_xyz = property(lambda self: self._xyz)
     get_scaling = property(lambda self: torch.exp(self._scaling))

@@ -93,6 +93,22 @@ class Trainer:
         self.surfels, self.deform = surfels, deform
         self.rasterizer_cls = rasterizer_cls  # None = the HIP operator; tests / the CPU baseline inject the oracle op
         self.cameras, self.targets, self.bg = cameras, targets, bg_color
+        self._lrs = (position_lr, deform_lr)
+        dev = surfels.get_xyz.device
+        self.fused_adam = dev.type == "cuda" if fused_adam is None else fused_adam
+        self._build_state()
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.iteration = 0
+        self._graph = None
+        self.overlap_allreduce = True  # DP: all-reduce the SH gradients while the deformation backward runs
+        self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
+        self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
+
+    def _build_state(self):
+        """Flat gradient bucket + optimiser over the current parameter tensors (again after Trainer.grow)."""
+        surfels, deform = self.surfels, self.deform
+        position_lr, deform_lr = self._lrs
         P = surfels.get_xyz.shape[0]
         self.P = P
         surf_params = [p for g in surfels.optimizer_groups() for p in g['params']]
@@ -104,8 +120,7 @@ class Trainer:
         self.bucket = FlatGradBucket(params, extra=2 * P)
         self.n_sh = surfels._features.numel() if getattr(surfels, "packed_sh", False) else 0
         dev = surfels.get_xyz.device
-        if fused_adam is None:
-            fused_adam = dev.type == "cuda"
+        fused_adam = self.fused_adam
         groups = surfels.optimizer_groups(position_lr=position_lr)
         deform_groups = [
             {'params': list(deform.network.parameters()), 'lr': deform_lr, 'name': 'deform'},
@@ -127,14 +142,8 @@ class Trainer:
         else:
             assert not getattr(surfels, "packed_sh", False), "packed SH needs the flat Adam kernel (two rates inside one parameter)"
             self.opt_surfels = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
-            self.opt_deform = torch.optim.Adam(deform_groups, lr=0.0, eps=1e-15)
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.iteration = 0
-        self._graph = None
-        self.overlap_allreduce = True  # DP: all-reduce the SH gradients while the deformation backward runs
-        self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
-        self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
+            if getattr(self, "opt_deform", None) is None:   # kept across Trainer.grow: the deformation parameters do not move
+                self.opt_deform = torch.optim.Adam(deform_groups, lr=0.0, eps=1e-15)
 
     # ---- whole-step HIP graph ------------------------------------------------------------------------------------
     def enable_graph(self, capacity):
@@ -152,6 +161,7 @@ class Trainer:
             raise RuntimeError("set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE importing torch to use "
                                "Trainer.enable_graph() (see DESIGN.md, 'HIP graphs')")
         dev = self.surfels.get_xyz.device
+        self._capacity = int(capacity)
         _C.set_capacity(int(capacity))
         # (rays_d [H*W,3], rays_o [3]) per view and the targets stay resident: the table rows point at them
         self._rays = [tuple(t.contiguous() for t in camera_rays(cam, dev)) for cam in self.cameras]
@@ -314,6 +324,90 @@ class Trainer:
                 self.opt_surfels.step(self.n_surfel_params, None, advance=False)
             else:
                 self.opt_surfels.step()
+
+    # ---- adaptive density control (train_gui.py:410-423; dgs_amd/densify.py) -----------------------------------------
+    def _moments(self):
+        from . import densify
+        return self.opt_surfels.moments if self.opt_deform is None else densify.TorchAdamMoments(self.opt_surfels)
+
+    def densify_and_prune(self, max_grad=0.0002, min_opacity=0.01, extent=1.0, max_screen_size=None, percent_dense=0.01,
+                          noise=None, seed=0):
+        """Clone / split / prune in place (no re-allocation, captured graphs stay valid).  Identical on every rank: the
+        statistics were summed over the ranks by the step, the random draw is seeded by (seed, iteration).
+        Returns (n_cloned, n_split, n_pruned)."""
+        from . import densify
+        dev = self.surfels.get_xyz.device
+        gen = torch.Generator(device=dev).manual_seed(int(seed) * 1000003 + self.iteration)
+        args = (max_grad, min_opacity, extent, max_screen_size)
+        out = densify.densify_and_prune(self.surfels, self._moments(), *args, percent_dense=percent_dense, noise=noise, generator=gen)
+        if out is None:   # slots exhausted: the one case that re-allocates (and re-captures)
+            alive = self.surfels.num_surfels
+            self.grow(max(int(1.5 * self.P), 3 * alive + 1024))
+            out = densify.densify_and_prune(self.surfels, self._moments(), *args, percent_dense=percent_dense, noise=noise, generator=gen)
+        return out
+
+    def reset_opacity(self):
+        from . import densify
+        densify.reset_opacity(self.surfels, self._moments())
+
+    def grow(self, capacity):
+        """Re-allocate the surfel slots (parameters, gradient bucket, Adam moments, statistics) to `capacity` and re-capture
+        the step's graphs if they were enabled.  Values, moments and the Adam step count carry over."""
+        from . import densify
+        s = self.surfels
+        old = s.get_xyz.shape[0]
+        assert capacity > old
+        moments = self._moments()
+        rows = densify.surfel_rows(s)
+        saved = {name: tuple(None if t is None else t.detach().clone() for t in moments(p)) for name, p in rows.items()}
+        deform_saved = [tuple(None if t is None else t.detach().clone() for t in self._param_moments(p)) for p in self.deform.parameters()]
+        if self.opt_deform is None:
+            t_saved = self.opt_surfels.t.clone()
+        else:
+            t_saved = {name: self.opt_surfels.state[p].get("step") for name, p in rows.items() if p in self.opt_surfels.state}
+        fill = {"opacity": densify.DEAD_LOGIT, "scaling": -6.0, "feature": -1e-2}
+        attr = {"xyz": "_xyz", "f_all": "_features", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+                "scaling": "_scaling", "rotation": "_rotation", "feature": "feature"}
+        n = capacity - old
+        with torch.no_grad():
+            for name, p in rows.items():
+                pad = torch.full((n,) + tuple(p.shape[1:]), fill.get(name, 0.0), dtype=p.dtype, device=p.device)
+                if name == "rotation":
+                    pad[:, 0] = 1
+                setattr(s, attr[name], torch.nn.Parameter(torch.cat((p.detach(), pad)).contiguous()))
+            for name in ("xyz_gradient_accum", "denom", "max_radii2D", "alive"):
+                b = getattr(s, name)
+                setattr(s, name, torch.cat((b, torch.zeros((n,) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device))))
+        for a in ("_radii", "_half"):
+            if hasattr(self, a):
+                delattr(self, a)
+        self._build_state()
+        moments = self._moments()
+        with torch.no_grad():
+            if self.opt_deform is None:
+                self.opt_surfels.t.copy_(t_saved)
+            for name, p in densify.surfel_rows(s).items():
+                m0, v0 = saved[name]
+                if m0 is None:
+                    continue
+                if self.opt_deform is not None:   # torch Adam creates its state lazily
+                    self.opt_surfels.state[p] = {"step": t_saved[name], "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+                m, v = moments(p)
+                m[:old] = m0
+                v[:old] = v0
+            for p, (m0, v0) in zip(self.deform.parameters(), deform_saved):
+                if m0 is not None and self.opt_deform is None:
+                    m, v = self.opt_surfels.moments(p)
+                    m.copy_(m0)
+                    v.copy_(v0)
+        if self._graph:
+            self._graph = None
+            self.enable_graph(self._capacity)
+
+    def _param_moments(self, p):
+        if self.opt_deform is None:
+            return self.opt_surfels.moments(p)
+        return (None, None)
 
     def view_for(self, iteration):
         """Shared deterministic schedule: step i renders views {i*world + rank} mod V."""
