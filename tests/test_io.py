@@ -1,0 +1,128 @@
+"""Data formats of SURVEY 8 f4 (dgs_amd/io.py).  The D-NeRF reader is pinned by what the imported reference read from the
+tiny dataset under tests/golden/dnerf_tiny (make_dnerf_golden.py), deform.pth by the reference's state_dict layout
+(make_io_golden.py).  The reference writes PLY through `plyfile`, which is absent here: the PLY layout is restated from the
+attribute list in gaussian_model.py:229-256 and checked as a format (header text, byte layout, round trips)."""
+import json
+import os
+import shutil
+
+import numpy as np
+import torch
+
+from dgs_amd import io as dio
+from dgs_amd.deform import ControlNodes
+from dgs_amd.model import SurfelModel
+from dgs_amd.synthetic import make_scene
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_dnerf_reader_matches_reference():
+    g = np.load(os.path.join(GOLD, "dnerf_golden.npz"))
+    for tag, white in (("black", False), ("white", True)):
+        for split in ("train", "test"):
+            frames = dio.read_transforms(os.path.join(GOLD, "dnerf_tiny"), "transforms_%s.json" % split, white_background=white)
+            k = "%s_%s_" % (tag, split)
+            assert [f.name for f in frames] == list(g[k + "name"])
+            np.testing.assert_allclose(np.stack([f.R for f in frames]), g[k + "R"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(np.stack([f.T for f in frames]), g[k + "T"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(np.array([[f.camera.FoVx, f.camera.FoVy] for f in frames]), g[k + "fov"], rtol=1e-12)
+            assert np.array_equal(np.array([float(f.camera.fid) for f in frames], np.float32), g[k + "fid"])
+            for name, mine in (("wvt", "world_view_transform"), ("full", "full_proj_transform"), ("center", "camera_center")):
+                got = np.stack([getattr(f.camera, mine).numpy() for f in frames])
+                np.testing.assert_allclose(got, g[k + name], rtol=1e-6, atol=1e-7)
+            assert np.array_equal(np.stack([f.image.numpy() for f in frames]), g[k + "image"])     # 8-bit values / 255: exact
+            assert np.array_equal(np.stack([f.alpha.numpy() for f in frames]), g[k + "alpha"])
+            if split == "train":
+                norm = dio.scene_normalization(frames)
+                np.testing.assert_allclose(norm["radius"], g[k + "radius"], rtol=1e-6)
+                np.testing.assert_allclose(norm["translate"], g[k + "translate"], rtol=1e-6, atol=1e-7)
+    assert frames[0].camera.image_height == 10 and frames[0].image.shape == (3, 10, 10)
+
+
+def test_load_dnerf_creates_the_initial_point_cloud(tmp_path):
+    root = tmp_path / "scene"
+    shutil.copytree(os.path.join(GOLD, "dnerf_tiny"), root)
+    d = dio.load_dnerf(str(root), num_pts=500)
+    assert len(d["train"]) == 4 and len(d["test"]) == 2 and os.path.exists(root / "points3d.ply")
+    pc = d["point_cloud"]
+    assert pc.points.shape == (500, 3) and np.abs(pc.points).max() <= 1.3 and pc.colors.min() >= 0.49 and pc.colors.max() <= 0.51
+    d2 = dio.load_dnerf(str(root), eval=False)      # second call reads the stored cloud back; eval=False merges the splits
+    assert np.array_equal(d2["point_cloud"].points, pc.points) and len(d2["train"]) == 6
+    scene = dio.scene_from_point_cloud(pc.points, pc.colors)
+    assert scene.xyz.shape == (500, 3) and scene.f_rest.shape == (500, 15, 3) and scene.log_scale.shape == (500, 2)
+    # scale = sqrt(mean squared distance to the 3 nearest neighbours), brute force
+    x = torch.tensor(pc.points, dtype=torch.float32)
+    d2m = torch.cdist(x, x).pow(2)
+    d2m.fill_diagonal_(float("inf"))
+    want = d2m.topk(3, largest=False).values.mean(1)
+    assert torch.allclose(torch.exp(scene.log_scale[:, 0]) ** 2, want, rtol=1e-3)
+    assert torch.allclose(torch.sigmoid(scene.opacity_logit), torch.full((500, 1), 0.1))
+
+
+def test_surfel_ply_layout_and_round_trip(tmp_path):
+    scene = make_scene(37, seed=4)
+    model = SurfelModel(scene, capacity=50)        # dead slots are not saved
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    dio.save_surfels(model, path)
+    raw = open(path, "rb").read()
+    names = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(45)] + ["opacity"] + \
+            ["scale_0", "scale_1"] + ["rot_%d" % i for i in range(4)] + ["fea_%d" % i for i in range(8)]
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex 37\n" + "".join("property float %s\n" % n for n in names) + "end_header\n"
+    assert raw.startswith(header.encode()) and len(raw) == len(header) + 37 * 4 * len(names)
+    table = np.frombuffer(raw[len(header):], "<f4").reshape(37, len(names))
+    assert np.array_equal(table[:, 0:3], scene.xyz.numpy()) and not table[:, 3:6].any()
+    # SH blocks are channel-major: f_rest_k = coefficient (k % 15) + 1 of channel k // 15
+    assert np.array_equal(table[:, 6:9], scene.f_dc[:, 0, :].numpy())
+    assert np.array_equal(table[:, 9 + 15 * 1 + 4], scene.f_rest[:, 4, 1].numpy())
+    assert np.array_equal(table[:, 54], scene.opacity_logit[:, 0].numpy()) and np.array_equal(table[:, 55:57], scene.log_scale.numpy())
+    back = dio.load_surfels(path)
+    for a, b in zip(back, scene):
+        assert torch.equal(a, b)
+    # the same file through the packed-SH model
+    packed = SurfelModel(scene, packed_sh=True)
+    dio.save_surfels(packed, str(tmp_path / "p.ply"))
+    assert open(str(tmp_path / "p.ply"), "rb").read() == raw
+
+
+def test_ply_reader_accepts_ascii_and_big_endian(tmp_path):
+    v = np.zeros(3, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    v["x"], v["y"], v["z"], v["red"], v["green"], v["blue"] = [1.5, -2, 3], [0, 0.25, 7], [9, 8, -7.5], [0, 128, 255], [1, 2, 3], [255, 0, 9]
+    head = "ply\nformat %s 1.0\ncomment made by hand\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n" \
+           "property uchar red\nproperty uchar green\nproperty uchar blue\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n"
+    with open(tmp_path / "a.ply", "w") as f:
+        f.write(head % "ascii")
+        for r in v:
+            f.write(" ".join(str(x) for x in r) + "\n")
+    with open(tmp_path / "b.ply", "wb") as f:
+        f.write((head % "binary_big_endian").encode())
+        f.write(v.astype([("x", ">f4"), ("y", ">f4"), ("z", ">f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")]).tobytes())
+    for name in ("a.ply", "b.ply"):
+        got = dio.read_ply(str(tmp_path / name))
+        for n in v.dtype.names:
+            assert np.array_equal(got[n], v[n]), (name, n)
+    dio.store_point_cloud(str(tmp_path / "c.ply"), np.stack([v["x"], v["y"], v["z"]], 1), np.stack([v["red"], v["green"], v["blue"]], 1))
+    pc = dio.fetch_point_cloud(str(tmp_path / "c.ply"))
+    assert np.array_equal(pc.points[:, 2], v["z"]) and np.allclose(pc.colors[:, 0], v["red"] / 255.0) and not pc.normals.any()
+
+
+def test_deform_weights_file_is_the_reference_layout(tmp_path):
+    keys = json.load(open(os.path.join(GOLD, "deform_state_keys.json")))
+    deform = ControlNodes(node_num=48, K=3, hyper_dim=8, local_frame=True)
+    path = dio.save_deform(deform, str(tmp_path), 3000)
+    assert path.endswith(os.path.join("deform", "iteration_3000", "deform.pth"))
+    saved = torch.load(path, weights_only=True)
+    assert sorted(saved) == sorted(k for k, _, _ in keys)
+    for k, shape, dtype in keys:
+        assert list(saved[k].shape) == shape and str(saved[k].dtype) == dtype, k
+    # a file as the reference writes it (its key order, a different node count) loads; the newest iteration is found
+    gen = torch.Generator().manual_seed(0)
+    ref_state = {}
+    for k, shape, dtype in keys:
+        shape = [64 if s == 48 else s for s in shape]
+        ref_state[k] = torch.tensor(True) if dtype == "torch.bool" else torch.randn(*shape, generator=gen)
+    os.makedirs(tmp_path / "deform" / "iteration_40000")
+    torch.save(ref_state, tmp_path / "deform" / "iteration_40000" / "deform.pth")
+    assert dio.load_deform(deform, str(tmp_path)) is True
+    assert deform.nodes.shape == (64, 11) and torch.equal(deform.network.linear[5].weight, ref_state["network.linear.5.weight"])
+    assert dio.load_deform(deform, str(tmp_path / "nothing_here")) is False
