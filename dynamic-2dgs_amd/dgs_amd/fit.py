@@ -1,0 +1,74 @@
+"""Fit a dynamic scene end to end on the pieces of this package: D-NeRF reader -> point-cloud initialisation -> captured
+train step -> in-place densification -> checkpoint files the reference can load.
+
+The loop is the part of GUI.train_step (train_gui.py:272-432) this build covers: the joint surfel + node-deformation step
+with the normal and distortion regularisers on, densification every `densify_interval` iterations between `densify_from`
+and `densify_until` (size threshold 20 after the first opacity reset), opacity reset every `opacity_reset_interval`
+(arguments/__init__.py:115-122).  Not here: the node warm-up stage, node densification, the SH degree ramp, ARAP / flow
+losses, the learning-rate schedules (the step runs at the rates of the end of the schedules, see Trainer) and the GUI.
+"""
+import os
+
+import torch
+
+from . import io as dio
+from .deform import ControlNodes
+from .model import SurfelModel
+from .train import Trainer
+
+
+def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
+        densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
+        graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None):
+    """Returns (trainer, losses).  slots: surfel slots to allocate (default 3x the initial point count; grown on demand).
+    list_capacity: rasterizer list entries for the captured step (default 96 per slot)."""
+    device = torch.device(device)
+    data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
+    pc = data["point_cloud"]
+    scene = dio.scene_from_point_cloud(pc.points, pc.colors)
+    P = scene.xyz.shape[0]
+    slots = int(slots or 3 * P)
+    on_gpu = device.type == "cuda" and rasterizer_cls is None
+    surfels = SurfelModel(scene, packed_sh=on_gpu, capacity=slots).to(device)
+    torch.manual_seed(seed)
+    deform = ControlNodes(node_num=min(node_num, P), K=3, hyper_dim=8, local_frame=True).to(device)
+    deform.init_from_points(surfels.get_xyz.detach()[surfels.alive], fps=True)
+    cams = [f.camera.to(device) for f in data["train"]]
+    targets = [f.image.to(device).contiguous() for f in data["train"]]
+    bg = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], device=device)
+    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False)
+    if graph is None:
+        graph = on_gpu
+    if graph:
+        tr.enable_graph(int(list_capacity or 96 * slots))
+    extent = float(data["normalization"]["radius"])
+    losses = []
+    for it in range(1, iterations + 1):
+        losses.append(tr.step())
+        if it < densify_until:                                                     # train_gui.py:410-423
+            if it > densify_from and it % densify_interval == 0:
+                size_threshold = 20 if it > opacity_reset_interval else None
+                counts = tr.densify_and_prune(densify_grad_threshold, 0.01, extent, size_threshold, seed=seed)
+                if log:
+                    log("[%d] cloned %d, split %d, pruned %d -> %d surfels (%d slots)" % ((it,) + tuple(counts) + (surfels.num_surfels, tr.P)))
+            if it % opacity_reset_interval == 0 or (white_background and it == densify_from):
+                tr.reset_opacity()
+    save(tr, model_path, iterations)
+    return tr, [float(l) for l in losses]
+
+
+def save(trainer, model_path, iteration):
+    """Scene.save + DeformModel.save_weights (scene/__init__.py, scene/deform_model.py:41-44): the two files of a checkpoint."""
+    dio.save_surfels(trainer.surfels, os.path.join(model_path, "point_cloud/iteration_{}".format(iteration), "point_cloud.ply"))
+    dio.save_deform(trainer.deform, model_path, iteration)
+
+
+def restore(model_path, iteration=-1, device="cpu", packed_sh=False, slots=None, node_num=512):
+    """Surfels + deformation of a checkpoint directory written by `save` (or by the reference)."""
+    it = dio.search_for_max_iteration(os.path.join(model_path, "point_cloud")) if iteration == -1 else iteration
+    scene = dio.load_surfels(os.path.join(model_path, "point_cloud/iteration_{}".format(it), "point_cloud.ply"))
+    surfels = SurfelModel(scene, packed_sh=packed_sh, capacity=slots).to(device)
+    deform = ControlNodes(node_num=node_num, K=3, hyper_dim=8, local_frame=True).to(device)
+    if not dio.load_deform(deform, model_path, iteration):
+        raise FileNotFoundError("no deform.pth under %s" % model_path)
+    return surfels, deform.to(device)

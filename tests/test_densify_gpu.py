@@ -60,3 +60,29 @@ def test_densification_in_place_under_graph_matches_eager():
     for x, y in zip(le, lg):
         assert abs(x - y) <= 1e-3 * abs(x), (le, lg)
     assert le[3] != le[2]
+
+
+def test_fit_end_to_end_with_growth_under_graph(tmp_path):
+    """dgs_amd.fit on the tiny D-NeRF fixture through the HIP path with captured graphs: the slots run out at the first
+    densification, the trainer grows and re-captures, training continues, the checkpoint restores."""
+    import os
+    import shutil
+    from diff_surfel_rasterization import _C
+    from dgs_amd import fit as fit_mod
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dnerf_tiny")
+    root = tmp_path / "scene"
+    shutil.copytree(gold, root)
+    logs = []
+    try:
+        tr, losses = fit_mod.fit(str(root), str(tmp_path / "out"), iterations=12, device="cuda:0", densify_from=3, densify_interval=4,
+                                 opacity_reset_interval=10, densify_grad_threshold=1e-9, slots=3100, node_num=64, num_pts=3000,
+                                 list_capacity=400000, log=logs.append)
+        torch.cuda.synchronize()
+        assert not _C.read_overflow()
+    finally:
+        _C.set_capacity(0)
+    assert len(losses) == 12 and all(l == l and l < 10 for l in losses), losses
+    assert len(logs) == 3 and tr.P > 3100 and tr.surfels.num_surfels > 3000, logs
+    surfels, deform = fit_mod.restore(str(tmp_path / "out"), node_num=64)
+    assert surfels.get_xyz.shape[0] == tr.surfels.num_surfels
+    assert torch.equal(surfels._xyz.detach(), tr.surfels._xyz.detach()[tr.surfels.alive].cpu())

@@ -126,3 +126,26 @@ def test_deform_weights_file_is_the_reference_layout(tmp_path):
     assert dio.load_deform(deform, str(tmp_path)) is True
     assert deform.nodes.shape == (64, 11) and torch.equal(deform.network.linear[5].weight, ref_state["network.linear.5.weight"])
     assert dio.load_deform(deform, str(tmp_path / "nothing_here")) is False
+
+
+def test_fit_tiny_scene_end_to_end_and_restore(tmp_path, monkeypatch):
+    """Reader -> initialisation -> steps with densification and opacity reset -> checkpoint -> restore, on the CPU with the
+    oracle operator serving the rasterizer call."""
+    import dgs_amd.render as render_mod
+    from dgs_amd import fit as fit_mod
+    from oracle_raster_op import OracleRasterizer
+    monkeypatch.setattr(render_mod, "GaussianRasterizer", OracleRasterizer)
+    root = tmp_path / "scene"
+    shutil.copytree(os.path.join(GOLD, "dnerf_tiny"), root)
+    logs = []
+    tr, losses = fit_mod.fit(str(root), str(tmp_path / "out"), iterations=7, device="cpu", densify_from=2, densify_interval=2,
+                             opacity_reset_interval=6, densify_grad_threshold=1e-9, slots=260, node_num=16, num_pts=200,
+                             rasterizer_cls=OracleRasterizer, log=logs.append)
+    assert len(losses) == 7 and all(l == l for l in losses) and len(logs) == 2
+    assert tr.surfels.num_surfels != 200 and tr.P >= 260
+    surfels, deform = fit_mod.restore(str(tmp_path / "out"), node_num=16)
+    alive = tr.surfels.alive
+    assert surfels.get_xyz.shape[0] == tr.surfels.num_surfels
+    assert torch.equal(surfels._xyz.detach(), tr.surfels._xyz.detach()[alive])
+    assert torch.equal(surfels._features_rest.detach(), tr.surfels._features_rest.detach()[alive])
+    assert torch.equal(deform.nodes.detach(), tr.deform.nodes.detach())
