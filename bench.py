@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--densify-every", type=int, default=0,
+                    help="also run the in-place densification every N timed steps (off by default: the metric is the plain step)")
+    ap.add_argument("--slots-factor", type=float, default=1.5, help="surfel slots per initial surfel when --densify-every is on")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,7 +137,7 @@ def main():
         _a = (_a @ _a).clamp_(-1, 1)
     torch.cuda.synchronize()
     del _a
-    tr = build_trainer(P, H, W, device)
+    tr = build_trainer(P, H, W, device, slots=int(args.slots_factor * P) if args.densify_every else None)
     use_graph = os.environ.get("DGS_NO_GRAPHS", "0") != "1"
     if use_graph:
         # whole-step HIP graphs: the rasterizer runs in capacity mode (no device->host read), 24 list entries per
@@ -147,8 +150,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     timed_losses = []
-    for _ in range(args.steps):
+    densify_ms, densify_counts = [], []
+    for i in range(args.steps):
         timed_losses.append(tr.step().clone())  # device-side copy; the reference reads loss.item() every step
+        if args.densify_every and (i + 1) % args.densify_every == 0:
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            # reference thresholds (arguments/__init__.py:115-122); extent = radius of the camera orbit
+            densify_counts.append(tr.densify_and_prune(0.0002, 0.01, 4.0, 20))
+            torch.cuda.synchronize()
+            densify_ms.append((time.perf_counter() - td) * 1e3)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -219,6 +230,10 @@ def main():
                        "launch": "whole-step HIP graph replay" if use_graph else "eager"},
             "roofline": roof("bwd"), "roofline_fwd": roof("fwd"),
         }
+        if args.densify_every:
+            out["densify"] = {"every": args.densify_every, "calls": len(densify_ms), "ms_per_call": [round(m, 3) for m in densify_ms],
+                              "cloned_split_pruned": [list(map(int, c)) for c in densify_counts], "slots": tr.P,
+                              "surfels_after": tr.surfels.num_surfels, "recaptured": tr.P != int(args.slots_factor * P)}
         if world == 1 and not args.no_cpu_baseline:
             del tr
             torch.cuda.empty_cache()

@@ -1060,6 +1060,11 @@ struct AdamSegs {
     float lr2[kAdamSeg];
     int period[kAdamSeg];
     int split[kAdamSeg];
+    // optional exponential schedule of lr (get_expon_lr_func, utils/general_utils.py:49-83, lr_delay_steps = 0), evaluated on
+    // the device from the step counter so that a captured step needs no host update: sched_steps 0 = constant
+    float lr_final[kAdamSeg];
+    float sched_steps[kAdamSeg];
+    float sched_t0;
 };
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, const float* __restrict__ grad,
@@ -1071,7 +1076,13 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
     const long long seg_len = sg.off[s + 1] - sg.off[s];
     const float t = step_count[0];
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    const float step_size = sg.lr[s] / bc1, step_size2 = sg.lr2[s] / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    float lr = sg.lr[s];
+    if (sg.sched_steps[s] > 0.0f) {
+        // the reference sets the rate AFTER optimizer.step(): step t runs at schedule(t - 1)
+        const float tau = fminf(fmaxf((t - 1.0f + sg.sched_t0) / sg.sched_steps[s], 0.0f), 1.0f);
+        lr = expf(logf(lr) * (1.0f - tau) + logf(sg.lr_final[s]) * tau);
+    }
+    const float step_size = lr / bc1, step_size2 = sg.lr2[s] / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     const unsigned period = (unsigned)sg.period[s], split = (unsigned)sg.split[s];
     float* __restrict__ p = sg.p[s];
     const long long base = sg.off[s];
@@ -1232,6 +1243,11 @@ int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offse
                           const int* periods, const int* splits, const float* grad, float* exp_avg, float* exp_avg_sq,
                           const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream);
 
+int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                        const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                        const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
+                        float eps, const void* plan, void* stream);
+
 int dgs_adam_step(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* grad, float* exp_avg,
                   float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
 {
@@ -1243,6 +1259,16 @@ int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offse
                           const int* periods, const int* splits, const float* grad, float* exp_avg, float* exp_avg_sq,
                           const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
 {
+    return dgs_adam_step_sched(nseg, params, offsets, lrs, lrs2, periods, splits, nullptr, nullptr, 0.0f, grad, exp_avg, exp_avg_sq,
+                               step_count, beta1, beta2, eps, plan, stream);
+}
+
+int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                        const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                        const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
+                        float eps, const void* plan, void* stream)
+{
+    if ((lrs_final != nullptr) != (sched_steps != nullptr)) return fail(-1, "dgs_adam_step_sched: pass lrs_final and sched_steps together");
     if (nseg <= 0 || nseg > kAdamSeg || !params || !offsets || !lrs || !grad || !exp_avg || !exp_avg_sq || !step_count || !plan)
         return fail(-1, "dgs_adam_step: bad argument");
     if ((lrs2 != nullptr) != (periods != nullptr) || (lrs2 != nullptr) != (splits != nullptr))
@@ -1254,7 +1280,12 @@ int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offse
         sg.period[s] = periods ? periods[s] : 0;
         sg.split[s] = splits ? splits[s] : 0;
         if (sg.period[s] < 0 || sg.split[s] < 0) return fail(-1, "dgs_adam_step_pattern: negative period / split");
+        sg.lr_final[s] = lrs_final ? lrs_final[s] : lrs[s];
+        sg.sched_steps[s] = sched_steps ? sched_steps[s] : 0.0f;
+        if (sg.sched_steps[s] > 0.0f && !(lrs[s] > 0.0f && sg.lr_final[s] > 0.0f))
+            return fail(-1, "dgs_adam_step_sched: a scheduled segment needs positive initial and final rates");
     }
+    sg.sched_t0 = sched_t0;
     sg.off[nseg] = offsets[nseg];
     const long long nb = adam_blocks(nseg, offsets);
     if (nb == 0) return 0;

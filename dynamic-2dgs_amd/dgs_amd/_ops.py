@@ -15,7 +15,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step",
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
-            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_lbs_supported", "dgs_regloss_backward_slot")
+            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot")
 
 
 def build(force=False, verbose=False):
@@ -69,6 +69,9 @@ def load():
         lib.dgs_adam_step_pattern.restype = ci
         lib.dgs_adam_step_pattern.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                               vp, vp]
+        lib.dgs_adam_step_sched.restype = ci
+        lib.dgs_adam_step_sched.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, vp, vp]
         for f in (lib.dgs_mlp_packed_floats, lib.dgs_mlp_saved_floats, lib.dgs_mlp_scratch_floats):
             f.restype = ctypes.c_size_t
         lib.dgs_mlp_packed_floats.argtypes = []
@@ -230,9 +233,11 @@ class FlatAdam:
     one flat fp32 buffer (dgs_amd.train.FlatGradBucket): ONE kernel launch per step instead of one multi-tensor
     launch per parameter group, with the step counter on the device (HIP-graph capturable)."""
 
-    def __init__(self, params, lrs, flat_grad, betas=(0.9, 0.999), eps=1e-15, patterns=None):
+    def __init__(self, params, lrs, flat_grad, betas=(0.9, 0.999), eps=1e-15, patterns=None, schedules=None, sched_t0=0.0):
         """patterns: optional {index: (period, split, lr2)}: element i of parameter `index` uses lr2 when
-        (i % period) >= split (dgs_adam_step_pattern)."""
+        (i % period) >= split (dgs_adam_step_pattern).
+        schedules: optional {index: (lr_final, max_steps)}: exponential decay from lrs[index] to lr_final over max_steps
+        steps, evaluated on the device from the step counter (dgs_adam_step_sched)."""
         lib = load()
         assert len(params) == len(lrs) <= 64
         self.params, self.lrs, self.betas, self.eps = list(params), [float(l) for l in lrs], betas, float(eps)
@@ -241,6 +246,10 @@ class FlatAdam:
         self._lr2 = (ctypes.c_float * n_)(*[float(patterns[i][2]) if i in patterns else self.lrs[i] for i in range(n_)])
         self._period = (ctypes.c_int * n_)(*[int(patterns[i][0]) if i in patterns else 0 for i in range(n_)])
         self._split = (ctypes.c_int * n_)(*[int(patterns[i][1]) if i in patterns else 0 for i in range(n_)])
+        schedules = schedules or {}
+        self._lr_final = (ctypes.c_float * n_)(*[float(schedules[i][0]) if i in schedules else self.lrs[i] for i in range(n_)])
+        self._sched_steps = (ctypes.c_float * n_)(*[float(schedules[i][1]) if i in schedules else 0.0 for i in range(n_)])
+        self.sched_t0 = float(sched_t0)
         dev = flat_grad.device
         n = sum(p.numel() for p in self.params)
         assert flat_grad.numel() >= n and flat_grad.is_contiguous()
@@ -273,7 +282,8 @@ class FlatAdam:
                 _check(lib, lib.dgs_adam_plan(k, off, plan.data_ptr(), _stream(dev)), "dgs_adam_plan")
             sl = lambda arr, typ: (typ * k)(*list(arr)[first:last])
             self._plans[key] = (k, sl(self._ptrs, ctypes.c_void_p), off, sl(self._lr, ctypes.c_float), sl(self._lr2, ctypes.c_float),
-                                sl(self._period, ctypes.c_int), sl(self._split, ctypes.c_int), plan)
+                                sl(self._period, ctypes.c_int), sl(self._split, ctypes.c_int), sl(self._lr_final, ctypes.c_float),
+                                sl(self._sched_steps, ctypes.c_float), plan)
         return self._plans[key]
 
     def moments(self, p):
@@ -291,13 +301,13 @@ class FlatAdam:
         lib = load()
         dev = self.grad.device
         last = self._n if last is None else last
-        k, ptrs, off, lr, lr2, period, split, plan = self._range(first, last)
+        k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, plan = self._range(first, last)
         if advance:
             self.t.add_(1.0)
         with torch.cuda.device(dev):
-            rc = lib.dgs_adam_step_pattern(k, ptrs, off, lr, lr2, period, split, self.grad.data_ptr(), self.exp_avg.data_ptr(),
-                                           self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0], self.betas[1], self.eps,
-                                           plan.data_ptr(), _stream(dev))
+            rc = lib.dgs_adam_step_sched(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, self.grad.data_ptr(),
+                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
+                                         self.betas[1], self.eps, plan.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_adam_step")
 
 

@@ -5,7 +5,7 @@ The loop is the part of GUI.train_step (train_gui.py:272-432) this build covers:
 with the normal and distortion regularisers on, densification every `densify_interval` iterations between `densify_from`
 and `densify_until` (size threshold 20 after the first opacity reset), opacity reset every `opacity_reset_interval`
 (arguments/__init__.py:115-122).  Not here: the node warm-up stage, node densification, the SH degree ramp, ARAP / flow
-losses, the learning-rate schedules (the step runs at the rates of the end of the schedules, see Trainer) and the GUI.
+losses and the GUI.  Learning rates follow the reference's exponential schedules (Trainer(lr_schedule=True)).
 """
 import os
 
@@ -36,7 +36,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     cams = [f.camera.to(device) for f in data["train"]]
     targets = [f.image.to(device).contiguous() for f in data["train"]]
     bg = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], device=device)
-    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False)
+    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True)
     if graph is None:
         graph = on_gpu
     if graph:

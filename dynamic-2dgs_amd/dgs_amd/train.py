@@ -78,6 +78,15 @@ class FlatGradBucket:
             self.flat[:self.n_grad].mul_(1.0 / dist.get_world_size(group))
 
 
+def expon_lr(step, lr_init, lr_final, max_steps):
+    """get_expon_lr_func (utils/general_utils.py:49-83) with lr_delay_steps = 0, the way the reference calls it."""
+    import math
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
 class Trainer:
     # Learning rates of the reference's exponential schedules at the END of their decay (iteration >= 40000:
     # xyz 1.6e-6 * spatial_lr_scale, deform 1.6e-6; arguments/__init__.py:103-108, scene/deform_model.py:38,
@@ -87,10 +96,22 @@ class Trainer:
     # num_rendered x14): the timed workload would no longer be the 200k-surfel scene the metric names.
     LATE_POSITION_LR = 0.0000016
     LATE_DEFORM_LR = 0.0000016
+    # lr_schedule=True: the reference's schedules from iteration 0 instead (arguments/__init__.py:104-108,126):
+    #   xyz: 1.6e-4 -> 1.6e-6 (x spatial_lr_scale 5) over 30000 steps (gaussian_model.py:203-212);
+    #   deformation network: 1.6e-4 * 5 -> 1.6e-6 over 40000 steps; the 'nodes' group STAYS at 1.6e-4 * 5 -- the reference's
+    #   update_learning_rate returns after the first matching group (scene/deform_model.py:58-63).
+    # On the HIP path the schedule is evaluated inside the Adam kernel from the device step counter (no host update, the
+    # captured graph stays valid); on the CPU path the group rates are set before each optimiser step.
+    SCHED_POSITION = (0.00016, 0.0000016, 30_000)
+    SCHED_DEFORM = (0.00016 * 5, 0.0000016, 40_000)
 
     def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=LATE_DEFORM_LR, position_lr=LATE_POSITION_LR,
-                 fused_adam=None, rasterizer_cls=None):
+                 fused_adam=None, rasterizer_cls=None, lr_schedule=False):
         self.surfels, self.deform = surfels, deform
+        self.lr_schedule = bool(lr_schedule)
+        if lr_schedule:
+            position_lr, deform_lr = self.SCHED_POSITION[0], self.SCHED_DEFORM[0]
+        self._steps_done = 0
         self.rasterizer_cls = rasterizer_cls  # None = the HIP operator; tests / the CPU baseline inject the oracle op
         self.cameras, self.targets, self.bg = cameras, targets, bg_color
         self._lrs = (position_lr, deform_lr)
@@ -137,11 +158,22 @@ class Trainer:
             pat_of = {id(p): g['pattern'] for g in groups for p in g['params'] if 'pattern' in g}
             plist = self.bucket.params  # bucket order == layout of the flat gradient buffer
             patterns = {i: pat_of[id(p)] for i, p in enumerate(plist) if id(p) in pat_of}
-            self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat, patterns=patterns)
+            schedules = {}
+            if self.lr_schedule:
+                net = {id(p) for p in deform.network.parameters()}
+                scale = groups[0]['lr'] / position_lr   # spatial_lr_scale, applied by optimizer_groups
+                for i, p in enumerate(plist):
+                    if p is surfels._xyz:
+                        schedules[i] = (self.SCHED_POSITION[1] * scale, self.SCHED_POSITION[2])
+                    elif id(p) in net:
+                        schedules[i] = (self.SCHED_DEFORM[1], self.SCHED_DEFORM[2])
+            self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat, patterns=patterns,
+                                             schedules=schedules, sched_t0=float(self._steps_done))
             self.opt_deform = None
         else:
             assert not getattr(surfels, "packed_sh", False), "packed SH needs the flat Adam kernel (two rates inside one parameter)"
             self.opt_surfels = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+            self._spatial = groups[0]['lr'] / position_lr
             if getattr(self, "opt_deform", None) is None:   # kept across Trainer.grow: the deformation parameters do not move
                 self.opt_deform = torch.optim.Adam(deform_groups, lr=0.0, eps=1e-15)
 
@@ -314,6 +346,13 @@ class Trainer:
                 s.denom.add_(self.bucket.extra[self.P:, None])
                 torch.maximum(s.max_radii2D, self._radii, out=s.max_radii2D)
             if self.opt_deform is not None:
+                if self.lr_schedule:
+                    k = self._steps_done
+                    for g in self.opt_surfels.param_groups:
+                        if g["name"] == "xyz":
+                            g["lr"] = expon_lr(k, self.SCHED_POSITION[0], self.SCHED_POSITION[1], self.SCHED_POSITION[2]) * self._spatial
+                    self.opt_deform.param_groups[0]["lr"] = expon_lr(k, *self.SCHED_DEFORM)
+                self._steps_done += 1
                 self.opt_surfels.step()
                 self.opt_deform.step()
             elif getattr(self.deform, "_join_pending", False):

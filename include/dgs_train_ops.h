@@ -91,6 +91,17 @@ int dgs_adam_step(int nseg, float* const* params /*host array of device pointers
 int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
                           const int* periods, const int* splits, const float* grad, float* exp_avg, float* exp_avg_sq,
                           const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream);
+/* Same with an optional exponential learning-rate schedule per segment, evaluated ON THE DEVICE from step_count (a captured
+ * step needs no host-side rate update): where sched_steps[s] > 0, step t of segment s runs at
+ *   exp(log(lrs[s]) (1 - tau) + log(lrs_final[s]) tau),  tau = clip((t - 1 + sched_t0) / sched_steps[s], 0, 1)
+ * i.e. get_expon_lr_func(lr_init, lr_final, max_steps) of utils/general_utils.py:49-83 (lr_delay_steps = 0, the only way
+ * the reference calls it) at the iteration the reference uses: update_learning_rate runs after optimizer.step
+ * (train_gui.py:427-432), so step t sees schedule(t - 1).  The pattern rate lrs2 is not scheduled (f_rest is constant in
+ * the reference).  lrs_final / sched_steps: host arrays of nseg entries, or both NULL. */
+int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                        const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                        const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
+                        float eps, const void* plan, void* stream);
 
 /* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:
  * posenc(xyz,10) | timenet(posenc(t,6)): 13->256->30, 8 x 256 ReLU layers, skip concat after layer 4, heads

@@ -3,7 +3,8 @@ utils/graphics_utils.py (getWorld2View2, getProjectionMatrix) in the build conta
   * sh_colors[d]: eval_sh(d, shs, dirs) for degrees 0..3 on the surfels of tests' small_case(P=300, seed=11) seen from its
     camera -- the view-dependent colour the rasterizer's preprocess must reproduce (forward.cu:20-71 is the same formula,
     plus 0.5 and the clamp at 0);
-  * world_view / projection matrices for two parameter sets.
+  * world_view / projection matrices for two parameter sets;
+  * lr_position / lr_deform: utils/general_utils.py get_expon_lr_func with the trainer's arguments at a few iterations.
 Run from the repo root:  python tests/golden/make_aux_golden.py
 """
 import importlib.util
@@ -50,6 +51,14 @@ def main():
         R, t = rot_y(c["theta"]), np.array(c["t"])
         out["w2v%d" % i] = gu.getWorld2View2(R, t).astype(np.float32)
         out["proj%d" % i] = gu.getProjectionMatrix(c["znear"], c["zfar"], c["fovx"], c["fovy"]).numpy().astype(np.float32)
+    # learning-rate schedules exactly as the trainer builds them (gaussian_model.py:203, deform_model.py:37)
+    gen = load("general_utils")
+    steps = np.array([0, 1, 2, 100, 2999, 15000, 29999, 30000, 39999, 40000, 60000])
+    pos = gen.get_expon_lr_func(lr_init=0.00016 * 5, lr_final=0.0000016 * 5, lr_delay_mult=0.01, max_steps=30000)
+    dfm = gen.get_expon_lr_func(lr_init=0.00016 * 5 * 1.0, lr_final=0.0000016 * 1.0, lr_delay_mult=0.01, max_steps=40000)
+    out["lr_steps"] = steps
+    out["lr_position"] = np.array([pos(int(k)) for k in steps], np.float64)
+    out["lr_deform"] = np.array([dfm(int(k)) for k in steps], np.float64)
     np.savez_compressed(os.path.join(HERE, "aux_golden.npz"), **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -50,3 +50,14 @@ def test_hip_preprocess_colours_match_reference_eval_sh():
     want = np.maximum(G["sh_colors3"] + 0.5, 0.0)
     got = raw["rec"][:, 15:18]
     assert np.abs(got[vis] - want[vis]).max() <= 2e-6
+
+
+def test_lr_schedules_match_reference():
+    """expon_lr + the Trainer's schedule constants against the imported get_expon_lr_func with the trainer's arguments."""
+    from dgs_amd.train import Trainer, expon_lr
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aux_golden.npz"))
+    p0, p1, pn = Trainer.SCHED_POSITION
+    d0, d1, dn = Trainer.SCHED_DEFORM
+    for k, want_p, want_d in zip(g["lr_steps"], g["lr_position"], g["lr_deform"]):
+        assert abs(expon_lr(int(k), p0 * 5, p1 * 5, pn) - want_p) <= 1e-12 * want_p
+        assert abs(expon_lr(int(k), d0, d1, dn) - want_d) <= 1e-12 * want_d

@@ -411,3 +411,34 @@ def test_fused_reg_loss_matches_render_postprocess():
     for c in (2, 3, 4, 5, 6, 7):
         scale = max(float(a[c].abs().max()), 1e-20)
         assert float((a[c] - b[c]).abs().max()) <= 2e-4 * scale, (c, float((a[c] - b[c]).abs().max()), scale)
+
+
+def test_flat_adam_device_schedule_matches_host_schedule():
+    """dgs_adam_step_sched: the exponential rate computed in the kernel from the device step counter against torch Adam whose
+    group rates are set on the host before every step (what the reference does, one step later: step t sees schedule(t-1))."""
+    from dgs_amd import _ops
+    from dgs_amd.train import FlatGradBucket, expon_lr
+    torch.manual_seed(1)
+    shapes = [(700, 3), (300, 16, 3), (256, 93), (11,)]
+    lrs = [8e-4, 0.0025, 8e-4, 0.05]
+    sched = {0: (8e-6, 50.0), 2: (1.6e-6, 20.0)}      # short horizons: the clip at max_steps is exercised too
+    a = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    bucket = FlatGradBucket(a)
+    flat = _ops.FlatAdam(a, lrs, bucket.flat, patterns={1: (48, 3, 0.0025 / 20)}, schedules=sched)
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=0.0, eps=1e-15)
+    mask = (torch.arange(300 * 48).cuda() % 48 >= 3).view(300, 16, 3)
+    for it in range(30):
+        g = [torch.randn(*s, generator=torch.Generator().manual_seed(100 * it + i)).cuda() * 1e-2 for i, s in enumerate(shapes)]
+        for i, (p, q, gi) in enumerate(zip(a, b, g)):
+            p.grad.copy_(gi)
+            q.grad = gi.clone()
+        for i, (lr_final, n) in sched.items():
+            ref.param_groups[i]["lr"] = expon_lr(it, lrs[i], lr_final, n)
+        before = b[1].detach().clone()
+        flat.step()
+        ref.step()
+        with torch.no_grad():   # the reference keeps the two SH rates in two parameters: emulate the second rate
+            b[1].copy_(torch.where(mask, before + (b[1] - before) / 20, b[1]))
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-7), (i, float((p - q).abs().max()))

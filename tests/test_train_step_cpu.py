@@ -130,3 +130,21 @@ def test_data_parallel_two_ranks_gloo():
     n = tr.bucket.n_grad
     expect = torch.cat([(flats[0][:n] + flats[1][:n]) / 2, flats[0][n:] + flats[1][n:]])
     assert torch.allclose(flat_dp, expect, rtol=1e-4, atol=1e-7)
+
+
+def test_trainer_lr_schedule_sets_the_reference_rates():
+    """CPU path: step t runs at schedule(t - 1) for xyz and the deformation network; the node group keeps its initial rate."""
+    from dgs_amd.train import expon_lr
+    surfels, deform, cams, targets, bg = _build(P=60, S=32, nodes=16, views=2)
+    tr = Trainer(surfels, deform, cams, targets, bg, lr_schedule=True)
+    seen = []
+    orig = tr.opt_surfels.step
+    tr.opt_surfels.step = lambda: (seen.append((tr.opt_surfels.param_groups[0]["lr"], tr.opt_deform.param_groups[0]["lr"],
+                                                 tr.opt_deform.param_groups[1]["lr"])), orig())[1]
+    for _ in range(3):
+        tr.step()
+    for k, (lx, ld, ln) in enumerate(seen):
+        assert abs(lx - expon_lr(k, 0.00016 * 5, 0.0000016 * 5, 30000)) <= 1e-12
+        assert abs(ld - expon_lr(k, 0.00016 * 5, 0.0000016, 40000)) <= 1e-12
+        assert ln == 0.00016 * 5
+    assert seen[0][0] == 0.00016 * 5 and seen[2][0] < seen[1][0] < seen[0][0]
