@@ -186,7 +186,7 @@ class Trainer:
         parallelism the all-reduce stays outside the graphs."""
         import os
         from diff_surfel_rasterization import _C
-        assert self.rasterizer_cls is None, "graph capture is for the HIP operator"
+        assert self.rasterizer_cls is None and self.opt_deform is None, "graph capture is for the HIP operator with the flat Adam kernel"
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
             # ROCm 7.2: the AQL-packet-capture replay path intermittently runs the step's memset nodes out of order
             # (observed: an L1 loss term of exactly 0, 1e18 gradients).  The knob is read when the HIP runtime starts.
@@ -206,10 +206,13 @@ class Trainer:
         self._sgt = self._scam.target
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):  # warm-up on a side stream (allocations, optimiser state) as torch.cuda.graph requires
+        with torch.cuda.stream(s):  # warm-up on a side stream (allocations, lazily created buffers) as torch.cuda.graph requires
+            # ... on a snapshot: the warm-up steps must not train (enable_graph is also called mid-run, by Trainer.grow)
+            snap = self._snapshot()
             for _ in range(3):
                 self._fwd_bwd(self._scam, self._sgt)
                 self._finish()
+            self._restore(snap)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
@@ -236,6 +239,26 @@ class Trainer:
         self._graph = True
         if _C.read_overflow():
             raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
+
+    def _snapshot(self):
+        sf = self.surfels
+        state = [p.detach().clone() for p in self.bucket.params]
+        opt = (self.opt_surfels.exp_avg.clone(), self.opt_surfels.exp_avg_sq.clone(), self.opt_surfels.t.clone())
+        stats = (sf.xyz_gradient_accum.clone(), sf.denom.clone(), sf.max_radii2D.clone())
+        return state, opt, stats
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        sf = self.surfels
+        state, opt, stats = snap
+        for p, q in zip(self.bucket.params, state):
+            p.copy_(q)
+        self.opt_surfels.exp_avg.copy_(opt[0])
+        self.opt_surfels.exp_avg_sq.copy_(opt[1])
+        self.opt_surfels.t.copy_(opt[2])
+        sf.xyz_gradient_accum.copy_(stats[0])
+        sf.denom.copy_(stats[1])
+        sf.max_radii2D.copy_(stats[2])
 
     def _forward(self, cam, gt):
         s, d = self.surfels, self.deform

@@ -11,11 +11,6 @@ def _build(slots, graph):
     tr = bench.build_trainer(20000, 256, 256, torch.device("cuda:0"), n_views=8, n_targets=2, slots=slots)
     if graph:
         tr.enable_graph(capacity=40 * 20000)
-    else:   # enable_graph() warms up with three steps on view 0
-        sched = [0, 0, 0] + list(range(64))
-        tr.view_for = lambda it: sched[it] % 8
-        for _ in range(3):
-            tr.step()
     return tr
 
 

@@ -60,8 +60,7 @@ def test_knn_refine_is_exact_for_any_seed():
 
 def test_graph_captured_step_matches_eager():
     """The whole-step HIP graph (rasterizer in capacity mode, no host synchronisation) must train like the eager
-    step: same loss trajectory.  enable_graph() runs three warm-up steps on view 0 before capturing, so the eager run
-    is given the same schedule (0,0,0 then 0,1,2).  Parameters are compared through the losses and a robust
+    step: same loss trajectory (enable_graph() warms up on a snapshot, it does not train).  Parameters are compared through the losses and a robust
     statistic only: the backward's fp32 atomics make near-zero gradients flip sign under Adam."""
     import bench
     from diff_surfel_rasterization import _C
@@ -72,12 +71,10 @@ def test_graph_captured_step_matches_eager():
         losses = []
         try:
             if graph:
+                before = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).clone()
                 tr.enable_graph(capacity=24 * 20000)
-            else:
-                sched = [0, 0, 0, 0, 1, 2]
-                tr.view_for = lambda it: sched[it]
-                for _ in range(3):
-                    tr.step()
+                assert torch.equal(before, torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]))
+                assert float(tr.opt_surfels.t) == 0.0 and float(tr.surfels.denom.sum()) == 0.0
             for _ in range(3):
                 losses.append(float(tr.step()))
             torch.cuda.synchronize()
