@@ -7,9 +7,11 @@ surfel becomes a dead slot, a new one is written into a dead slot, a split paren
 Addresses never change, so the captured HIP graphs of the train step, the flat gradient bucket and the flat Adam state stay
 valid across densification, and nothing is re-captured or re-allocated until the slots run out (`Trainer.grow`).
 
-A dead slot costs nothing on the hot path and needs no special casing in the kernels: its opacity logit is DEAD_LOGIT
-(sigmoid == 0 exactly, so it is culled before binning and alpha < 1/255 everywhere), every gradient that reaches it is
-exactly zero, and Adam with zero gradient and zero moments leaves a parameter unchanged (0 / (0 + eps)).
+A dead slot needs no special casing in the kernels: its opacity logit is DEAD_LOGIT (sigmoid == 0 exactly, so it produces no
+tile-list entries and alpha < 1/255 everywhere), every gradient that reaches it is exactly zero, and Adam with zero gradient
+and zero moments leaves a parameter unchanged (0 / (0 + eps)).  It costs the rasterizer's lists, sort and blend nothing, but it
+still passes through the per-surfel kernels (neighbour search, skinning, preprocess, Adam): measured 0.37 ms per 100 k dead
+slots next to 200 k live ones (1.34 -> 1.71 ms per step), which is why Trainer.grow adds a quarter, not multiples.
 
 Data parallelism: the statistics are summed over the ranks inside the step's bucket all-reduce, parameters are replicas, and
 the only random draw comes from a generator seeded identically on every rank -- each rank performs the same surgery and the
@@ -60,8 +62,8 @@ def densify_and_prune(model, moments, max_grad, min_opacity, extent, max_screen_
     """GaussianModel.densify_and_prune (gaussian_model.py:466-482) on slots.  `moments(p)` returns the two Adam moment
     tensors of parameter p (shaped like p) or (None, None).  `noise`: optional standard-normal draws [N * n_split, 3] in the
     reference's order (row k * n_split + j = child k of the j-th split surfel); otherwise drawn from `generator`.
-    Returns (n_cloned, n_split, n_pruned) or None if the free slots do not suffice (nothing has been modified then:
-    call Trainer.grow and retry)."""
+    Returns (n_cloned, n_split, n_pruned), or the int number of MISSING slots if the free ones do not suffice (nothing has
+    been modified then: call Trainer.grow and retry)."""
     alive = model.alive
     rows = surfel_rows(model)
     grads = model.xyz_gradient_accum / model.denom
@@ -76,7 +78,7 @@ def densify_and_prune(model, moments, max_grad, min_opacity, extent, max_screen_
     free = (~alive).nonzero().squeeze(1)
     need = n_clone + (N - 1) * n_split          # a split parent's slot takes its first child
     if need > free.numel():
-        return None
+        return need - free.numel()
 
     # children of the split surfels: N samples of the surfel's own (planar) Gaussian, scales shrunk by 0.8 N
     std = torch.exp(model._scaling[src_split]).repeat(N, 1)

@@ -20,14 +20,14 @@ from .train import Trainer
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None):
-    """Returns (trainer, losses).  slots: surfel slots to allocate (default 3x the initial point count; grown on demand).
+    """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot)."""
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
     scene = dio.scene_from_point_cloud(pc.points, pc.colors)
     P = scene.xyz.shape[0]
-    slots = int(slots or 3 * P)
+    slots = int(slots or 1.25 * P)
     on_gpu = device.type == "cuda" and rasterizer_cls is None
     surfels = SurfelModel(scene, packed_sh=on_gpu, capacity=slots).to(device)
     torch.manual_seed(seed)

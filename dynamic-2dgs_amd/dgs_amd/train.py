@@ -402,9 +402,9 @@ class Trainer:
         gen = torch.Generator(device=dev).manual_seed(int(seed) * 1000003 + self.iteration)
         args = (max_grad, min_opacity, extent, max_screen_size)
         out = densify.densify_and_prune(self.surfels, self._moments(), *args, percent_dense=percent_dense, noise=noise, generator=gen)
-        if out is None:   # slots exhausted: the one case that re-allocates (and re-captures)
-            alive = self.surfels.num_surfels
-            self.grow(max(int(1.5 * self.P), 3 * alive + 1024))
+        if isinstance(out, int):   # slots exhausted: the one case that re-allocates (and re-captures)
+            # a dead slot still costs the per-surfel kernels their share of the step: grow by a quarter, not by multiples
+            self.grow(-(-max(int(1.25 * self.P), self.P + 2 * out) // 1024) * 1024)
             out = densify.densify_and_prune(self.surfels, self._moments(), *args, percent_dense=percent_dense, noise=noise, generator=gen)
         return out
 
