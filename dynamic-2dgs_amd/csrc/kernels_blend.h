@@ -157,9 +157,14 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
         if (tid < n) {
             const uint32_t id = a.point_list[range.x + (uint32_t)(b * kBatch + tid)];
             const float4* src = a.rec + (size_t)id * kRecQuads;
+            float4 q[kStagedQuads];
 #pragma unroll
-            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = src[c];
-            { const float4 bx = src[5]; smask = quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
+            for (int c = 0; c < kStagedQuads; c++) q[c] = src[c];
+            const float4 bx = src[5];
+#pragma unroll
+            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = q[c];
+            // which of the tile's four 8x8 quadrants can this entry touch: bounding box, refined by the exact footprint
+            smask = quad_mask_conic(as_quad(q[0]), as_quad(q[1]), as_quad(q[2]), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -371,9 +376,14 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
             const uint32_t id = a.point_list[range.x + (uint32_t)e_mine];
             s_id[tid] = id;
             const float4* src = a.rec + (size_t)id * kRecQuads;
+            float4 q[kStagedQuads];
 #pragma unroll
-            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = src[c];
-            { const float4 bx = src[5]; smask = quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy); }
+            for (int c = 0; c < kStagedQuads; c++) q[c] = src[c];
+            const float4 bx = src[5];
+#pragma unroll
+            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = q[c];
+            // which of the tile's four 8x8 quadrants can this entry touch: bounding box, refined by the exact footprint
+            smask = quad_mask_conic(as_quad(q[0]), as_quad(q[1]), as_quad(q[2]), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {

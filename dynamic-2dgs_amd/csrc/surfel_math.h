@@ -220,6 +220,59 @@ DGS_HD uint32_t quad_mask(float x_lo, float x_hi, float y_lo, float y_hi, float 
     return ((x0 && y0) ? 1u : 0u) | ((x1 && y0) ? 2u : 0u) | ((x0 && y1) ? 4u : 0u) | ((x1 && y1) ? 8u : 0u);
 }
 
+// Refinement of quad_mask (NOT in the reference): the footprint {alpha >= 1/255} is the union of the conic
+//   Q(x, y) = |P.xy|^2 - tau P.z^2 <= 0,   P(x, y) = Tu x Tv + x (Tv x Tw) + y (Tw x Tu)     (rho3d <= tau, forward.cu:359-384)
+// and the low-pass disc |xy - centre|^2 <= tau / 2 (rho2d <= tau), tau = 2 ln(255 o).  A thin or tilted splat fills a small
+// part of its bounding box, so a fifth of the quadrants the box test lets through hold no passing pixel.  Here Q is
+// minimised over the 8x8 block of pixel centres of each quadrant (convex when the conic is an ellipse: interior minimiser or
+// the four clamped edges).  fp32 throughout, in tile-centred coordinates; the same cancellation as in the per-pixel
+// evaluation applies (relative error up to ~4e-4 of tau for sub-pixel splats far from the principal point), so tau is
+// inflated by 1 % + 0.01 -- half a percent of the footprint's extent.  Anything that is not a proper ellipse keeps the box
+// mask.  tests/hostmath proves on the test scenes that no quadrant with a passing pixel is ever dropped.
+DGS_HD uint32_t quad_mask_conic(const Quad& q0, const Quad& q1, const Quad& q2, uint32_t box_mask, float px0, float py0)
+{
+    if (box_mask == 0u) return 0u;
+    const float tau = 2.0f * logf(255.0f * q2.w) * 1.01f + 0.01f;
+    if (!(tau > 0.0f)) return 0u;                       // opacity below 1/255 (or not a number): no pixel can pass
+    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y, Twx = q1.z, Twy = q1.w, Twz = q2.x;
+    const float Ax = Tuy * Tvz - Tuz * Tvy, Ay = Tuz * Tvx - Tux * Tvz, Az = Tux * Tvy - Tuy * Tvx;
+    const float Bx = Tvy * Twz - Tvz * Twy, By = Tvz * Twx - Tvx * Twz, Bz = Tvx * Twy - Tvy * Twx;
+    const float Cx = Twy * Tuz - Twz * Tuy, Cy = Twz * Tux - Twx * Tuz, Cz = Twx * Tuy - Twy * Tux;
+    const float X0 = px0 + 8.0f, Y0 = py0 + 8.0f;       // pixel centres of the tile: (X0 + u, Y0 + v), u, v in -7.5 .. 7.5
+    const float Px = Ax + X0 * Bx + Y0 * Cx, Py = Ay + X0 * By + Y0 * Cy, Pz = Az + X0 * Bz + Y0 * Cz;
+    // Q(u, v) = a u^2 + 2 c u v + b v^2 + 2 d u + 2 e v + f
+    const float a = Bx * Bx + By * By - tau * Bz * Bz, b = Cx * Cx + Cy * Cy - tau * Cz * Cz;
+    const float c = Bx * Cx + By * Cy - tau * Bz * Cz;
+    const float d = Px * Bx + Py * By - tau * Pz * Bz, e = Px * Cx + Py * Cy - tau * Pz * Cz;
+    const float f = Px * Px + Py * Py - tau * Pz * Pz;
+    const float det = a * b - c * c;
+    if (!(a > 0.0f && b > 0.0f && det > 1e-6f * a * b)) return box_mask;   // not a bounded, well-conditioned ellipse
+    const float inv_det = 1.0f / det, inv_a = 1.0f / a, inv_b = 1.0f / b;
+    const float uc = (c * e - b * d) * inv_det, vc = (c * d - a * e) * inv_det;
+    const float tol = 2e-6f * (64.0f * (a + b) + 16.0f * (fabsf(d) + fabsf(e)) + fabsf(f));
+    // (the ellipse is never empty: rho3d = 0 at the splat's origin.  Its minimum VALUE is not used -- f + d uc + e vc
+    // cancels catastrophically for thin tilted footprints.)
+    const float r2 = 0.5f * tau, cx = q2.y - X0, cy = q2.z - Y0;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const float u0 = (w & 1) ? 0.5f : -7.5f, u1 = u0 + 7.0f, v0 = (w & 2) ? 0.5f : -7.5f, v1 = v0 + 7.0f;
+        // low-pass disc: distance from the centre to the block of pixel centres
+        const float gx = fmaxf(fmaxf(u0 - cx, cx - u1), 0.0f), gy = fmaxf(fmaxf(v0 - cy, cy - v1), 0.0f);
+        bool hit = gx * gx + gy * gy <= r2 * 1.0001f;
+        hit |= (uc >= u0) & (uc <= u1) & (vc >= v0) & (vc <= v1);
+        auto Qf = [&](float u, float v) { return u * (a * u + 2.0f * (c * v + d)) + v * (b * v + 2.0f * e) + f; };
+        auto clampf = [](float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); };
+        float qm = Qf(u0, clampf(-(c * u0 + e) * inv_b, v0, v1));
+        qm = fminf(qm, Qf(u1, clampf(-(c * u1 + e) * inv_b, v0, v1)));
+        qm = fminf(qm, Qf(clampf(-(c * v0 + d) * inv_a, u0, u1), v0));
+        qm = fminf(qm, Qf(clampf(-(c * v1 + d) * inv_a, u0, u1), v1));
+        hit |= qm <= tol;
+        m |= hit ? (1u << w) : 0u;
+    }
+    return m & box_mask;
+}
+
 // Packed tile rectangle: x0 | x1 << 16, y0 | y1 << 16
 struct TileRect { uint32_t xs, ys; };
 

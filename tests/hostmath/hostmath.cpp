@@ -45,8 +45,9 @@ void hm_preprocess(int P, int D, int M, const float* means3D, const float* scale
 }
 
 // Bit w of the result: some pixel of quadrant w (8x8, lane_pixel) of tile (tx,ty) passes the alpha test for this record.
-// -1: the branchy and branch-free evaluations disagree; -2: a quadrant is reachable although the record's
-// bounding box (q5) says it is not (quadrant culling of the blend kernels would be wrong).
+// Bits 4..7: the quadrant mask the blend kernels use (box test refined by quad_mask_conic); bits 8..11: the box test alone.
+// -1: the branchy and branch-free evaluations disagree; -2 / -3: a quadrant is reachable although the record's
+// bounding box (q5) / the conic refinement says it is not (quadrant culling of the blend kernels would be wrong).
 int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
 {
     int any = 0;
@@ -60,9 +61,11 @@ int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
             if (ka != kb) return -1;
             any |= ka ? (1 << ((ly >> 3) * 2 + (lx >> 3))) : 0;
         }
-    const uint32_t mask = quad_mask(r[20], r[21], r[22], r[23], (float)(tx * 16), (float)(ty * 16));
-    if (any & ~(int)mask) return -2;
-    return any;
+    const uint32_t box = quad_mask(r[20], r[21], r[22], r[23], (float)(tx * 16), (float)(ty * 16));
+    const uint32_t mask = quad_mask_conic(Q(r, 0), Q(r, 1), Q(r, 2), box, (float)(tx * 16), (float)(ty * 16));
+    if (any & ~(int)box) return -2;
+    if (any & ~(int)mask) return -3;   // the conic refinement dropped a quadrant that holds a passing pixel
+    return any | ((int)mask << 4) | ((int)box << 8);
 }
 
 // planar [c,H,W] outputs like the reference's image state
@@ -151,12 +154,13 @@ static int g_shape = 1;   // wave shape for hm_blend_stats: 0 = 16x4 strips (rou
 extern "C" void hm_set_shape(int s) { g_shape = s; }
 static inline int lane_of(int w, int k)   // pixel index (y*16 + x) of lane k of wave w
 {
-    if (g_shape == 1) { const int x = 8 * (w & 1) + (k & 7), y = 8 * (w >> 1) + (k >> 3); return y * 16 + x; }
+    if (g_shape >= 1) { const int x = 8 * (w & 1) + (k & 7), y = 8 * (w >> 1) + (k >> 3); return y * 16 + x; }
     return 64 * w + k;
 }
 static inline bool wave_sees(int w, const float* r, float px0, float py0)
 {
-    if (g_shape == 1) {
+    if (g_shape == 1) return (quad_mask_conic(Q(r, 0), Q(r, 1), Q(r, 2), quad_mask(r[20], r[21], r[22], r[23], px0, py0), px0, py0) >> w) & 1u;
+    if (g_shape == 2) {   // 8x8 quadrants, bounding box only (before the conic refinement)
         const float xf = px0 + 8.0f * (w & 1) + 0.5f, yf = py0 + 8.0f * (w >> 1) + 0.5f;
         return r[21] >= xf && r[20] <= xf + 7.0f && r[23] >= yf && r[22] <= yf + 7.0f;
     }

@@ -112,7 +112,12 @@ def test_hostmath_pipeline_matches_oracle(hm, cfg):
 
 
 @pytest.mark.parametrize("cfg", CASES + [dict(P=600, H=96, W=112, seed=31, view=6, scale_mul=0.6, sh_degree=1),
-                                         dict(P=300, H=64, W=64, seed=32, view=0, scale_mul=5.0, sh_degree=0, radius=1.6)])
+                                         dict(P=300, H=64, W=64, seed=32, view=0, scale_mul=5.0, sh_degree=0, radius=1.6),
+                                         # sub-pixel splats far from the principal point (worst fp32 cancellation), wide image
+                                         dict(P=1500, H=48, W=800, seed=33, view=3, scale_mul=0.08, sh_degree=0),
+                                         dict(P=800, H=400, W=64, seed=34, view=5, scale_mul=0.25, sh_degree=0),
+                                         # camera inside the cloud: splats crossing the camera plane, huge footprints
+                                         dict(P=400, H=80, W=96, seed=35, view=1, scale_mul=3.0, sh_degree=0, radius=0.9)])
 def test_tight_tile_rects_are_conservative(hm, cfg):
     """The opacity-aware rectangles (surfel_math.h tight_tile_rect) must be sub-rectangles of the reference's and
     may only drop (surfel, tile) pairs in which NO pixel passes the alpha test -- so rendered results cannot
@@ -130,6 +135,7 @@ def test_tight_tile_rects_are_conservative(hm, cfg):
         out[tight] = (radii, rec, tiles, rects)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1][:, :20], out[1][1][:, :20])  # radii / records untouched
     dropped = kept = 0
+    quads = np.zeros(3, np.int64)   # quadrants with a passing pixel / let through by the conic mask / by the box alone
     for i in np.nonzero(out[0][0] > 0)[0]:
         (xs0, ys0), (xs1, ys1) = out[0][3][i], out[1][3][i]
         ref = (xs0 & 0xffff, xs0 >> 16, ys0 & 0xffff, ys0 >> 16)
@@ -142,9 +148,14 @@ def test_tight_tile_rects_are_conservative(hm, cfg):
                 r = hm.hm_tile_reachable(W, H, int(tx), int(ty), p(np.ascontiguousarray(out[1][1][i])))
                 assert r != -1, "pair_eval / pair_eval_bf disagree"
                 assert r != -2, "bounding box culls a reachable 8x8 quadrant (surfel %d, tile %d,%d)" % (i, tx, ty)
+                assert r != -3, "conic mask culls a reachable 8x8 quadrant (surfel %d, tile %d,%d)" % (i, tx, ty)
+                if inside:
+                    quads += [bin(r & 15).count("1"), bin((r >> 4) & 15).count("1"), bin((r >> 8) & 15).count("1")]
                 if not inside:
-                    assert r == 0, "tight rectangle dropped a reachable tile (surfel %d, tile %d,%d)" % (i, tx, ty)
+                    assert (r & 15) == 0, "tight rectangle dropped a reachable tile (surfel %d, tile %d,%d)" % (i, tx, ty)
                     dropped += 1
                 else:
                     kept += 1
     assert dropped > 0 and kept > 0
+    assert quads[0] <= quads[1] <= quads[2]
+    print("quadrants reachable / conic mask / box mask:", quads)

@@ -19,7 +19,7 @@ hm.hm_preprocess(P, case["sh_degree"], sh.shape[1], p(m3), p(sc), p(rot), p(op),
                  ctypes.c_float(case["tanfovx"]), ctypes.c_float(case["tanfovy"]), p(radii), p(rec), p(tiles), p(rects), 1)
 ranges, plist = orc.field("ranges"), orc.field("point_list")
 print("mean radius %.1f px, R(ref lists) %d" % (radii[radii > 0].mean(), orc.num_rendered))
-for shape, name in ((0, "16x4"), (1, "8x8")):
+for shape, name in ((0, "16x4 strips, box"), (2, "8x8 quadrants, box"), (1, "8x8 quadrants, box + conic (the kernels)")):
   hm.hm_set_shape(shape)
   out = np.zeros(12)
   hm.hm_blend_stats(W, H, p(np.ascontiguousarray(ranges)), p(np.ascontiguousarray(plist)), p(rec), p(out))
