@@ -121,3 +121,47 @@ def test_data_parallel_two_ranks_on_the_hip_path():
     scale = expect.abs().max()
     assert float(err.max()) <= 2e-3 * float(scale), (float(err.max()), float(scale))
     assert float(err.median()) <= 1e-6 * float(scale)
+
+
+def _rccl_worker(port, q):
+    """One rank over the REAL backend (nccl = RCCL) with the trainer told it is one of two: every mechanism of the multi-GPU
+    step runs -- communicator next to graph capture, asynchronous all-reduce of the SH slice between graph 1a and 1b, the
+    MAX reduction of the radii -- except that the sums have a single contribution."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        res = {}
+        for graph in (False, True):
+            tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
+            tr.world = 2                       # take the data-parallel code path
+            assert tr._split_ok()
+            if graph:
+                tr.enable_graph(capacity=24 * 20000)
+                assert tr._g1b is not None and tr._g2 is not None
+            res[graph] = [float(tr.step()) for _ in range(4)]
+            torch.cuda.synchronize()
+            assert not _C.read_overflow()
+            _C.set_capacity(0)
+        q.put((res[False], res[True]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_split_step_over_rccl_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    proc = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    proc.start()
+    eager, graph = q.get()
+    proc.join(180)
+    assert proc.exitcode == 0
+    for a, b in zip(eager, graph):
+        assert 0.0 < a < 10.0 and abs(a - b) <= 1e-3 * abs(a), (eager, graph)
