@@ -217,24 +217,28 @@ class Trainer:
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
         self._g1b = None
+        # thread-local capture mode: with a process group alive, the collective library's watchdog thread polls events while
+        # this thread captures; under the default ("global") mode such a call from ANOTHER thread invalidates the capture
+        # and the watchdog dies with the error (seen once in three runs on ROCm 7 / RCCL 2.26)
+        mode = {"capture_error_mode": "thread_local"}
         self._split = self._split_ok()
         if self._split:
             # data parallel: graph 1a = forward + backward down to the rasterizer inputs (SH gradients final), eager async
             # all-reduce of the SH segment, graph 1b = rest of the backward, eager all-reduce of the rest, graph 2 = update
-            with torch.cuda.graph(self._g1):
+            with torch.cuda.graph(self._g1, **mode):
                 self._sloss = self._fwd_bwd_a(self._scam, self._sgt)
             self._g1b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g1b, pool=self._g1.pool()):
+            with torch.cuda.graph(self._g1b, pool=self._g1.pool(), **mode):
                 self._fwd_bwd_b()
         else:
-            with torch.cuda.graph(self._g1):
+            with torch.cuda.graph(self._g1, **mode):
                 self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
                 if self.world == 1:
                     self._finish()
         self._g2 = None
         if self.world > 1:
             self._g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+            with torch.cuda.graph(self._g2, pool=self._g1.pool(), **mode):
                 self._finish(reduce=False)
         self._graph = True
         if _C.read_overflow():
