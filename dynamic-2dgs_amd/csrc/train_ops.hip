@@ -1065,6 +1065,7 @@ struct AdamSegs {
     float lr_final[kAdamSeg];
     float sched_steps[kAdamSeg];
     float sched_t0;
+    float gscale;   // gradients are read as grad * gscale (data parallel: the bucket holds the SUM over ranks, gscale = 1 / world)
 };
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, const float* __restrict__ grad,
@@ -1090,7 +1091,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
     for (int k = 0; k < kAdamChunk / 256; k++) {
         const long long i = (long long)pl.y + k * 256 + threadIdx.x;
         if (i < seg_len) {
-            const float g = grad[base + i];
+            const float g = grad[base + i] * sg.gscale;
             const float mi = b1 * m[base + i] + (1.0f - b1) * g;
             const float vi = b2 * v[base + i] + (1.0f - b2) * g * g;
             m[base + i] = mi;
@@ -1245,7 +1246,7 @@ int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offse
 
 int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
                         const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
-                        const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
+                        float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
                         float eps, const void* plan, void* stream);
 
 int dgs_adam_step(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* grad, float* exp_avg,
@@ -1259,13 +1260,13 @@ int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offse
                           const int* periods, const int* splits, const float* grad, float* exp_avg, float* exp_avg_sq,
                           const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
 {
-    return dgs_adam_step_sched(nseg, params, offsets, lrs, lrs2, periods, splits, nullptr, nullptr, 0.0f, grad, exp_avg, exp_avg_sq,
+    return dgs_adam_step_sched(nseg, params, offsets, lrs, lrs2, periods, splits, nullptr, nullptr, 0.0f, 1.0f, grad, exp_avg, exp_avg_sq,
                                step_count, beta1, beta2, eps, plan, stream);
 }
 
 int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
                         const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
-                        const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
+                        float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
                         float eps, const void* plan, void* stream)
 {
     if ((lrs_final != nullptr) != (sched_steps != nullptr)) return fail(-1, "dgs_adam_step_sched: pass lrs_final and sched_steps together");
@@ -1286,6 +1287,7 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
             return fail(-1, "dgs_adam_step_sched: a scheduled segment needs positive initial and final rates");
     }
     sg.sched_t0 = sched_t0;
+    sg.gscale = grad_scale;
     sg.off[nseg] = offsets[nseg];
     const long long nb = adam_blocks(nseg, offsets);
     if (nb == 0) return 0;

@@ -70,8 +70,8 @@ def load():
         lib.dgs_adam_step_pattern.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                               vp, vp]
         lib.dgs_adam_step_sched.restype = ci
-        lib.dgs_adam_step_sched.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_float,
-                                            ctypes.c_float, ctypes.c_float, vp, vp]
+        lib.dgs_adam_step_sched.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp,
+                                            ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp]
         for f in (lib.dgs_mlp_packed_floats, lib.dgs_mlp_saved_floats, lib.dgs_mlp_scratch_floats):
             f.restype = ctypes.c_size_t
         lib.dgs_mlp_packed_floats.argtypes = []
@@ -250,6 +250,7 @@ class FlatAdam:
         self._lr_final = (ctypes.c_float * n_)(*[float(schedules[i][0]) if i in schedules else self.lrs[i] for i in range(n_)])
         self._sched_steps = (ctypes.c_float * n_)(*[float(schedules[i][1]) if i in schedules else 0.0 for i in range(n_)])
         self.sched_t0 = float(sched_t0)
+        self.grad_scale = 1.0   # gradients are read as grad * grad_scale (1 / world when the bucket holds the sum over ranks)
         dev = flat_grad.device
         n = sum(p.numel() for p in self.params)
         assert flat_grad.numel() >= n and flat_grad.is_contiguous()
@@ -305,7 +306,8 @@ class FlatAdam:
         if advance:
             self.t.add_(1.0)
         with torch.cuda.device(dev):
-            rc = lib.dgs_adam_step_sched(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, self.grad.data_ptr(),
+            rc = lib.dgs_adam_step_sched(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
+                                         self.grad.data_ptr(),
                                          self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
                                          self.betas[1], self.eps, plan.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_adam_step")

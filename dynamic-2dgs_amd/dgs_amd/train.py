@@ -72,10 +72,12 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, group=None):
+    def all_reduce_mean(self, group=None, average=True):
+        """average=False leaves the SUM in the bucket (the flat Adam kernel then reads grad / world itself)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat[:self.n_grad].mul_(1.0 / dist.get_world_size(group))
+            if average:
+                self.flat[:self.n_grad].mul_(1.0 / dist.get_world_size(group))
 
 
 def expon_lr(step, lr_init, lr_final, max_steps):
@@ -210,8 +212,11 @@ class Trainer:
             # ... on a snapshot: the warm-up steps must not train (enable_graph is also called mid-run, by Trainer.grow)
             snap = self._snapshot()
             for _ in range(3):
-                self._fwd_bwd(self._scam, self._sgt)
-                self._finish()
+                if self._split_ok():
+                    self._split_step(self._scam, self._sgt)
+                else:
+                    self._fwd_bwd(self._scam, self._sgt)
+                    self._finish()
             self._restore(snap)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -235,11 +240,15 @@ class Trainer:
                 self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
                 if self.world == 1:
                     self._finish()
-        self._g2 = None
+        self._g2 = self._g2a = None
         if self.world > 1:
+            if self._split:
+                self._g2a = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g2a, pool=self._g1.pool(), **mode):
+                    self._finish_sh()
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g2, pool=self._g1.pool(), **mode):
-                self._finish(reduce=False)
+                self._finish(reduce=False, sh_done=self._split)
         self._graph = True
         if _C.read_overflow():
             raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
@@ -348,22 +357,34 @@ class Trainer:
     def _reduce_sh_start(self):
         return dist.all_reduce(self.bucket.flat[:self.n_sh], op=dist.ReduceOp.SUM, async_op=True)
 
-    def _reduce_rest(self, work_sh):
-        dist.all_reduce(self.bucket.flat[self.n_sh:], op=dist.ReduceOp.SUM)
-        dist.all_reduce(self._radii, op=dist.ReduceOp.MAX)
-        work_sh.wait()
-        self.bucket.flat[:self.bucket.n_grad].mul_(1.0 / self.world)
+    def _reduce_rest_start(self):
+        return [dist.all_reduce(self.bucket.flat[self.n_sh:], op=dist.ReduceOp.SUM, async_op=True),
+                dist.all_reduce(self._radii, op=dist.ReduceOp.MAX, async_op=True)]
+
+    @property
+    def _fold_mean(self):
+        """Flat Adam kernel: the bucket keeps the SUM over the ranks and the kernel reads grad / world (no averaging pass)."""
+        return self.opt_deform is None and self.world > 1
 
     def _reduce(self):
-        self.bucket.all_reduce_mean()
+        self.bucket.all_reduce_mean(average=not self._fold_mean)
         if self.world > 1:
             dist.all_reduce(self._radii, op=dist.ReduceOp.MAX)
 
-    def _finish(self, reduce=True):
+    def _finish_sh(self):
+        """Data-parallel split step: the SH coefficients (first bucket segment, first parameter) can be updated as soon as their
+        all-reduce is done -- while the rest of the bucket is still on the wire."""
+        with torch.no_grad():
+            self.opt_surfels.grad_scale = 1.0 / self.world
+            self.opt_surfels.step(0, 1)
+
+    def _finish(self, reduce=True, sh_done=False):
         s = self.surfels
         with torch.no_grad():
             if reduce:
                 self._reduce()
+            if self.opt_deform is None:
+                self.opt_surfels.grad_scale = 1.0 / self.world if self._fold_mean else 1.0
             if self.rasterizer_cls is None and s.get_xyz.is_cuda:
                 from . import _ops
                 _ops.densify_accumulate(self.bucket.extra[:self.P], self.bucket.extra[self.P:], self._radii, s.xyz_gradient_accum,
@@ -382,6 +403,8 @@ class Trainer:
                 self._steps_done += 1
                 self.opt_surfels.step()
                 self.opt_deform.step()
+            elif sh_done:
+                self.opt_surfels.step(1, None, advance=False)
             elif getattr(self.deform, "_join_pending", False):
                 # the node-MLP backward is still running on the side stream (64 workgroups): update the surfels, which do
                 # not depend on it, meanwhile; then join and update the deformation parameters
@@ -488,7 +511,11 @@ class Trainer:
             if self._g1b is not None:
                 work = self._reduce_sh_start()   # runs on the collective's stream while graph 1b replays
                 self._g1b.replay()
-                self._reduce_rest(work)
+                rest = self._reduce_rest_start()
+                work.wait()
+                self._g2a.replay()               # SH update while the rest of the bucket is on the wire
+                for w in rest:
+                    w.wait()
                 self._g2.replay()
             elif self._g2 is not None:
                 self._reduce()
@@ -496,13 +523,21 @@ class Trainer:
             return self._sloss
         cam, gt = self.cameras[v], self.targets[v % len(self.targets)]
         if self._split_ok():
-            loss = self._fwd_bwd_a(cam, gt)
-            work = self._reduce_sh_start()
-            self._fwd_bwd_b()
-            with torch.no_grad():
-                self._reduce_rest(work)
-            self._finish(reduce=False)
-            return loss
+            return self._split_step(cam, gt)
         loss = self._fwd_bwd(cam, gt)
         self._finish()
+        return loss
+
+    def _split_step(self, cam, gt):
+        """Data-parallel step, eager: backward half a | SH all-reduce (async) | backward half b | all-reduce of the rest
+        (async) | SH update | update of everything else."""
+        loss = self._fwd_bwd_a(cam, gt)
+        work = self._reduce_sh_start()
+        self._fwd_bwd_b()
+        rest = self._reduce_rest_start()
+        work.wait()
+        self._finish_sh()
+        for w in rest:
+            w.wait()
+        self._finish(reduce=False, sh_done=True)
         return loss

@@ -97,10 +97,12 @@ int dgs_adam_step_pattern(int nseg, float* const* params, const long long* offse
  * i.e. get_expon_lr_func(lr_init, lr_final, max_steps) of utils/general_utils.py:49-83 (lr_delay_steps = 0, the only way
  * the reference calls it) at the iteration the reference uses: update_learning_rate runs after optimizer.step
  * (train_gui.py:427-432), so step t sees schedule(t - 1).  The pattern rate lrs2 is not scheduled (f_rest is constant in
- * the reference).  lrs_final / sched_steps: host arrays of nseg entries, or both NULL. */
+ * the reference).  lrs_final / sched_steps: host arrays of nseg entries, or both NULL.
+ * grad_scale: every gradient is read as grad * grad_scale (data parallel: the bucket holds the sum over the ranks and
+ * grad_scale = 1 / world replaces a separate averaging pass over the bucket; 1 otherwise). */
 int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
                         const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
-                        const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
+                        float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
                         float eps, const void* plan, void* stream);
 
 /* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:

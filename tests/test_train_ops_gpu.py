@@ -439,3 +439,26 @@ def test_flat_adam_device_schedule_matches_host_schedule():
             b[1].copy_(torch.where(mask, before + (b[1] - before) / 20, b[1]))
     for i, (p, q) in enumerate(zip(a, b)):
         assert torch.allclose(p, q, rtol=2e-5, atol=2e-7), (i, float((p - q).abs().max()))
+
+
+def test_flat_adam_grad_scale_is_the_mean_of_a_summed_bucket():
+    """grad_scale = 1 / world on a bucket holding the sum over `world` ranks == plain Adam on the mean."""
+    from dgs_amd import _ops
+    from dgs_amd.train import FlatGradBucket
+    torch.manual_seed(2)
+    shapes = [(500, 16, 3), (500, 3), (33,)]
+    a = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ba, bb = FlatGradBucket(a), FlatGradBucket(b)
+    oa = _ops.FlatAdam(a, [1e-3] * 3, ba.flat, patterns={0: (48, 3, 5e-5)})
+    ob = _ops.FlatAdam(b, [1e-3] * 3, bb.flat, patterns={0: (48, 3, 5e-5)})
+    oa.grad_scale = 0.25
+    for it in range(5):
+        g = torch.randn(ba.flat.numel(), generator=torch.Generator().manual_seed(it)).cuda()
+        ba.flat.copy_(4.0 * g)       # "sum over four ranks"
+        bb.flat.copy_(g)
+        oa.step(0, 1)                # split launches as in the data-parallel step
+        oa.step(1, None, advance=False)
+        ob.step()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)     # 4 g * 0.25 is exact in binary floating point
