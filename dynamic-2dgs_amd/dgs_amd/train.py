@@ -6,7 +6,8 @@ L1 + D-SSIM + normal + distortion loss -> backward -> [DP] one flat all-reduce -
 
 Data parallelism (new design, the reference is single-process): every rank holds a full replica, renders its
 own view of the step's batch, and all gradients live in ONE flat fp32 bucket that is all-reduced once per
-step over RCCL/xGMI (backend "nccl"; "gloo" in the CPU tests).  The bucket tail carries the densification
+step over RCCL/xGMI (backend "nccl"; "gloo" in the CPU tests) -- on the HIP path in two asynchronous slices that overlap the
+rest of the backward and the SH update.  The bucket tail carries the densification
 statistics (train_gui.py:411, gaussian_model.py:484-486) so replicas stay identical without a second sum.
 """
 import torch
