@@ -312,6 +312,95 @@ __global__ void __launch_bounds__(256) sort_tiles_lds_kernel(const uint2* ranges
     for (int i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)s_keys[i];
 }
 
+// Register-resident variant for buckets of up to 2048 entries (the common case; the LDS network above spends its time in
+// the LDS pipe: four 64-bit LDS operations per compared pair and stage).  Thread t of the 256 keeps the keys of elements
+// t + 256 s (s < SLOTS) in registers; the partner of element e in stage (kk, j) is e ^ j, and e keeps the smaller key iff
+// ((e & j) == 0) == ((e & kk) == 0).  So
+//   j >= 256 : the partner is another slot of the same thread  -> compare-exchange in registers, no data movement;
+//   j <  64  : the partner is the same slot of lane ^ j        -> two ds_bpermute per key;
+//   j = 64, 128 : another wave                                 -> one round trip through LDS (9 of the 66 stages at 2048).
+// Value of `v` in lane (lane ^ j): two ds_bpermute.  (DPP quad permutes / bank-masked row shifts for j <= 8 were measured and
+// are slower: 76 us against 49 us for the kernel at 200 k surfels -- the VALU, not the LDS pipe, is what the network saturates.)
+__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v, int j)
+{
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return ((uint64_t)(uint32_t)__shfl_xor((int)hi, j, 64) << 32) | (uint32_t)__shfl_xor((int)lo, j, 64);
+}
+
+template <int SLOTS, int DS>
+__device__ __forceinline__ void sort_cx_slots(uint64_t (&k)[SLOTS], int kk, int tid)
+{
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        if (s & DS) continue;
+        const bool up = ((tid + 256 * s) & kk) == 0;
+        const uint64_t a = k[s], b = k[s | DS];
+        const bool sw = (a > b) == up;
+        k[s] = sw ? b : a;
+        k[s | DS] = sw ? a : b;
+    }
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void sort_tile_regs(uint64_t* s_keys, const uint64_t* gk, int n, uint32_t* out, int tid)
+{
+    uint64_t k[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        const int e = tid + 256 * s;
+        k[s] = e < n ? gk[e] : ~0ull;
+    }
+    for (int kk = 2; kk <= 256 * SLOTS; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= 256) {
+                if constexpr (SLOTS >= 2) { if (j == 256) sort_cx_slots<SLOTS, 1>(k, kk, tid); }
+                if constexpr (SLOTS >= 4) { if (j == 512) sort_cx_slots<SLOTS, 2>(k, kk, tid); }
+                if constexpr (SLOTS >= 8) { if (j == 1024) sort_cx_slots<SLOTS, 4>(k, kk, tid); }
+                continue;
+            }
+            const bool lower = (tid & j) == 0;
+            if (j >= 64) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; s++) s_keys[tid + 256 * s] = k[s];
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SLOTS; s++) {
+                    const uint64_t p = s_keys[(tid ^ j) + 256 * s];
+                    const bool keep_min = lower == ((((tid + 256 * s) & kk)) == 0);
+                    k[s] = ((p < k[s]) == keep_min) ? p : k[s];
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int s = 0; s < SLOTS; s++) {
+                    const uint64_t p = lane_xor_u64(k[s], j);
+                    const bool keep_min = lower == ((((tid + 256 * s) & kk)) == 0);
+                    k[s] = ((p < k[s]) == keep_min) ? p : k[s];
+                }
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        const int e = tid + 256 * s;
+        if (e < n) out[e] = (uint32_t)k[s];
+    }
+}
+
+__global__ void __launch_bounds__(256) sort_tiles_reg_kernel(const uint2* ranges, const uint64_t* keys, uint32_t* point_list)
+{
+    __shared__ uint64_t s_keys[2048];
+    const uint2 rg = ranges[blockIdx.x];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= 0 || n > 2048) return;
+    const uint64_t* gk = keys + rg.x;
+    uint32_t* out = point_list + rg.x;
+    const int tid = threadIdx.x;
+    if (n <= 256) sort_tile_regs<1>(s_keys, gk, n, out, tid);
+    else if (n <= 512) sort_tile_regs<2>(s_keys, gk, n, out, tid);
+    else if (n <= 1024) sort_tile_regs<4>(s_keys, gk, n, out, tid);
+    else sort_tile_regs<8>(s_keys, gk, n, out, tid);
+}
+
 __global__ void __launch_bounds__(256) sort_tiles_global_kernel(const uint2* ranges, const uint64_t* keys, uint64_t* scratch /*[2R]*/,
                                                                 uint32_t* point_list, int lo)
 {

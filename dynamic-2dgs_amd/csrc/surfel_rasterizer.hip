@@ -16,6 +16,7 @@ namespace {
 
 thread_local std::string g_err;
 bool g_tight_rects = true;  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
+bool g_sort_regs = true;    // per-tile sort of <= 2048 entries in registers (kernels_preprocess.h sort_tiles_reg_kernel)
 int g_tile_order = 3;       // kernels_blend.h tile_for_block (3 = longest tile first)
 int g_capacity = 0;         // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
 int* g_overflow = nullptr;  // device flag raised by a capacity overflow
@@ -220,6 +221,7 @@ int dgs_set_option(int key, int value)
 {
     if (key == 0) { g_tight_rects = value != 0; return 0; }
     if (key == 1 && value >= 0 && value <= 3) { g_tile_order = value; return 0; }
+    if (key == 3) { g_sort_regs = value != 0; return 0; }
     if (key == 2 && value >= 0) {
         if (value > 0 && !g_overflow) {
             if (hipMalloc((void**)&g_overflow, 4) != hipSuccess) return fail(DGS_ERR_HIP, "hipMalloc failed");
@@ -412,8 +414,12 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
         DGS_STAGE("scatter_keys", debug, stream);
         // ---- K5 per-tile sort (stable radix order of rasterizer_impl.cu:304-309 = (tile, depth bits, surfel index))
         uint32_t* plist = (uint32_t*)(bin + bl.point_list);
-        hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
-                           (const uint64_t*)keys, plist, 0);
+        if (g_sort_regs)
+            hipLaunchKernelGGL(dgs::sort_tiles_reg_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                               (const uint64_t*)keys, plist);
+        else
+            hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                               (const uint64_t*)keys, plist, 0);
         // capacity mode does not know the longest list on the host: ONE fallback launch (global scratch) covers every tile
         // above 2048 entries instead of two mostly empty ones
         if (longest > 2048u && !capacity_mode)

@@ -107,7 +107,9 @@ void dgs_set_tight_rects(int on);
  *         device->host read of the forward (rasterizer_impl.cu:281-282), which makes forward + backward legal inside
  *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do
  *         not fit renders as background and raises a flag readable with dgs_read_overflow(); value 0 restores the
- *         exact-size mode. Returns DGS_OK or an error. */
+ *         exact-size mode,
+ * key 3 = per-tile sort of lists up to 2048 entries: 1 register-resident network [default], 0 the LDS network.
+ * Returns DGS_OK or an error. */
 int dgs_set_option(int key, int value);
 
 /* 1 if a capacity overflow happened since the last reset (blocking device read; call it outside hot loops). */

@@ -20,10 +20,13 @@ ap.add_argument("--W", type=int, default=800)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--views", type=int, default=8)
 ap.add_argument("--order", type=int, default=-1)
+ap.add_argument("--sort-regs", type=int, default=-1, help="0: LDS bitonic network, 1: register-resident network (default of the library)")
 a = ap.parse_args()
 dev = "cuda:0"
 if a.order >= 0:
     _C.set_option(1, a.order)
+if a.sort_regs >= 0:
+    _C.set_option(3, a.sort_regs)
 cases = [small_case(P=a.P, H=a.H, W=a.W, seed=0, view=v * (64 // a.views), n_views=64) for v in range(a.views)]
 leaf = {k: cases[0][k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
 rasts = [GaussianRasterizer(settings_from_case(c, dev)) for c in cases]
