@@ -149,3 +149,14 @@ def test_fit_tiny_scene_end_to_end_and_restore(tmp_path, monkeypatch):
     assert torch.equal(surfels._xyz.detach(), tr.surfels._xyz.detach()[alive])
     assert torch.equal(surfels._features_rest.detach(), tr.surfels._features_rest.detach()[alive])
     assert torch.equal(deform.nodes.detach(), tr.deform.nodes.detach())
+
+
+def test_scene_from_point_cloud_matches_reference_create_from_pcd():
+    """Against GaussianModel.create_from_pcd of the imported reference (make_init_golden.py; its CUDA-only distCUDA2 replaced
+    by the published 3-NN semantics)."""
+    g = np.load(os.path.join(GOLD, "init_golden.npz"))
+    scene = dio.scene_from_point_cloud(g["points"], g["colors"])
+    for mine, key, tol in ((scene.xyz, "xyz", 0), (scene.f_dc, "f_dc", 1e-6), (scene.f_rest, "f_rest", 0), (scene.rotation, "rotation", 0),
+                           (scene.opacity_logit, "opacity", 1e-6), (scene.feature, "feature", 0), (scene.log_scale, "scaling", 2e-5)):
+        assert mine.shape == g[key].shape, key
+        np.testing.assert_allclose(mine.numpy(), g[key], rtol=tol, atol=tol, err_msg=key)
