@@ -4,7 +4,8 @@ train step -> in-place densification -> checkpoint files the reference can load.
 The loop is the part of GUI.train_step (train_gui.py:272-432) this build covers: the joint surfel + node-deformation step
 with the normal and distortion regularisers on, densification every `densify_interval` iterations between `densify_from`
 and `densify_until` (size threshold 20 after the first opacity reset), opacity reset every `opacity_reset_interval`
-(arguments/__init__.py:115-122).  Not here: the node warm-up stage, node densification, the SH degree ramp, ARAP / flow
+(arguments/__init__.py:115-122), the one forced node densification / pruning at iteration 10000.  Not here: the node warm-up
+stage, the SH degree ramp, ARAP / flow
 losses and the GUI.  Learning rates follow the reference's exponential schedules (Trainer(lr_schedule=True)).
 """
 import os
@@ -19,7 +20,7 @@ from .train import Trainer
 
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
-        graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None):
+        graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot)."""
     device = torch.device(device)
@@ -46,6 +47,10 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     for it in range(1, iterations + 1):
         losses.append(tr.step())
         if it < densify_until:                                                     # train_gui.py:410-423
+            if it == node_densify_at:       # node_force_densify_prune_step; the periodic variant is off by default in the reference
+                counts = tr.densify_nodes(densify_grad_threshold)
+                if log and counts:
+                    log("[%d] nodes: added %d, pruned %d -> %d" % ((it,) + tuple(counts) + (deform.node_num,)))
             if it > densify_from and it % densify_interval == 0:
                 size_threshold = 20 if it > opacity_reset_interval else None
                 counts = tr.densify_and_prune(densify_grad_threshold, 0.01, extent, size_threshold, seed=seed)

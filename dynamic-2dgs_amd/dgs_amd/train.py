@@ -494,6 +494,58 @@ class Trainer:
             self._graph = None
             self.enable_graph(self._capacity)
 
+    def densify_nodes(self, max_grad=0.0002):
+        """DeformModel.densify (train_gui.py:413-415, utils/time_utils.py:1286-1385) with the surfels' accumulated view-space
+        gradient.  The node count changes, so the bucket / optimiser are rebuilt (moments and step count carry over) and the
+        step is re-captured; on the HIP path the count is padded to a multiple of 64 (fused MLP kernels) with unreachable
+        nodes.  Returns (n_added, n_pruned) or None if nothing changed."""
+        s, d = self.surfels, self.deform
+        fused = self.opt_deform is None
+        with torch.no_grad():
+            x_grad = s.xyz_gradient_accum / s.denom
+            alive = s.alive
+            old = {id(p): tuple(None if t is None else t.detach().clone() for t in self._any_moments(p)) for p in self.bucket.params}
+            t_saved = self.opt_surfels.t.clone() if fused else None
+            res = d.densify_nodes(max_grad, s.get_xyz.detach()[alive], x_grad[alive], s.feature.detach()[alive], moments=self._any_moments,
+                                  pad_to=64 if fused else 1)
+            if res is None:
+                return None
+            n_add, n_prune, node_moments = res
+            if not fused:   # torch Adam keyed its state by the replaced parameter objects
+                self.opt_deform = None
+            for a in ("_half",):
+                if hasattr(self, a):
+                    delattr(self, a)
+            self._build_state()
+            new_nodes = {id(getattr(d, n)): mv for n, mv in node_moments.items()}
+            if fused:
+                self.opt_surfels.t.copy_(t_saved)
+            for p in self.bucket.params:
+                m0, v0 = new_nodes.get(id(p), old.get(id(p), (None, None)))
+                if m0 is None:
+                    continue
+                if not fused:
+                    opt = self.opt_deform if any(p is q for g in self.opt_deform.param_groups for q in g["params"]) else self.opt_surfels
+                    opt.state[p] = {"step": torch.tensor(float(self._steps_done)), "exp_avg": m0.clone(), "exp_avg_sq": v0.clone()}
+                else:
+                    m, v = self.opt_surfels.moments(p)
+                    m.copy_(m0)
+                    v.copy_(v0)
+        if self._graph:
+            self._graph = None
+            self.enable_graph(self._capacity)
+        return n_add, n_prune
+
+    def _any_moments(self, p):
+        """Adam moments of any parameter of the bucket, whichever optimiser holds it."""
+        if self.opt_deform is None:
+            return self.opt_surfels.moments(p)
+        for opt in (self.opt_surfels, self.opt_deform):
+            st = opt.state.get(p, None)
+            if st:
+                return st["exp_avg"], st["exp_avg_sq"]
+        return None, None
+
     def _param_moments(self, p):
         if self.opt_deform is None:
             return self.opt_surfels.moments(p)

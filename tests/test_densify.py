@@ -189,3 +189,53 @@ def test_replicas_stay_identical_through_densification_two_ranks_gloo():
         assert p.exitcode == 0
     assert same
     assert counts[0] + counts[1] > 0 and alive == 200 + counts[0] + counts[1] - counts[2]
+
+
+def test_node_densification_matches_reference():
+    """ControlNodes.densify_nodes against the imported reference's ControlNodeWarp.densify (make_node_densify_golden.py):
+    importance, new nodes at the weighted means, pruned orphans, Adam moments of the three node parameters."""
+    from dgs_amd.deform import ControlNodes
+    g = np.load(os.path.join(os.path.dirname(GOLD), "node_densify_golden.npz"))
+    t = lambda k: torch.from_numpy(g[k].copy())
+    d = ControlNodes(node_num=48, K=3, hyper_dim=8, local_frame=True)
+    with torch.no_grad():
+        d.nodes.copy_(t("pre_nodes")); d._node_radius.copy_(t("pre__node_radius")); d._node_weight.copy_(t("pre__node_weight"))
+    mom = {id(getattr(d, n)): (t("pre_m_" + n), t("pre_v_" + n)) for n in ("nodes", "_node_radius", "_node_weight")}
+    imp, avg, edges = d.node_importance(t("x"), t("x_grad").norm(dim=-1), t("feature"))
+    np.testing.assert_allclose(imp.numpy(), g["importance"], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(edges.numpy(), g["edge_count"], rtol=2e-5, atol=1e-9)
+    ok = ~np.isnan(g["avg_x"]).any(axis=1)
+    assert np.array_equal(ok, ~avg.isnan().any(dim=1).numpy())
+    np.testing.assert_allclose(avg.numpy()[ok], g["avg_x"][ok], rtol=2e-4, atol=1e-6)
+    n_add, n_prune, new_m = d.densify_nodes(0.0002, t("x"), t("x_grad"), t("feature"), moments=lambda p: mom[id(p)])
+    assert (n_add, n_prune) == (6, 4) and d.node_num == g["post_nodes"].shape[0] == 50
+    for n in ("nodes", "_node_radius", "_node_weight"):
+        np.testing.assert_allclose(getattr(d, n).detach().numpy(), g["post_" + n], rtol=2e-4, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(new_m[n][0].numpy(), g["post_m_" + n], rtol=1e-6, atol=0, err_msg=n)
+        np.testing.assert_allclose(new_m[n][1].numpy(), g["post_v_" + n], rtol=1e-6, atol=0, err_msg=n)
+    # padding to a multiple of 64: the extra nodes are unreachable and come out again at the next call
+    d2 = ControlNodes(node_num=48, K=3, hyper_dim=8, local_frame=True)
+    with torch.no_grad():
+        d2.nodes.copy_(t("pre_nodes")); d2._node_radius.copy_(t("pre__node_radius")); d2._node_weight.copy_(t("pre__node_weight"))
+    d2.densify_nodes(0.0002, t("x"), t("x_grad"), t("feature"), pad_to=64)
+    assert d2.node_num == 64 and torch.equal(d2.nodes.detach()[:50], d.nodes.detach())
+    _, _, idx = d2.nn_weights(t("x"), t("feature"))
+    assert int(idx.max()) < 50
+    res = d2.densify_nodes(1e9, t("x"), torch.zeros_like(t("x_grad")), t("feature"))
+    assert res is not None and res[0] == 0 and res[1] >= 14 and d2.node_num <= 50
+
+
+def test_trainer_densifies_nodes_and_keeps_training(_oracle_backend):
+    surfels, deform, cams, targets, bg = _build(P=200)
+    tr = Trainer(surfels, deform, cams, targets, bg)
+    for _ in range(2):
+        tr.step()
+    with torch.no_grad():
+        deform.nodes[3:6, :3] += 50.0      # orphan three nodes
+    t_before = tr.opt_deform.state[deform.network.linear[0].weight]["exp_avg"].clone()
+    out = tr.densify_nodes(max_grad=1e-7)
+    assert out is not None and out[1] >= 3 and deform.node_num == 32 + out[0] - out[1]
+    assert torch.equal(tr.opt_deform.state[deform.network.linear[0].weight]["exp_avg"], t_before)   # network moments carried over
+    assert tr.opt_deform.state[deform.nodes]["exp_avg"].shape == deform.nodes.shape
+    l = float(tr.step())
+    assert l == l and deform.nodes.grad is not None and deform.nodes.grad.shape == deform.nodes.shape

@@ -81,3 +81,34 @@ def test_fit_end_to_end_with_growth_under_graph(tmp_path):
     surfels, deform = fit_mod.restore(str(tmp_path / "out"), node_num=64)
     assert surfels.get_xyz.shape[0] == tr.surfels.num_surfels
     assert torch.equal(surfels._xyz.detach(), tr.surfels._xyz.detach()[tr.surfels.alive].cpu())
+
+
+def test_node_densification_under_graph():
+    """Node count changes -> bucket / optimiser rebuilt, step re-captured, count padded to a multiple of 64 for the MFMA node
+    MLP; training continues with finite losses and the unreachable padding nodes never selected."""
+    import bench
+    from diff_surfel_rasterization import _C
+    from dgs_amd.deform import ControlNodes
+    dev = torch.device("cuda:0")
+    try:
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2)
+        tr.enable_graph(capacity=40 * 20000)
+        losses = [float(tr.step()) for _ in range(3)]
+        with torch.no_grad():
+            tr.deform.nodes[10:40, :3] += 30.0        # thirty orphans
+        m_before = tr.opt_surfels.moments(tr.surfels._xyz)[0].clone()
+        t_before = float(tr.opt_surfels.t)
+        out = tr.densify_nodes(max_grad=1e9)          # prune only: 1024 - 30 live nodes, padded back to 1024
+        assert out is not None and out[0] == 0 and out[1] >= 30
+        M = tr.deform.node_num
+        assert M % 64 == 0 and M >= 1024 + out[0] - out[1] and tr.deform.can_assemble(tr.surfels)
+        assert torch.equal(tr.opt_surfels.moments(tr.surfels._xyz)[0], m_before) and float(tr.opt_surfels.t) == t_before
+        losses += [float(tr.step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert not _C.read_overflow()
+        assert all(l == l and 0 < l < 10 for l in losses), losses
+        n_live = 1024 + out[0] - out[1]
+        idx = tr.deform._knn_seed
+        assert int(idx.max()) < n_live
+    finally:
+        _C.set_capacity(0)
