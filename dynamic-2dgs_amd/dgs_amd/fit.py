@@ -4,8 +4,9 @@ train step -> in-place densification -> checkpoint files the reference can load.
 The loop is the part of GUI.train_step (train_gui.py:272-432) this build covers: the joint surfel + node-deformation step
 with the normal and distortion regularisers on, densification every `densify_interval` iterations between `densify_from`
 and `densify_until` (size threshold 20 after the first opacity reset), opacity reset every `opacity_reset_interval`
-(arguments/__init__.py:115-122), the one forced node densification / pruning at iteration 10000.  Not here: the node warm-up
-stage, the SH degree ramp, ARAP / flow
+(arguments/__init__.py:115-122), the one forced node densification / pruning at iteration 10000, the SH degree ramp
+(one degree per 1000 iterations from 0).  Not here: the node warm-up
+stage, ARAP / flow
 losses and the GUI.  Learning rates follow the reference's exponential schedules (Trainer(lr_schedule=True)).
 """
 import os
@@ -20,7 +21,7 @@ from .train import Trainer
 
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
-        graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000):
+        graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot)."""
     device = torch.device(device)
@@ -30,7 +31,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     P = scene.xyz.shape[0]
     slots = int(slots or 1.25 * P)
     on_gpu = device.type == "cuda" and rasterizer_cls is None
-    surfels = SurfelModel(scene, packed_sh=on_gpu, capacity=slots).to(device)
+    surfels = SurfelModel(scene, active_sh_degree=0 if oneup_sh_degree_step else 3, packed_sh=on_gpu, capacity=slots).to(device)
     torch.manual_seed(seed)
     deform = ControlNodes(node_num=min(node_num, P), K=3, hyper_dim=8, local_frame=True).to(device)
     deform.init_from_points(surfels.get_xyz.detach()[surfels.alive], fps=True)
@@ -45,6 +46,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     extent = float(data["normalization"]["radius"])
     losses = []
     for it in range(1, iterations + 1):
+        if oneup_sh_degree_step and it % oneup_sh_degree_step == 0:                # train_gui.py:233-235
+            tr.oneup_sh_degree()
         losses.append(tr.step())
         if it < densify_until:                                                     # train_gui.py:410-423
             if it == node_densify_at:       # node_force_densify_prune_step; the periodic variant is off by default in the reference

@@ -440,6 +440,18 @@ class Trainer:
         from . import densify
         densify.reset_opacity(self.surfels, self._moments())
 
+    def oneup_sh_degree(self):
+        """GaussianModel.oneupSHdegree (gaussian_model.py:139-141).  The active degree is an argument of the rasterizer
+        launches, i.e. part of the captured step: re-capture (three times per run at the reference's schedule)."""
+        s = self.surfels
+        if s.active_sh_degree >= s.max_sh_degree:
+            return False
+        s.active_sh_degree += 1
+        if self._graph:
+            self._graph = None
+            self.enable_graph(self._capacity)
+        return True
+
     def grow(self, capacity):
         """Re-allocate the surfel slots (parameters, gradient bucket, Adam moments, statistics) to `capacity` and re-capture
         the step's graphs if they were enabled.  Values, moments and the Adam step count carry over."""

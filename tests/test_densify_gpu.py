@@ -71,7 +71,8 @@ def test_fit_end_to_end_with_growth_under_graph(tmp_path):
     try:
         tr, losses = fit_mod.fit(str(root), str(tmp_path / "out"), iterations=12, device="cuda:0", densify_from=3, densify_interval=4,
                                  opacity_reset_interval=10, densify_grad_threshold=1e-9, slots=3100, node_num=64, num_pts=3000,
-                                 list_capacity=400000, log=logs.append)
+                                 list_capacity=400000, log=logs.append, oneup_sh_degree_step=5)
+        assert tr.surfels.active_sh_degree == 2       # ramped (and re-captured) at iterations 5 and 10
         torch.cuda.synchronize()
         assert not _C.read_overflow()
     finally:

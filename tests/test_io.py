@@ -140,7 +140,8 @@ def test_fit_tiny_scene_end_to_end_and_restore(tmp_path, monkeypatch):
     logs = []
     tr, losses = fit_mod.fit(str(root), str(tmp_path / "out"), iterations=7, device="cpu", densify_from=2, densify_interval=2,
                              opacity_reset_interval=6, densify_grad_threshold=1e-9, slots=260, node_num=16, num_pts=200,
-                             rasterizer_cls=OracleRasterizer, log=logs.append)
+                             rasterizer_cls=OracleRasterizer, log=logs.append, oneup_sh_degree_step=3)
+    assert tr.surfels.active_sh_degree == 2           # iterations 3 and 6
     assert len(losses) == 7 and all(l == l for l in losses) and len(logs) == 2
     assert tr.surfels.num_surfels != 200 and tr.P >= 260
     surfels, deform = fit_mod.restore(str(tmp_path / "out"), node_num=16)
