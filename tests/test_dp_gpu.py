@@ -33,12 +33,17 @@ def _graph_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
-        tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
-        tr.enable_graph(capacity=24 * 20000)   # graph 1 = forward + backward, eager all-reduce, graph 2 = statistics + Adam
+        tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2, slots=30000)
+        tr.enable_graph(capacity=40 * 20000)   # graphs 1a / 1b = forward + backward halves, eager all-reduces, graphs 2a / 2 = updates
         losses = [float(tr.step()) for _ in range(3)]
+        # in-place densification between replays: every rank must perform the same surgery (summed statistics, seeded noise)
+        counts = tr.densify_and_prune(max_grad=2e-5, min_opacity=0.02, extent=5.0, max_screen_size=20, seed=11)
+        assert sum(counts) > 0, counts
+        tr.reset_opacity()
+        losses += [float(tr.step()) for _ in range(2)]
         torch.cuda.synchronize()
         assert not _C.read_overflow()
-        params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
+        params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params] + [tr.surfels.alive.float()]).cpu()
         gp = [torch.zeros_like(params) for _ in range(world)]
         dist.all_gather(gp, params)
         if rank == 0:
