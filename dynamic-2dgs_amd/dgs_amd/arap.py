@@ -1,0 +1,123 @@
+"""As-rigid-as-possible regulariser of the control nodes: ControlNodeWarp.arap_loss
+(utils/time_utils.py:1080-1089) with cal_connectivity_from_points / estimate_rotation / cal_arap_error
+(utils/deform_utils.py:58-110,130-166,177-205) and the landmark schedule of its weight (time_utils.py:485-503,791-792).
+
+It acts on the M control nodes only (M x 2 time samples x 10 neighbours, one batched 3x3 SVD): PyTorch operations on whatever
+device the nodes live on.  Active for iterations < 20000 in the reference (weight 1e-4 -> 1e-5 -> 0); the captured train step
+of this package is the regime after that, so the regulariser runs eagerly (Trainer(arap=True)).
+The random draws of the reference (the time samples, the 512-node subsample) can be passed in, so that results are
+reproducible and comparable with the reference's.
+"""
+import math
+
+import torch
+
+LAMBDA_ARAP_LANDMARKS = (1e-4, 1e-4, 1e-5, 1e-5, 0)
+LAMBDA_ARAP_STEPS = (0, 5000, 10000, 20000, 20001)
+
+
+def landmark_interpolate(landmarks, steps, step):
+    """utils/time_utils.py:485-503, interpolation='log'."""
+    stage = sum(1 for s in steps if step >= s)
+    if stage == len(steps):
+        return max(0, landmarks[-1])
+    if stage == 0:
+        return 0
+    l1, l2 = landmarks[stage - 1], landmarks[stage]
+    if l2 <= 0:
+        return 0
+    ratio = (step - steps[stage - 1]) / (steps[stage] - steps[stage - 1])
+    return math.exp(math.log(l1) * (1 - ratio) + math.log(l2) * ratio)
+
+
+def lambda_arap(iteration):
+    return landmark_interpolate(LAMBDA_ARAP_LANDMARKS, LAMBDA_ARAP_STEPS, iteration)
+
+
+def connectivity_from_points(points, K=10, radius=0.1, least_edge_num=3):
+    """cal_connectivity_from_points, mode 'nn' with adaptive weighting: the K nearest other points of every point; beyond
+    the first `least_edge_num`, neighbours farther than `radius` are dropped.  Returns the edge lists (ii, jj, nn) and the
+    [Nv, K] weights."""
+    Nv = points.shape[0]
+    d = (points[:, None, :] - points[None, :, :]).pow(2).sum(-1)
+    nn_dist, nn_idx = d.topk(min(K + 1, Nv), dim=1, largest=False)
+    nn_dist, nn_idx = nn_dist[:, 1:].clone(), nn_idx[:, 1:].clone()         # without themselves
+    far = nn_dist[:, least_edge_num:] >= radius ** 2
+    nn_idx[:, least_edge_num:] = torch.where(far, torch.full_like(nn_idx[:, least_edge_num:], -1), nn_idx[:, least_edge_num:])
+    nn_dist[:, least_edge_num:] = torch.where(far, torch.full_like(nn_dist[:, least_edge_num:], float("inf")), nn_dist[:, least_edge_num:])
+    weight = torch.exp(-nn_dist / nn_dist.mean())
+    weight = weight / weight.sum(dim=-1, keepdim=True)
+    Kn = nn_idx.shape[1]
+    ii = torch.arange(Nv, device=points.device)[:, None].expand(Nv, Kn).reshape(-1)
+    jj = nn_idx.reshape(-1)
+    nn = torch.arange(Kn, device=points.device)[None].expand(Nv, Kn).reshape(-1)
+    mask = jj != -1
+    return ii[mask], jj[mask], nn[mask], weight
+
+
+def edge_matrix(verts, shape, ii, jj, nn):
+    """produce_edge_matrix_nfmt: E[i, n] = p_i - p_(J[n])."""
+    E = torch.zeros(shape, dtype=verts.dtype, device=verts.device)
+    E[ii, nn] = verts[ii] - verts[jj]
+    return E
+
+
+@torch.no_grad()
+def estimate_rotation(source, target, ii, jj, nn, K, weight, sample_idx):
+    """Per-node best-fit rotation source edges -> target edges (weighted Procrustes through a batched SVD)."""
+    Nv = source.shape[0]
+    src = edge_matrix(source, (Nv, K, 3), ii, jj, nn)[sample_idx]
+    tgt = edge_matrix(target, (Nv, K, 3), ii, jj, nn)[sample_idx]
+    S = torch.bmm(src.permute(0, 2, 1), weight[..., None] * tgt)
+    unchanged = torch.unique(torch.where((src == tgt).all(dim=1))[0])
+    S[unchanged] = 0
+    U, sig, W = torch.svd(S)
+    R = torch.bmm(W, U.permute(0, 2, 1))
+    flip = torch.nonzero(torch.det(R) <= 0, as_tuple=False).flatten()
+    if flip.numel() > 0:
+        Umod = U.clone()
+        cols = torch.argmin(sig[flip], dim=1)
+        Umod[flip, :, cols] *= -1
+        R[flip] = torch.bmm(W[flip], Umod[flip].permute(0, 2, 1))
+    return R
+
+
+def arap_error(nodes_sequence, ii, jj, nn, K=10, sample_num=512, sample_idx=None, generator=None):
+    """cal_arap_error with unit edge weights: sum over the later frames of | target edges - R source edges |^2 for (a
+    subsample of) the nodes.  nodes_sequence [Nt, Nv, 3]."""
+    Nt, Nv, _ = nodes_sequence.shape
+    dev = nodes_sequence.device
+    weight = torch.zeros(Nv, K, dtype=nodes_sequence.dtype, device=dev)
+    weight[ii, nn] = 1
+    if sample_idx is None:
+        if Nv > sample_num:   # with replacement, like np.random.choice
+            sample_idx = torch.randint(0, Nv, (sample_num,), generator=generator, device=dev)
+        else:
+            sample_idx = torch.arange(Nv, device=dev)
+    src = edge_matrix(nodes_sequence[0], (Nv, K, 3), ii, jj, nn)[sample_idx]
+    weight = weight[sample_idx]
+    err = nodes_sequence.new_zeros(())
+    for t in range(1, Nt):
+        R = estimate_rotation(nodes_sequence[0], nodes_sequence[t], ii, jj, nn, K, weight, sample_idx)
+        tgt = edge_matrix(nodes_sequence[t], (Nv, K, 3), ii, jj, nn)[sample_idx]
+        rigid = torch.bmm(R, src.permute(0, 2, 1)).permute(0, 2, 1)
+        err = err + (weight * (tgt - rigid).norm(dim=2) ** 2).sum()
+    return err
+
+
+def arap_loss(deform, t=None, delta_t=0.05, t_samp_num=2, t_samp=None, sample_idx=None, generator=None):
+    """ControlNodeWarp.arap_loss: node positions at `t_samp_num` random times within delta_t of t (or of a random time),
+    connectivity from the first sample, ARAP error of the later samples against it."""
+    nodes = deform.nodes
+    dev = nodes.device
+    M = nodes.shape[0]
+    if t_samp is None:
+        rnd = lambda *s: torch.rand(*s, generator=generator, device=dev)
+        t0 = rnd([]) if t is None else t.reshape(-1)[0] + delta_t * (rnd([]) - 0.5)
+        t_samp = rnd(t_samp_num) * delta_t + t0 - 0.5 * delta_t
+    T = t_samp.shape[0]
+    x = nodes[:, None, :3].detach().expand(M, T, 3).reshape(-1, 3)
+    d_xyz = deform.network(x, t_samp[None, :, None].expand(M, T, 1).reshape(-1, 1))["d_xyz"].view(M, T, 3)
+    nodes_t = nodes[:, None, :3].detach() + d_xyz
+    ii, jj, nn, _ = connectivity_from_points(nodes_t[:, 0], K=10)
+    return arap_error(nodes_t.permute(1, 0, 2), ii, jj, nn, sample_idx=sample_idx, generator=generator)

@@ -6,8 +6,8 @@ with the normal and distortion regularisers on, densification every `densify_int
 and `densify_until` (size threshold 20 after the first opacity reset), opacity reset every `opacity_reset_interval`
 (arguments/__init__.py:115-122), the one forced node densification / pruning at iteration 10000, the SH degree ramp
 (one degree per 1000 iterations from 0).  Not here: the node warm-up
-stage, ARAP / flow
-losses and the GUI.  Learning rates follow the reference's exponential schedules (Trainer(lr_schedule=True)).
+stage, the flow losses and the GUI.  `arap=True` adds the control nodes' ARAP regulariser with the reference's weight schedule
+(the step then runs eagerly until the weight reaches zero at iteration 20001, and captured from there).  Learning rates follow the reference's exponential schedules (Trainer(lr_schedule=True)).
 """
 import os
 
@@ -21,7 +21,8 @@ from .train import Trainer
 
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
-        graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000):
+        graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
+        arap=False):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot)."""
     device = torch.device(device)
@@ -38,10 +39,13 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     cams = [f.camera.to(device) for f in data["train"]]
     targets = [f.image.to(device).contiguous() for f in data["train"]]
     bg = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], device=device)
-    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True)
+    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True, arap=arap)
     if graph is None:
         graph = on_gpu
-    if graph:
+    tr.arap_from = 3000                                                # opt.warm_up (arguments/__init__.py:102)
+    from .arap import LAMBDA_ARAP_STEPS
+    graph_from = LAMBDA_ARAP_STEPS[-1] if (arap and graph) else 0      # the regulariser runs eagerly while its weight is non-zero
+    if graph and not graph_from:
         tr.enable_graph(int(list_capacity or 96 * slots))
     extent = float(data["normalization"]["radius"])
     losses = []
@@ -49,6 +53,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
         if oneup_sh_degree_step and it % oneup_sh_degree_step == 0:                # train_gui.py:233-235
             tr.oneup_sh_degree()
         losses.append(tr.step())
+        if graph_from and it == graph_from - 1:
+            tr.enable_graph(int(list_capacity or 96 * tr.P))
         if it < densify_until:                                                     # train_gui.py:410-423
             if it == node_densify_at:       # node_force_densify_prune_step; the periodic variant is off by default in the reference
                 counts = tr.densify_nodes(densify_grad_threshold)

@@ -109,8 +109,12 @@ class Trainer:
     SCHED_DEFORM = (0.00016 * 5, 0.0000016, 40_000)
 
     def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=LATE_DEFORM_LR, position_lr=LATE_POSITION_LR,
-                 fused_adam=None, rasterizer_cls=None, lr_schedule=False):
+                 fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False):
         self.surfels, self.deform = surfels, deform
+        # ARAP regulariser of the control nodes with the reference's weight schedule (dgs_amd/arap.py; non-zero for
+        # iterations < 20000).  Eager only: it draws random times and runs a batched SVD, neither belongs in a captured step.
+        self.arap = bool(arap)
+        self.arap_from = 0   # first iteration that adds it (the reference: after opt.warm_up = 3000, train_gui.py:315)
         self.lr_schedule = bool(lr_schedule)
         if lr_schedule:
             position_lr, deform_lr = self.SCHED_POSITION[0], self.SCHED_DEFORM[0]
@@ -190,6 +194,9 @@ class Trainer:
         import os
         from diff_surfel_rasterization import _C
         assert self.rasterizer_cls is None and self.opt_deform is None, "graph capture is for the HIP operator with the flat Adam kernel"
+        if self.arap:
+            from .arap import lambda_arap
+            assert lambda_arap(self.iteration + 1) == 0, "the ARAP regulariser is still active: capture the step after iteration 20000"
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
             # ROCm 7.2: the AQL-packet-capture replay path intermittently runs the step's memset nodes out of order
             # (observed: an L1 loss term of exactly 0, 1e18 gradients).  The knob is read when the HIP runtime starts.
@@ -288,6 +295,13 @@ class Trainer:
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
                          postprocess=not fused)
         loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt) if fused else training_loss(pkg, gt)
+        if self.arap:
+            from . import arap
+            lam = arap.lambda_arap(self.iteration)       # train_gui.py:315-316, utils/time_utils.py:1228-1232
+            if lam > 0 and self.iteration > self.arap_from:
+                if getattr(self, "_arap_gen", None) is None:
+                    self._arap_gen = torch.Generator(device=s.get_xyz.device).manual_seed(1234 + self.rank)
+                loss = loss + lam * arap.arap_loss(d, generator=self._arap_gen)
         if fused and getattr(self, "_unit", None) is None:
             self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
         return loss, pkg, asm, fused

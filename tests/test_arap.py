@@ -1,0 +1,77 @@
+"""dgs_amd.arap against the imported reference's ControlNodeWarp.arap_loss (tests/golden/make_arap_golden.py): loss value and
+its gradient, with and without the 512-node subsample; the weight schedule."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from dgs_amd import arap
+from dgs_amd.deform import ControlNodes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_deform_golden import fill_params  # noqa: E402
+
+
+def _model(g, tag):
+    M = g[tag + "_nodes"].shape[0]
+    d = ControlNodes(node_num=M, K=3, hyper_dim=8, local_frame=True)
+    fill_params(d)
+    with torch.no_grad():
+        d.network.gaussian_warp.weight.mul_(50.0)
+        d.nodes.copy_(torch.from_numpy(g[tag + "_nodes"].copy()))
+    return d
+
+
+def test_arap_loss_matches_reference():
+    g = np.load(os.path.join(HERE, "golden", "arap_golden.npz"))
+    for tag in ("small", "large"):
+        d = _model(g, tag)
+        idx = torch.from_numpy(g[tag + "_sample_idx"].copy()).long() if tag + "_sample_idx" in g else None
+        loss = arap.arap_loss(d, t_samp=torch.from_numpy(g[tag + "_t_samp"].copy()), sample_idx=idx)
+        assert abs(float(loss) - float(g[tag + "_loss"])) <= 2e-4 * float(g[tag + "_loss"]), (tag, float(loss), float(g[tag + "_loss"]))
+        loss.backward()
+        got, want = d.network.gaussian_warp.weight.grad.numpy(), g[tag + "_grad_warp"]
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), tag
+    assert "large_sample_idx" in g and "small_sample_idx" not in g
+
+
+def test_arap_loss_draws_its_own_samples():
+    g = np.load(os.path.join(HERE, "golden", "arap_golden.npz"))
+    d = _model(g, "large")
+    gen = torch.Generator().manual_seed(5)
+    a = arap.arap_loss(d, t=torch.tensor([0.4]), generator=gen)
+    b = arap.arap_loss(d, t=torch.tensor([0.4]), generator=torch.Generator().manual_seed(5))
+    c = arap.arap_loss(d, generator=gen)
+    assert float(a) == float(b) and float(a) > 0 and float(c) > 0 and float(c) != float(a)
+
+
+def test_lambda_arap_schedule_matches_reference():
+    g = np.load(os.path.join(HERE, "golden", "arap_golden.npz"))
+    for s, want in zip(g["lambda_steps"], g["lambda_arap"]):
+        assert abs(arap.lambda_arap(int(s)) - want) <= 1e-12 * max(want, 1e-30), (s, want)
+
+
+def test_trainer_adds_the_weighted_arap_term(monkeypatch):
+    import dgs_amd.render as render_mod
+    from dgs_amd.train import Trainer
+    from oracle_raster_op import OracleRasterizer
+    from test_train_step_cpu import _build
+    monkeypatch.setattr(render_mod, "GaussianRasterizer", OracleRasterizer)
+    res = {}
+    for on in (False, True):
+        surfels, deform, cams, targets, bg = _build(P=120, S=32, nodes=24, views=2)
+        tr = Trainer(surfels, deform, cams, targets, bg, arap=on)
+        tr.iteration = 100                      # lambda = 1e-4
+        tr.opt_surfels.step = lambda: None
+        tr.opt_deform.step = lambda: None
+        loss = float(tr.step())
+        res[on] = (loss, deform.network.gaussian_warp.weight.grad.clone(), deform)
+    d = res[True][2]
+    term = 1e-4 * float(arap.arap_loss(d, generator=torch.Generator().manual_seed(1234)))
+    assert term > 0 and abs((res[True][0] - res[False][0]) - term) <= 1e-6 * abs(res[True][0]) + 1e-3 * term
+    assert not torch.equal(res[True][1], res[False][1])
+    # weight zero after iteration 20000: the term vanishes
+    tr.iteration = 25000
+    assert arap.lambda_arap(tr.iteration) == 0
