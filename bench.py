@@ -78,6 +78,28 @@ def blend_bytes(S_per_launch, ntiles, HW, backward):
     return b
 
 
+def measured_hbm_ceiling(device, mib=1024, iters=20):
+    """What this box's HBM actually delivers to a trivially streaming kernel (SURVEY.md section 8d asks for it next to the vendor
+    peak): device-to-device copy (read + write) and the triad a = b + s*c (two reads + one write) over `mib` MiB buffers, far
+    beyond the 256 MB Infinity Cache."""
+    n = mib * (1 << 20) // 4
+    a, b, c = (torch.empty(n, dtype=torch.float32, device=device).fill_(v) for v in (0.0, 1.0, 2.0))
+    out = {}
+    for name, fn, nbuf in (("copy", lambda: a.copy_(b), 2), ("triad", lambda: torch.add(b, c, alpha=0.5, out=a), 3)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(nbuf * n * 4 * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(P, H, W, budget_s=25.0):
     """The oracle-backed CPU port of the same train step, bounded sample (about 10-30 s of CPU work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -234,6 +256,14 @@ def main():
             out["densify"] = {"every": args.densify_every, "calls": len(densify_ms), "ms_per_call": [round(m, 3) for m in densify_ms],
                               "cloned_split_pruned": [list(map(int, c)) for c in densify_counts], "slots": tr.P,
                               "surfels_after": tr.surfels.num_surfels, "recaptured": tr.P != int(args.slots_factor * P)}
+        try:
+            ceil = measured_hbm_ceiling(device)
+            for r in (out["roofline"], out["roofline_fwd"]):
+                if r:
+                    r["measured_hbm_ceiling"] = {"copy_GBs": ceil["copy"], "triad_GBs": ceil["triad"],
+                                                 "method": "torch d2d copy / triad over 1 GiB fp32 buffers, 20 iterations, HIP events"}
+        except Exception as ex:   # never lose the result line over the side measurement
+            print("warning: HBM ceiling measurement failed: %r" % (ex,), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             del tr
             torch.cuda.empty_cache()
