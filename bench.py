@@ -46,6 +46,7 @@ WORKLOADS = {
     "c3": (150_000, 800, 800),
     "c4": (300_000, 800, 800),
     "c5": (1_000_000, 1600, 1600),
+    "c2": (50_000, 800, 800),          # BASELINE.json configs[1]: static canonical render, FORWARD ONLY, no deformation
     "tiny": (5_000, 128, 128),
 }
 
@@ -123,6 +124,54 @@ def cpu_baseline(P, H, W, budget_s=25.0):
             "sample": "%d full train steps (views) of the same %dk-surfel %dx%d workload, %.1f s" % (n, P // 1000, W, H, dt)}
 
 
+def forward_only(args, P, H, W, device):
+    """configs[1] of BASELINE.json: static canonical surfels rendered forward-only through the operator surface
+    (GaussianRasterizer), one view per step, eager launches.  Same JSON contract; the roofline object is the forward blend."""
+    import math
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    from dgs_amd.cameras import orbit_cameras
+    from dgs_amd.synthetic import activated, make_scene
+    xyz, scales, rots, opac, shs = (t.to(device) for t in activated(make_scene(P, seed=0)))
+    bg = torch.zeros(3, device=device)
+    rasts = []
+    for cam in orbit_cameras(64, W, H):
+        cam = cam.to(device)
+        rasts.append(GaussianRasterizer(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0,
+            viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center,
+            prefiltered=False, debug=False)))
+    m2 = torch.zeros_like(xyz)
+
+    def step(i):
+        with torch.no_grad():
+            return rasts[i % len(rasts)](means3D=xyz, means2D=m2, opacities=opac, shs=shs, scales=scales, rotations=rots)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    _C.profile_enable(True)
+    _C.profile_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = _C.profile_read()
+    _C.profile_enable(False)
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    n, ms, S = prof["fwd_n"], prof["fwd_ms"], prof["fwd_S"]
+    bytes_per = blend_bytes(S / max(n, 1), ntiles, H * W, backward=False)
+    gbs = bytes_per / (ms / max(n, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
+    out = {"metric": "render views/sec (fwd only), %dx%d, %dk surfels" % (W, H, P // 1000), "value": round(args.steps / dt, 3), "unit": "views/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "c2: static canonical render of S(%d surfels, %dx%d, seed 0), forward only, no deformation" % (P, W, H),
+                      "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "launch": "eager, through GaussianRasterizer.forward"},
+           "roofline": {"bound": "hbm", "kernel": "blend_fwd_kernel", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "timing": "HIP events on the launch stream, the timed steps themselves",
+                        "avg_kernel_ms": round(ms / max(n, 1), 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S / max(n, 1))}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +200,10 @@ def main():
 
     from diff_surfel_rasterization import _C
     P, H, W = WORKLOADS[args.workload]
+    if args.workload == "c2":
+        if world > 1:
+            raise SystemExit("--workload c2 is the single-GPU forward-only case")
+        return forward_only(args, P, H, W, device)
     # wake the device up (clocks, allocator) before anything is timed: fresh boxes occasionally ran the first
     # second of work several times slower
     _a = torch.randn(4096, 4096, device=device)

@@ -222,3 +222,17 @@ def test_long_tile_lists_use_all_sort_paths():
     assert hip["R"] == orc.num_rendered
     assert np.array_equal(hip["point_list"], orc.field("point_list"))
     frac_close(hip["color"], orc.color, 2e-5, 1e-5, 5e-4, 2e-2, "color")  # 96x96 image: one flipped pixel is 1.1e-4
+
+
+def test_config_c2_static_forward_only_50k_800():
+    """BASELINE.json configs[1]: static canonical render, 50 k surfels, 800x800, forward only -- every output against the
+    oracle at the stated tolerance (colour |err| <= 2e-5 on all but 1e-4 of the pixels, i.e. PSNR > 90 dB), radii exact."""
+    from gpu_utils import frac_close, run_hip
+    case = small_case(P=50000, H=800, W=800, seed=0, view=11, n_views=64)
+    orc = oracle_from_case(case)
+    hip = run_hip(case, debug=False)
+    assert float((hip["radii"] != orc.radii).mean()) <= 1e-4
+    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
+    frac_close(hip["allmap"], orc.allmap, 1e-4, 5e-5, 1e-4, 2e-1, "allmap")
+    mse = float(((hip["color"] - orc.color) ** 2).mean())
+    assert mse < 1e-9      # PSNR > 90 dB for a [0, 1] image
