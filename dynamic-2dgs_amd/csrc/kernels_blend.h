@@ -1,7 +1,7 @@
 // kernels_blend.h -- per-tile forward and backward alpha blend for gfx950.
 //
-// One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 8x8 pixel quadrant (see lane_pixel)
-// rows 4w..4w+3, so all 64 lanes of a wave consume the same staged surfel at the same time.
+// One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 8x8 pixel quadrant (w & 1, w >> 1) of the
+// tile (surfel_math.h lane_pixel), so all 64 lanes of a wave consume the same staged surfel at the same time.
 // The tile's depth-sorted list is consumed in batches of 256 entries whose packed 96-B records are gathered
 // into LDS as five float4 planes (20 KB; the sixth quad, the surfel's exact pixel bounding box, is consumed at
 // staging time: each entry is tested against the four 8x8 quadrants and the four per-quadrant ballots become 64-bit
@@ -274,11 +274,21 @@ struct BlendBwdArgs {
     float* acc;               // [P, kAccFloats], zeroed
 };
 
-// Reduce 16 per-lane values over the 64 lanes of a wave with a halving butterfly: 8+4+2+1 exchanges
-// bring value k to the lanes with (lane >> 2) == k, two more finish the quad.  17 cross-lane ops
-// instead of 16 * 6.  The exchanges are ds_bpermute on purpose: the kernel is VALU-bound and the LDS pipe is idle, a
-// VALU-only variant (v_permlane32/16_swap + DPP adds, 38 instructions) measured 5 % slower end to end.  On return every lane of quad k holds the wave total of v[k].
-__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane)
+// ---- wave reduction of the 16 per-surfel partials of one (wave, entry) visit --------------------------------------------
+// DGS_BWD_REDUCE selects the implementation (A/B builds; the default is the measured best):
+//   0  halving butterfly on the LDS crossbar: 17 ds_bpermute + 30 v_cndmask + 17 v_add (round-1 kernel),
+//   1  matrix pipe: 16 x v_mfma_f32_16x16x4_f32 (exact fp32) with the partial as the A operand and a one-hot column
+//      selector as B:  D[i][n] += sum_k v_n[lane 16 k + i]  -- one instruction folds the four 16-lane rows of value n into
+//      column n of ONE 16x16 accumulator, so after the 16 instructions lane (q, n) holds four row sums of value n; three
+//      adds and two cross-row exchanges finish.  The blend kernels issue no other MFMA, the pipe is otherwise idle,
+//   2  hybrid: v_permlane32_swap folds the two wave halves first (values n and n + 8 share a register), then 8 MFMAs.
+// On return lane l holds the wave total of v[l & 15] (variants 1, 2) / v[l >> 2] (variant 0); reduce16_slot() tells which.
+#ifndef DGS_BWD_REDUCE
+#define DGS_BWD_REDUCE 3
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_reduce16_butterfly(float (&v)[16], int lane)
 {
     float a8[8], a4[4], a2[2], a1;
     const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
@@ -310,6 +320,107 @@ __device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane)
     return a1;
 }
 
+__device__ __forceinline__ float mfma_rows_finish(const f32x4_t& d0, const f32x4_t& d1)
+{
+    float p = ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
+    p += __shfl_xor(p, 16, 64);
+    p += __shfl_xor(p, 32, 64);
+    return p;
+}
+
+__device__ __forceinline__ float wave_reduce16_mfma(float (&v)[16], int lane)
+{
+    // two accumulators (even / odd columns) so that consecutive MFMAs do not wait for each other's result
+    f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    const int col = lane & 15;
+#pragma unroll
+    for (int n = 0; n < 16; n += 2) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[n], col == n ? 1.f : 0.f, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[n + 1], col == n + 1 ? 1.f : 0.f, d1, 0, 0, 0);
+    }
+    return mfma_rows_finish(d0, d1);
+}
+
+__device__ __forceinline__ float wave_reduce16_hybrid(float (&v)[16], int lane)
+{
+    f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    const int col = (lane & 15) - ((lane & 32) >> 2);   // lanes 32..63 carry value n + 8 in register n
+#pragma unroll
+    for (int n = 0; n < 8; n += 2) {
+        float h[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            // after the swap x = (lower half of v[n], lower half of v[n+8]), y = (upper half of v[n], upper half of v[n+8])
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[n + u]), __float_as_uint(v[n + u + 8]), false, false);
+            h[u] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h[0], col == n ? 1.f : 0.f, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h[1], col == n + 1 ? 1.f : 0.f, d1, 0, 0, 0);
+    }
+    return mfma_rows_finish(d0, d1);
+}
+
+// Variant 3: no LDS crossbar at all.  v_permlane32_swap / v_permlane16_swap fold the wave halves and the row pairs (after
+// them row r holds value i + 4 r in register i), then DPP adds with bank-masked writes fold a 16-lane row: row_mirror
+// (lane l + lane 15-l -> lanes 0..7 keep registers 0,1, lanes 8..15 registers 2,3), row_half_mirror, two quad permutes.
+// Any pairing works for a sum; the mirrors are the ones DPP offers across 8 and 4 lanes.  On return every lane of quad k
+// holds the wave total of v[k] (same as variant 0).
+__device__ __forceinline__ float wave_reduce16_dpp(float (&v)[16], int lane)
+{
+    float h[8], g[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+        h[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[i]), __float_as_uint(h[i + 4]), false, false);
+        g[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    float f0, f1, e;
+    // s_nop: a DPP source written by the previous VALU instruction needs two wait states (the assembler does not insert them)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(f0), "=&v"(f1), "=&v"(e)
+        : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
+    return e;
+}
+
+__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane)
+{
+#if DGS_BWD_REDUCE == 3
+    return wave_reduce16_dpp(v, lane);
+#elif DGS_BWD_REDUCE == 0
+    return wave_reduce16_butterfly(v, lane);
+#elif DGS_BWD_REDUCE == 1
+    return wave_reduce16_mfma(v, lane);
+#else
+    return wave_reduce16_hybrid(v, lane);
+#endif
+}
+
+// which of the 16 values lane `lane` holds after wave_reduce16, or -1 if the lane holds a duplicate
+__device__ __forceinline__ int reduce16_slot(int lane)
+{
+#if DGS_BWD_REDUCE == 0 || DGS_BWD_REDUCE == 3
+    return (lane & 3) == 0 ? (lane >> 2) : -1;
+#else
+    return lane < 16 ? lane : -1;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -317,7 +428,10 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-__global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a)  // 4 waves/SIMD: keeps the allocator at <= 128 VGPRs
+#ifndef DGS_BWD_MINWAVES
+#define DGS_BWD_MINWAVES 4
+#endif
+__global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
 {
     __shared__ float4 s_rec[kStagedQuads][kBatch];
     __shared__ uint32_t s_id[kBatch];
@@ -365,6 +479,7 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
         wave_last = o > wave_last ? o : wave_last;
     }
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);  // uniform by construction: keeps the entry masks below in SGPRs
+    const int rslot = reduce16_slot(lane);
 
     const int rounds = (L + kBatch - 1) / kBatch;
     for (int b = 0; b < rounds; b++) {
@@ -405,23 +520,16 @@ __global__ void __launch_bounds__(kTilePix, 4) blend_bwd_kernel(BlendBwdArgs a) 
                 PairEval ev;
                 const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), ev) && (e < st.last_contributor);
                 if (__ballot(ok) == 0ull) return;
-                float out[kAccFloats];
-#pragma unroll
-                for (int k = 0; k < 18; k++) out[k] = 0.f;
-                bool flat = false;
-                if (ok) {
-                    pixbwd_step(st, ev, e, pfx, pfy, as_quad(q1), as_quad(q2), as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]), out);
-                    flat = !ev.use3d;
-                }
-                float* dst = a.acc + (size_t)s_id[jc] * kAccFloats;
-                float v16[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) v16[k] = out[k];
-                const float tot = wave_reduce16(v16, lane);
-                if ((lane & 3) == 0) atomicAdd(dst + (lane >> 2), tot);
-                if (__ballot(flat) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
-                    const float mx = wave_sum(out[kAccMean2D + 0]);
-                    const float my = wave_sum(out[kAccMean2D + 1]);
+                // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step)
+                float out[16], out2d[2];
+                pixbwd_step(st, ev, ok, e, pfx, pfy, as_quad(q1), as_quad(q2), as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]), out, out2d);
+                // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
+                float* dst = a.acc + (size_t)__builtin_amdgcn_readfirstlane(s_id[jc]) * kAccFloats;
+                const float tot = wave_reduce16(out, lane);
+                if (rslot >= 0) atomicAdd(dst + rslot, tot);
+                if (__ballot(ok && !ev.use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                    const float mx = wave_sum(out2d[0]);
+                    const float my = wave_sum(out2d[1]);
                     if (lane == 0) { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
                 }
             };

@@ -464,15 +464,18 @@ DGS_HD bool pixfwd_blend(PixFwd& s, const PairEval& e, const Quad& q3, const Qua
     return true;
 }
 
-// Running per-pixel state of the backward blend (backward.cu:191-247).
+// Running per-pixel state of the backward blend (backward.cu:191-247), reduced to what the recurrences need.
+//
+// The reference carries eight "colour behind this entry" recurrences (accum_rec[3], accum_depth_rec, accum_alpha_rec,
+// accum_normal_rec[3]) plus last_dL_dT, each with its own `last_*` value, and adds (value_i - accum_i) * g per channel
+// into dL_dalpha.  All nine follow the same linear blend  X <- a_prev * value_prev + (1 - a_prev) * X  (last_dL_dT is the
+// same recurrence folded one entry early), so their g-weighted sum follows it too: with
+//     u_i = colour_i . g_pix + depth_i g_depth + g_alpha + normal_i . g_normal + dL_dweight_i
+// one scalar `acc` replaces the fifteen state values:  dL_dalpha_i = (u_i - acc) T_i + background term,
+// acc <- acc + alpha_i (u_i - acc).  Same mathematics, different rounding order (not bit-identical to the oracle).
 struct PixBwd {
     float T, T_final;
-    float last_alpha;
-    float accum_rec[3], last_color[3];
-    float accum_depth_rec, last_depth;
-    float accum_alpha_rec;
-    float accum_normal_rec[3], last_normal[3];
-    float last_dL_dT;
+    float acc;           // sum over channels of g * "what lies behind the current entry" (see above)
     float final_D, final_D2, final_A;
     float g_pix[3];      // dL/dcolour
     float g_depth, g_alpha, g_normal[3], g_meddepth, g_dist, g_medw;
@@ -484,10 +487,8 @@ DGS_HD void pixbwd_init(PixBwd& s, float T_final, float dist1, float dist2, int 
                         const float* gothers /*8*/, const float* bg)
 {
     s.T = s.T_final = T_final;
-    s.last_alpha = 0.f;
-    for (int c = 0; c < 3; c++) { s.accum_rec[c] = s.last_color[c] = 0.f; s.accum_normal_rec[c] = s.last_normal[c] = 0.f; s.g_pix[c] = gpix[c]; }
-    s.accum_depth_rec = s.last_depth = s.accum_alpha_rec = 0.f;
-    s.last_dL_dT = 0.f;
+    s.acc = 0.f;
+    for (int c = 0; c < 3; c++) s.g_pix[c] = gpix[c];
     s.final_D = dist1; s.final_D2 = dist2; s.final_A = 1.f - T_final;
     s.g_depth = gothers[0]; s.g_alpha = gothers[1];
     s.g_normal[0] = gothers[2]; s.g_normal[1] = gothers[3]; s.g_normal[2] = gothers[4];
@@ -496,75 +497,55 @@ DGS_HD void pixbwd_init(PixBwd& s, float T_final, float dist1, float dist2, int 
     s.last_contributor = last; s.med_c = med_c;
 }
 
-// backward.cu:325-446 for one contributing entry (`contributor` = 0-based list index).
-// Writes this pixel's 18 partial derivatives into out[kAccFloats] (slots of AccSlot).
-DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, int contributor, float pfx, float pfy, const Quad& q1, const Quad& q2,
-                        const Quad& q3, const Quad& q4, float* out)
+// backward.cu:325-446 for one list entry (`contributor` = 0-based list index), branch-free: `ok` says whether this pixel
+// blends the entry (alpha test passed and the entry lies in front of the pixel's last contributor).  A pixel that does
+// not blend it runs the same instructions on neutral values (alpha = G = 0, depth = 1, s = 0) and leaves its state and
+// all sixteen outputs exactly unchanged / zero -- so a wave needs no divergent region, no zero-filled outputs for idle
+// lanes and no register copies at the join.  The rho2d <= rho3d case (backward.cu:436-443) is folded in the same way:
+// s = 0 and 1/p.z = 0 reduce the 3-D formulas to dL_dT[8] += dL_dz, and the screen-space gradient goes to out2d.
+//   out[0..2] dL_dcolour, out[3..5] dL_dnormal, out[6..14] dL_dtransMat, out[15] dL_dopacity (AccSlot order), out2d = dL_dmean2D.
+// dL_dk = cross(l, dL_dp) and dL_dl = cross(dL_dp, k) of the reference are parallel to (s.x, s.y, 1) because dL_dp, k and
+// l are all orthogonal to p = k x l: dL_dk = (l.x dp.y - l.y dp.x) (s, 1), dL_dl = (dp.x k.y - dp.y k.x) (s, 1).
+DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, bool ok, int contributor, float pfx, float pfy, const Quad& q1, const Quad& q2,
+                        const Quad& q3, const Quad& q4, float* out /*[16]*/, float* out2d /*[2]*/)
 {
-    const float alpha = e.alpha, G = e.G;
-    const float one_m_a = 1.f - alpha;
-    const float inv_1ma = fast_rcp(one_m_a);  // alpha <= 0.99: well conditioned
+    const bool m3 = ok & e.use3d;
+    const float alpha = ok ? e.alpha : 0.f;
+    const float G = ok ? e.G : 0.f;
+    const float c_d = ok ? e.depth : 1.f;
+    const float sx = m3 ? e.sx : 0.f, sy = m3 ? e.sy : 0.f, inv_pz = m3 ? e.inv_pz : 0.f;
+    const float inv_1ma = ok ? fast_rcp(1.f - alpha) : 1.f;  // alpha <= 0.99: well conditioned
     s.T = s.T * inv_1ma;
     const float w = alpha * s.T;
-    const float col[3] = {q3.w, q4.x, q4.y};
-    const float nrm[3] = {q3.x, q3.y, q3.z};
-    float dL_dalpha = 0.f;
-    for (int c = 0; c < 3; c++) {
-        s.accum_rec[c] = s.last_alpha * s.last_color[c] + (1.f - s.last_alpha) * s.accum_rec[c];
-        s.last_color[c] = col[c];
-        dL_dalpha += (col[c] - s.accum_rec[c]) * s.g_pix[c];
-        out[kAccColor + c] = w * s.g_pix[c];
-    }
-    float dL_dz = 0.f, dL_dweight = 0.f;
-    const float c_d = e.depth;
     const float r_d = fast_rcp(c_d);
     const float m_d = mapped_depth_r(c_d, r_d);
     const float dmd_dd = (20.0f / 99.8f) * (r_d * r_d);
-    if (contributor == s.med_c - 1) { dL_dz += s.g_meddepth; dL_dweight += s.g_medw; }
-    dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2.f * m_d * s.final_D) * s.g_dist;
-    dL_dalpha += dL_dweight - s.last_dL_dT;
-    s.last_dL_dT = dL_dweight * alpha + one_m_a * s.last_dL_dT;
-    const float dL_dmd = 2.0f * w * (m_d * s.final_A - s.final_D) * s.g_dist;
-    dL_dz += dL_dmd * dmd_dd;
-    s.accum_depth_rec = s.last_alpha * s.last_depth + (1.f - s.last_alpha) * s.accum_depth_rec;
-    s.last_depth = c_d;
-    dL_dalpha += (c_d - s.accum_depth_rec) * s.g_depth;
-    s.accum_alpha_rec = s.last_alpha + (1.f - s.last_alpha) * s.accum_alpha_rec;
-    dL_dalpha += (1.f - s.accum_alpha_rec) * s.g_alpha;
-    for (int c = 0; c < 3; c++) {
-        s.accum_normal_rec[c] = s.last_alpha * s.last_normal[c] + (1.f - s.last_alpha) * s.accum_normal_rec[c];
-        s.last_normal[c] = nrm[c];
-        dL_dalpha += (nrm[c] - s.accum_normal_rec[c]) * s.g_normal[c];
-        out[kAccNormal + c] = w * s.g_normal[c];
-    }
-    dL_dalpha *= s.T;
-    s.last_alpha = alpha;
-    dL_dalpha += (-s.T_final * inv_1ma) * s.bg_dot;
-    const float dL_dG = q2.w * dL_dalpha;
-    dL_dz += w * s.g_depth;
-
-    const float Twx = q1.z, Twy = q1.w;
-    if (e.use3d) {
-        const float dsx = dL_dG * -G * e.sx + dL_dz * Twx;
-        const float dsy = dL_dG * -G * e.sy + dL_dz * Twy;
-        const float ax = dsx * e.inv_pz, ay = dsy * e.inv_pz;
-        const float dpx = ax, dpy = ay, dpz = -(ax * e.sx + ay * e.sy);
-        // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
-        const float dkx = e.ly * dpz - e.lz * dpy, dky = e.lz * dpx - e.lx * dpz, dkz = e.lx * dpy - e.ly * dpx;
-        const float dlx = dpy * e.kz - dpz * e.ky, dly = dpz * e.kx - dpx * e.kz, dlz = dpx * e.ky - dpy * e.kx;
-        out[kAccT + 0] = -dkx; out[kAccT + 1] = -dky; out[kAccT + 2] = -dkz;
-        out[kAccT + 3] = -dlx; out[kAccT + 4] = -dly; out[kAccT + 5] = -dlz;
-        out[kAccT + 6] = pfx * dkx + pfy * dlx + dL_dz * e.sx;
-        out[kAccT + 7] = pfx * dky + pfy * dly + dL_dz * e.sy;
-        out[kAccT + 8] = pfx * dkz + pfy * dlz + dL_dz;
-        out[kAccMean2D + 0] = 0.f; out[kAccMean2D + 1] = 0.f;
-    } else {
-        for (int c = 0; c < 8; c++) out[kAccT + c] = 0.f;
-        out[kAccT + 8] = dL_dz;
-        out[kAccMean2D + 0] = dL_dG * (-G * 2.0f * e.dx);
-        out[kAccMean2D + 1] = dL_dG * (-G * 2.0f * e.dy);
-    }
+    const bool is_med = ok & (contributor == s.med_c - 1);
+    float dL_dweight = (s.final_D2 + m_d * m_d * s.final_A - 2.f * m_d * s.final_D) * s.g_dist;
+    dL_dweight += is_med ? s.g_medw : 0.f;
+    float u = q3.w * s.g_pix[0] + q4.x * s.g_pix[1] + q4.y * s.g_pix[2];
+    u += c_d * s.g_depth + s.g_alpha;
+    u += q3.x * s.g_normal[0] + q3.y * s.g_normal[1] + q3.z * s.g_normal[2];
+    u += dL_dweight;
+    const float d = u - s.acc;
+    const float dL_dalpha = d * s.T - (s.T_final * inv_1ma) * s.bg_dot;
+    s.acc += alpha * d;
+    float dL_dz = (2.0f * w * (m_d * s.final_A - s.final_D) * s.g_dist) * dmd_dd + w * s.g_depth;
+    dL_dz += is_med ? s.g_meddepth : 0.f;
+    out[kAccColor + 0] = w * s.g_pix[0]; out[kAccColor + 1] = w * s.g_pix[1]; out[kAccColor + 2] = w * s.g_pix[2];
+    out[kAccNormal + 0] = w * s.g_normal[0]; out[kAccNormal + 1] = w * s.g_normal[1]; out[kAccNormal + 2] = w * s.g_normal[2];
     out[kAccOpacity] = G * dL_dalpha;
+    const float nGdG = -(G * (q2.w * dL_dalpha));   // -G dL_dG
+    const float dsx = nGdG * sx + dL_dz * q1.z, dsy = nGdG * sy + dL_dz * q1.w;
+    const float ax = dsx * inv_pz, ay = dsy * inv_pz;   // dL_dp.xy; dL_dp.z = -(ax s.x + ay s.y)
+    const float n1 = e.ly * ax - e.lx * ay;             // -dL_dk.z
+    const float n2 = ay * e.kx - ax * e.ky;             // -dL_dl.z
+    const float m3w = dL_dz - (pfx * n1 + pfy * n2);
+    out[kAccT + 0] = n1 * sx; out[kAccT + 1] = n1 * sy; out[kAccT + 2] = n1;
+    out[kAccT + 3] = n2 * sx; out[kAccT + 4] = n2 * sy; out[kAccT + 5] = n2;
+    out[kAccT + 6] = m3w * sx; out[kAccT + 7] = m3w * sy; out[kAccT + 8] = m3w;
+    const float f2 = (ok & !e.use3d) ? 2.0f * nGdG : 0.f;   // dL_dG * (-G * FilterInvSquare), backward.cu:436-443
+    out2d[0] = f2 * e.dx; out2d[1] = f2 * e.dy;
 }
 
 // ---------------------------------------------------------------------------------------------

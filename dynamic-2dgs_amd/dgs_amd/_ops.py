@@ -18,17 +18,21 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot")
 
 
-def build(force=False, verbose=False):
-    src = os.path.join(_CSRC, "train_ops.hip")
+def _deps():
     hdr = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dgs_train_ops.h")
-    deps = [src, hdr, os.path.join(_CSRC, "node_mlp.h")]
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + [src, "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=_CSRC)
-    return LIB_PATH
+    return [os.path.join(_CSRC, "train_ops.hip"), hdr, os.path.join(_CSRC, "node_mlp.h")]
+
+
+def source_hash():
+    import _dgs_build
+    return _dgs_build.source_hash(_deps(), HIPCC_FLAGS)
+
+
+def build(force=False, verbose=False):
+    """hipcc, in-tree; rebuilt whenever the hash of sources + flags differs from the one recorded with the binary."""
+    import _dgs_build
+    cmd = ["hipcc"] + HIPCC_FLAGS + [os.path.join(_CSRC, "train_ops.hip"), "-o", LIB_PATH]
+    return _dgs_build.build(LIB_PATH, cmd, _deps(), HIPCC_FLAGS, _CSRC, force=force, verbose=verbose)[0]
 
 
 def exported_symbols():

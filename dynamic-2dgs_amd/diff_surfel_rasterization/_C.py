@@ -10,8 +10,6 @@ call fails loudly.
 """
 import ctypes
 import os
-import subprocess
-
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
@@ -31,18 +29,23 @@ _EXPORTS = ("dgs_abi_version", "dgs_last_error", "dgs_rasterizer_mark_visible", 
             "dgs_profile_read")
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    src_times = [os.path.getmtime(os.path.join(_CSRC, s)) for s in _SOURCES]
+def _deps():
     hdr = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dgs_surfel_rasterizer.h")
-    src_times.append(os.path.getmtime(hdr))
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(src_times):
-        return LIB_PATH
+    return [os.path.join(_CSRC, s) for s in _SOURCES] + [hdr]
+
+
+def source_hash():
+    """Hash of the sources + flags the library is built from (recorded next to the .so and with the PMC profiles)."""
+    import _dgs_build
+    return _dgs_build.source_hash(_deps(), HIPCC_FLAGS)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).  Rebuilds whenever the hash of
+    sources + flags differs from the one recorded with the existing binary."""
+    import _dgs_build
     cmd = ["hipcc"] + HIPCC_FLAGS + [os.path.join(_CSRC, "surfel_rasterizer.hip"), "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=_CSRC)
-    return LIB_PATH
+    return _dgs_build.build(LIB_PATH, cmd, _deps(), HIPCC_FLAGS, _CSRC, force=force, verbose=verbose)[0]
 
 
 def load():

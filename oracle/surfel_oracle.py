@@ -23,14 +23,29 @@ _PTR_FIELDS = {
 }
 
 
-def build(force=False):
-    """Compile liboracle_f32.so / liboracle_f64.so with gcc (oracle/Makefile)."""
-    need = force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle_f32.so", "liboracle_f64.so"))
-    if not need:
-        src_m = os.path.getmtime(os.path.join(_HERE, "surfel_oracle.c"))
-        need = any(os.path.getmtime(os.path.join(_HERE, n)) < src_m for n in ("liboracle_f32.so", "liboracle_f64.so"))
-    if need:
+def build(force=False, verbose=False):
+    """Compile liboracle_f32.so / liboracle_f64.so with gcc (oracle/Makefile).  Rebuilt when the hash of the C source +
+    Makefile differs from the one recorded next to the binaries (file times are not trusted)."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in ("surfel_oracle.c", "Makefile"):
+        with open(os.path.join(_HERE, n), "rb") as f:
+            h.update(f.read())
+    want = h.hexdigest()[:16]
+    stamp = os.path.join(_HERE, "liboracle.srchash")
+    have = None
+    if os.path.exists(stamp):
+        with open(stamp) as f:
+            have = f.read().strip()
+    libs_ok = all(os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle_f32.so", "liboracle_f64.so"))
+    if force or not libs_ok or have != want:
+        if verbose:
+            print("[build] compiling oracle (inputs %s)" % want)
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
+    elif verbose:
+        print("[build] reused   oracle (inputs %s)" % want)
 
 
 def _lib(dtype):

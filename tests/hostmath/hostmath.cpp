@@ -96,12 +96,13 @@ void hm_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_li
         }
 }
 
-void hm_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, const float* bg,
+long hm_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, const float* bg,
                   const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dothers,
                   float* acc /*[P,20]*/)
 {
     const int tiles_x = (W + 15) / 16, HW = W * H;
     std::vector<double> dacc((size_t)P * kAccFloats, 0.0);
+    long bad = 0;   // non-zero (or NaN) outputs from a pixel that does not blend the entry
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             const int tile = (py / 16) * tiles_x + px / 16;
@@ -117,13 +118,18 @@ void hm_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* p
                 const uint32_t id = point_list[r0 + (uint32_t)e];
                 const float* r = rec + (size_t)id * kRecFloats;
                 PairEval ev;
-                if (!pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
-                float out[kAccFloats] = {0};
-                pixbwd_step(st, ev, e, pfx, pfy, Q(r, 1), Q(r, 2), Q(r, 3), Q(r, 4), out);
-                for (int c = 0; c < 18; c++) dacc[(size_t)id * kAccFloats + c] += out[c];
+                // like the kernel: entries the pixel does not blend go through the same step with ok = false
+                const bool ok = pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev);
+                float out[16], out2d[2];
+                pixbwd_step(st, ev, ok, e, pfx, pfy, Q(r, 1), Q(r, 2), Q(r, 3), Q(r, 4), out, out2d);
+                for (int c = 0; c < 16; c++) dacc[(size_t)id * kAccFloats + c] += out[c];
+                dacc[(size_t)id * kAccFloats + kAccMean2D] += out2d[0];
+                dacc[(size_t)id * kAccFloats + kAccMean2D + 1] += out2d[1];
+                if (!ok) for (int c = 0; c < 18; c++) if (c < 16 ? out[c] != 0.f : out2d[c - 16] != 0.f) bad++;
             }
         }
     for (size_t i = 0; i < dacc.size(); i++) acc[i] = (float)dacc[i];
+    return bad;
 }
 
 void hm_surfel_bwd(int P, int D, int M, const float* means3D, const float* scales, const float* rots, const float* shs,

@@ -18,8 +18,9 @@ HDR = os.path.join(os.path.dirname(HERE), "dynamic-2dgs_amd", "csrc", "surfel_ma
 
 @pytest.fixture(scope="module")
 def hm():
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", SRC, "-o", LIB])
+    import _dgs_build
+    flags = ["-O2", "-ffp-contract=off", "-shared", "-fPIC"]
+    _dgs_build.build(LIB, ["g++"] + flags + [SRC, "-o", LIB], [SRC, HDR], flags, os.path.dirname(SRC))
     return ctypes.CDLL(LIB)
 
 
@@ -85,7 +86,9 @@ def test_hostmath_pipeline_matches_oracle(hm, cfg):
     go = g.standard_normal((8, H, W)).astype(np.float32)
     og = orc.backward(gc, go)
     acc = np.zeros((P, 20), np.float32)
-    hm.hm_blend_bwd(P, W, H, p(ranges), p(plist), p(rec), p(bg), p(final_T), p(ncontrib), p(gc), p(go), p(acc))
+    hm.hm_blend_bwd.restype = ctypes.c_long
+    bad = hm.hm_blend_bwd(P, W, H, p(ranges), p(plist), p(rec), p(bg), p(final_T), p(ncontrib), p(gc), p(go), p(acc))
+    assert bad == 0, "%d non-zero / NaN partials from pixels that do not blend an entry (branch-free step)" % bad
     dmean2D = np.zeros((P, 3), np.float32)
     dmean3D = np.zeros((P, 3), np.float32)
     dT = np.zeros((P, 9), np.float32)
