@@ -1,8 +1,14 @@
 // surfel_rasterizer.hip -- host orchestration + C ABI (include/dgs_surfel_rasterizer.h) of the
 // MI355X surfel rasterizer.  Stage order follows CudaRasterizer::Rasterizer::forward / backward
 // (rasterizer_impl.cu:198-342, :346-448 of the reference); everything runs on the caller's stream.
+//
+// State.  The reference's entry points are stateless and re-entrant across devices.  Everything this
+// library adds on top (tile-list policy, capacity mode and its overflow flag, the pinned word of the one device->host
+// read, the kernel-timing hook) lives in a dgs_context; the reference-shaped entry points use one lazily created default
+// context PER DEVICE, so two devices -- or two threads with their own contexts -- never share mutable state.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -15,11 +21,6 @@
 namespace {
 
 thread_local std::string g_err;
-bool g_tight_rects = true;  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
-bool g_sort_regs = true;    // per-tile sort of <= 2048 entries in registers (kernels_preprocess.h sort_tiles_reg_kernel)
-int g_tile_order = 3;       // kernels_blend.h tile_for_block (3 = longest tile first)
-int g_capacity = 0;         // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
-int* g_overflow = nullptr;  // device flag raised by a capacity overflow
 
 int fail(int code, const std::string& msg)
 {
@@ -127,6 +128,40 @@ dgs::Camera make_camera(const float* view_dev, const float* campos_dev, int W, i
     return cam;
 }
 
+// ---- optional kernel timing (bench.py roofline leg) ------------------------------------------------
+__global__ void sum_tile_last_kernel(const uint32_t* tile_last, int n, unsigned long long* dst)
+{
+    unsigned long long acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += tile_last[i];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, acc);
+}
+
+// Profile mode 2: device timestamps instead of HIP events.  Events cannot be recorded inside a captured graph on ROCm
+// (hipErrorInvalidHandle), a one-thread kernel can: it appends (constant-rate 100 MHz counter, tag) to a ring, so the
+// blend kernels are timed INSIDE the replayed whole-step graph -- the launch mode the headline number uses.
+constexpr unsigned kStampCap = 4096;
+__global__ void stamp_kernel(unsigned long long* ring, unsigned* count, unsigned tag)
+{
+    const unsigned long long t = wall_clock64();
+    const unsigned i = atomicAdd(count, 1u);
+    ring[2 * (i % kStampCap)] = t;
+    ring[2 * (i % kStampCap) + 1] = tag;
+}
+
+struct Prof {
+    std::atomic<int> mode{0};                // 0 off, 1 HIP events (eager launches), 2 device timestamps (capturable)
+    unsigned long long* counters = nullptr;  // device: [0] sum of S over timed fwd launches, [1] over bwd launches
+    unsigned long long* ring = nullptr;      // device: kStampCap x (timestamp, tag)
+    unsigned* ring_count = nullptr;          // device
+    std::mutex mu;
+    struct Pair { hipEvent_t a, b; int kind; };
+    std::vector<Pair> pending;
+    std::vector<Pair> pool;
+    double ms[2] = {0, 0};
+    long n[2] = {0, 0};
+};
+
 // Small pinned staging word for num_rendered (the one device->host read of the forward).
 struct HostStage {
     uint32_t* u = nullptr;   // [2] num_rendered, longest tile list
@@ -140,36 +175,68 @@ struct HostStage {
         return 0;
     }
 };
-HostStage g_stage;
 
-// ---- optional kernel timing (bench.py roofline leg) ------------------------------------------------
-__global__ void sum_tile_last_kernel(const uint32_t* tile_last, int n, unsigned long long* dst)
+}  // namespace
+
+struct dgs_context {
+    int device = 0;
+    std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
+    std::atomic<int> sort_regs{1};    // per-tile sort of <= 2048 entries in registers (kernels_preprocess.h)
+    std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
+    std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
+    std::atomic<int*> overflow{nullptr};  // device flag raised by a capacity overflow (library- or caller-owned)
+    int* overflow_owned = nullptr;
+    std::mutex mu;                    // lazy allocations
+    HostStage stage;
+    Prof prof;
+};
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_default_mu;
+dgs_context* g_default[kMaxDevices] = {};
+
+dgs_context* default_context()
 {
-    unsigned long long acc = 0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += tile_last[i];
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(dst, acc);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default[dev]) {
+        g_default[dev] = new dgs_context();
+        g_default[dev]->device = dev;
+    }
+    return g_default[dev];
 }
 
-struct Prof {
-    bool on = false;
-    unsigned long long* counters = nullptr;  // device: [0] sum of S over timed fwd launches, [1] over bwd launches
-    std::mutex mu;
-    struct Pair { hipEvent_t a, b; int kind; };
-    std::vector<Pair> pending;
-    std::vector<Pair> pool;
-    double ms[2] = {0, 0};
-    long n[2] = {0, 0};
-};
-Prof g_prof;
-
-bool prof_begin(int kind, hipStream_t s, Prof::Pair& p)
+// the library-owned overflow flag, allocated on the context's device the first time capacity mode is switched on
+int ensure_overflow(dgs_context* c)
 {
-    if (!g_prof.on) return false;
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    if (!g_prof.pool.empty()) {
-        p = g_prof.pool.back();
-        g_prof.pool.pop_back();
+    if (c->overflow.load()) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->overflow.load()) return 0;
+    int* p = nullptr;
+    if (hipMalloc((void**)&p, 4) != hipSuccess) return fail(DGS_ERR_HIP, "hipMalloc failed");
+    (void)hipMemset(p, 0, 4);
+    c->overflow_owned = p;
+    c->overflow.store(p);
+    return 0;
+}
+
+bool prof_begin(dgs_context* c, int kind, hipStream_t s, Prof::Pair& p)
+{
+    Prof& pr = c->prof;
+    const int mode = pr.mode.load();
+    if (mode == 0) return false;
+    if (mode == 2) {
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, pr.ring, pr.ring_count, (unsigned)(2 * kind));
+        p.kind = kind;
+        return true;
+    }
+    std::lock_guard<std::mutex> lk(pr.mu);
+    if (!pr.pool.empty()) {
+        p = pr.pool.back();
+        pr.pool.pop_back();
     } else {
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return false;
     }
@@ -178,17 +245,18 @@ bool prof_begin(int kind, hipStream_t s, Prof::Pair& p)
     return true;
 }
 
-void prof_end(hipStream_t s, Prof::Pair& p, const uint32_t* tile_last, int ntiles)
+void prof_end(dgs_context* c, hipStream_t s, Prof::Pair& p, const uint32_t* tile_last, int ntiles)
 {
-    (void)hipEventRecord(p.b, s);
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.pending.push_back(p);
-    // S = sum over tiles of the list length actually traversed (SURVEY.md section 8d), for the roofline
-    if (!g_prof.counters) {
-        if (hipMalloc((void**)&g_prof.counters, 16) != hipSuccess) { g_prof.counters = nullptr; return; }
-        (void)hipMemsetAsync(g_prof.counters, 0, 16, s);
+    Prof& pr = c->prof;
+    if (pr.mode.load() == 2) {
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, pr.ring, pr.ring_count, (unsigned)(2 * p.kind + 1));
+    } else {
+        (void)hipEventRecord(p.b, s);
+        std::lock_guard<std::mutex> lk(pr.mu);
+        pr.pending.push_back(p);
     }
-    hipLaunchKernelGGL(sum_tile_last_kernel, dim3(1), dim3(256), 0, s, tile_last, ntiles, g_prof.counters + p.kind);
+    // S = sum over tiles of the list length actually traversed (SURVEY.md section 8d), for the roofline
+    if (pr.counters) hipLaunchKernelGGL(sum_tile_last_kernel, dim3(1), dim3(256), 0, s, tile_last, ntiles, pr.counters + p.kind);
 }
 
 int check_common(int P, int W, int H, const void* means3D)
@@ -206,64 +274,160 @@ int dgs_abi_version(void) { return DGS_ABI_VERSION; }
 
 const char* dgs_last_error(void) { return g_err.c_str(); }
 
-void dgs_set_tight_rects(int on) { g_tight_rects = on != 0; }
-
-int dgs_read_overflow(int reset)
+// ---- contexts ---------------------------------------------------------------------------------------------------------
+dgs_context* dgs_context_create(void)
 {
-    if (!g_overflow) return 0;
-    int v = 0;
-    if (hipMemcpy(&v, g_overflow, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(DGS_ERR_HIP, "hipMemcpy failed");
-    if (reset && v) (void)hipMemset(g_overflow, 0, 4);
-    return v;
+    dgs_context* c = new dgs_context();
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) c->device = dev;
+    return c;
 }
 
-int dgs_set_option(int key, int value)
+void dgs_context_destroy(dgs_context* c)
 {
-    if (key == 0) { g_tight_rects = value != 0; return 0; }
-    if (key == 1 && value >= 0 && value <= 3) { g_tile_order = value; return 0; }
-    if (key == 3) { g_sort_regs = value != 0; return 0; }
+    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);
+        for (auto& d : g_default)
+            if (d == c) d = nullptr;
+    }
+    if (c->overflow_owned) (void)hipFree(c->overflow_owned);
+    if (c->stage.u) (void)hipHostFree(c->stage.u);
+    if (c->prof.counters) (void)hipFree(c->prof.counters);
+    if (c->prof.ring) (void)hipFree(c->prof.ring);
+    if (c->prof.ring_count) (void)hipFree(c->prof.ring_count);
+    for (auto& p : c->prof.pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : c->prof.pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    delete c;
+}
+
+int dgs_context_set_option(dgs_context* c, int key, int value)
+{
+    if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (key == 0) { c->tight_rects.store(value != 0); return DGS_OK; }
+    if (key == 1 && value >= 0 && value <= 3) { c->tile_order.store(value); return DGS_OK; }
+    if (key == 3) { c->sort_regs.store(value != 0); return DGS_OK; }
     if (key == 2 && value >= 0) {
-        if (value > 0 && !g_overflow) {
-            if (hipMalloc((void**)&g_overflow, 4) != hipSuccess) return fail(DGS_ERR_HIP, "hipMalloc failed");
-            (void)hipMemset(g_overflow, 0, 4);
-        }
-        g_capacity = value;
-        return 0;
+        if (value > 0)
+            if (int e = ensure_overflow(c)) return e;
+        c->capacity.store(value);
+        return DGS_OK;
     }
     return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_set_option: unknown key / value");
 }
 
-void dgs_profile_enable(int on) { g_prof.on = on != 0; }
-
-void dgs_profile_reset(void)
+int dgs_context_set_overflow_flag(dgs_context* c, int* device_flag)
 {
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    for (auto& p : g_prof.pending) g_prof.pool.push_back(p);
-    g_prof.pending.clear();
-    g_prof.ms[0] = g_prof.ms[1] = 0;
-    g_prof.n[0] = g_prof.n[1] = 0;
-    if (g_prof.counters) (void)hipMemset(g_prof.counters, 0, 16);
+    if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (device_flag) {
+        c->overflow.store(device_flag);
+        return DGS_OK;
+    }
+    c->overflow.store(c->overflow_owned);   // back to the library-owned flag (allocated on demand)
+    if (!c->overflow_owned && c->capacity.load() > 0) return ensure_overflow(c);
+    return DGS_OK;
 }
 
-int dgs_profile_read(double* out, int cap)
+int dgs_context_read_overflow(dgs_context* c, int reset)
 {
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    for (auto& p : g_prof.pending) {
+    if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
+    int* flag = c->overflow.load();
+    if (!flag) return 0;
+    int v = 0;
+    if (hipMemcpy(&v, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(DGS_ERR_HIP, "hipMemcpy failed");
+    if (reset && v) (void)hipMemset(flag, 0, 4);
+    return v;
+}
+
+int dgs_context_profile_enable(dgs_context* c, int mode)
+{
+    if (!c || mode < 0 || mode > 2) return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_profile_enable: mode must be 0, 1 or 2");
+    Prof& pr = c->prof;
+    if (mode != 0) {   // allocate now: nothing may be allocated later, while a stream capture is in progress
+        std::lock_guard<std::mutex> lk(pr.mu);
+        if (!pr.counters) {
+            DGS_HIP(hipMalloc((void**)&pr.counters, 16));
+            DGS_HIP(hipMemset(pr.counters, 0, 16));
+        }
+        if (mode == 2 && !pr.ring) {
+            DGS_HIP(hipMalloc((void**)&pr.ring, (size_t)kStampCap * 16));
+            DGS_HIP(hipMalloc((void**)&pr.ring_count, 4));
+            DGS_HIP(hipMemset(pr.ring_count, 0, 4));
+        }
+    }
+    pr.mode.store(mode);
+    return DGS_OK;
+}
+
+void dgs_context_profile_reset(dgs_context* c)
+{
+    if (!c) return;
+    Prof& pr = c->prof;
+    std::lock_guard<std::mutex> lk(pr.mu);
+    for (auto& p : pr.pending) pr.pool.push_back(p);
+    pr.pending.clear();
+    pr.ms[0] = pr.ms[1] = 0;
+    pr.n[0] = pr.n[1] = 0;
+    if (pr.counters) (void)hipMemset(pr.counters, 0, 16);
+    if (pr.ring_count) (void)hipMemset(pr.ring_count, 0, 4);
+}
+
+int dgs_context_profile_read(dgs_context* c, double* out, int cap)
+{
+    if (!c || !out) return fail(DGS_ERR_INVALID_ARGUMENT, "NULL pointer");
+    Prof& pr = c->prof;
+    std::lock_guard<std::mutex> lk(pr.mu);
+    for (auto& p : pr.pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            g_prof.ms[p.kind] += ms;
-            g_prof.n[p.kind] += 1;
+            pr.ms[p.kind] += ms;
+            pr.n[p.kind] += 1;
         }
-        g_prof.pool.push_back(p);
+        pr.pool.push_back(p);
     }
-    g_prof.pending.clear();
-    unsigned long long cnt[2] = {0, 0};
-    if (g_prof.counters) (void)hipMemcpy(cnt, g_prof.counters, 16, hipMemcpyDeviceToHost);
-    const double v[6] = {g_prof.ms[0], (double)g_prof.n[0], g_prof.ms[1], (double)g_prof.n[1], (double)cnt[0], (double)cnt[1]};
+    pr.pending.clear();
+    if (pr.ring && pr.ring_count) {
+        // device timestamps (mode 2): begin/end stamps come in stream order; pair them per kind
+        (void)hipDeviceSynchronize();
+        unsigned cnt = 0;
+        (void)hipMemcpy(&cnt, pr.ring_count, 4, hipMemcpyDeviceToHost);
+        if (cnt > 0) {
+            const unsigned n = cnt < kStampCap ? cnt : kStampCap;
+            std::vector<unsigned long long> h(2 * (size_t)kStampCap);
+            (void)hipMemcpy(h.data(), pr.ring, (size_t)kStampCap * 16, hipMemcpyDeviceToHost);
+            unsigned long long open_t[2] = {0, 0};
+            bool open[2] = {false, false};
+            const unsigned first = cnt <= kStampCap ? 0u : cnt % kStampCap;   // oldest entry still in the ring
+            for (unsigned k = 0; k < n; k++) {
+                const unsigned i = (first + k) % kStampCap;
+                const unsigned tag = (unsigned)h[2 * i + 1];
+                const int kind = (int)(tag >> 1) & 1;
+                if ((tag & 1u) == 0) { open_t[kind] = h[2 * i]; open[kind] = true; }
+                else if (open[kind]) {
+                    pr.ms[kind] += (double)(h[2 * i] - open_t[kind]) * 1e-5;   // 100 MHz ticks -> ms
+                    pr.n[kind] += 1;
+                    open[kind] = false;
+                }
+            }
+            (void)hipMemset(pr.ring_count, 0, 4);
+        }
+    }
+    unsigned long long cntS[2] = {0, 0};
+    if (pr.counters) (void)hipMemcpy(cntS, pr.counters, 16, hipMemcpyDeviceToHost);
+    const double v[6] = {pr.ms[0], (double)pr.n[0], pr.ms[1], (double)pr.n[1], (double)cntS[0], (double)cntS[1]};
     int k = cap < 6 ? cap : 6;
     for (int i = 0; i < k; i++) out[i] = v[i];
     return k;
 }
+
+// ---- the same knobs on the default context of the calling thread's current device --------------------------------------
+void dgs_set_tight_rects(int on) { (void)dgs_context_set_option(default_context(), 0, on); }
+int dgs_set_option(int key, int value) { return dgs_context_set_option(default_context(), key, value); }
+int dgs_set_overflow_flag(int* device_flag) { return dgs_context_set_overflow_flag(default_context(), device_flag); }
+int dgs_read_overflow(int reset) { return dgs_context_read_overflow(default_context(), reset); }
+void dgs_profile_enable(int mode) { (void)dgs_context_profile_enable(default_context(), mode); }
+void dgs_profile_reset(void) { dgs_context_profile_reset(default_context()); }
+int dgs_profile_read(double* out, int cap) { return dgs_context_profile_read(default_context(), out, cap); }
 
 int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* offsets, int cap)
 {
@@ -299,7 +463,7 @@ int dgs_rasterizer_mark_visible(int P, const float* means3D, const float* viewma
     return DGS_OK;
 }
 
-int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_alloc_fn binning_alloc, void* binning_ctx,
+int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_alloc_fn binning_alloc, void* binning_ctx,
                            dgs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
                            int height, const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, float scale_modifier, const float* rotations,
@@ -309,6 +473,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
 {
     (void)scale_modifier; (void)projmatrix; (void)prefiltered;
     hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
     if (int e = check_common(P, width, height, means3D)) return e;
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(DGS_ERR_INVALID_ARGUMENT, "allocator callback is NULL");
     if (!out_color || !out_others || !background || !viewmatrix || !cam_pos) return fail(DGS_ERR_INVALID_ARGUMENT, "NULL pointer");
@@ -341,7 +506,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     pa.radii = radii;
     pa.rec = (float4*)(geom + gl.rec);
     pa.rects = (uint2*)(geom + gl.rects);
-    pa.tight = g_tight_rects ? 1 : 0;
+    pa.tight = ctx->tight_rects.load() ? 1 : 0;
     pa.row_inv = 0;
     size_t sh_lds = 0;
     if (!colors_precomp && shs) {
@@ -367,26 +532,29 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
                            (const uint2*)pa.rects, il.tiles_x, tile_counts);
     }
     DGS_STAGE("count_tiles", debug, stream);
+    const int capacity = ctx->capacity.load();
+    int* overflow = ctx->overflow.load();
     // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
     hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(256), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
-                       il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)g_capacity, g_overflow);
+                       il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)capacity, overflow);
     DGS_STAGE("scan_tiles", debug, stream);
 
     // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285).
     // Capacity mode skips the round trip: the buffer is sized for g_capacity entries, every sort variant is
     // launched (each tile picks its own), and the value returned to the caller is the capacity.
     uint32_t R_u = 0, longest = 0;
-    const bool capacity_mode = g_capacity > 0;
+    const bool capacity_mode = capacity > 0;
     if (capacity_mode) {
-        R_u = (uint32_t)g_capacity;
+        R_u = (uint32_t)capacity;
         longest = 0xffffffffu;
     } else {
-        std::lock_guard<std::mutex> lk(g_stage.mu);
-        if (g_stage.ensure()) return fail(DGS_ERR_HIP, "hipHostMalloc failed");
-        DGS_HIP(hipMemcpyAsync(g_stage.u, geom + gl.total, 8, hipMemcpyDeviceToHost, stream));
+        // one pinned word per context: concurrent forwards of the same context take turns here (other contexts do not wait)
+        std::lock_guard<std::mutex> lk(ctx->stage.mu);
+        if (ctx->stage.ensure()) return fail(DGS_ERR_HIP, "hipHostMalloc failed");
+        DGS_HIP(hipMemcpyAsync(ctx->stage.u, geom + gl.total, 8, hipMemcpyDeviceToHost, stream));
         DGS_HIP(hipStreamSynchronize(stream));
-        R_u = g_stage.u[0];
-        longest = g_stage.u[1];
+        R_u = ctx->stage.u[0];
+        longest = ctx->stage.u[1];
     }
     if (R_u > 0x7fffffffu) return fail(DGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
     const int R = (int)R_u;
@@ -414,7 +582,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
         DGS_STAGE("scatter_keys", debug, stream);
         // ---- K5 per-tile sort (stable radix order of rasterizer_impl.cu:304-309 = (tile, depth bits, surfel index))
         uint32_t* plist = (uint32_t*)(bin + bl.point_list);
-        if (g_sort_regs)
+        if (ctx->sort_regs.load())
             hipLaunchKernelGGL(dgs::sort_tiles_reg_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
                                (const uint64_t*)keys, plist);
         else
@@ -436,7 +604,7 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     fa.ranges = ranges;
     fa.point_list = (const uint32_t*)(bin + bl.point_list);
     fa.rec = pa.rec;
-    fa.W = width; fa.H = height; fa.tiles_x = il.tiles_x; fa.tiles_y = il.tiles_y; fa.mode = g_tile_order;
+    fa.W = width; fa.H = height; fa.tiles_x = il.tiles_x; fa.tiles_y = il.tiles_y; fa.mode = ctx->tile_order.load();
     fa.order = (const uint32_t*)(img + il.order_fwd);
     if (fa.mode == 3) {
         hipLaunchKernelGGL(dgs::tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint2*)ranges, (const uint32_t*)nullptr,
@@ -451,14 +619,14 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
     fa.out_others = out_others;
     const int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, fa.mode);
     Prof::Pair pp;
-    const bool timed = prof_begin(0, stream, pp);
+    const bool timed = prof_begin(ctx, 0, stream, pp);
     hipLaunchKernelGGL(dgs::blend_fwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, fa);
-    if (timed) prof_end(stream, pp, fa.tile_last, il.ntiles);
+    if (timed) prof_end(ctx, stream, pp, fa.tile_last, il.ntiles);
     DGS_STAGE("blend_fwd", debug, stream);
     return R;
 }
 
-int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                             const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                             const float* rotations, const float* transMat_precomp, const float* viewmatrix,
                             const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
@@ -469,6 +637,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
 {
     (void)scale_modifier; (void)projmatrix;
     hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
     if (int e = check_common(P, width, height, means3D)) return e;
     if (P == 0) return DGS_OK;  // rasterize_points.cu:204
     if (transMat_precomp) return fail(DGS_ERR_UNSUPPORTED, "transMat_precomp (cov3D_precomp) is not supported");
@@ -495,7 +664,7 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
         ba.ranges = (const uint2*)(img_buffer + il.ranges);
         ba.point_list = (const uint32_t*)(binning_buffer + bl.point_list);
         ba.rec = (const float4*)(geom_buffer + gl.rec);
-        ba.W = width; ba.H = height; ba.tiles_x = il.tiles_x; ba.tiles_y = il.tiles_y; ba.mode = g_tile_order;
+        ba.W = width; ba.H = height; ba.tiles_x = il.tiles_x; ba.tiles_y = il.tiles_y; ba.mode = ctx->tile_order.load();
         ba.order = (const uint32_t*)(img_buffer + il.order_bwd);
         if (ba.mode == 3) {  // by the traversed length the forward measured
             hipLaunchKernelGGL(dgs::tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint2*)nullptr,
@@ -511,9 +680,9 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
         ba.acc = acc;
         const int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, ba.mode);
         Prof::Pair pp;
-        const bool timed = prof_begin(1, stream, pp);
+        const bool timed = prof_begin(ctx, 1, stream, pp);
         hipLaunchKernelGGL(dgs::blend_bwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
-        if (timed) prof_end(stream, pp, ba.tile_last, il.ntiles);
+        if (timed) prof_end(ctx, stream, pp, ba.tile_last, il.ntiles);
         DGS_STAGE("blend_bwd", debug, stream);
     }
 
@@ -537,6 +706,37 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
     hipLaunchKernelGGL(dgs::surfel_bwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), sh_lds, stream, sa);
     DGS_STAGE("surfel_bwd", debug, stream);
     return DGS_OK;
+}
+
+
+// ---- the reference-shaped entry points (rasterizer.h:20-87): default context of the current device ------------------
+int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_alloc_fn binning_alloc, void* binning_ctx,
+                           dgs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                           int height, const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                           const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                           float* out_others, int* radii, int debug, void* stream)
+{
+    return dgs_context_forward(default_context(), geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+                               background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                               transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+                               out_others, radii, debug, stream);
+}
+
+int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                            const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                            char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix,
+                            const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+                            float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
+                            float* dL_drot, int debug, void* stream)
+{
+    return dgs_context_backward(default_context(), P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales,
+                                scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
+                                geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_depths, dL_dmean2D, dL_dnormal, dL_dopacity,
+                                dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, debug, stream);
 }
 
 }  // extern "C"

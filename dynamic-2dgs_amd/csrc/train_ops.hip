@@ -883,10 +883,10 @@ __global__ void __launch_bounds__(256) densify_view_kernel(int P, const int* rad
 }
 // running statistics: xyz_gradient_accum += grad_norm, denom += visible, max_radii2D = max(max_radii2D, radii_vis)
 __global__ void __launch_bounds__(256) densify_accum_kernel(int P, const float* grad_norm, const float* visible, const int* radii_vis,
-                                                            float* accum, float* denom, int* max_radii)
+                                                            float* accum, float* denom, int* max_radii, const int* skip)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
+    if (i >= P || (skip && skip[0] != 0)) return;
     accum[i] += grad_norm[i];
     denom[i] += visible[i];
     max_radii[i] = max(max_radii[i], radii_vis[i]);
@@ -1068,10 +1068,36 @@ struct AdamSegs {
     float gscale;   // gradients are read as grad * gscale (data parallel: the bucket holds the SUM over ranks, gscale = 1 / world)
 };
 
+// Guard of a training step (dgs_step_guard): skip[0] != 0 means "this step must not change anything" -- a rank's rasterizer
+// ran out of list capacity and rendered background (under data parallelism the flag rides in the MAX all-reduce of the radii,
+// so every rank sees the same value) -- and the update kernels return without touching parameters, moments, statistics or
+// the step count.
+__global__ void step_guard_kernel(const int* __restrict__ skip, float* __restrict__ step_count, float* __restrict__ status,
+                                  float* __restrict__ host_ring, int ring_len)
+{
+    // one thread.  status: [0] skip flag of this step, [1] number of skipped steps so far, [2] guarded steps so far
+    const bool sk = skip && skip[0] != 0;
+    if (!sk) step_count[0] += 1.0f;
+    const float n_skipped = status[1] + (sk ? 1.0f : 0.0f);
+    const float n_steps = status[2] + 1.0f;
+    status[0] = sk ? 1.0f : 0.0f;
+    status[1] = n_skipped;
+    status[2] = n_steps;
+    if (host_ring) {   // pinned host memory: (step index, skip flag, skipped so far, 0) of the last ring_len steps
+        float* e = host_ring + 4 * ((long long)n_steps % ring_len);
+        e[1] = sk ? 1.0f : 0.0f;
+        e[2] = n_skipped;
+        e[3] = 0.0f;
+        __threadfence_system();
+        e[0] = n_steps;   // written last: a reader that sees the index sees the payload
+    }
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step_count,
-                                                   float b1, float b2, float eps)
+                                                   float b1, float b2, float eps, const int* __restrict__ skip)
 {
+    if (skip && skip[0] != 0) return;   // guarded step (see step_guard_kernel)
     const int2 pl = plan[blockIdx.x];            // (segment, first element of this block inside the segment)
     const int s = pl.x;
     const long long seg_len = sg.off[s + 1] - sg.off[s];
@@ -1249,6 +1275,11 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
                         float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
                         float eps, const void* plan, void* stream);
 
+int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                          const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                          float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
+                          float beta2, float eps, const void* plan, const int* skip, void* stream);
+
 int dgs_adam_step(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* grad, float* exp_avg,
                   float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
 {
@@ -1268,6 +1299,22 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
                         const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                         float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
                         float eps, const void* plan, void* stream)
+{
+    return dgs_adam_step_guarded(nseg, params, offsets, lrs, lrs2, periods, splits, lrs_final, sched_steps, sched_t0, grad_scale, grad,
+                                 exp_avg, exp_avg_sq, step_count, beta1, beta2, eps, plan, nullptr, stream);
+}
+
+int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, void* stream)
+{
+    if (!step_count || !status || (host_ring && ring_len <= 0)) return fail(-1, "dgs_step_guard: bad argument");
+    hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, skip, step_count, status, host_ring, ring_len);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-4, "step_guard_kernel: launch failed");
+}
+
+int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                          const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                          float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
+                          float beta2, float eps, const void* plan, const int* skip, void* stream)
 {
     if ((lrs_final != nullptr) != (sched_steps != nullptr)) return fail(-1, "dgs_adam_step_sched: pass lrs_final and sched_steps together");
     if (nseg <= 0 || nseg > kAdamSeg || !params || !offsets || !lrs || !grad || !exp_avg || !exp_avg_sq || !step_count || !plan)
@@ -1292,7 +1339,7 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
     const long long nb = adam_blocks(nseg, offsets);
     if (nb == 0) return 0;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, grad, exp_avg,
-                       exp_avg_sq, step_count, beta1, beta2, eps);
+                       exp_avg_sq, step_count, beta1, beta2, eps, skip);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("adam_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -1512,15 +1559,21 @@ int dgs_densify_view(int P, const int* radii, const float* g_means2D, float* gra
     return hipGetLastError() == hipSuccess ? 0 : fail(-4, "densify_view_kernel: launch failed");
 }
 
-int dgs_densify_accumulate(int P, const float* grad_norm, const float* visible, const int* radii_vis, float* accum, float* denom,
-                           int* max_radii, void* stream)
+int dgs_densify_accumulate_guarded(int P, const float* grad_norm, const float* visible, const int* radii_vis, float* accum, float* denom,
+                                   int* max_radii, const int* skip, void* stream)
 {
     if (P < 0 || (P > 0 && (!grad_norm || !visible || !radii_vis || !accum || !denom || !max_radii)))
         return fail(-1, "dgs_densify_accumulate: bad argument");
     if (P == 0) return 0;
     hipLaunchKernelGGL(densify_accum_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, grad_norm, visible, radii_vis,
-                       accum, denom, max_radii);
+                       accum, denom, max_radii, skip);
     return hipGetLastError() == hipSuccess ? 0 : fail(-4, "densify_accum_kernel: launch failed");
+}
+
+int dgs_densify_accumulate(int P, const float* grad_norm, const float* visible, const int* radii_vis, float* accum, float* denom,
+                           int* max_radii, void* stream)
+{
+    return dgs_densify_accumulate_guarded(P, grad_norm, visible, radii_vis, accum, denom, max_radii, nullptr, stream);
 }
 
 int dgs_knn_points2(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,

@@ -15,7 +15,8 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_lbs_scratch_bytes", "dgs_lbs_forward", "dgs_lbs_backward", "dgs_adam_plan_bytes", "dgs_adam_plan", "dgs_adam_step",
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
-            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot")
+            "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
+            "dgs_step_guard", "dgs_adam_step_guarded", "dgs_densify_accumulate_guarded")
 
 
 def _deps():
@@ -111,6 +112,13 @@ def load():
         lib.dgs_densify_view.argtypes = [ci, vp, vp, vp, vp, vp, vp]
         lib.dgs_densify_accumulate.restype = ci
         lib.dgs_densify_accumulate.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp]
+        lib.dgs_step_guard.restype = ci
+        lib.dgs_step_guard.argtypes = [vp, vp, vp, vp, ci, vp]
+        lib.dgs_adam_step_guarded.restype = ci
+        lib.dgs_adam_step_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp,
+                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        lib.dgs_densify_accumulate_guarded.restype = ci
+        lib.dgs_densify_accumulate_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]
         if lib.dgs_train_ops_abi_version() != 1:
             raise RuntimeError("libdgs_train_ops.so ABI version mismatch")
         _lib = lib
@@ -255,6 +263,10 @@ class FlatAdam:
         self._sched_steps = (ctypes.c_float * n_)(*[float(schedules[i][1]) if i in schedules else 0.0 for i in range(n_)])
         self.sched_t0 = float(sched_t0)
         self.grad_scale = 1.0   # gradients are read as grad * grad_scale (1 / world when the bucket holds the sum over ranks)
+        # step guard (dgs_step_guard): `skip` = a device int32 that is non-zero when this step must not change anything (a
+        # rank's rasterizer overflowed its list capacity); None = every step is applied
+        self.skip = None
+        self.host_ring = None    # optional pinned float tensor [ring_len, 4] the guard kernel reports into
         dev = flat_grad.device
         n = sum(p.numel() for p in self.params)
         assert flat_grad.numel() >= n and flat_grad.is_contiguous()
@@ -266,6 +278,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.status = torch.zeros(3, dtype=torch.float32, device=dev)   # skip flag of the last step, skipped steps, guarded steps
         self._n = len(self.params)
         self._ptrs = (ctypes.c_void_p * self._n)(*[p.data_ptr() for p in self.params])
         self._off = (ctypes.c_longlong * (self._n + 1))(*off)
@@ -307,13 +320,16 @@ class FlatAdam:
         dev = self.grad.device
         last = self._n if last is None else last
         k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, plan = self._range(first, last)
-        if advance:
-            self.t.add_(1.0)
+        skip = None if self.skip is None else self.skip.data_ptr()
         with torch.cuda.device(dev):
-            rc = lib.dgs_adam_step_sched(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
-                                         self.grad.data_ptr(),
-                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
-                                         self.betas[1], self.eps, plan.data_ptr(), _stream(dev))
+            if advance:   # one-thread kernel: t += 1 unless the step is to be skipped; bookkeeping for the host
+                ring = self.host_ring
+                _check(lib, lib.dgs_step_guard(skip, self.t.data_ptr(), self.status.data_ptr(), None if ring is None else ring.data_ptr(),
+                                               0 if ring is None else ring.shape[0], _stream(dev)), "dgs_step_guard")
+            rc = lib.dgs_adam_step_guarded(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
+                                           self.grad.data_ptr(),
+                                           self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
+                                           self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
         _check(lib, rc, "dgs_adam_step")
 
 
@@ -650,10 +666,12 @@ def densify_view(radii, g_means2D, grad_norm, visible, radii_vis):
     _check(lib, rc, "dgs_densify_view")
 
 
-def densify_accumulate(grad_norm, visible, radii_vis, accum, denom, max_radii):
+def densify_accumulate(grad_norm, visible, radii_vis, accum, denom, max_radii, skip=None):
+    """skip: optional device int32; non-zero leaves the running statistics untouched (see dgs_step_guard)."""
     lib = load()
     P = radii_vis.shape[0]
     with torch.cuda.device(radii_vis.device):
-        rc = lib.dgs_densify_accumulate(P, grad_norm.data_ptr(), visible.data_ptr(), radii_vis.data_ptr(), accum.data_ptr(),
-                                        denom.data_ptr(), max_radii.data_ptr(), _stream(radii_vis.device))
+        rc = lib.dgs_densify_accumulate_guarded(P, grad_norm.data_ptr(), visible.data_ptr(), radii_vis.data_ptr(), accum.data_ptr(),
+                                                denom.data_ptr(), max_radii.data_ptr(), None if skip is None else skip.data_ptr(),
+                                                _stream(radii_vis.device))
     _check(lib, rc, "dgs_densify_accumulate")

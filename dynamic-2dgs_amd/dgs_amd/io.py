@@ -164,15 +164,21 @@ def load_deform(deform, model_path, iteration=-1):
         return False
     state = torch.load(path, map_location="cpu", weights_only=True)
     own = deform.state_dict()
-    extra = [k for k in state if k not in own and k != "inited"]
+    # The reference's ControlNodeWarp.load_state_dict (utils/time_utils.py:845-865) takes the node tensors by name, hands the
+    # `gs_*` entries (the nodes' own GaussianModel, written by its state_dict :867-872 once train_setting has run -- every file
+    # of a real training run has them) to `as_gaussians`, and loads the rest with strict=False.  The node Gaussians are only
+    # used by the reference's node-rendering warm-up, which is not part of this path: they and any other key this model does
+    # not own are skipped; an own key the file lacks is an error (a silently half-loaded network would be worse).
+    skipped = [k for k in state if k not in own and k != "inited"]
     missing = [k for k in own if k not in state]
-    if extra or missing:
-        raise KeyError("deform.pth does not match this deformation model: unexpected %s, missing %s" % (extra, missing))
+    if missing:
+        raise KeyError("deform.pth lacks %s (file has %d entries, %d of them not owned by this model)" % (missing, len(state), len(skipped)))
     if state["nodes"].shape != own["nodes"].shape:   # node densification changes the node count: adopt the file's
         with torch.no_grad():
             for k in ("nodes", "_node_radius", "_node_weight"):
                 getattr(deform, k).data = torch.empty_like(state[k], device=own[k].device)
-    deform.load_state_dict({k: v for k, v in state.items() if k != "inited"})
+    deform.load_state_dict({k: v for k, v in state.items() if k in own})
+    load_deform.skipped_keys = skipped
     return True
 
 
@@ -294,16 +300,23 @@ def load_dnerf(path, white_background=False, eval=True, extension=".png", resolu
 
 
 # ---- initialisation from a point cloud ------------------------------------------------------------------------------------
-def mean_nn_dist2(points, k=3, chunk=2048):
+def mean_nn_dist2(points, k=3, chunk=1024):
     """simple_knn distCUDA2 (submodules/simple-knn/simple_knn.cu:148-183): mean SQUARED distance of every point to its k
-    nearest other points (exact).  Init-time only; a chunked distance matrix on whatever device `points` lives on."""
+    nearest other points (exact).  Init-time only.  Candidates come from the |q|^2 + |p|^2 - 2 q.p expansion (one [chunk, P]
+    matrix, a GEMM); the k+8 best of them are re-evaluated with exact differences, so the expansion's cancellation error
+    (~1e-7 |p|^2) can only matter if it reorders neighbours whose distances differ by less than that."""
     P = points.shape[0]
+    kk = min(k, P - 1)
+    cand = min(kk + 8, P - 1)
     out = torch.empty(P, dtype=points.dtype, device=points.device)
+    n2 = (points * points).sum(-1)
     for a in range(0, P, chunk):
         q = points[a:a + chunk]
-        d = (q[:, None, :] - points[None, :, :]).pow(2).sum(-1)
+        d = n2[a:a + chunk, None] + n2[None, :] - 2.0 * (q @ points.t())
         d[torch.arange(q.shape[0], device=d.device), torch.arange(a, a + q.shape[0], device=d.device)] = float("inf")   # not itself
-        out[a:a + chunk] = d.topk(min(k, P - 1), dim=1, largest=False).values.mean(dim=1)
+        idx = d.topk(cand, dim=1, largest=False).indices
+        exact = (q[:, None, :] - points[idx]).pow(2).sum(-1)
+        out[a:a + chunk] = exact.topk(kk, dim=1, largest=False).values.mean(dim=1)
     return out
 
 

@@ -90,6 +90,14 @@ def expon_lr(step, lr_init, lr_final, max_steps):
     return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
+def split_step_allowed(world, overlap_allreduce, hip_fused_path, arap_active):
+    """May the data-parallel step be split at the rasterizer inputs (backward half a | SH all-reduce | half b)?
+    Half a differentiates the loss with respect to the ASSEMBLED rasterizer inputs only.  The ARAP regulariser reaches the
+    deformation network directly (deform.network(...) inside arap_loss), not through those inputs, so while it is active the
+    split would silently drop its gradient: the step then runs unsplit (one backward over everything, one all-reduce)."""
+    return bool(world > 1 and overlap_allreduce and hip_fused_path and not arap_active)
+
+
 class Trainer:
     # Learning rates of the reference's exponential schedules at the END of their decay (iteration >= 40000:
     # xyz 1.6e-6 * spatial_lr_scale, deform 1.6e-6; arguments/__init__.py:103-108, scene/deform_model.py:38,
@@ -132,6 +140,11 @@ class Trainer:
         self.overlap_allreduce = True  # DP: all-reduce the SH gradients while the deformation backward runs
         self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
         self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
+        # step guard (capacity mode): see _init_guard / _check_guard
+        self._guard_steps = 0
+        self._guard_events = {}
+        self._skipped_seen = 0
+        self.overflow_recoveries = 0
 
     def _build_state(self):
         """Flat gradient bucket + optimiser over the current parameter tensors (again after Trainer.grow)."""
@@ -174,9 +187,11 @@ class Trainer:
                         schedules[i] = (self.SCHED_POSITION[1] * scale, self.SCHED_POSITION[2])
                     elif id(p) in net:
                         schedules[i] = (self.SCHED_DEFORM[1], self.SCHED_DEFORM[2])
+            old = getattr(self, "opt_surfels", None)
             self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat, patterns=patterns,
                                              schedules=schedules, sched_t0=float(self._steps_done))
             self.opt_deform = None
+            self._init_guard(old)
         else:
             assert not getattr(surfels, "packed_sh", False), "packed SH needs the flat Adam kernel (two rates inside one parameter)"
             self.opt_surfels = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
@@ -184,8 +199,64 @@ class Trainer:
             if getattr(self, "opt_deform", None) is None:   # kept across Trainer.grow: the deformation parameters do not move
                 self.opt_deform = torch.optim.Adam(deform_groups, lr=0.0, eps=1e-15)
 
+    # ---- step guard: a capacity overflow must not train anything -----------------------------------------------------
+    GUARD_LAG = 2     # the host looks at the report of the step issued two steps earlier (already finished: no stall)
+    GUARD_RING = 8
+
+    def _init_guard(self, old_opt=None):
+        """Capacity mode has no host read inside the step, so a view whose tile lists do not fit renders as background and
+        only raises a device flag (self._oflag, handed to the rasterizer).  The Adam and statistics kernels read that flag ON
+        THE DEVICE and change nothing when it is set.  Data parallel: the flag rides as element P of the radii tensor through
+        the step's MAX all-reduce (any rank's overflow stops every rank; no extra collective) and the kernels read the reduced
+        copy.  The guard kernel also reports (step, flag, skipped) into a pinned ring that step() polls GUARD_LAG steps
+        later -- the same lag on every rank, so all ranks recover at the same step: double the capacity, re-capture, and
+        redo the skipped views."""
+        dev = self.bucket.flat.device
+        if getattr(self, "_oflag", None) is None:
+            self._oflag = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._ring = torch.zeros(self.GUARD_RING, 4, dtype=torch.float32).pin_memory()
+        # radii of the rendered view (max over the ranks after the all-reduce) + 4 control ints; [P] = overflow flag
+        self._radii = torch.zeros(self.P + 4, dtype=torch.int32, device=dev)
+        self._radii_scratch = None
+        opt = self.opt_surfels
+        opt.skip = self._radii[self.P:self.P + 1] if self.world_size_hint() > 1 else self._oflag
+        opt.host_ring = self._ring
+        if old_opt is not None and hasattr(old_opt, "status"):   # rebuilt state (grow / node densification): counters carry over
+            opt.status.copy_(old_opt.status)
+
+    def world_size_hint(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _check_guard(self):
+        """Poll the report of the guarded step issued GUARD_LAG steps ago; recover if it (or, the flag being sticky, any
+        step since) was skipped."""
+        k = self._guard_steps - self.GUARD_LAG
+        ev = self._guard_events.pop(k, None)
+        if k < 1 or ev is None:
+            return
+        ev.synchronize()
+        e = self._ring[k % self.GUARD_RING]
+        if int(e[0]) == k and float(e[1]) > 0:
+            self._recover_overflow()
+
+    def _recover_overflow(self):
+        from diff_surfel_rasterization import _C
+        torch.cuda.synchronize()
+        skipped = int(self.opt_surfels.status[1].item())
+        redo = skipped - self._skipped_seen
+        self._skipped_seen = skipped
+        if not self._graph or getattr(self, "_capacity", 0) <= 0:
+            raise RuntimeError("rasterizer capacity overflow outside capacity mode")
+        self.iteration -= redo          # the skipped steps changed nothing: their views are rendered again
+        self._oflag.zero_()
+        self._guard_events.clear()
+        self.overflow_recoveries += 1
+        self._capacity = 2 * self._capacity
+        self._graph = None
+        self.enable_graph(self._capacity, validate=False)
+
     # ---- whole-step HIP graph ------------------------------------------------------------------------------------
-    def enable_graph(self, capacity):
+    def enable_graph(self, capacity, validate=True):
         """Capture deform -> render -> loss -> backward (-> Adam when single-GPU) into HIP graphs and replay them per
         step: the step is ~400 small launches and otherwise bound by the host, not the GPU.  Needs the rasterizer's
         capacity mode (`capacity` list entries; no device->host read inside the step).  Per view, one 256-byte row (camera,
@@ -205,6 +276,8 @@ class Trainer:
         dev = self.surfels.get_xyz.device
         self._capacity = int(capacity)
         _C.set_capacity(int(capacity))
+        if getattr(self, "_oflag", None) is not None:
+            _C.set_overflow_flag(self._oflag)   # the captured launches keep THIS trainer's flag
         # (rays_d [H*W,3], rays_o [3]) per view and the targets stay resident: the table rows point at them
         self._rays = [tuple(t.contiguous() for t in camera_rays(cam, dev)) for cam in self.cameras]
         self._targets_c = [t.contiguous() for t in self.targets]
@@ -258,13 +331,16 @@ class Trainer:
             with torch.cuda.graph(self._g2, pool=self._g1.pool(), **mode):
                 self._finish(reduce=False, sh_done=self._split)
         self._graph = True
-        if _C.read_overflow():
+        # validate: the warm-up rendered the first view -- fail now rather than let the step guard double the capacity later
+        # (validate=False leaves it to the guard: every view, not just the first, is covered by it anyway)
+        if _C.read_overflow() and validate:
             raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
 
     def _snapshot(self):
         sf = self.surfels
         state = [p.detach().clone() for p in self.bucket.params]
-        opt = (self.opt_surfels.exp_avg.clone(), self.opt_surfels.exp_avg_sq.clone(), self.opt_surfels.t.clone())
+        opt = (self.opt_surfels.exp_avg.clone(), self.opt_surfels.exp_avg_sq.clone(), self.opt_surfels.t.clone(),
+               self.opt_surfels.status.clone())
         stats = (sf.xyz_gradient_accum.clone(), sf.denom.clone(), sf.max_radii2D.clone())
         return state, opt, stats
 
@@ -277,6 +353,7 @@ class Trainer:
         self.opt_surfels.exp_avg.copy_(opt[0])
         self.opt_surfels.exp_avg_sq.copy_(opt[1])
         self.opt_surfels.t.copy_(opt[2])
+        self.opt_surfels.status.copy_(opt[3])
         sf.xyz_gradient_accum.copy_(stats[0])
         sf.denom.copy_(stats[1])
         sf.max_radii2D.copy_(stats[2])
@@ -319,21 +396,28 @@ class Trainer:
                 dsr.set_sh_grad_sink(None)
         return fn()
 
-    def _statistics(self, pkg, fused):
+    def _statistics(self, pkg, fused, early_radii=False):
         with torch.no_grad():
             # densification statistics of this view into the bucket tail (summed over ranks)
-            if not hasattr(self, "_radii"):
-                self._radii = torch.zeros_like(pkg["radii"])
+            if getattr(self, "_radii", None) is None:
+                self._radii = torch.zeros(self.P + 4, dtype=pkg["radii"].dtype, device=pkg["radii"].device)
             if fused:
                 from . import _ops
-                _ops.densify_view(pkg["radii"], pkg["viewspace_points"].grad, self.bucket.extra[:self.P], self.bucket.extra[self.P:],
-                                  self._radii)
+                radii_vis = self._radii
+                if early_radii:   # split step: radii + flag were copied (and their all-reduce started) right after the forward
+                    if self._radii_scratch is None:
+                        self._radii_scratch = torch.empty_like(self._radii)
+                    radii_vis = self._radii_scratch
+                elif self.world > 1 and getattr(self, "_oflag", None) is not None:
+                    self._radii[self.P:self.P + 1].copy_(self._oflag)
+                _ops.densify_view(pkg["radii"], pkg["viewspace_points"].grad, self.bucket.extra[:self.P], self.bucket.extra[self.P:2 * self.P],
+                                  radii_vis)
             else:
                 vis = pkg["visibility_filter"]
                 g2 = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
                 self.bucket.extra[:self.P].copy_(torch.where(vis, g2, torch.zeros_like(g2)))
-                self.bucket.extra[self.P:].copy_(vis.to(torch.float32))
-                self._radii.copy_(torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"])))
+                self.bucket.extra[self.P:2 * self.P].copy_(vis.to(torch.float32))
+                self._radii[:self.P].copy_(torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"])))
 
     def _fwd_bwd(self, cam, gt):
         d = self.deform
@@ -346,10 +430,18 @@ class Trainer:
         return loss.detach()
 
     # ---- data parallel: the backward in two halves with the SH all-reduce in between ---------------------------------
+    def _arap_active(self):
+        """True while the ARAP term is part of the loss of the step being built (same test as _forward)."""
+        if not self.arap:
+            return False
+        from .arap import lambda_arap
+        return lambda_arap(self.iteration) > 0 and self.iteration > self.arap_from
+
     def _split_ok(self):
         s = self.surfels
-        return (self.world > 1 and self.overlap_allreduce and self.rasterizer_cls is None and s.get_xyz.is_cuda and self.fuse_deform
-                and getattr(s, "packed_sh", False) and self.sh_grad_sink and self.n_sh > 0 and self.deform.can_assemble(s))
+        hip_fused = (self.rasterizer_cls is None and s.get_xyz.is_cuda and self.fuse_deform and getattr(s, "packed_sh", False)
+                     and self.sh_grad_sink and self.n_sh > 0 and self.deform.can_assemble(s))
+        return split_step_allowed(self.world, self.overlap_allreduce, hip_fused, self._arap_active())
 
     def _fwd_bwd_a(self, cam, gt):
         """Forward, loss and the backward down to the rasterizer's inputs: afterwards the SH segment of the bucket is final."""
@@ -358,6 +450,9 @@ class Trainer:
         grads = self._run_backward(lambda: torch.autograd.grad(loss, list(asm) + [leaf], grad_outputs=self._unit, allow_unused=True), fused)
         leaf.grad = grads[4]
         self._half = (asm, grads[:4], pkg)
+        with torch.no_grad():   # final after the forward: their MAX all-reduce starts first (the guard of the SH update needs it)
+            self._radii[:self.P].copy_(pkg["radii"])   # radii are 0 for culled surfels: same as the masked copy of _statistics
+            self._radii[self.P:self.P + 1].copy_(self._oflag)
         return loss.detach()
 
     def _fwd_bwd_b(self):
@@ -366,15 +461,17 @@ class Trainer:
         keep = [(a, g) for a, g in zip(asm, g_asm) if g is not None]
         torch.autograd.backward([a for a, _ in keep], [g for _, g in keep])
         self.deform.finish_backward(join=True)
-        self._statistics(pkg, True)
+        self._statistics(pkg, True, early_radii=True)
         self._half = None
 
     def _reduce_sh_start(self):
         return dist.all_reduce(self.bucket.flat[:self.n_sh], op=dist.ReduceOp.SUM, async_op=True)
 
+    def _reduce_radii_start(self):
+        return dist.all_reduce(self._radii, op=dist.ReduceOp.MAX, async_op=True)
+
     def _reduce_rest_start(self):
-        return [dist.all_reduce(self.bucket.flat[self.n_sh:], op=dist.ReduceOp.SUM, async_op=True),
-                dist.all_reduce(self._radii, op=dist.ReduceOp.MAX, async_op=True)]
+        return [dist.all_reduce(self.bucket.flat[self.n_sh:], op=dist.ReduceOp.SUM, async_op=True)]
 
     @property
     def _fold_mean(self):
@@ -402,12 +499,12 @@ class Trainer:
                 self.opt_surfels.grad_scale = 1.0 / self.world if self._fold_mean else 1.0
             if self.rasterizer_cls is None and s.get_xyz.is_cuda:
                 from . import _ops
-                _ops.densify_accumulate(self.bucket.extra[:self.P], self.bucket.extra[self.P:], self._radii, s.xyz_gradient_accum,
-                                        s.denom, s.max_radii2D)
+                _ops.densify_accumulate(self.bucket.extra[:self.P], self.bucket.extra[self.P:2 * self.P], self._radii[:self.P], s.xyz_gradient_accum,
+                                        s.denom, s.max_radii2D, skip=self.opt_surfels.skip if self.opt_deform is None else None)
             else:
                 s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
-                s.denom.add_(self.bucket.extra[self.P:, None])
-                torch.maximum(s.max_radii2D, self._radii, out=s.max_radii2D)
+                s.denom.add_(self.bucket.extra[self.P:2 * self.P, None])
+                torch.maximum(s.max_radii2D, self._radii[:self.P], out=s.max_radii2D)
             if self.opt_deform is not None:
                 if self.lr_schedule:
                     k = self._steps_done
@@ -494,9 +591,10 @@ class Trainer:
             for name in ("xyz_gradient_accum", "denom", "max_radii2D", "alive"):
                 b = getattr(s, name)
                 setattr(s, name, torch.cat((b, torch.zeros((n,) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device))))
-        for a in ("_radii", "_half"):
+        for a in ("_half",):
             if hasattr(self, a):
                 delattr(self, a)
+        self._radii = None
         self._build_state()
         moments = self._moments()
         with torch.no_grad():
@@ -518,6 +616,8 @@ class Trainer:
                     v.copy_(v0)
         if self._graph:
             self._graph = None
+            # the list capacity follows the slot count (the same entries per surfel as before)
+            self._capacity = int(-(-self._capacity * capacity // old))
             self.enable_graph(self._capacity)
 
     def densify_nodes(self, max_grad=0.0002):
@@ -582,15 +682,34 @@ class Trainer:
         return (iteration * self.world + self.rank) % len(self.cameras)
 
     def step(self):
+        guarded = self.opt_deform is None and getattr(self, "_oflag", None) is not None
+        if guarded:
+            self._check_guard()
+            if not self._graph:   # eager launches read the context's current flag (a captured step has its own baked in)
+                from diff_surfel_rasterization import _C
+                _C.set_overflow_flag(self._oflag)
         v = self.view_for(self.iteration)
         self.iteration += 1
+        loss = self._step_view(v)
+        if guarded:
+            self._guard_steps += 1
+            ev = torch.cuda.Event()
+            ev.record()
+            self._guard_events[self._guard_steps] = ev
+            if len(self._guard_events) > 2 * self.GUARD_RING:
+                self._guard_events.pop(min(self._guard_events))
+        return loss
+
+    def _step_view(self, v):
         if self._graph:
             self._scam.load(self._vtab[v])   # one 256-byte copy: camera matrices, time, and the pointers of target / ray table
             self._g1.replay()
             if self._g1b is not None:
+                rwork = self._reduce_radii_start()   # radii + overflow flag (small): first, the SH update's guard reads it
                 work = self._reduce_sh_start()   # runs on the collective's stream while graph 1b replays
                 self._g1b.replay()
                 rest = self._reduce_rest_start()
+                rwork.wait()
                 work.wait()
                 self._g2a.replay()               # SH update while the rest of the bucket is on the wire
                 for w in rest:
@@ -611,9 +730,11 @@ class Trainer:
         """Data-parallel step, eager: backward half a | SH all-reduce (async) | backward half b | all-reduce of the rest
         (async) | SH update | update of everything else."""
         loss = self._fwd_bwd_a(cam, gt)
+        rwork = self._reduce_radii_start()
         work = self._reduce_sh_start()
         self._fwd_bwd_b()
         rest = self._reduce_rest_start()
+        rwork.wait()
         work.wait()
         self._finish_sh()
         for w in rest:

@@ -26,7 +26,9 @@ _lib = None
 
 _EXPORTS = ("dgs_abi_version", "dgs_last_error", "dgs_rasterizer_mark_visible", "dgs_rasterizer_forward",
             "dgs_rasterizer_backward", "dgs_debug_layout", "dgs_set_tight_rects", "dgs_set_option", "dgs_read_overflow", "dgs_profile_enable", "dgs_profile_reset",
-            "dgs_profile_read")
+            "dgs_profile_read", "dgs_set_overflow_flag", "dgs_context_create", "dgs_context_destroy", "dgs_context_set_option",
+            "dgs_context_set_overflow_flag", "dgs_context_read_overflow", "dgs_context_profile_enable", "dgs_context_profile_reset",
+            "dgs_context_profile_read", "dgs_context_forward", "dgs_context_backward")
 
 
 def _deps():
@@ -65,14 +67,36 @@ def load():
     lib.dgs_last_error.argtypes = []
     lib.dgs_rasterizer_mark_visible.restype = ci
     lib.dgs_rasterizer_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    fwd_args = [_ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
+                cf, cf, ci, vp, vp, vp, ci, vp]
+    bwd_args = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                vp, vp, vp, vp, vp, ci, vp]
     lib.dgs_rasterizer_forward.restype = ci
-    lib.dgs_rasterizer_forward.argtypes = (
-        [_ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
-         cf, cf, ci, vp, vp, vp, ci, vp])
+    lib.dgs_rasterizer_forward.argtypes = fwd_args
     lib.dgs_rasterizer_backward.restype = ci
-    lib.dgs_rasterizer_backward.argtypes = (
-        [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-         vp, vp, vp, vp, vp, ci, vp])
+    lib.dgs_rasterizer_backward.argtypes = bwd_args
+    lib.dgs_context_forward.restype = ci
+    lib.dgs_context_forward.argtypes = [vp] + fwd_args
+    lib.dgs_context_backward.restype = ci
+    lib.dgs_context_backward.argtypes = [vp] + bwd_args
+    lib.dgs_context_create.restype = vp
+    lib.dgs_context_create.argtypes = []
+    lib.dgs_context_destroy.restype = None
+    lib.dgs_context_destroy.argtypes = [vp]
+    lib.dgs_context_set_option.restype = ci
+    lib.dgs_context_set_option.argtypes = [vp, ci, ci]
+    lib.dgs_context_set_overflow_flag.restype = ci
+    lib.dgs_context_set_overflow_flag.argtypes = [vp, vp]
+    lib.dgs_context_read_overflow.restype = ci
+    lib.dgs_context_read_overflow.argtypes = [vp, ci]
+    lib.dgs_context_profile_enable.restype = ci
+    lib.dgs_context_profile_enable.argtypes = [vp, ci]
+    lib.dgs_context_profile_reset.restype = None
+    lib.dgs_context_profile_reset.argtypes = [vp]
+    lib.dgs_context_profile_read.restype = ci
+    lib.dgs_context_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ci]
+    lib.dgs_set_overflow_flag.restype = ci
+    lib.dgs_set_overflow_flag.argtypes = [vp]
     lib.dgs_debug_layout.restype = ci
     lib.dgs_debug_layout.argtypes = [ci, ci, ci, ci, ci, ctypes.POINTER(sz), ci]
     lib.dgs_set_tight_rects.restype = None
@@ -87,7 +111,7 @@ def load():
     lib.dgs_profile_reset.argtypes = []
     lib.dgs_profile_read.restype = ci
     lib.dgs_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ci]
-    if lib.dgs_abi_version() != 1:
+    if lib.dgs_abi_version() != 2:
         raise RuntimeError("libdgs_surfel_rasterizer.so ABI version mismatch")
     _lib = lib
     return lib
@@ -140,9 +164,49 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class Context:
+    """An explicit library context (dgs_context_create): its own options, overflow flag, staging word and timing state.
+    The operator surface uses the per-device default context; a caller that drives one device from several threads, or wants
+    different options side by side, passes `context=` to rasterize_gaussians / rasterize_gaussians_backward."""
+
+    def __init__(self, device=None):
+        lib = load()
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            self.handle = ctypes.c_void_p(lib.dgs_context_create())
+        if not self.handle:
+            raise RuntimeError("dgs_context_create failed")
+
+    def set_option(self, key, value):
+        lib = load()
+        rc = lib.dgs_context_set_option(self.handle, int(key), int(value))
+        if rc < 0:
+            _raise(lib, rc, "context.set_option")
+
+    def set_overflow_flag(self, tensor):
+        lib = load()
+        rc = lib.dgs_context_set_overflow_flag(self.handle, None if tensor is None else tensor.data_ptr())
+        if rc < 0:
+            _raise(lib, rc, "context.set_overflow_flag")
+        self._flag = tensor   # keep it alive
+
+    def read_overflow(self, reset=True):
+        return bool(load().dgs_context_read_overflow(self.handle, 1 if reset else 0))
+
+    def close(self):
+        if self.handle:
+            load().dgs_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, context=None):
     """-> (num_rendered, out_color[3,H,W], out_others[8,H,W], radii[P] i32, geomBuffer, binningBuffer, imgBuffer)"""
     lib = load()
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -169,7 +233,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         sc, rot, tm = _f32c(scales), _f32c(rotations), _f32c(transMat_precomp)
         vm, pm, shc, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(sh), _f32c(campos)
         with torch.cuda.device(dev):
-            rendered = lib.dgs_rasterizer_forward(
+            entry = lib.dgs_rasterizer_forward if context is None else (lambda *a: lib.dgs_context_forward(context.handle, *a))
+            rendered = entry(
                 geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), _ptr(bg), W, H, _ptr(m3), _ptr(shc),
                 _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp),
                 float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), out_color.data_ptr(), out_others.data_ptr(),
@@ -181,7 +246,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, dL_dsh_out=None):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, dL_dsh_out=None, context=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
     dL_dscales[P,2], dL_drotations[P,4])  -- rasterize_points.cu:239"""
     lib = load()
@@ -211,7 +276,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         rad = radii.contiguous()
         gb, bb, ib = geomBuffer.contiguous(), binningBuffer.contiguous(), imageBuffer.contiguous()
         with torch.cuda.device(dev):
-            rc = lib.dgs_rasterizer_backward(
+            entry = lib.dgs_rasterizer_backward if context is None else (lambda *a: lib.dgs_context_backward(context.handle, *a))
+            rc = entry(
                 P, int(degree), int(M), int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc), float(scale_modifier),
                 _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx), float(tan_fovy), _ptr(rad), _ptr(gb),
                 _ptr(bb), _ptr(ib), _ptr(gc), _ptr(go), dL_dmeans2D.data_ptr(), dL_dnormal.data_ptr(), dL_dopacity.data_ptr(),
@@ -269,8 +335,29 @@ def read_overflow(reset=True):
     return bool(load().dgs_read_overflow(1 if reset else 0))
 
 
-def profile_enable(on=True):
-    load().dgs_profile_enable(1 if on else 0)
+_OVERFLOW_FLAG = None
+
+
+def set_overflow_flag(tensor):
+    """Hand the default context of the tensor's device a caller-owned int32[1] overflow flag (dgs_set_overflow_flag), so that
+    the caller's own kernels can read it on the device; None returns to the library-owned flag."""
+    global _OVERFLOW_FLAG
+    lib = load()
+    if tensor is not None:
+        assert tensor.dtype == torch.int32 and tensor.numel() == 1 and tensor.is_cuda
+        with torch.cuda.device(tensor.device):
+            rc = lib.dgs_set_overflow_flag(tensor.data_ptr())
+    else:
+        rc = lib.dgs_set_overflow_flag(None)
+    if rc < 0:
+        _raise(lib, rc, "set_overflow_flag")
+    _OVERFLOW_FLAG = tensor   # keep it alive while the library points at it
+
+
+def profile_enable(mode=True):
+    """0 / False: off; 1 / True: HIP events around the blend kernels (eager launches); 2: device timestamps, legal inside a
+    captured graph (see dgs_profile_enable)."""
+    load().dgs_profile_enable(int(mode))
 
 
 def profile_reset():

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 1
+#define DGS_ABI_VERSION 2
 
 /* Replaces std::function<char*(size_t N)> (rasterizer.h:31-33, rasterize_points.cu:31-37): must return a
  * device buffer of at least `bytes` bytes, 128-byte aligned, usable on `stream`. */
@@ -71,8 +71,12 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
                            float* out_others, int* radii, int debug, void* stream);
 
 /* CudaRasterizer::Rasterizer::backward, rasterizer.h:59-87 / rasterizer_impl.cu:346-448.
- * R = the value forward returned. All dL_d* outputs must be zero-initialised by the caller
- * (rasterize_points.cu:194-202). Shapes: dL_dpix[3,H,W], dL_depths[8,H,W], dL_dmean2D[P,3],
+ * R = the value forward returned.  Every dL_d* row of a VISIBLE surfel (radii > 0) is written exactly once -- stored,
+ * not accumulated: the per-pixel atomics of the reference are replaced by one private 80-byte accumulator row per surfel
+ * that the per-surfel kernel reads back -- and rows of culled surfels are not touched.  With caller-zeroed outputs (the
+ * reference's contract, rasterize_points.cu:194-202) the results are the reference's; a caller may also pass a buffer it
+ * wants only the visible rows overwritten in (diff_surfel_rasterization.set_sh_grad_sink does that for dL_dsh, of which
+ * only the first (D+1)^2 coefficients are written, as in the reference).  Shapes: dL_dpix[3,H,W], dL_depths[8,H,W], dL_dmean2D[P,3],
  * dL_dnormal[P,3], dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
  * dL_dscale[P,2], dL_drot[P,4].  Returns DGS_OK or a negative dgs_status. */
 int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -83,6 +87,38 @@ int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background,
                             const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
                             float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
                             float* dL_drot, int debug, void* stream);
+
+/* ---- contexts -----------------------------------------------------------------------------------------------------
+ * The reference's entry points carry no state (rasterizer.h:20-87) and are re-entrant across devices and threads.  What
+ * this library adds -- tile-list policy, capacity mode with its overflow flag, the pinned word of the one device->host
+ * read, the kernel-timing hook -- is held by a dgs_context.  dgs_rasterizer_forward/backward and the knobs further down
+ * act on a default context that exists once PER DEVICE (the calling thread's current HIP device); a caller that drives
+ * one device from several threads, or wants different options side by side, creates its own contexts.  Options are
+ * atomics: changing one while another thread is inside a call affects that call or the next, never corrupts it. */
+typedef struct dgs_context dgs_context;
+dgs_context* dgs_context_create(void);          /* bound to the calling thread's current HIP device */
+void dgs_context_destroy(dgs_context* ctx);
+int dgs_context_set_option(dgs_context* ctx, int key, int value);               /* keys: see dgs_set_option */
+int dgs_context_set_overflow_flag(dgs_context* ctx, int* device_flag);         /* see dgs_set_overflow_flag */
+int dgs_context_read_overflow(dgs_context* ctx, int reset);
+int dgs_context_profile_enable(dgs_context* ctx, int mode);
+void dgs_context_profile_reset(dgs_context* ctx);
+int dgs_context_profile_read(dgs_context* ctx, double* out, int cap);
+/* dgs_rasterizer_forward / dgs_rasterizer_backward with an explicit context (same arguments after it) */
+int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_alloc_fn binning_alloc,
+                        void* binning_ctx, dgs_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                        int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                        float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_others, int* radii,
+                        int debug, void* stream);
+int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                         char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix, const float* dL_depths,
+                         float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                         float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream);
 
 /* ---- introspection used by the parity tests and bench.py (not part of the reference surface) ---- */
 
@@ -101,26 +137,31 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
  * gradients are the same either way; num_rendered and the private lists differ. */
 void dgs_set_tight_rects(int on);
 
-/* Development knobs for A/B measurements (defaults are the tuned values): key 0 = tight rects (0/1),
+/* Knobs (default context of the current device; defaults are the tuned values): key 0 = tight rects (0/1),
  * key 1 = blend tile order (0 row-major, 1 XCD-contiguous, 2 XCD row-interleaved, 3 longest-list-first [default]),
  * key 2 = capacity mode: value > 0 sizes the binning buffer for `value` list entries and removes the one
  *         device->host read of the forward (rasterizer_impl.cu:281-282), which makes forward + backward legal inside
  *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do
- *         not fit renders as background and raises a flag readable with dgs_read_overflow(); value 0 restores the
- *         exact-size mode,
+ *         not fit renders as background and raises the overflow flag; value 0 restores the exact-size mode,
  * key 3 = per-tile sort of lists up to 2048 entries: 1 register-resident network [default], 0 the LDS network.
  * Returns DGS_OK or an error. */
 int dgs_set_option(int key, int value);
 
+/* The capacity-overflow flag is one int32 in device memory, OR-ed to 1 by the forward whose lists did not fit.  By default
+ * the library owns it (dgs_read_overflow).  A trainer that must not act on such a frame hands in its own flag here and lets
+ * its optimiser kernels read it on the device (skip the update) -- no host round trip; NULL returns to the library's. */
+int dgs_set_overflow_flag(int* device_flag);
+
 /* 1 if a capacity overflow happened since the last reset (blocking device read; call it outside hot loops). */
 int dgs_read_overflow(int reset);
 
-/* Kernel timing hook for bench.py: when enabled, the library brackets the forward and backward blend
- * kernels with HIP events on the launch stream; dgs_profile_read returns accumulated milliseconds and
- * launch counts since the last reset: out[0..1] fwd blend (ms, n), out[2..3] bwd blend (ms, n),
- * out[4], out[5] = sum over the timed fwd / bwd launches of S = sum_tiles(entries traversed), the unit
- * of the algorithmic-bytes formula. */
-void dgs_profile_enable(int on);
+/* Kernel timing hook for bench.py.  mode 1: the library brackets the forward and backward blend kernels with HIP events on
+ * the launch stream (eager launches only); mode 2: with one-thread kernels that append the device's constant-rate
+ * (100 MHz) counter to a ring -- legal inside a captured graph, so the kernels are timed in the launch mode the replayed
+ * step uses; mode 0: off.  dgs_profile_read returns accumulated milliseconds and launch counts since the last reset:
+ * out[0..1] fwd blend (ms, n), out[2..3] bwd blend (ms, n), out[4], out[5] = sum over the timed fwd / bwd launches of
+ * S = sum_tiles(entries traversed), the unit of the algorithmic-bytes formula. */
+void dgs_profile_enable(int mode);
 void dgs_profile_reset(void);
 int dgs_profile_read(double* out, int cap);
 

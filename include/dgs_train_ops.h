@@ -105,6 +105,22 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
                         float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1, float beta2,
                         float eps, const void* plan, void* stream);
 
+/* Guarded step.  In capacity mode (dgs_surfel_rasterizer.h) a view whose tile lists do not fit renders as background and
+ * raises an int32 device flag; nothing on the host knows yet.  The kernels below read such a flag ON THE DEVICE (`skip`:
+ * the rasterizer's flag itself, or -- data parallel -- a copy that went through a MAX all-reduce so that every rank sees
+ * "some rank overflowed"):
+ *   dgs_step_guard(skip, step_count, status, host_ring, ring_len): one thread; advances the Adam step count unless
+ *     skip[0] != 0; status[3] = {skip flag of this step, skipped steps so far, guarded steps so far}; if host_ring (pinned,
+ *     device-accessible host memory, 4 floats per entry) is given, entry (steps % ring_len) <- (steps, flag, skipped, 0) so
+ *     the host can poll the outcome of step k a few steps later without synchronising,
+ *   dgs_adam_step_guarded / dgs_densify_accumulate_guarded: return without changing anything when skip[0] != 0.
+ * A frame that overflowed therefore trains nothing -- not the parameters, not the moments, not the statistics. */
+int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, void* stream);
+int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                          const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                          float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
+                          float beta2, float eps, const void* plan, const int* skip, void* stream);
+
 /* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:
  * posenc(xyz,10) | timenet(posenc(t,6)): 13->256->30, 8 x 256 ReLU layers, skip concat after layer 4, heads
  * local_rotation 4 / warp 3 / rotation 4 / scaling 2) forward + backward as four kernels on fp32 MFMA.
@@ -182,6 +198,9 @@ int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, c
 int dgs_densify_view(int P, const int* radii, const float* g_means2D, float* grad_norm, float* visible, int* radii_vis, void* stream);
 int dgs_densify_accumulate(int P, const float* grad_norm, const float* visible, const int* radii_vis, float* accum, float* denom,
                            int* max_radii, void* stream);
+/* ... with the step guard (see dgs_step_guard) */
+int dgs_densify_accumulate_guarded(int P, const float* grad_norm, const float* visible, const int* radii_vis, float* accum, float* denom,
+                                   int* max_radii, const int* skip, void* stream);
 
 /* Exact K nearest neighbours seeded with a previous answer: idx[N,K] holds any earlier result on entry (typically last
  * step's; stale, random or invalid entries only cost time) and the exact answer of dgs_knn_points2 on exit.  The scan over

@@ -75,3 +75,26 @@ def test_trainer_adds_the_weighted_arap_term(monkeypatch):
     # weight zero after iteration 20000: the term vanishes
     tr.iteration = 25000
     assert arap.lambda_arap(tr.iteration) == 0
+
+
+def test_split_dp_step_is_refused_while_arap_is_active(monkeypatch):
+    """The split data-parallel backward differentiates w.r.t. the assembled rasterizer inputs only; the ARAP term reaches
+    the network weights directly, so while its weight is non-zero the trainer must fall back to the unsplit step."""
+    import dgs_amd.render as render_mod
+    from dgs_amd.train import Trainer, split_step_allowed
+    from oracle_raster_op import OracleRasterizer
+    from test_train_step_cpu import _build
+    assert split_step_allowed(2, True, True, False) is True
+    assert split_step_allowed(2, True, True, True) is False      # ARAP active
+    assert split_step_allowed(1, True, True, False) is False     # single rank: nothing to overlap
+    assert split_step_allowed(2, True, False, False) is False    # not the fused HIP path
+    monkeypatch.setattr(render_mod, "GaussianRasterizer", OracleRasterizer)
+    surfels, deform, cams, targets, bg = _build(P=60, S=32, nodes=24, views=2)
+    tr = Trainer(surfels, deform, cams, targets, bg, arap=True)
+    tr.iteration = 100
+    assert tr._arap_active()
+    tr.iteration = 25000                                        # weight schedule has reached zero
+    assert not tr._arap_active()
+    tr.arap = False
+    tr.iteration = 100
+    assert not tr._arap_active()

@@ -7,6 +7,7 @@ import os
 import shutil
 
 import numpy as np
+import pytest
 import torch
 
 from dgs_amd import io as dio
@@ -126,6 +127,25 @@ def test_deform_weights_file_is_the_reference_layout(tmp_path):
     assert dio.load_deform(deform, str(tmp_path)) is True
     assert deform.nodes.shape == (64, 11) and torch.equal(deform.network.linear[5].weight, ref_state["network.linear.5.weight"])
     assert dio.load_deform(deform, str(tmp_path / "nothing_here")) is False
+    # a file from a real training run also carries the node Gaussians (`gs_` + GaussianModel.param_names(),
+    # utils/time_utils.py:867-872, scene/gaussian_model.py:77-78): skipped like the reference's strict=False load does for
+    # everything it does not own -- the owned tensors still load
+    full = dict(ref_state)
+    for name, shape in (("_xyz", (64, 3)), ("_features_dc", (64, 1, 3)), ("_features_rest", (64, 15, 3)), ("_scaling", (64, 2)),
+                        ("_rotation", (64, 4)), ("_opacity", (64, 1)), ("max_radii2D", (64,)), ("xyz_gradient_accum", (64, 1))):
+        full["gs_" + name] = torch.randn(*shape, generator=gen)
+    full["network.linear.5.weight"] = full["network.linear.5.weight"] + 1.0
+    os.makedirs(tmp_path / "deform" / "iteration_41000")
+    torch.save(full, tmp_path / "deform" / "iteration_41000" / "deform.pth")
+    assert dio.load_deform(deform, str(tmp_path)) is True
+    assert torch.equal(deform.network.linear[5].weight, full["network.linear.5.weight"])
+    assert sorted(dio.load_deform.skipped_keys) == sorted(k for k in full if k.startswith("gs_"))
+    # an own key missing from the file is an error, not a silent partial load
+    del full["network.linear.5.weight"]
+    os.makedirs(tmp_path / "deform" / "iteration_42000")
+    torch.save(full, tmp_path / "deform" / "iteration_42000" / "deform.pth")
+    with pytest.raises(KeyError):
+        dio.load_deform(deform, str(tmp_path))
 
 
 def test_fit_tiny_scene_end_to_end_and_restore(tmp_path, monkeypatch):

@@ -108,6 +108,53 @@ def test_capacity_overflow_is_flagged_not_fatal():
     assert abs(out["color"]).max() > 0
 
 
+def test_capacity_overflow_skips_the_step_and_recovers():
+    """A view whose tile lists do not fit the capacity must train NOTHING (parameters, moments, statistics, step count),
+    on the device, without any host read in the step; the trainer notices two steps later, doubles the capacity,
+    re-captures and redoes the skipped views -- the run ends where a run with enough capacity ends."""
+    import bench
+    from diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+    P, steps = 20000, 5
+
+    def flat(tr):
+        return torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).clone()
+
+    try:
+        ref = bench.build_trainer(P, 256, 256, dev, n_views=8, n_targets=2)
+        ref.enable_graph(capacity=24 * P)
+        ref_losses = [float(ref.step()) for _ in range(steps)]
+        torch.cuda.synchronize()
+        assert ref.overflow_recoveries == 0 and float(ref.opt_surfels.status[1]) == 0
+        want, want_stats = flat(ref).cpu(), ref.surfels.denom.clone().cpu()
+
+        tr = bench.build_trainer(P, 256, 256, dev, n_views=8, n_targets=2)
+        start = flat(tr)
+        tr.enable_graph(capacity=4000, validate=False)        # every view overflows this
+        tr.step()
+        tr.step()
+        torch.cuda.synchronize()
+        # the two overflowing steps changed nothing at all
+        assert torch.equal(flat(tr), start) and float(tr.opt_surfels.t) == 0.0 and float(tr.surfels.denom.sum()) == 0.0
+        assert float(tr.opt_surfels.exp_avg.abs().sum()) == 0.0 and float(tr.opt_surfels.status[1]) == 2.0
+        losses = {}
+        calls = 0
+        while float(tr.opt_surfels.t) < steps and calls < 200:   # the host reads here only because the test wants to stop
+            it = tr.iteration
+            l = tr.step()
+            calls += 1
+            losses[it] = l.clone()
+        torch.cuda.synchronize()
+        assert float(tr.opt_surfels.t) == steps and tr.overflow_recoveries >= 3 and tr._capacity >= 32000
+        assert tr.iteration == steps + (int(tr.opt_surfels.status[1]) - tr._skipped_seen)
+        got = flat(tr).cpu()
+        assert torch.isfinite(got).all() and float((got - want).abs().median()) < 1e-6
+        assert float((tr.surfels.denom.cpu() - want_stats).abs().sum()) <= 4   # every view counted exactly once (a borderline radius may flip: atomics order)
+    finally:
+        _C.set_capacity(0)
+        _C.set_overflow_flag(None)
+
+
 def test_fused_lbs_matches_torch_autograd():
     """dgs_lbs_forward/backward against the PyTorch formulation of ControlNodes.forward (itself golden-pinned
     against the reference on the CPU): outputs and every gradient that leaves the deformation module."""
