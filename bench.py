@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-legs", action="store_true",
+                    help="skip the extra kernel-timing passes after the timed region (PMC runs of tools/pmc_kernels.sh use this)")
     ap.add_argument("--densify-every", type=int, default=0,
                     help="also run the in-place densification every N timed steps (off by default: the metric is the plain step)")
     ap.add_argument("--slots-factor", type=float, default=1.5, help="surfel slots per initial surfel when --densify-every is on")
@@ -248,49 +250,78 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # ---- roofline leg: the same K steps again, launched eagerly so that the library can bracket the two blend
-    # kernels with HIP events on the launch stream (events cannot be read per replay inside a captured graph).
-    # Kernel durations do not depend on how the launch was issued.
-    tr._graph = None
-    _C.set_capacity(0)
-    _C.profile_enable(True)
-    _C.profile_reset()
-    eager_losses = [float(tr.step()) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    prof = _C.profile_read()
-    _C.profile_enable(False)
-    # self-check of the graph replay: the eager steps continue the same training run, so the two loss series must agree
-    ref = sum(eager_losses) / len(eager_losses)
-    if not all(l == l and 0.8 * ref <= l <= 1.25 * ref for l in timed_losses):
-        raise SystemExit("graph-replayed steps disagree with eager steps (losses %s vs eager mean %.5f): result invalid"
-                         % (["%.4f" % l for l in timed_losses], ref))
+    # ---- roofline legs (after the timed region; the headline value above is not affected) -------------------------------
+    # (1) in-graph: the step is re-captured with the library's device-timestamp hook on (one-thread kernels before and after
+    #     each blend launch append the 100 MHz device counter to a ring -- legal inside a captured graph, where HIP events
+    #     are not) and the same K steps are replayed: the blend kernels are timed in the launch mode the headline uses;
+    # (2) eager: the same K steps launched one by one with HIP events around the blend launches -- the classic clock, kept
+    #     as a cross-check (the device idles between eager launches and the kernels run a few % faster there).
+    prof_graph = prof = None
+    eager_losses = []
+    if not args.no_roofline_legs:
+        if use_graph:
+            _C.profile_enable(2)
+            tr._graph = None
+            tr.enable_graph(capacity=tr._capacity)
+            torch.cuda.synchronize()
+            _C.profile_reset()      # drop the stamps of the capture's warm-up launches: only replays are counted
+            for _ in range(args.steps):
+                tr.step()
+            torch.cuda.synchronize()
+            prof_graph = _C.profile_read()
+            _C.profile_enable(0)
+        tr._graph = None
+        _C.set_capacity(0)
+        _C.profile_enable(1)
+        _C.profile_reset()
+        eager_losses = [float(tr.step()) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        prof = _C.profile_read()
+        _C.profile_enable(0)
+        # self-check of the graph replay: the eager steps continue the same training run, so the two loss series must agree
+        ref = sum(eager_losses) / len(eager_losses)
+        if not all(l == l and 0.8 * ref <= l <= 1.25 * ref for l in timed_losses):
+            raise SystemExit("graph-replayed steps disagree with eager steps (losses %s vs eager mean %.5f): result invalid"
+                             % (["%.4f" % l for l in timed_losses], ref))
 
     if rank == 0:
         ntiles = ((W + 15) // 16) * ((H + 15) // 16)
 
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # runs, corrected as MI355X_MICROARCH.md prescribes); only meaningful for the workload they were taken on
-        traffic = {}
+        # HBM traffic per launch from the committed PMC passes (tools/pmc_kernels.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # in separate runs of THIS command, corrected as MI355X_MICROARCH.md prescribes).  Reported only when the file was
+        # taken on this workload AND on the library sources that are loaded now (hash of sources + flags).
+        traffic, traffic_src = {}, None
+        pmc_path = os.path.join("profiles", "r02_pmc_blend_%s.json" % args.workload)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")) as f:
-                pmc = json.load(f)["kernels"]
-            if args.workload == "metric":
-                traffic = {"fwd": pmc["dgs::blend_fwd_kernel"]["hbm_traffic_bytes_per_launch"],
-                           "bwd": pmc["dgs::blend_bwd_kernel"]["hbm_traffic_bytes_per_launch"]}
-        except Exception:
-            traffic = {}
+            with open(os.path.join(ROOT, pmc_path)) as f:
+                pmc = json.load(f)
+            if pmc.get("workload") == args.workload and pmc.get("library_source_hash") == _C.source_hash():
+                traffic = {"fwd": pmc["kernels"]["dgs::blend_fwd_kernel"]["hbm_traffic_bytes_per_launch"],
+                           "bwd": pmc["kernels"]["dgs::blend_bwd_kernel"]["hbm_traffic_bytes_per_launch"]}
+                traffic_src = "%s (bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes of this command; library sources %s)" % (
+                    pmc_path, pmc["library_source_hash"])
+            else:
+                traffic_src = "%s is for workload %s / library sources %s, loaded library is %s: not reported" % (
+                    pmc_path, pmc.get("workload"), pmc.get("library_source_hash"), _C.source_hash())
+        except Exception as ex:
+            traffic_src = "no PMC profile for this workload (%s)" % type(ex).__name__
 
         def roof(kind):
-            n, ms, S = prof[kind + "_n"], prof[kind + "_ms"], prof[kind + "_S"]
-            if n == 0 or ms <= 0:
+            # the fraction is computed from the in-graph duration when the step is graph-replayed (the headline's launch mode)
+            main, other = (prof_graph, prof) if prof_graph and prof_graph[kind + "_n"] else (prof, None)
+            if not main or main[kind + "_n"] == 0 or main[kind + "_ms"] <= 0:
                 return None
+            n, ms, S = main[kind + "_n"], main[kind + "_ms"], main[kind + "_S"]
             bytes_per = blend_bytes(S / n, ntiles, H * W, backward=(kind == "bwd"))
             gbs = bytes_per / (ms / n * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "blend_%s_kernel" % kind, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(kind),
-                    "traffic_source": "profiles/r01_pmc_kernels.json (bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB)" if kind in traffic else None,
-                    "timing": "HIP events on the launch stream, eager re-run of the timed steps",
-                    "avg_kernel_ms": round(ms / n, 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S / n)}
+            r = {"bound": "hbm", "kernel": "blend_%s_kernel" % kind, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(kind), "traffic_source": traffic_src,
+                 "timing": ("device timestamps (100 MHz counter) around the kernel inside the replayed whole-step graph, %d launches" % n)
+                 if main is prof_graph else ("HIP events on the launch stream, eager launches, %d launches" % n),
+                 "avg_kernel_ms": round(ms / n, 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S / n)}
+            if other and other[kind + "_n"]:
+                r["avg_kernel_ms_eager_events"] = round(other[kind + "_ms"] / other[kind + "_n"], 4)
+            return r
 
         out = {
             "metric": "train views/sec (fwd+bwd), 800x800, 200k surfels" if args.workload == "metric"

@@ -184,6 +184,8 @@ struct dgs_context {
     std::atomic<int> sort_regs{1};    // per-tile sort of <= 2048 entries in registers (kernels_preprocess.h)
     std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
+    std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
+    std::atomic<int> grid_limit_fwd{0};   // > 0 (diagnostic, key 5): same for the forward blend (the other tiles' state is zero-filled)
     std::atomic<int*> overflow{nullptr};  // device flag raised by a capacity overflow (library- or caller-owned)
     int* overflow_owned = nullptr;
     std::mutex mu;                    // lazy allocations
@@ -307,6 +309,8 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (key == 0) { c->tight_rects.store(value != 0); return DGS_OK; }
     if (key == 1 && value >= 0 && value <= 3) { c->tile_order.store(value); return DGS_OK; }
     if (key == 3) { c->sort_regs.store(value != 0); return DGS_OK; }
+    if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
+    if (key == 5 && value >= 0) { c->grid_limit_fwd.store(value); return DGS_OK; }
     if (key == 2 && value >= 0) {
         if (value > 0)
             if (int e = ensure_overflow(c)) return e;
@@ -617,7 +621,12 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     fa.tile_last = (uint32_t*)(img + il.tile_last);
     fa.out_color = out_color;
     fa.out_others = out_others;
-    const int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, fa.mode);
+    int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, fa.mode);
+    if (const int lim = ctx->grid_limit_fwd.load()) {
+        grid = lim < grid ? lim : grid;
+        DGS_HIP(hipMemsetAsync(img + il.final_T, 0, il.ranges - il.final_T, stream));   // final_T, n_contrib of the skipped tiles
+        DGS_HIP(hipMemsetAsync(img + il.tile_last, 0, (size_t)il.ntiles * 4, stream));
+    }
     Prof::Pair pp;
     const bool timed = prof_begin(ctx, 0, stream, pp);
     hipLaunchKernelGGL(dgs::blend_fwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, fa);
@@ -678,7 +687,8 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         ba.dL_dpix = dL_dpix;
         ba.dL_dothers = dL_depths;
         ba.acc = acc;
-        const int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, ba.mode);
+        int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, ba.mode);
+        if (const int lim = ctx->grid_limit_bwd.load()) grid = lim < grid ? lim : grid;
         Prof::Pair pp;
         const bool timed = prof_begin(ctx, 1, stream, pp);
         hipLaunchKernelGGL(dgs::blend_bwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);

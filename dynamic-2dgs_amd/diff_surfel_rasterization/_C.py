@@ -50,6 +50,19 @@ def build(force=False, verbose=False):
     return _dgs_build.build(LIB_PATH, cmd, _deps(), HIPCC_FLAGS, _CSRC, force=force, verbose=verbose)[0]
 
 
+PRECISE_LIB_PATH = os.path.join(_CSRC, "libdgs_surfel_rasterizer_precise.so")
+
+
+def build_precise(force=False, verbose=False):
+    """Test-only twin of the library with -DDGS_PRECISE_MATH: IEEE division and expf() instead of v_rcp_f32 / v_exp_f32 in
+    the per-pixel arithmetic (surfel_math.h fast_rcp / fast_exp).  tests/test_precise_math_gpu.py loads it in a subprocess
+    (DGS_SURFEL_LIB) to show how much of the distance to the oracle the fast intrinsics account for; never the product."""
+    import _dgs_build
+    flags = HIPCC_FLAGS + ["-DDGS_PRECISE_MATH"]
+    cmd = ["hipcc"] + flags + [os.path.join(_CSRC, "surfel_rasterizer.hip"), "-o", PRECISE_LIB_PATH]
+    return _dgs_build.build(PRECISE_LIB_PATH, cmd, _deps(), flags, _CSRC, force=force, verbose=verbose)[0]
+
+
 def load():
     """dlopen the library and declare the prototypes of include/dgs_surfel_rasterizer.h."""
     global _lib

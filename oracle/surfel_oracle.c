@@ -360,15 +360,15 @@ static void render_fwd(OracleState* st, const real* feat, const real* bg, real* 
                     if (test_T < (real)0.0001) break; /* done = true; :400-405 */
                     real A = 1 - T;
                     real m = mapped_depth(depth);
-                    real w = alpha * T;
+                    /* literal operand order of forward.cu:413-433: `x * alpha * T` is (x * alpha) * T, not x * (alpha * T) */
                     real error = m * m * A + dist2 - 2 * m * dist1;
-                    distortion += error * w;
-                    if ((double)T > 0.5) { median_depth = depth; median_weight = w; median_contributor = (float)contributor; }
-                    for (int ch = 0; ch < 3; ch++) N[ch] += no[ch] * w;
-                    D += depth * w;
-                    dist1 += m * w;
-                    dist2 += m * m * w;
-                    for (int ch = 0; ch < 3; ch++) C[ch] += feat[3 * id + ch] * w;
+                    distortion += error * alpha * T;
+                    if ((double)T > 0.5) { median_depth = depth; median_weight = alpha * T; median_contributor = (float)contributor; }
+                    for (int ch = 0; ch < 3; ch++) N[ch] += no[ch] * alpha * T;
+                    D += depth * alpha * T;
+                    dist1 += m * alpha * T;
+                    dist2 += m * m * alpha * T;
+                    for (int ch = 0; ch < 3; ch++) C[ch] += feat[3 * id + ch] * alpha * T;
                     T = test_T;
                     last_contributor = contributor;
                 }

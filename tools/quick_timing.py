@@ -20,6 +20,7 @@ ap.add_argument("--W", type=int, default=800)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--views", type=int, default=8)
 ap.add_argument("--order", type=int, default=-1)
+ap.add_argument("--grid-limit", type=int, default=0, help="diagnostic: blend kernels process only the N heaviest tiles")
 ap.add_argument("--sort-regs", type=int, default=-1, help="0: LDS bitonic network, 1: register-resident network (default of the library)")
 a = ap.parse_args()
 dev = "cuda:0"
@@ -50,11 +51,19 @@ for i in range(3):
 torch.cuda.synchronize()
 _C.profile_enable(True)
 _C.profile_reset()
+if a.grid_limit > 0:
+    _C.set_option(5, a.grid_limit)
 t = time.time()
 for i in range(a.iters):
     step(i, bwd=False)
 torch.cuda.synchronize()
 tf = (time.time() - t) / a.iters
+if a.grid_limit > 0:
+    prf = _C.profile_read()
+    print("forward blend limited to the %d heaviest tiles: %.3f ms/launch" % (a.grid_limit, prf["fwd_ms"] / max(prf["fwd_n"], 1)))
+    _C.set_option(5, 0)
+    _C.set_option(4, a.grid_limit)
+    _C.profile_reset()
 t = time.time()
 for i in range(a.iters):
     step(i)
