@@ -51,7 +51,8 @@ WORKLOADS = {
 }
 
 
-def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None, packed_sh=None, slots=None):
+def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None, packed_sh=None, slots=None,
+                  sort_surfels=None):
     from dgs_amd.cameras import orbit_cameras
     from dgs_amd.deform import ControlNodes
     from dgs_amd.model import SurfelModel
@@ -67,7 +68,13 @@ def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None,
     cams = [c.to(device) for c in orbit_cameras(n_views, W, H)]
     targets = [target_image(H, W, seed=1 + v).to(device) for v in range(n_targets)]
     bg = torch.zeros(3, device=device)
-    return Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam)
+    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam)
+    if sort_surfels is None:
+        sort_surfels = torch.device(device).type == "cuda" and rasterizer_cls is None and os.environ.get("DGS_SORT_SURFELS", "1") != "0"
+    if sort_surfels:
+        tr.sort_surfels()   # storage order = nearest control node: part of the initialisation, like the reference's own
+                            # Morton ordering inside simple-knn; the per-step kernels of the deformation rely on it for speed
+    return tr
 
 
 def blend_bytes(S_per_launch, ntiles, HW, backward):

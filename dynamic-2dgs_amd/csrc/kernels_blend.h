@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "surfel_math.h"
+#include "wave_reduce.h"
 
 namespace dgs {
 
@@ -281,8 +282,10 @@ struct BlendBwdArgs {
 //      selector as B:  D[i][n] += sum_k v_n[lane 16 k + i]  -- one instruction folds the four 16-lane rows of value n into
 //      column n of ONE 16x16 accumulator, so after the 16 instructions lane (q, n) holds four row sums of value n; three
 //      adds and two cross-row exchanges finish.  The blend kernels issue no other MFMA, the pipe is otherwise idle,
-//   2  hybrid: v_permlane32_swap folds the two wave halves first (values n and n + 8 share a register), then 8 MFMAs.
-// On return lane l holds the wave total of v[l & 15] (variants 1, 2) / v[l >> 2] (variant 0); reduce16_slot() tells which.
+//   2  hybrid: v_permlane32_swap folds the two wave halves first (values n and n + 8 share a register), then 8 MFMAs,
+//   3  (default) VALU only: permlane swaps across rows, bank-masked DPP adds inside a row (wave_reduce.h).
+// Measured at 200k / 800x800 (blend bwd, ms): 0: 0.338, 1: 0.548 (the matrix pipe -- 16 x 32 cycles per visit -- becomes the
+// bottleneck), 2: 0.455, 3: 0.315.  On return lane l holds the wave total of v[l & 15] (variants 1, 2) / v[l >> 2] (variant 0); reduce16_slot() tells which.
 #ifndef DGS_BWD_REDUCE
 #define DGS_BWD_REDUCE 3
 #endif
@@ -360,48 +363,10 @@ __device__ __forceinline__ float wave_reduce16_hybrid(float (&v)[16], int lane)
     return mfma_rows_finish(d0, d1);
 }
 
-// Variant 3: no LDS crossbar at all.  v_permlane32_swap / v_permlane16_swap fold the wave halves and the row pairs (after
-// them row r holds value i + 4 r in register i), then DPP adds with bank-masked writes fold a 16-lane row: row_mirror
-// (lane l + lane 15-l -> lanes 0..7 keep registers 0,1, lanes 8..15 registers 2,3), row_half_mirror, two quad permutes.
-// Any pairing works for a sum; the mirrors are the ones DPP offers across 8 and 4 lanes.  On return every lane of quad k
-// holds the wave total of v[k] (same as variant 0).
-__device__ __forceinline__ float wave_reduce16_dpp(float (&v)[16], int lane)
-{
-    float h[8], g[4];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
-        h[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[i]), __float_as_uint(h[i + 4]), false, false);
-        g[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    float f0, f1, e;
-    // s_nop: a DPP source written by the previous VALU instruction needs two wait states (the assembler does not insert them)
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %1, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-        : "=&v"(f0), "=&v"(f1), "=&v"(e)
-        : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]));
-    return e;
-}
-
 __device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane)
 {
 #if DGS_BWD_REDUCE == 3
-    return wave_reduce16_dpp(v, lane);
+    return wave_reduce16_dpp(v);   // wave_reduce.h: permlane swaps + bank-masked DPP adds, no LDS
 #elif DGS_BWD_REDUCE == 0
     return wave_reduce16_butterfly(v, lane);
 #elif DGS_BWD_REDUCE == 1

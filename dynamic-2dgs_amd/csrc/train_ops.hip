@@ -14,6 +14,7 @@
 
 #include "../../include/dgs_train_ops.h"
 #include "node_mlp.h"
+#include "wave_reduce.h"
 
 namespace {
 
@@ -678,10 +679,43 @@ inline size_t lbs_bwd_lds_bytes(int M, int H)
            (size_t)M * kLbsSlots * sizeof(unsigned short) + 16;
 }
 
-template <bool ASM>
-__global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
+// Coherent variant (COH): for surfels STORED IN THE ORDER OF THEIR NEAREST CONTROL NODE (Trainer.sort_surfels) the 64 points
+// of a wave share one or two nodes in the first neighbour slot and ~10 in the others.  The wave sums each node's
+// contributions across its lanes (wave_reduce.h: permlane swaps + DPP, no LDS) and issues ONE 23-lane global atomic per
+// (wave, node) into a single [M][G] table -- no per-workgroup tables (24 MB of partials to write and re-read), no LDS, 782
+// small workgroups instead of 256 large ones.  Measured at 200 k surfels / 1024 nodes: 97 + 15 us (LDS tables + reduction of
+// the partials) -> 77 + 5 us; the kernel is memory-latency bound either way (3 waves per SIMD in total, PMC: 62 % of the
+// wave cycles parked on s_waitcnt); a variant that first combined the waves of a 512-thread workgroup in an LDS hash table
+// (4x fewer global atomics) measured 96 us -- the atomics are not what it waits for.
+// Correct for any order; an unsorted cloud makes the loop below run once per DISTINCT node of a wave (up to 64 times).
+constexpr int kCohThreads = 256;
+
+__device__ __forceinline__ void lbs_combine(bool valid, int j, const float* cv, int G, float* __restrict__ table)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    while (todo != 0ull) {
+        const int jl = __builtin_amdgcn_readlane(j, __builtin_ctzll(todo));   // wave-uniform node id
+        const bool sel = valid && j == jl;
+        float lo[16], hi[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            lo[c] = (sel && c < G) ? cv[c] : 0.f;
+            hi[c] = (sel && 16 + c < G && 16 + c < kLbsAttr + kLbsHmax + 2) ? cv[(16 + c) < (kLbsAttr + kLbsHmax + 2) ? 16 + c : 0] : 0.f;
+        }
+        const float r0 = dgs::wave_reduce16_dpp(lo);   // quad q holds the wave total of column q
+        const float r1 = dgs::wave_reduce16_dpp(hi);   // ... of column 16 + q
+        const int q = lane >> 2, sub = lane & 3;
+        const int col = sub == 0 ? q : (sub == 1 ? 16 + q : -1);
+        if (col >= 0 && col < G) atomicAdd(table + (size_t)jl * G + col, sub == 0 ? r0 : r1);
+        todo &= ~__ballot(sel);
+    }
+}
+
+template <bool ASM, bool COH>
+__global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
                                                       float* g_feature, int gf_stride, int accumulate,
-                                                      float* partial /*[kLbsBlocks][M][G]*/, int chunk, AsmArgs s_)
+                                                      float* partial /*[kLbsBlocks][M][G], COH: [M][G] zeroed*/, int chunk, AsmArgs s_)
 {
     extern __shared__ float s_tab[];  // [M][G], G = 13 + H + 2, then the exchange buffer and the integer arrays of lbs_deliver
     const int G = kLbsAttr + a.H + 2, GS = lbs_exch_stride(G);
@@ -690,12 +724,15 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
     int* s_cnt = reinterpret_cast<int*>(s_exch + (size_t)kLbsBwdThreads * GS);
     int* s_over = s_cnt + a.M;
     unsigned short* s_slot = reinterpret_cast<unsigned short*>(s_over + 2);
-    for (int i = threadIdx.x; i < a.M * G; i += kLbsBwdThreads) s_tab[i] = 0.f;
-    for (int i = threadIdx.x; i < a.M; i += kLbsBwdThreads) s_cnt[i] = 0;
-    if (threadIdx.x == 0) *s_over = 0;
-    __syncthreads();
+    constexpr int kThreads = COH ? kCohThreads : kLbsBwdThreads;
+    if (!COH) {
+        for (int i = threadIdx.x; i < a.M * G; i += kLbsBwdThreads) s_tab[i] = 0.f;
+        for (int i = threadIdx.x; i < a.M; i += kLbsBwdThreads) s_cnt[i] = 0;
+        if (threadIdx.x == 0) *s_over = 0;
+        __syncthreads();
+    }
     const int begin = blockIdx.x * chunk, end = min(a.N, (int)(blockIdx.x + 1) * chunk);
-    for (int n0 = begin; n0 < end; n0 += kLbsBwdThreads) {   // uniform trip count: lbs_deliver synchronises the workgroup
+    for (int n0 = begin; n0 < end; n0 += kThreads) {   // uniform trip count: lbs_deliver synchronises the workgroup
         const int n = n0 + threadIdx.x;
         const bool valid = n < end;
         LbsPoint p;
@@ -813,7 +850,8 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
 #pragma unroll
             for (int h = kLbsHmax; h < kLbsHmax + 2; h++) cv[kLbsAttr + h] = h == a.H ? d_rad : (h == a.H + 1 ? d_w : 0.f);
             }
-            lbs_deliver(valid, j, cv, G, GS, a.M, s_tab, s_exch, s_cnt, s_slot, s_over);
+            if (COH) lbs_combine(valid, j, cv, G, partial);
+            else lbs_deliver(valid, j, cv, G, GS, a.M, s_tab, s_exch, s_cnt, s_slot, s_over);
         }
         if (valid)
         for (int h = 0; h < kLbsHmax; h++)
@@ -822,18 +860,19 @@ __global__ void __launch_bounds__(kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, cons
                 *dst = accumulate ? *dst + gfeat[h] : gfeat[h];
             }
     }
+    if (COH) return;
     __syncthreads();
     float* dst = partial + (size_t)blockIdx.x * a.M * G;
     for (int i = threadIdx.x; i < a.M * G; i += kLbsBwdThreads) dst[i] = s_tab[i];
 }
 
-__global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, int M, int H, float* g_ntab, float* g_attrs)
+__global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, int M, int H, float* g_ntab, float* g_attrs, int nparts)
 {
     const int G = kLbsAttr + H + 2, T = 3 + H + 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M * G) return;
     float acc = 0.f;
-    for (int b = 0; b < kLbsBlocks; b++) acc += partial[(size_t)b * M * G + i];
+    for (int b = 0; b < nparts; b++) acc += partial[(size_t)b * M * G + i];
     const int node = i / G, c = i - node * G;
     if (c < kLbsAttr) g_attrs[(size_t)node * kLbsAttr + c] = acc;
     else g_ntab[(size_t)node * T + 3 + (c - kLbsAttr)] = acc;
@@ -844,13 +883,13 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, i
 // (through sigmoid), written or added in place; the attribute gradients are always written (the node MLP consumes them)
 __global__ void __launch_bounds__(256) lbs_reduce_raw_kernel(const float* partial, int M, int H, const float* rad_raw,
                                                              const float* w_raw, float* g_nodes, float* g_rad_raw, float* g_w_raw,
-                                                             float* g_attrs, int accumulate)
+                                                             float* g_attrs, int accumulate, int nparts)
 {
     const int G = kLbsAttr + H + 2, T = 3 + H;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M * G) return;
     float acc = 0.f;
-    for (int b = 0; b < kLbsBlocks; b++) acc += partial[(size_t)b * M * G + i];
+    for (int b = 0; b < nparts; b++) acc += partial[(size_t)b * M * G + i];
     const int node = i / G, c = i - node * G;
     if (c < kLbsAttr) { g_attrs[(size_t)node * kLbsAttr + c] = acc; }
     else if (c < kLbsAttr + H) {
@@ -1207,10 +1246,10 @@ int dgs_lbs_backward(int N, int M, int H, const float* x, const float* feature, 
     if (!scratch) return fail(-1, "dgs_lbs_backward: scratch is NULL");
     LbsArgs a{N, M, H, feature_stride, x, feature, idx, ntab, attrs, mask, 3 + H + 2, nullptr, nullptr};
     const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
-    hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, g_xyz, g_rot, g_scale,
+    hipLaunchKernelGGL((lbs_bwd_kernel<false, false>), dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, g_xyz, g_rot, g_scale,
                        g_feature, H, 0, (float*)scratch, chunk > 0 ? chunk : 1, AsmArgs{});
     hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
-                       g_ntab, g_attrs);
+                       g_ntab, g_attrs, kLbsBlocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("lbs_bwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -1482,12 +1521,23 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
     s.scaling_raw = scaling_raw; s.rotation_raw = rotation_raw; s.opacity_raw = opacity_raw;
     s.g_means3D = g_means3D; s.g_scales = g_scales; s.g_rotations = g_rotations; s.g_opacity = g_opacity;
     s.g_xyz = g_xyz; s.g_scaling_raw = g_scaling_raw; s.g_rotation_raw = g_rotation_raw; s.g_opacity_raw = g_opacity_raw;
-    const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
-    hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate, (float*)scratch,
-                       chunk > 0 ? chunk : 1, s);
-    hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
-                       node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate);
+    if (accumulate & 2) {
+        // coherent variant (surfels stored by nearest node): one zeroed [M][G] table, wave-level sums, global atomics
+        const hipError_t me = hipMemsetAsync(scratch, 0, (size_t)M * G * sizeof(float), (hipStream_t)stream);
+        if (me != hipSuccess) return fail(-4, std::string("dgs_deform_backward: ") + hipGetErrorString(me));
+        hipLaunchKernelGGL((lbs_bwd_kernel<true, true>), dim3((N + kCohThreads - 1) / kCohThreads), dim3(kCohThreads), 0, (hipStream_t)stream, a,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1,
+                           (float*)scratch, kCohThreads, s);
+        hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
+                           node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1);
+    } else {
+        const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
+        hipLaunchKernelGGL((lbs_bwd_kernel<true, false>), dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1, (float*)scratch,
+                           chunk > 0 ? chunk : 1, s);
+        hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
+                           node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, kLbsBlocks);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("lbs_bwd_kernel<asm>: ") + hipGetErrorString(e));
     return 0;

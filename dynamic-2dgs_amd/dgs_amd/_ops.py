@@ -21,7 +21,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
 
 def _deps():
     hdr = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dgs_train_ops.h")
-    return [os.path.join(_CSRC, "train_ops.hip"), hdr, os.path.join(_CSRC, "node_mlp.h")]
+    return [os.path.join(_CSRC, "train_ops.hip"), hdr, os.path.join(_CSRC, "node_mlp.h"), os.path.join(_CSRC, "wave_reduce.h")]
 
 
 def source_hash():
@@ -527,7 +527,7 @@ class _FusedDeform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                g_attrs_out=None):
+                g_attrs_out=None, coherent=False):
         lib = load()
         dev = xyz.device
         N, M = xyz.shape[0], nodes.shape[0]
@@ -550,7 +550,7 @@ class _FusedDeform(torch.autograd.Function):
                                         _stream(dev))
         _check(lib, rc, "dgs_deform_forward")
         ctx.save_for_backward(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx)
-        ctx.mask, ctx.H, ctx.sink, ctx.g_attrs_out = mask, H, sink, g_attrs_out
+        ctx.mask, ctx.H, ctx.sink, ctx.g_attrs_out, ctx.coherent = mask, H, sink, g_attrs_out, bool(coherent)
         return means3D, scales, rots, opac
 
     @staticmethod
@@ -578,15 +578,17 @@ class _FusedDeform(torch.autograd.Function):
                 node_weight.data_ptr(), attrs.data_ptr(), None if mask is None else mask.data_ptr(), scaling.data_ptr(),
                 rotation.data_ptr(), opacity.data_ptr(), g_means.data_ptr(), g_scales.data_ptr(), g_rots.data_ptr(), g_opac.data_ptr(),
                 outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), outs[5].data_ptr(),
-                outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), acc, scratch.data_ptr(), _stream(dev))
+                outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), acc | (2 if ctx.coherent else 0), scratch.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_deform_backward")
-        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None)
+        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None)
 
 
 def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False,
-                 g_attrs_out=None):
+                 g_attrs_out=None, coherent=False):
     """Raw surfel parameters + node tables + node attributes -> (means3D, scales, rotations, opacity) for the rasterizer.
-    grad_sink=True: gradients of the eight parameters are ADDED to their existing .grad tensors by the kernels."""
+    grad_sink=True: gradients of the eight parameters are ADDED to their existing .grad tensors by the kernels.
+    coherent=True: the surfels are stored in the order of their nearest node (Trainer.sort_surfels) -- the backward sums per
+    wave and issues global atomics instead of building 256 per-workgroup LDS tables (dgs_deform_backward, accumulate bit 1)."""
     params = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
     sink = None
     if grad_sink and torch.is_grad_enabled():
@@ -594,7 +596,7 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
         if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
             raise RuntimeError("fused_deform(grad_sink=True): every parameter needs a contiguous fp32 .grad")
     return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                              g_attrs_out)
+                              g_attrs_out, coherent)
 
 
 class _FusedTrainLoss(torch.autograd.Function):

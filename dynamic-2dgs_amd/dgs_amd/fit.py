@@ -42,6 +42,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True, arap=arap)
     if graph is None:
         graph = on_gpu
+    if on_gpu:
+        tr.sort_surfels()
     tr.arap_from = 3000                                                # opt.warm_up (arguments/__init__.py:102)
     from .arap import LAMBDA_ARAP_STEPS
     graph_from = LAMBDA_ARAP_STEPS[-1] if (arap and graph) else 0      # the regulariser runs eagerly while its weight is non-zero
@@ -63,6 +65,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
             if it > densify_from and it % densify_interval == 0:
                 size_threshold = 20 if it > opacity_reset_interval else None
                 counts = tr.densify_and_prune(densify_grad_threshold, 0.01, extent, size_threshold, seed=seed)
+                if on_gpu:
+                    tr.sort_surfels()   # children landed in free slots anywhere: restore the node order (in place, no re-capture)
                 if log:
                     log("[%d] cloned %d, split %d, pruned %d -> %d surfels (%d slots)" % ((it,) + tuple(counts) + (surfels.num_surfels, tr.P)))
             if it % opacity_reset_interval == 0 or (white_background and it == densify_from):

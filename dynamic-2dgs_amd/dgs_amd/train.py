@@ -551,6 +551,44 @@ class Trainer:
         from . import densify
         densify.reset_opacity(self.surfels, self._moments())
 
+    # ---- storage order of the surfels ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def reorder_surfels(self, perm):
+        """Permute the surfel slots IN PLACE (new slot i <- old slot perm[i]): parameters, both Adam moments, densification
+        statistics, the alive mask, the neighbour-search seed.  No address changes, so captured graphs stay valid.  The order
+        of the surfels carries no meaning (the reference appends and deletes rows freely); outputs change only through
+        ties between equal-depth surfels (broken by index) and floating-point summation order."""
+        from . import densify
+        s = self.surfels
+        perm = perm.to(s.get_xyz.device)
+        assert perm.shape == (self.P,)
+        moments = self._moments()
+        for p in densify.surfel_rows(s).values():
+            p.data.copy_(p.data[perm])
+            for m in moments(p):
+                if m is not None:
+                    m.copy_(m[perm])
+        for name in ("xyz_gradient_accum", "denom", "max_radii2D", "alive"):
+            b = getattr(s, name)
+            b.copy_(b[perm])
+        seed = getattr(self.deform, "_knn_seed", None)
+        if seed is not None and seed.shape[0] == self.P:
+            seed.copy_(seed[perm])
+
+    @torch.no_grad()
+    def sort_surfels(self):
+        """Store the surfels in the order of their nearest control node (dead slots last).  On MI355X this is what makes the
+        per-surfel kernels of the deformation coherent: the 64 surfels of a wave then read the same one or two node rows
+        (broadcast loads), and the skinning backward can sum a wave's contributions to a node in registers and issue one
+        atomic per (wave, node) (dgs_deform_backward, coherent variant; 97 -> ~20 us at 200 k surfels / 1024 nodes) instead
+        of building 256 LDS tables.  Call after initialisation and after densification; stale order only costs time."""
+        s, d = self.surfels, self.deform
+        x, nodes = s.get_xyz.detach(), d.nodes.detach()[:, :3]
+        near = torch.cat([torch.cdist(x[i:i + 16384], nodes).argmin(1) for i in range(0, x.shape[0], 16384)])
+        near = torch.where(s.alive, near, torch.full_like(near, nodes.shape[0]))
+        self.reorder_surfels(torch.argsort(near, stable=True))
+        d.coherent_surfels = bool(x.is_cuda and self.rasterizer_cls is None)
+
     def oneup_sh_degree(self):
         """GaussianModel.oneupSHdegree (gaussian_model.py:139-141).  The active degree is an argument of the rasterizer
         launches, i.e. part of the captured step: re-capture (three times per run at the reference's schedule)."""

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("DGS_SURFEL_LIB", os.path.join(_CSRC, LIB_NAME))  # ov
 # of the scalar forms (no throughput gain) plus v_mov shuffles to pair the operands; measured -17 % / -19 % on the
 # forward / backward blend kernels without it.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
-_SOURCES = ["surfel_rasterizer.hip", "kernels_blend.h", "kernels_preprocess.h", "surfel_math.h"]
+_SOURCES = ["surfel_rasterizer.hip", "kernels_blend.h", "kernels_preprocess.h", "surfel_math.h", "wave_reduce.h"]
 
 _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 _lib = None

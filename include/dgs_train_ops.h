@@ -153,7 +153,11 @@ int dgs_knn_points2(int N, int M, int D1, int D2, int K, const float* x1, const 
  * nodes[M,3+H] = [xyz (detached) | hyper]; mask may be NULL (= 1).  backward: g_attrs[M,13] is always overwritten; all
  * other gradient arrays are overwritten (accumulate = 0; the xyz columns of g_nodes are zeroed) or added to
  * (accumulate = 1, e.g. the .grad views of a flat gradient bucket).  g_feature has the row stride of feature.
- * scratch: dgs_lbs_scratch_bytes(M, H) bytes. */
+ * accumulate bit 1 (value 2, 3) selects the COHERENT backward for point sets stored in the order of their nearest node
+ * (dgs_amd.train.Trainer.sort_surfels): the 64 points of a wave then share one or two nodes per neighbour slot, their
+ * contributions are summed across the wave and one 23-lane global atomic per (wave, node) goes into a single [M][13+H+2]
+ * table -- instead of 256 per-workgroup LDS tables of 94 KB.  Same results for any order (float summation order aside);
+ * an unsorted set makes it slow, not wrong.  scratch: dgs_lbs_scratch_bytes(M, H) bytes. */
 int dgs_deform_forward(int N, int M, int H, const float* xyz, const float* feature, int feature_stride, const long long* idx,
                        const float* nodes, const float* node_radius_raw, const float* node_weight_raw, const float* attrs,
                        const float* mask, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,

@@ -304,17 +304,26 @@ def test_fused_deform_assembled_matches_torch_autograd():
     cot_g = torch.Generator().manual_seed(11)
     cot = [torch.randn(N, c, generator=cot_g).cuda() for c in (3, 2, 4, 1)]
     res = {}
-    for mode in ("torch", "fused", "sink"):
+    # "coherent": the wave-sum + global-atomic backward for node-sorted storage order -- on the unsorted cloud (worst case:
+    # ~64 distinct nodes per wave) and on the cloud sorted by nearest node ("sorted": the torch result is permuted to compare)
+    near_perm = None
+    for mode in ("torch", "fused", "sink", "coherent", "sorted"):
         torch.manual_seed(1)
-        pc = SurfelModel(make_scene(N, seed=3)).cuda()
+        scene = make_scene(N, seed=3)
+        if mode == "sorted":
+            scene = type(scene)(*[t_[near_perm.cpu()].contiguous() for t_ in scene])
+        pc = SurfelModel(scene).cuda()
         m = ControlNodes(node_num=Mn, K=3, hyper_dim=8, local_frame=True).cuda()
-        m.init_from_points(pc._xyz.detach())
+        m.init_from_points(SurfelModel(make_scene(N, seed=3)).cuda()._xyz.detach())   # same nodes whatever the storage order
+        if near_perm is None:
+            near_perm = torch.argsort(torch.cdist(pc._xyz.detach(), m.nodes.detach()[:, :3]).argmin(1), stable=True)
         g = torch.Generator().manual_seed(3)
         with torch.no_grad():
             m.nodes[:, 3:] += 0.02 * torch.randn(Mn, 8, generator=g).cuda()
             m._node_weight += 0.5 * torch.randn(Mn, 1, generator=g).cuda()
             m._node_radius += 0.2 * torch.randn(Mn, generator=g).cuda()
-            pc.feature += 0.05 * torch.randn(N, 8, generator=g).cuda()
+            df = 0.05 * torch.randn(N, 8, generator=g).cuda()
+            pc.feature += df[near_perm] if mode == "sorted" else df
             for head in (m.network.gaussian_warp, m.network.gaussian_rotation, m.network.gaussian_scaling, m.network.local_rotation):
                 head.weight.mul_(3e3)
         params = dict(list(pc.named_parameters()) + [("deform." + n, p) for n, p in m.named_parameters()])
@@ -326,11 +335,20 @@ def test_fused_deform_assembled_matches_torch_autograd():
         else:
             assert m.can_assemble(pc)
             m.grad_sink = mode == "sink"
+            m.coherent_surfels = mode in ("coherent", "sorted")
             if m.grad_sink:
                 for p in params.values():
                     p.grad = torch.full_like(p, 0.5)
             out = m.forward_assembled(pc, t)
-        sum((o * c).sum() for o, c in zip(out, cot)).backward()
+        cot_m = [c[near_perm] for c in cot] if mode == "sorted" else cot
+        sum((o * c).sum() for o, c in zip(out, cot_m)).backward()
+        if mode == "sorted":   # back to the original order for the comparison
+            inv = torch.empty_like(near_perm)
+            inv[near_perm] = torch.arange(N, device=near_perm.device)
+            out = tuple(o[inv] for o in out)
+            for n_, p_ in pc.named_parameters():
+                if p_.grad is not None:
+                    p_.grad = p_.grad[inv]
         grads = {}
         for n, p in params.items():
             if p.grad is None:
@@ -344,7 +362,7 @@ def test_fused_deform_assembled_matches_torch_autograd():
         err = float((u - v).abs().max())
         assert err <= tol * scale, "%s: err %.3e scale %.3e" % (name, err, scale)
 
-    for mode in ("fused", "sink"):
+    for mode in ("fused", "sink", "coherent", "sorted"):
         for i, (a, b) in enumerate(zip(res["torch"][0], res[mode][0])):
             close(a, b, "%s out %d" % (mode, i), 2e-5)
         for n, ga in res["torch"][1].items():

@@ -5,8 +5,11 @@ path, nsteps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "preprocess_fwd_kernel" in r["Kernel_Name"]]
-# layout of bench.py --steps K: warm-up (eager + capture) ... K replayed steps, then K eager profile steps
-first = len(starts) - 2 * nsteps
+# layout of bench.py --steps K: warm-up (eager + capture) ... K replayed steps [timed], then the roofline legs: re-capture
+# (3 eager warm-up steps) + K replayed steps with timestamps + K eager steps.  argv[4] = rasterizer forwards after the timed
+# region (default: the two legs; 0 with bench.py --no-roofline-legs)
+tail = int(sys.argv[4]) if len(sys.argv) > 4 else 2 * nsteps + 3
+first = len(starts) - nsteps - tail
 lo, hi = starts[first + 1], starts[first + nsteps - 1]
 seg = rows[lo:hi]
 n = nsteps - 2

@@ -15,7 +15,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pr
 ls $O/${TAG}_prof | head
 F=$(ls $O/${TAG}_prof/*kernel_stats.csv 2>/dev/null | head -1); T=$(ls $O/${TAG}_prof/*kernel_trace.csv 2>/dev/null | head -1)
 [ -n "$F" ] && cp $F $O/${TAG}_bench_graph_200k_800_kernel_stats.csv
-[ -n "$T" ] && python $R/tools/graph_step_profile.py $T 10 > $O/${TAG}_graph_step_summary.txt 2>&1 && head -12 $O/${TAG}_graph_step_summary.txt
+[ -n "$T" ] && python $R/tools/graph_step_profile.py $T 10 30 > $O/${TAG}_graph_step_summary.txt 2>&1 && head -12 $O/${TAG}_graph_step_summary.txt
 rm -rf $O/${TAG}_prof
 echo "== PMC passes on the blend kernels"
 cd $R && bash tools/pmc_kernels.sh ${TAG} 'dgs::blend' 2>&1 | tail -4
