@@ -686,7 +686,8 @@ inline size_t lbs_bwd_lds_bytes(int M, int H)
 // small workgroups instead of 256 large ones.  Measured at 200 k surfels / 1024 nodes: 97 + 15 us (LDS tables + reduction of
 // the partials) -> 77 + 5 us; the kernel is memory-latency bound either way (3 waves per SIMD in total, PMC: 62 % of the
 // wave cycles parked on s_waitcnt); a variant that first combined the waves of a 512-thread workgroup in an LDS hash table
-// (4x fewer global atomics) measured 96 us -- the atomics are not what it waits for.
+// (4x fewer global atomics) measured 96 us, issuing every atomic of a point after its last load / store 78 us, and forcing
+// 128 VGPRs (all 3125 waves resident at once, 68 spills) 82 us -- neither the atomics nor the residency is what it waits for.
 // Correct for any order; an unsorted cloud makes the loop below run once per DISTINCT node of a wave (up to 64 times).
 constexpr int kCohThreads = 256;
 
@@ -859,6 +860,7 @@ __global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_ke
                 float* dst = g_feature + (size_t)n * gf_stride + h;
                 *dst = accumulate ? *dst + gfeat[h] : gfeat[h];
             }
+
     }
     if (COH) return;
     __syncthreads();
