@@ -401,21 +401,157 @@ __global__ void __launch_bounds__(256) sort_tiles_reg_kernel(const uint2* ranges
     else sort_tile_regs<8>(s_keys, gk, n, out, tid);
 }
 
-__global__ void __launch_bounds__(256) sort_tiles_global_kernel(const uint2* ranges, const uint64_t* keys, uint64_t* scratch /*[2R]*/,
+// ---- per-tile radix sort ---------------------------------------------------------------------------------------------
+// One workgroup per tile bucket, LSD radix on the depth bits with 8-bit digits, everything in LDS:
+//   * only the bits that DIFFER inside the bucket are sorted: depths of one tile share sign, most of the exponent and often
+//     more (xor of the bucket's min and max), typically 3 passes instead of 4;
+//   * a pass is a stable counting sort: wave w owns a contiguous quarter of the bucket; for each of its 64-element slots the
+//     lanes that hold the same digit find each other with 8 ballots (one per digit bit), rank = population count of the
+//     peers below the lane, a wave-private LDS histogram carries the running count from slot to slot; the 4 x 256 wave
+//     histograms are scanned by the 256 threads (digit-major, then wave) and every element is written to its final place;
+//   * the (depth, surfel index) order of the reference's stable radix sort (rasterizer_impl.cu:304-309: ties in depth keep the
+//     emission order = ascending surfel index) is restored at the end: the bucket arrives in arbitrary order, so equal
+//     depths -- exact float equality, i.e. duplicated surfels -- come out in arbitrary order; each such run is sorted by
+//     index by the thread that finds its head.
+// O(n) operations per pass instead of the O(n log^2 n) compare-exchanges of the bitonic network (which saturated the VALU:
+// 62 us at 200 k surfels / 800x800); keys are 32-bit here (depth bits; the index rides along as payload).
+template <int CAP>
+__global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* ranges, int ntiles, const uint64_t* keys, uint32_t* point_list, int lo)
+{
+    __shared__ uint32_t s_key[2][CAP];
+    __shared__ uint32_t s_val[2][CAP];
+    __shared__ uint32_t s_hist[4][256];      // per wave: running digit counts, then exclusive global offsets
+    __shared__ uint32_t s_red[8];
+    // grid-stride over the tiles: the launch for long lists uses a small grid (a 132 KB workgroup per tile that exits at once
+    // would cost ten dispatch rounds of 2500 workgroups for nothing)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= lo || n > CAP) continue;
+    __syncthreads();   // the previous tile's last reads of the LDS arrays
+    const uint64_t* gk = keys + rg.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- load, and the bits in which the bucket's depths differ
+    uint32_t kand = 0xffffffffu, kor = 0u;
+    for (int i = tid; i < n; i += 256) {
+        const uint64_t k = gk[i];
+        const uint32_t d = (uint32_t)(k >> 32);
+        s_key[0][i] = d;
+        s_val[0][i] = (uint32_t)k;
+        kand &= d; kor |= d;
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        kand &= (uint32_t)__shfl_xor((int)kand, sft, 64);
+        kor |= (uint32_t)__shfl_xor((int)kor, sft, 64);
+    }
+    if (lane == 0) { s_red[wave] = kand; s_red[4 + wave] = kor; }
+    __syncthreads();
+    const uint32_t diff = (s_red[0] & s_red[1] & s_red[2] & s_red[3]) ^ (s_red[4] | s_red[5] | s_red[6] | s_red[7]);
+    const int nbits = diff ? 32 - __builtin_clz(diff) : 0;
+    // wave w owns elements [w0, w1): contiguous, so array order == (wave, slot, lane) order
+    const int per = (n + 3) >> 2;
+    const int w0 = wave * per, w1 = min(n, w0 + per);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int cur = 0;
+    for (int shift = 0; shift < nbits; shift += 8, cur ^= 1) {
+        s_hist[wave][lane] = 0; s_hist[wave][lane + 64] = 0; s_hist[wave][lane + 128] = 0; s_hist[wave][lane + 192] = 0;
+        // (wave-private rows: the wave's own LDS operations are ordered, no barrier needed before the first slot)
+        const uint32_t* kin = s_key[cur];
+        const uint32_t* vin = s_val[cur];
+        // ---- rank inside the wave's range
+        constexpr int kMaxSlots = (CAP / 4 + 63) / 64;
+        uint32_t my_rank[kMaxSlots];      // rank of my element of slot e among the wave's elements with the same digit
+#pragma unroll
+        for (int e = 0; e < kMaxSlots; e++) {
+            const int pos = w0 + e * 64 + lane;
+            if (w0 + e * 64 >= w1) break;                     // wave-uniform
+            const bool live = pos < w1;
+            const uint32_t d = live ? ((kin[pos] >> shift) & 255u) : 256u;   // 256: no peer among the live lanes
+            unsigned long long peers = __ballot(live);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            const uint32_t below = (uint32_t)__popcll(peers & lt_mask), total = (uint32_t)__popcll(peers);
+            uint32_t base = 0;
+            if (live) base = s_hist[wave][d];
+            my_rank[e] = base + below;
+            if (live && below == 0) s_hist[wave][d] = base + total;   // one leader per digit
+        }
+        __syncthreads();
+        // ---- exclusive offsets over (digit, wave): thread t = digit t
+        {
+            const uint32_t c0 = s_hist[0][tid], c1 = s_hist[1][tid], c2 = s_hist[2][tid], c3 = s_hist[3][tid];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            uint32_t inc = tot;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)inc, dd, 64);
+                if (lane >= dd) inc += up;
+            }
+            if (lane == 63) s_red[wave] = inc;
+            __syncthreads();
+            uint32_t off = inc - tot;
+            for (int w = 0; w < wave; w++) off += s_red[w];
+            s_hist[0][tid] = off; s_hist[1][tid] = off + c0; s_hist[2][tid] = off + c0 + c1; s_hist[3][tid] = off + c0 + c1 + c2;
+        }
+        __syncthreads();
+        // ---- scatter
+        uint32_t* kout = s_key[cur ^ 1];
+        uint32_t* vout = s_val[cur ^ 1];
+#pragma unroll
+        for (int e = 0; e < kMaxSlots; e++) {
+            const int pos = w0 + e * 64 + lane;
+            if (w0 + e * 64 >= w1) break;
+            if (pos < w1) {
+                const uint32_t k = kin[pos];
+                const uint32_t dst = s_hist[wave][(k >> shift) & 255u] + my_rank[e];
+                kout[dst] = k;
+                vout[dst] = vin[pos];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- ties in depth: ascending surfel index (the head of a run sorts it; runs are duplicated surfels, i.e. short)
+    uint32_t* kf = s_key[cur];
+    uint32_t* vf = s_val[cur];
+    for (int i = tid; i < n - 1; i += 256) {
+        if (kf[i] == kf[i + 1] && (i == 0 || kf[i - 1] != kf[i])) {
+            int end = i + 2;
+            while (end < n && kf[end] == kf[i]) end++;
+            for (int a = i + 1; a < end; a++) {          // insertion sort of vf[i, end)
+                const uint32_t v = vf[a];
+                int b = a - 1;
+                while (b >= i && vf[b] > v) { vf[b + 1] = vf[b]; b--; }
+                vf[b + 1] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) point_list[rg.x + i] = vf[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) sort_tiles_global_kernel(const uint2* ranges, int ntiles, const uint64_t* keys, uint64_t* scratch /*[2R]*/,
                                                                 uint32_t* point_list, int lo)
 {
-    const uint2 rg = ranges[blockIdx.x];
-    const int n = (int)(rg.y - rg.x);
-    if (n <= lo) return;
-    const uint64_t* gk = keys + rg.x;
-    uint64_t* sk = scratch + 2 * (size_t)rg.x;
-    const int tid = threadIdx.x;
-    int n2 = 1;
-    while (n2 < n) n2 <<= 1;
-    for (int i = tid; i < n2; i += 256) sk[i] = i < n ? gk[i] : ~0ull;
-    __syncthreads();
-    bitonic_network(sk, n2, tid, false);
-    for (int i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)sk[i];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // grid-stride: launched with a small grid
+        const uint2 rg = ranges[tile];
+        const int n = (int)(rg.y - rg.x);
+        if (n <= lo) continue;
+        const uint64_t* gk = keys + rg.x;
+        uint64_t* sk = scratch + 2 * (size_t)rg.x;
+        const int tid = threadIdx.x;
+        int n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        for (int i = tid; i < n2; i += 256) sk[i] = i < n ? gk[i] : ~0ull;
+        __syncthreads();
+        bitonic_network(sk, n2, tid, false);
+        for (int i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)sk[i];
+        __syncthreads();
+    }
 }
 
 struct SurfelBwdArgs {

@@ -181,7 +181,7 @@ struct HostStage {
 struct dgs_context {
     int device = 0;
     std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
-    std::atomic<int> sort_regs{1};    // per-tile sort of <= 2048 entries in registers (kernels_preprocess.h)
+    std::atomic<int> sort_regs{2};    // per-tile sort: 2 LSD radix in LDS (default), 1 bitonic network in registers, 0 bitonic in LDS
     std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
@@ -308,7 +308,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
     if (key == 0) { c->tight_rects.store(value != 0); return DGS_OK; }
     if (key == 1 && value >= 0 && value <= 3) { c->tile_order.store(value); return DGS_OK; }
-    if (key == 3) { c->sort_regs.store(value != 0); return DGS_OK; }
+    if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 5 && value >= 0) { c->grid_limit_fwd.store(value); return DGS_OK; }
     if (key == 2 && value >= 0) {
@@ -563,7 +563,7 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     if (R_u > 0x7fffffffu) return fail(DGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
     const int R = (int)R_u;
 
-    const bool need_global_sort = longest > 16384u;
+    const bool need_global_sort = longest > (ctx->sort_regs.load() == 2 ? 8192u : 16384u);
     BinningLayout bl(R, need_global_sort);
     char* bin = binning_alloc(binning_ctx, bl.bytes);
     if (!bin) return fail(DGS_ERR_ALLOC, "binning allocator returned NULL");
@@ -586,20 +586,36 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         DGS_STAGE("scatter_keys", debug, stream);
         // ---- K5 per-tile sort (stable radix order of rasterizer_impl.cu:304-309 = (tile, depth bits, surfel index))
         uint32_t* plist = (uint32_t*)(bin + bl.point_list);
-        if (ctx->sort_regs.load())
-            hipLaunchKernelGGL(dgs::sort_tiles_reg_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
-                               (const uint64_t*)keys, plist);
-        else
-            hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+        const int sort_mode = ctx->sort_regs.load();
+        if (sort_mode == 2) {
+            // per-tile LSD radix sort (default): lists up to 2048 entries in 32 KB of LDS, up to 8192 in 128 KB.  Every tile
+            // picks its kernel on the device; when the longest list is known on the host (exact-size mode) the launches
+            // that cannot have work are skipped.
+            const int big_grid = il.ntiles < 256 ? il.ntiles : 256;   // long lists are rare: grid-stride over the tiles
+            hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
                                (const uint64_t*)keys, plist, 0);
-        // capacity mode does not know the longest list on the host: ONE fallback launch (global scratch) covers every tile
-        // above 2048 entries instead of two mostly empty ones
-        if (longest > 2048u && !capacity_mode)
-            hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<16384>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
-                               (const uint64_t*)keys, plist, 2048);
-        if (need_global_sort)
-            hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
-                               (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, capacity_mode ? 2048 : 16384);
+            if (longest > 2048u)
+                hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<8192>), dim3(big_grid), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
+                                   (const uint64_t*)keys, plist, 2048);
+            if (longest > 8192u)
+                hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(big_grid), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
+                                   (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, 8192);
+        } else {
+            if (sort_mode == 1)
+                hipLaunchKernelGGL(dgs::sort_tiles_reg_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                                   (const uint64_t*)keys, plist);
+            else
+                hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                                   (const uint64_t*)keys, plist, 0);
+            // capacity mode does not know the longest list on the host: ONE fallback launch (global scratch) covers every tile
+            // above 2048 entries instead of two mostly empty ones
+            if (longest > 2048u && !capacity_mode)
+                hipLaunchKernelGGL((dgs::sort_tiles_lds_kernel<16384>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
+                                   (const uint64_t*)keys, plist, 2048);
+            if (need_global_sort)
+                hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(il.ntiles < 256 ? il.ntiles : 256), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
+                                   (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, capacity_mode ? 2048 : 16384);
+        }
         DGS_STAGE("sort_tiles", debug, stream);
     }
 

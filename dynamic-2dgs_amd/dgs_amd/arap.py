@@ -109,6 +109,9 @@ def arap_loss(deform, t=None, delta_t=0.05, t_samp_num=2, t_samp=None, sample_id
     """ControlNodeWarp.arap_loss: node positions at `t_samp_num` random times within delta_t of t (or of a random time),
     connectivity from the first sample, ARAP error of the later samples against it."""
     nodes = deform.nodes
+    live = getattr(deform, "live_nodes", None)
+    if live is not None and not bool(live.all()):
+        nodes = nodes[live]     # padding nodes (ControlNodes.live_nodes) would become each other's neighbours
     dev = nodes.device
     M = nodes.shape[0]
     if t_samp is None:

@@ -151,6 +151,11 @@ def save_deform(deform, model_path, iteration):
     out = os.path.join(model_path, "deform/iteration_{}".format(iteration))
     os.makedirs(out, exist_ok=True)
     state = {k: v.detach().cpu() for k, v in deform.state_dict().items()}
+    live = getattr(deform, "live_nodes", None)
+    if live is not None and not bool(live.all()):   # padding rows of the fused kernels are not part of the model
+        keep = live.cpu()
+        for k in ("nodes", "_node_radius", "_node_weight"):
+            state[k] = state[k][keep].contiguous()
     state.setdefault("inited", torch.tensor(True))   # buffer of the reference's ControlNodeWarp
     torch.save(state, os.path.join(out, "deform.pth"))
     return os.path.join(out, "deform.pth")

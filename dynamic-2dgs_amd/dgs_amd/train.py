@@ -473,6 +473,15 @@ class Trainer:
     def _reduce_rest_start(self):
         return [dist.all_reduce(self.bucket.flat[self.n_sh:], op=dist.ReduceOp.SUM, async_op=True)]
 
+    def wire_bytes_per_step(self):
+        """Bytes each rank hands to the collectives per step (payload of the all-reduces; what actually crosses the links is
+        2 (n-1)/n times that for a ring).  {'sh': SH gradients (all-reduced while the rest of the backward runs), 'rest': all
+        other gradients + the densification statistics of the view, 'radii': int32 radii + the overflow flag (MAX)}."""
+        n_flat = self.bucket.flat.numel()
+        n_radii = self.P + 4
+        sh = self.n_sh if self._split_ok() else 0
+        return {"sh": 4 * sh, "rest": 4 * (n_flat - sh), "radii": 4 * n_radii, "total": 4 * (n_flat + n_radii)}
+
     @property
     def _fold_mean(self):
         """Flat Adam kernel: the bucket keeps the SUM over the ranks and the kernel reads grad / world (no averaging pass)."""

@@ -143,7 +143,7 @@ void dgs_set_tight_rects(int on);
  *         device->host read of the forward (rasterizer_impl.cu:281-282), which makes forward + backward legal inside
  *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do
  *         not fit renders as background and raises the overflow flag; value 0 restores the exact-size mode,
- * key 3 = per-tile sort of lists up to 2048 entries: 1 register-resident network [default], 0 the LDS network,
+ * key 3 = per-tile sort: 2 LSD radix sort in LDS [default], 1 bitonic network with the keys in registers, 0 bitonic network in LDS,
  * key 4 / key 5 = diagnostic: the backward / forward blend processes only the first `value` tiles of its dispatch order
  *         (0 = all); results are then incomplete -- for measuring how long the heaviest tiles run on an otherwise idle device.
  * Returns DGS_OK or an error. */

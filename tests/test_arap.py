@@ -98,3 +98,28 @@ def test_split_dp_step_is_refused_while_arap_is_active(monkeypatch):
     tr.arap = False
     tr.iteration = 100
     assert not tr._arap_active()
+
+
+def test_padding_nodes_are_invisible_to_arap_and_checkpoints(tmp_path):
+    """densify_nodes(pad_to=64) parks padding nodes far outside the scene; the ARAP connectivity and the checkpoint must
+    behave as if they did not exist."""
+    from dgs_amd import io as dio
+    torch.manual_seed(0)
+    d = ControlNodes(node_num=40, K=3, hyper_dim=8, local_frame=True)
+    d.init_from_points(torch.rand(500, 3) * 2 - 1)
+    ts = torch.tensor([0.3, 0.33])
+    ref = arap.arap_loss(d, t_samp=ts, sample_idx=None, generator=torch.Generator().manual_seed(1))
+    n_pad = 24
+    with torch.no_grad():
+        pad = torch.zeros(n_pad, d.nodes.shape[1])
+        pad[:, :3] = d.FAR
+        d.nodes = torch.nn.Parameter(torch.cat((d.nodes.detach(), pad)))
+        d._node_radius = torch.nn.Parameter(torch.cat((d._node_radius.detach(), d._node_radius.detach().mean().expand(n_pad))))
+        d._node_weight = torch.nn.Parameter(torch.cat((d._node_weight.detach(), torch.zeros(n_pad, 1))))
+    assert int(d.live_nodes.sum()) == 40 and d.nodes.shape[0] == 64
+    got = arap.arap_loss(d, t_samp=ts, sample_idx=None, generator=torch.Generator().manual_seed(1))
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-9)
+    path = dio.save_deform(d, str(tmp_path), 7)
+    saved = torch.load(path, weights_only=True)
+    assert saved["nodes"].shape[0] == 40 and saved["_node_radius"].shape[0] == 40 and saved["_node_weight"].shape[0] == 40
+    assert torch.equal(saved["nodes"], d.nodes.detach()[:40])

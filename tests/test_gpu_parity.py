@@ -205,20 +205,55 @@ def test_full_size_properties():
         grad_close(a[k], og[k], k)
 
 
-def test_long_tile_lists_use_all_sort_paths():
-    """Zoomed-in view of big splats: single tiles hold > 2048 and > 16384 entries, which exercises the 128 KB LDS
-    sort and the global-memory fallback of the tile-bucketed sort; the lists must still equal the reference order."""
+@pytest.mark.parametrize("sort_mode", [2, 1, 0])
+def test_equal_depths_keep_surfel_index_order(sort_mode, reference_rects):
+    """Duplicated surfels have bit-identical depths: the reference's stable radix sort lists them in emission order
+    (ascending surfel index, rasterizer_impl.cu:304-309).  Every per-tile sort (radix with its tie pass, both bitonic
+    networks on (depth, index) keys) must reproduce that -- lists bit-equal to the oracle's."""
+    from diff_surfel_rasterization import _C
+    from gpu_utils import run_hip_raw
+    case = small_case(P=3000, H=96, W=112, seed=5, view=2, scale_mul=1.5)
+    with torch.no_grad():   # three groups of duplicates: runs of 2, 4 and 7 equal depths, indices far apart
+        for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+            t = case[k]
+            t[1500:2000] = t[0:500]
+            t[2000:2200] = t[0:200]
+            t[2200:2260] = t[0:60]
+            for r in range(3):
+                t[2300 + 60 * r:2360 + 60 * r] = t[0:60]
+    orc = oracle_from_case(case)
+    d = orc.field("depths")
+    assert d[0] == d[1500] == d[2000] == d[2200] == d[2300] == d[2360] == d[2420]
+    _C.set_option(3, sort_mode)
+    try:
+        hip = run_hip_raw(case)
+    finally:
+        _C.set_option(3, 2)
+    assert hip["R"] == orc.num_rendered
+    assert np.array_equal(hip["point_list"], orc.field("point_list"))
+
+
+@pytest.mark.parametrize("sort_mode,P", [(2, 30000), (2, 9000), (1, 30000)])
+def test_long_tile_lists_use_all_sort_paths(sort_mode, P):
+    """Zoomed-in view of big splats: single tiles hold thousands of entries.  P = 30000: 11 k .. 17 k per tile (radix mode:
+    the global-memory fallback above 8192; bitonic mode: the 128 KB LDS network and, above 16384, the fallback); P = 9000:
+    4 k .. 7 k per tile (the 128 KB radix kernel).  The lists must still equal the reference order."""
     from diff_surfel_rasterization import _C
     from gpu_utils import frac_close, run_hip_raw
-    case = small_case(P=30000, H=96, W=96, seed=41, view=2, scale_mul=6.0, sh_degree=0, radius=2.2)
+    case = small_case(P=P, H=96, W=96, seed=41, view=2, scale_mul=6.0, sh_degree=0, radius=2.2)
     orc = oracle_from_case(case)
     lens = (orc.field("ranges")[:, 1] - orc.field("ranges")[:, 0])
-    assert lens.max() > 16384 and ((lens > 4096) & (lens <= 16384)).any()
+    if P == 30000:
+        assert lens.max() > 16384 and ((lens > 8192) & (lens <= 16384)).any()
+    else:
+        assert lens.min() > 2048 and lens.max() <= 8192
     _C.set_tight_rects(False)
+    _C.set_option(3, sort_mode)
     try:
         hip = run_hip_raw(case)
     finally:
         _C.set_tight_rects(True)
+        _C.set_option(3, 2)
     assert hip["R"] == orc.num_rendered
     assert np.array_equal(hip["point_list"], orc.field("point_list"))
     frac_close(hip["color"], orc.color, 2e-5, 1e-5, 5e-4, 2e-2, "color")  # 96x96 image: one flipped pixel is 1.1e-4

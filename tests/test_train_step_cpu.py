@@ -85,7 +85,21 @@ def _dp_worker(rank, world, port, q):
         surfels, deform, cams, targets, bg = _build()
         tr = Trainer(surfels, deform, cams, targets, bg)
         assert tr.view_for(0) == rank
+        # bytes on the wire: count what the step hands to the collectives and compare with the trainer's own accounting
+        sent = []
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(t, *a, **k):
+            sent.append(t.numel() * t.element_size())
+            return real_all_reduce(t, *a, **k)
+        dist.all_reduce = counting_all_reduce
         tr.step()
+        dist.all_reduce = real_all_reduce
+        wire = tr.wire_bytes_per_step()
+        P_ = surfels.get_xyz.shape[0]
+        n_deform = sum(p.numel() for p in deform.parameters() if p.requires_grad)
+        # 66 floats per surfel (xyz 3, SH 48, opacity 1, scaling 2, rotation 4, hyper feature 8) + deformation + 2 statistics
+        assert wire["total"] == 4 * (66 * P_ + n_deform + 2 * P_) + 4 * (P_ + 4) and sum(sent) == wire["total"], (sent, wire)
         flat_after = tr.bucket.flat.clone()
         tr.step()
         params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params])
