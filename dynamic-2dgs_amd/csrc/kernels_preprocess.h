@@ -16,7 +16,8 @@
 
 namespace dgs {
 
-constexpr int kSurfelBlock = 256;
+constexpr int kSurfelBlock = 64;    // one wave per workgroup: 12.25 KB of LDS for its SH rows -> 13 workgroups per CU = 832 surfels, so that the 782
+                                     // surfels per CU of a 200 k cloud are resident in ONE round (256-thread workgroups: 3 per CU = 768, a second round for 14)
 
 struct PreprocessArgs {
     int P, D, M;
@@ -578,7 +579,7 @@ struct SurfelBwdArgs {
 
 // Fused computeAABB-bwd + preprocessCUDA-bwd (backward.cu:533-649).  Outputs are caller-zeroed
 // (rasterize_points.cu:194-202); culled surfels are left untouched.
-__global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs a)
+__global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs a)   // 135 VGPRs; forcing 128 (full residency, 3 spills) measured 43 against 41 us: bandwidth-bound
 {
     // SH rows (192 B per surfel at degree 3) are the bulk of this kernel's traffic and one-thread-per-surfel access to
     // them is a 64-way scatter per instruction: the workgroup's rows are staged through LDS with coalesced transfers in

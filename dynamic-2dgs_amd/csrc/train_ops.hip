@@ -536,14 +536,15 @@ struct LbsPoint {
     int j[kLbsK];
 };
 
-__device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, float* xq /*[3+Hmax]*/)
+template <int HM = kLbsHmax>
+__device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, float* xq /*[3+HM]*/)
 {
     const int T = a.tstride;
     xq[0] = a.x[3 * n]; xq[1] = a.x[3 * n + 1]; xq[2] = a.x[3 * n + 2];
     {
         float fr[16];
         load_row(a.feature + (size_t)n * a.fstride, a.H < 16 ? a.H : 16, fr);
-        for (int h = 0; h < kLbsHmax; h++) xq[3 + h] = fr[h];
+        for (int h = 0; h < HM; h++) xq[3 + h] = fr[h];
     }
     p.W = 0.f;
 #pragma unroll
@@ -554,7 +555,7 @@ __device__ __forceinline__ void lbs_eval(const LbsArgs& a, int n, LbsPoint& p, f
         load_row(a.ntab + (size_t)j * T, T < 16 ? T : 16, nd);
         load_row(a.attrs + (size_t)j * kLbsAttr, kLbsAttr, at);
         float dist = 0.f;
-        for (int c = 0; c < 3 + kLbsHmax; c++)
+        for (int c = 0; c < 3 + HM; c++)
             if (c < 3 + a.H) { const float t = xq[c] - nd[c]; dist += t * t; }
         const float r = a.rad_raw ? expf(a.rad_raw[j]) : a.ntab[(size_t)j * T + 3 + a.H];
         const float wg = a.w_raw ? sigmoidf_(a.w_raw[j]) : a.ntab[(size_t)j * T + 3 + a.H + 1];
@@ -686,40 +687,59 @@ inline size_t lbs_bwd_lds_bytes(int M, int H)
 // small workgroups instead of 256 large ones.  Measured at 200 k surfels / 1024 nodes: 97 + 15 us (LDS tables + reduction of
 // the partials) -> 77 + 5 us; the kernel is memory-latency bound either way (3 waves per SIMD in total, PMC: 62 % of the
 // wave cycles parked on s_waitcnt); a variant that first combined the waves of a 512-thread workgroup in an LDS hash table
-// (4x fewer global atomics) measured 96 us, issuing every atomic of a point after its last load / store 78 us, and forcing
-// 128 VGPRs (all 3125 waves resident at once, 68 spills) 82 us -- neither the atomics nor the residency is what it waits for.
+// (4x fewer global atomics) measured 96 us, issuing every atomic of a point after its last load / store 78 us.
+// What it waits for is RESIDENCY: 200 k surfels are 3125 waves, 153 VGPRs allow 3 waves per SIMD = 3072 -- the last 53 waves
+// (14 workgroups) run in a second round and the kernel takes two wave lifetimes.  Forcing 128 VGPRs spilled 68 registers
+// (82 us); specialising the kernel for the trainer's hyper dimension (template HT = 8: arrays sized for it, static indices)
+// needs 127 without a spill: all waves resident in one round, 77 -> 53 us.
 // Correct for any order; an unsorted cloud makes the loop below run once per DISTINCT node of a wave (up to 64 times).
 constexpr int kCohThreads = 256;
 
-__device__ __forceinline__ void lbs_combine(bool valid, int j, const float* cv, int G, float* __restrict__ table)
+template <int CVN>
+__device__ __forceinline__ void lbs_combine(bool valid, int j, const float (&cv)[CVN], int G, float* __restrict__ table)
 {
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(valid);
     while (todo != 0ull) {
         const int jl = __builtin_amdgcn_readlane(j, __builtin_ctzll(todo));   // wave-uniform node id
         const bool sel = valid && j == jl;
-        float lo[16], hi[16];
+        // columns 0..15, then 16..23 (G <= 24 here: 13 attributes + H <= 9 + 2; wider tables take the generic path below)
+        float r0, r1 = 0.f, r2 = 0.f;
+        {
+            float lo[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            lo[c] = (sel && c < G) ? cv[c] : 0.f;
-            hi[c] = (sel && 16 + c < G && 16 + c < kLbsAttr + kLbsHmax + 2) ? cv[(16 + c) < (kLbsAttr + kLbsHmax + 2) ? 16 + c : 0] : 0.f;
+            for (int c = 0; c < 16; c++) lo[c] = (sel && c < G && c < CVN) ? cv[c < CVN ? c : 0] : 0.f;
+            r0 = dgs::wave_reduce16_dpp(lo);   // quad q holds the wave total of column q
         }
-        const float r0 = dgs::wave_reduce16_dpp(lo);   // quad q holds the wave total of column q
-        const float r1 = dgs::wave_reduce16_dpp(hi);   // ... of column 16 + q
-        const int q = lane >> 2, sub = lane & 3;
-        const int col = sub == 0 ? q : (sub == 1 ? 16 + q : -1);
-        if (col >= 0 && col < G) atomicAdd(table + (size_t)jl * G + col, sub == 0 ? r0 : r1);
+        {
+            float hi[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) hi[c] = (sel && 16 + c < G && 16 + c < CVN) ? cv[16 + c < CVN ? 16 + c : 0] : 0.f;
+            r1 = dgs::wave_reduce8_dpp(hi);    // lanes 8 k .. 8 k + 7 hold the total of column 16 + k
+        }
+        if (CVN > 24 && G > 24) {              // hyper_dim > 9: four more columns (wave-uniform, never taken by the trainer)
+            float hi[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) hi[c] = (sel && 24 + c < G && 24 + c < CVN) ? cv[24 + c < CVN ? 24 + c : 0] : 0.f;
+            r2 = dgs::wave_reduce8_dpp(hi);
+        }
+        const int sub4 = lane & 3, sub8 = lane & 7;
+        const int col = sub4 == 0 ? (lane >> 2) : (sub8 == 1 ? 16 + (lane >> 3) : (sub8 == 2 ? 24 + (lane >> 3) : -1));
+        if (col >= 0 && col < G) atomicAdd(table + (size_t)jl * G + col, sub4 == 0 ? r0 : (sub8 == 1 ? r1 : r2));
         todo &= ~__ballot(sel);
     }
 }
 
-template <bool ASM, bool COH>
+// HT > 0: hyper dimension known at compile time (a.H == HT): arrays sized for it, static indexing (the trainer's H = 8)
+template <bool ASM, bool COH, int HT = 0>
 __global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
                                                       float* g_feature, int gf_stride, int accumulate,
                                                       float* partial /*[kLbsBlocks][M][G], COH: [M][G] zeroed*/, int chunk, AsmArgs s_)
 {
     extern __shared__ float s_tab[];  // [M][G], G = 13 + H + 2, then the exchange buffer and the integer arrays of lbs_deliver
-    const int G = kLbsAttr + a.H + 2, GS = lbs_exch_stride(G);
+    constexpr int HM = HT > 0 ? HT : kLbsHmax;
+    const int H = HT > 0 ? HT : a.H;
+    const int G = kLbsAttr + H + 2, GS = lbs_exch_stride(G);
     const int T = a.tstride;
     float* s_exch = s_tab + (size_t)a.M * G;
     int* s_cnt = reinterpret_cast<int*>(s_exch + (size_t)kLbsBwdThreads * GS);
@@ -737,11 +757,11 @@ __global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_ke
         const int n = n0 + threadIdx.x;
         const bool valid = n < end;
         LbsPoint p;
-        float xq[3 + kLbsHmax];
+        float xq[3 + HM];
         float gx[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gs[2] = {0, 0};
         float inv = 0.f, m = 0.f;
         if (valid) {
-            lbs_eval(a, n, p, xq);
+            lbs_eval<HM>(a, n, p, xq);
             inv = 1.0f / p.W;
             m = a.mask ? a.mask[n] : 1.0f;
         if (!ASM) {
@@ -798,11 +818,11 @@ __global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_ke
             mean += p.w[k] * inv * v;
         }
         }
-        float gfeat[kLbsHmax];
-        for (int h = 0; h < kLbsHmax; h++) gfeat[h] = 0.f;
+        float gfeat[HM];
+        for (int h = 0; h < HM; h++) gfeat[h] = 0.f;
 #pragma unroll
         for (int k = 0; k < kLbsK; k++) {
-            float cv[kLbsAttr + kLbsHmax + 2];   // this point's contribution to node p.j[k]: [attrs 13 | hyper H | radius | weight]
+            float cv[kLbsAttr + HM + 2];   // this point's contribution to node p.j[k]: [attrs 13 | hyper H | radius | weight]
             int j = 0;
             if (valid) {
             j = p.j[k];
@@ -842,21 +862,21 @@ __global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_ke
             const float ddist = -de / (2.f * rad * rad);
             const float d_rad = de * p.dist[k] / (rad * rad * rad), d_w = dw * p.e[k];
 #pragma unroll
-            for (int h = 0; h < kLbsHmax; h++) {
-                const float gd = h < a.H ? 2.f * (xq[3 + h] - nd[3 + h]) * ddist : 0.f;
+            for (int h = 0; h < HM; h++) {
+                const float gd = h < H ? 2.f * (xq[3 + h] - nd[3 + h]) * ddist : 0.f;
                 gfeat[h] += gd;
                 // columns 13 .. 13+H-1: node hyper coordinates, then radius, weight (static register indices only)
-                cv[kLbsAttr + h] = h < a.H ? -gd : (h == a.H ? d_rad : (h == a.H + 1 ? d_w : 0.f));
+                cv[kLbsAttr + h] = h < H ? -gd : (h == H ? d_rad : (h == H + 1 ? d_w : 0.f));
             }
 #pragma unroll
-            for (int h = kLbsHmax; h < kLbsHmax + 2; h++) cv[kLbsAttr + h] = h == a.H ? d_rad : (h == a.H + 1 ? d_w : 0.f);
+            for (int h = HM; h < HM + 2; h++) cv[kLbsAttr + h] = h == H ? d_rad : (h == H + 1 ? d_w : 0.f);
             }
             if (COH) lbs_combine(valid, j, cv, G, partial);
             else lbs_deliver(valid, j, cv, G, GS, a.M, s_tab, s_exch, s_cnt, s_slot, s_over);
         }
         if (valid)
-        for (int h = 0; h < kLbsHmax; h++)
-            if (h < a.H) {
+        for (int h = 0; h < HM; h++)
+            if (h < H) {
                 float* dst = g_feature + (size_t)n * gf_stride + h;
                 *dst = accumulate ? *dst + gfeat[h] : gfeat[h];
             }
@@ -1527,7 +1547,8 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
         // coherent variant (surfels stored by nearest node): one zeroed [M][G] table, wave-level sums, global atomics
         const hipError_t me = hipMemsetAsync(scratch, 0, (size_t)M * G * sizeof(float), (hipStream_t)stream);
         if (me != hipSuccess) return fail(-4, std::string("dgs_deform_backward: ") + hipGetErrorString(me));
-        hipLaunchKernelGGL((lbs_bwd_kernel<true, true>), dim3((N + kCohThreads - 1) / kCohThreads), dim3(kCohThreads), 0, (hipStream_t)stream, a,
+        auto kern = H == 8 ? lbs_bwd_kernel<true, true, 8> : lbs_bwd_kernel<true, true, 0>;   // the trainer's hyper_dim, specialised
+        hipLaunchKernelGGL(kern, dim3((N + kCohThreads - 1) / kCohThreads), dim3(kCohThreads), 0, (hipStream_t)stream, a,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1,
                            (float*)scratch, kCohThreads, s);
         hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,

@@ -44,4 +44,34 @@ __device__ __forceinline__ float wave_reduce16_dpp(float (&v)[16])
     return e;
 }
 
+// Eight values: on return the eight lanes 8k .. 8k+7 hold the wave total of v[k].
+__device__ __forceinline__ float wave_reduce8_dpp(float (&v)[8])
+{
+    float h[4], g[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        h[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // lanes 0..31: value i, lanes 32..63: value i + 4
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[i]), __float_as_uint(h[i + 2]), false, false);
+        g[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // row r: value i + 2 r
+    }
+    float f, e;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"       // lanes 0..7 of a row: value 2 r
+        "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xc\n\t"       // lanes 8..15:         value 2 r + 1
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %1, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(f), "=&v"(e)
+        : "v"(g[0]), "v"(g[1]));
+    return e;
+}
+
 }  // namespace dgs
