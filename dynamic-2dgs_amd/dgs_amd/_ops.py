@@ -45,6 +45,8 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s not found; build it with __graft_entry__.build()" % LIB_PATH)
+        from diff_surfel_rasterization._C import _refuse_stale
+        _refuse_stale(LIB_PATH, source_hash, build)   # never run a binary built from other sources than the tree's
         lib = ctypes.CDLL(LIB_PATH)
         vp, ci = ctypes.c_void_p, ctypes.c_int
         lib.dgs_train_ops_abi_version.restype = ci

@@ -63,6 +63,22 @@ def build_precise(force=False, verbose=False):
     return _dgs_build.build(PRECISE_LIB_PATH, cmd, _deps(), flags, _CSRC, force=force, verbose=verbose)[0]
 
 
+def _refuse_stale(lib_path, hash_fn, build_fn):
+    """A binary built from other sources than the ones in the tree must never be what the tests or the bench measure: if the
+    hash recorded next to it differs from the hash of the current sources + flags, rebuild; if that is impossible, fail."""
+    import _dgs_build
+    if os.path.basename(lib_path) not in (LIB_NAME, "libdgs_train_ops.so") or os.path.dirname(os.path.abspath(lib_path)) != os.path.abspath(_CSRC):
+        return   # DGS_SURFEL_LIB override: an explicit A/B or twin build (its own flags), the caller's responsibility
+    have, want = _dgs_build.recorded_hash(lib_path), hash_fn()
+    if have == want:
+        return
+    try:
+        build_fn()
+    except Exception as ex:
+        raise RuntimeError("%s was built from other sources (recorded inputs %s, tree %s) and cannot be rebuilt here: %r"
+                           % (lib_path, have, want, ex))
+
+
 def load():
     """dlopen the library and declare the prototypes of include/dgs_surfel_rasterizer.h."""
     global _lib
@@ -72,6 +88,7 @@ def load():
         raise RuntimeError(
             "%s not found: the MI355X surfel rasterizer has no CPU fallback. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)." % LIB_PATH)
+    _refuse_stale(LIB_PATH, source_hash, build)
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     lib.dgs_abi_version.restype = ci
