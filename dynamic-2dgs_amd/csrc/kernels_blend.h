@@ -71,10 +71,11 @@ __device__ __forceinline__ int tile_for_block(int bid, int tiles_x, int tiles_y,
 // puts the long tiles first and lets the short ones fill the tail.
 constexpr int kOrderBins = 1024;
 
-__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, const uint32_t* weights, int ntiles, uint32_t* order)
+// body shared by tile_order_kernel and scan_tiles_kernel (which orders the forward's tiles right after it has scanned their
+// counts: one launch less in the step); all 1024 threads of the workgroup must call it
+__device__ __forceinline__ void tile_order_body(const uint2* ranges, const uint32_t* weights, int ntiles, uint32_t* order, uint32_t* s_hist /*[kOrderBins]*/,
+                                                uint32_t* s_wsum /*[16]*/)
 {
-    __shared__ uint32_t s_hist[kOrderBins];
-    __shared__ uint32_t s_wsum[16];
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
     __syncthreads();
@@ -107,6 +108,13 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, c
         const uint32_t pos = atomicAdd(&s_hist[bin], 1u);
         order[pos] = (uint32_t)t;
     }
+}
+
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, const uint32_t* weights, int ntiles, uint32_t* order)
+{
+    __shared__ uint32_t s_hist[kOrderBins];
+    __shared__ uint32_t s_wsum[16];
+    tile_order_body(ranges, weights, ntiles, order, s_hist, s_wsum);
 }
 
 // grid size that covers every tile under `mode`

@@ -88,6 +88,8 @@ __global__ void __launch_bounds__(kSurfelBlock) preprocess_fwd_kernel(Preprocess
 // atomics on 2500 hot counters measured 7.5 G/s on MI355X (1.5 M pairs = 200 us); LDS atomics make this ~20 us and
 // the scatter below reuses the same chunking, so bucket positions need no global atomics either.
 constexpr int kBinGroups = 256;
+constexpr int kBinThreads = 1024;   // 16 waves per workgroup (one workgroup per CU): a chunk of ~782 surfels is ONE trip of the loop below instead of
+                                    // three dependent ones (radii -> rectangle -> LDS atomics); count 12 -> 7, scatter 17 -> 14 us
 
 struct BinArgs {
     int P, ntiles, tiles_x, chunk;   // chunk = surfels per workgroup
@@ -99,14 +101,14 @@ struct BinArgs {
     uint64_t* keys;         // [R] (scatter only)
 };
 
-__global__ void __launch_bounds__(256) count_tiles_lds_kernel(BinArgs a)
+__global__ void __launch_bounds__(kBinThreads) count_tiles_lds_kernel(BinArgs a)
 {
     extern __shared__ uint32_t s_hist[];
     const int g = blockIdx.x, tid = threadIdx.x;
-    for (int t = tid; t < a.ntiles; t += 256) s_hist[t] = 0;
+    for (int t = tid; t < a.ntiles; t += kBinThreads) s_hist[t] = 0;
     __syncthreads();
     const int end = min(a.P, (g + 1) * a.chunk);
-    for (int idx = g * a.chunk + tid; idx < end; idx += 256) {
+    for (int idx = g * a.chunk + tid; idx < end; idx += kBinThreads) {
         if (!(a.radii[idx] > 0)) continue;
         const uint2 r = a.rects[idx];
         const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
@@ -114,17 +116,19 @@ __global__ void __launch_bounds__(256) count_tiles_lds_kernel(BinArgs a)
             for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
     }
     __syncthreads();
-    for (int t = tid; t < a.ntiles; t += 256) a.M[(size_t)g * a.ntiles + t] = s_hist[t];
+    for (int t = tid; t < a.ntiles; t += kBinThreads) a.M[(size_t)g * a.ntiles + t] = s_hist[t];
 }
 
-// Column pass over M.  Block = 64 tiles x 4 row groups (kBinGroups / 4 = 64 rows per thread, all loads independent
-// and in flight together); the four partial sums of a tile meet in LDS.
+// Column pass over M.  Block = 64 tiles x kColGroups row groups (kBinGroups / kColGroups rows per thread, all loads
+// independent and in flight together); the partial sums of a tile meet in LDS.  The grid is only T / 64 workgroups, so the
+// parallelism has to come from inside the workgroup: 16 groups of 16 rows (1024 threads) instead of 4 of 64.
 //   counts == nullptr : M[g][t] <- ranges[t].x + sum_{g' < g} M[g'][t]   (where workgroup g starts writing tile t)
 //   counts != nullptr : counts[t] = sum_g M[g][t]
-__global__ void __launch_bounds__(256) column_pass_kernel(uint32_t* M, int ntiles, const uint2* ranges, uint32_t* counts)
+constexpr int kColGroups = 16;
+__global__ void __launch_bounds__(64 * kColGroups) column_pass_kernel(uint32_t* M, int ntiles, const uint2* ranges, uint32_t* counts)
 {
-    constexpr int kRows = kBinGroups / 4;
-    __shared__ uint32_t s_part[4][64];
+    constexpr int kRows = kBinGroups / kColGroups;
+    __shared__ uint32_t s_part[kColGroups][64];
     const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + tx;
     uint32_t v[kRows];
@@ -139,7 +143,12 @@ __global__ void __launch_bounds__(256) column_pass_kernel(uint32_t* M, int ntile
     __syncthreads();
     if (t >= ntiles) return;
     if (counts) {
-        if (ry == 0) counts[t] = s_part[0][tx] + s_part[1][tx] + s_part[2][tx] + s_part[3][tx];
+        if (ry == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int r = 0; r < kColGroups; r++) tot += s_part[r][tx];
+            counts[t] = tot;
+        }
         return;
     }
     uint32_t run = ranges[t].x;
@@ -153,15 +162,15 @@ __global__ void __launch_bounds__(256) column_pass_kernel(uint32_t* M, int ntile
 
 // duplicateWithKeys (rasterizer_impl.cu:70-111) for the tile-bucketed sort: the tile id is implied by the bucket, so
 // the key only carries (depth, surfel index) -- the tie-break order of the reference's stable radix sort.
-__global__ void __launch_bounds__(256) scatter_keys_lds_kernel(BinArgs a)
+__global__ void __launch_bounds__(kBinThreads) scatter_keys_lds_kernel(BinArgs a)
 {
     extern __shared__ uint32_t s_cur[];
     const int g = blockIdx.x, tid = threadIdx.x;
     if (a.state[2] != 0u) return;  // capacity overflow: nothing may be written
-    for (int t = tid; t < a.ntiles; t += 256) s_cur[t] = a.M[(size_t)g * a.ntiles + t];
+    for (int t = tid; t < a.ntiles; t += kBinThreads) s_cur[t] = a.M[(size_t)g * a.ntiles + t];
     __syncthreads();
     const int end = min(a.P, (g + 1) * a.chunk);
-    for (int idx = g * a.chunk + tid; idx < end; idx += 256) {
+    for (int idx = g * a.chunk + tid; idx < end; idx += kBinThreads) {
         if (!(a.radii[idx] > 0)) continue;
         const uint2 r = a.rects[idx];
         const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
@@ -189,43 +198,59 @@ __global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P,
 // *total_out = num_rendered (rasterizer_impl.cu:281).
 // `cap` > 0 (capacity mode, no host round trip): if the lists do not fit the pre-sized binning buffer every tile is
 // left empty (the frame renders as background) and *overflow is raised instead of writing out of bounds.
-__global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
-                                                         uint32_t* total_out /*[3]: num_rendered, longest list, overflow*/,
-                                                         uint32_t cap, int* overflow)
+__global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
+                                                          uint32_t* total_out /*[3]: num_rendered, longest list, overflow*/,
+                                                          uint32_t cap, int* overflow, uint32_t* order /*or null*/)
 {
     __shared__ uint32_t s_wsum[4], s_wmax[4];
+    __shared__ uint32_t s_hist[1024];
+    __shared__ uint32_t s_osum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (ntiles + 255) / 256;
-    const int t0 = tid * per, t1 = min(ntiles, t0 + per);
-    uint32_t sum = 0, mx = 0;
-    for (int t = t0; t < t1; t++) { const uint32_t c = counts[t]; sum += c; mx = max(mx, c); }
-    uint32_t inc = sum;
+    if (tid < 256) {   // the scan proper: 256 threads, `per` consecutive tiles each
+        const int per = (ntiles + 255) / 256;
+        const int t0 = tid * per, t1 = min(ntiles, t0 + per);
+        uint32_t sum = 0, mx = 0;
+        for (int t = t0; t < t1; t++) { const uint32_t c = counts[t]; sum += c; mx = max(mx, c); }
+        uint32_t inc = sum;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t n = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += n;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t n = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += n;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+        if (lane == 63) s_wsum[wave] = inc;
+        if (lane == 0) s_wmax[wave] = mx;
+        s_hist[tid] = inc - sum;   // exclusive prefix inside the wave, parked for after the barrier
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    if (lane == 63) s_wsum[wave] = inc;
-    if (lane == 0) s_wmax[wave] = mx;
     __syncthreads();
-    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    const bool over = cap > 0 && total > cap;
-    uint32_t run = inc - sum;
-    for (int w = 0; w < wave; w++) run += s_wsum[w];
-    for (int t = t0; t < t1; t++) {
-        const uint32_t c = over ? 0u : counts[t];
-        if (over) run = 0;
-        ranges[t] = make_uint2(run, run + c);
-        if (cursor) cursor[t] = run;
-        run += c;
+    if (tid < 256) {
+        const int per = (ntiles + 255) / 256;
+        const int t0 = tid * per, t1 = min(ntiles, t0 + per);
+        const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        const bool over = cap > 0 && total > cap;
+        uint32_t run = s_hist[tid];
+        for (int w = 0; w < wave; w++) run += s_wsum[w];
+        for (int t = t0; t < t1; t++) {
+            const uint32_t c = over ? 0u : counts[t];
+            if (over) run = 0;
+            ranges[t] = make_uint2(run, run + c);
+            if (cursor) cursor[t] = run;
+            run += c;
+        }
+        if (tid == 0) {
+            total_out[0] = total;
+            total_out[1] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+            total_out[2] = over ? 1u : 0u;
+            if (over && overflow) atomicOr(overflow, 1);
+        }
     }
-    if (tid == 0) {
-        total_out[0] = total;
-        total_out[1] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-        total_out[2] = over ? 1u : 0u;
-        if (over && overflow) atomicOr(overflow, 1);
+    if (order) {
+        // dispatch order of the forward blend (longest list first, kernels_blend.h): the ranges were just written by this
+        // workgroup, visible to all of its threads after the fence + barrier
+        __threadfence_block();
+        __syncthreads();
+        tile_order_body(ranges, nullptr, ntiles, order, s_hist, s_osum);
     }
 }
 

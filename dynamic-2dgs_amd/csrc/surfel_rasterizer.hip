@@ -527,8 +527,8 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     ba_.state = (const uint32_t*)(geom + gl.total);
     const size_t hist_bytes = (size_t)il.ntiles * 4;
     if (il.lds_bins) {
-        hipLaunchKernelGGL(dgs::count_tiles_lds_kernel, dim3(dgs::kBinGroups), dim3(256), hist_bytes, stream, ba_);
-        hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(256), 0, stream, cursor, il.ntiles,
+        hipLaunchKernelGGL(dgs::count_tiles_lds_kernel, dim3(dgs::kBinGroups), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
+        hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(64 * dgs::kColGroups), 0, stream, cursor, il.ntiles,
                            (const uint2*)nullptr, tile_counts);
     } else {
         DGS_HIP(hipMemsetAsync(tile_counts, 0, hist_bytes, stream));
@@ -539,8 +539,10 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     const int capacity = ctx->capacity.load();
     int* overflow = ctx->overflow.load();
     // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
-    hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(256), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
-                       il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)capacity, overflow);
+    const int tile_order = ctx->tile_order.load();
+    hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
+                       il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)capacity, overflow,
+                       tile_order == 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr);   // + the forward's dispatch order
     DGS_STAGE("scan_tiles", debug, stream);
 
     // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285).
@@ -571,10 +573,10 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         // ---- K4 scatter (depth, index) keys into the tile buckets
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         if (il.lds_bins) {
-            hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(256), 0, stream, cursor, il.ntiles,
+            hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(64 * dgs::kColGroups), 0, stream, cursor, il.ntiles,
                                (const uint2*)ranges, (uint32_t*)nullptr);
             ba_.keys = keys;
-            hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups), dim3(256), hist_bytes, stream, ba_);
+            hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
         } else {
             dgs::ScatterArgs sa;
             sa.P = P; sa.radii = radii; sa.rec = pa.rec; sa.rects = pa.rects; sa.cursor = cursor;
@@ -624,13 +626,8 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     fa.ranges = ranges;
     fa.point_list = (const uint32_t*)(bin + bl.point_list);
     fa.rec = pa.rec;
-    fa.W = width; fa.H = height; fa.tiles_x = il.tiles_x; fa.tiles_y = il.tiles_y; fa.mode = ctx->tile_order.load();
-    fa.order = (const uint32_t*)(img + il.order_fwd);
-    if (fa.mode == 3) {
-        hipLaunchKernelGGL(dgs::tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint2*)ranges, (const uint32_t*)nullptr,
-                           il.ntiles, (uint32_t*)(img + il.order_fwd));
-        DGS_STAGE("tile_order_fwd", debug, stream);
-    }
+    fa.W = width; fa.H = height; fa.tiles_x = il.tiles_x; fa.tiles_y = il.tiles_y; fa.mode = tile_order;
+    fa.order = (const uint32_t*)(img + il.order_fwd);   // written by scan_tiles_kernel
     fa.bg = background;
     fa.final_T = (float*)(img + il.final_T);
     fa.n_contrib = (uint32_t*)(img + il.n_contrib);
