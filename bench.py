@@ -236,7 +236,8 @@ def main():
     timed_losses = []
     densify_ms, densify_counts = [], []
     for i in range(args.steps):
-        timed_losses.append(tr.step().clone())  # device-side copy; the reference reads loss.item() every step
+        tr.step()   # the loss of every step lands in the trainer's pinned report ring (guard kernel): no copy kernel, no sync here;
+                    # the reference reads loss.item() -- a host synchronisation -- every step
         if args.densify_every and (i + 1) % args.densify_every == 0:
             torch.cuda.synchronize()
             td = time.perf_counter()
@@ -249,9 +250,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if use_graph and _C.read_overflow():
+    if use_graph and (_C.read_overflow() or tr.overflow_recoveries):
         raise SystemExit("rasterizer capacity overflow during the timed region: result invalid")
-    timed_losses = [float(x) for x in timed_losses]
+    timed_losses = tr.loss_history(args.steps)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -905,13 +905,14 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, i
 // (through sigmoid), written or added in place; the attribute gradients are always written (the node MLP consumes them)
 __global__ void __launch_bounds__(256) lbs_reduce_raw_kernel(const float* partial, int M, int H, const float* rad_raw,
                                                              const float* w_raw, float* g_nodes, float* g_rad_raw, float* g_w_raw,
-                                                             float* g_attrs, int accumulate, int nparts)
+                                                             float* g_attrs, int accumulate, int nparts, float* clear)
 {
     const int G = kLbsAttr + H + 2, T = 3 + H;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M * G) return;
     float acc = 0.f;
     for (int b = 0; b < nparts; b++) acc += partial[(size_t)b * M * G + i];
+    if (clear) clear[i] = 0.f;   // coherent variant with a persistent table: leave it zeroed for the next backward (no memset launch)
     const int node = i / G, c = i - node * G;
     if (c < kLbsAttr) { g_attrs[(size_t)node * kLbsAttr + c] = acc; }
     else if (c < kLbsAttr + H) {
@@ -1000,6 +1001,7 @@ struct RegArgs {
     float ln, ld;
     const float* const* rays_slot;   // non-null: rays_d = *rays_slot (chosen per graph replay by rewriting one pointer)
     int write_all;                   // backward: also store the zeros of planes 0, 1, 7 and of the border (caller zero-fills plane 5 only)
+    float* zero_plane;               // forward: optional [H,W] plane to clear (the backward's atomics target: saves its fill launch)
 };
 
 // back-projected point of pixel (y, x)
@@ -1032,6 +1034,7 @@ __global__ void __launch_bounds__(256) regloss_fwd_kernel(RegArgs a, float* loss
     float val = 0.f;
     if (x < a.W && y < a.H) {
         const size_t q = (size_t)y * a.W + x;
+        if (a.zero_plane) a.zero_plane[q] = 0.f;
         float dot = 0.f;
         if (x >= 1 && y >= 1 && x < a.W - 1 && y < a.H - 1) {
             float dx[3], dy[3], v[3];
@@ -1134,7 +1137,7 @@ struct AdamSegs {
 // so every rank sees the same value) -- and the update kernels return without touching parameters, moments, statistics or
 // the step count.
 __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restrict__ step_count, float* __restrict__ status,
-                                  float* __restrict__ host_ring, int ring_len)
+                                  float* __restrict__ host_ring, int ring_len, const float* __restrict__ loss)
 {
     // one thread.  status: [0] skip flag of this step, [1] number of skipped steps so far, [2] guarded steps so far
     const bool sk = skip && skip[0] != 0;
@@ -1148,7 +1151,7 @@ __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restric
         float* e = host_ring + 4 * ((long long)n_steps % ring_len);
         e[1] = sk ? 1.0f : 0.0f;
         e[2] = n_skipped;
-        e[3] = 0.0f;
+        e[3] = loss ? loss[0] : 0.0f;   // the step's loss: the host can read a history without a copy kernel per step
         __threadfence_system();
         e[0] = n_steps;   // written last: a reader that sees the index sees the payload
     }
@@ -1281,7 +1284,7 @@ int dgs_regloss_forward(int H, int W, const float* allmap, const float* rays_d, 
                         float lambda_normal, float lambda_dist, float* loss, void* stream)
 {
     if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !loss) return fail(-1, "dgs_regloss_forward: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr, 0};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr, 0, nullptr};
     hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, loss, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_fwd_kernel: ") + hipGetErrorString(e));
@@ -1292,7 +1295,7 @@ int dgs_regloss_backward(int H, int W, const float* allmap, const float* rays_d,
                          float lambda_normal, float lambda_dist, const float* g, float* d_allmap, void* stream)
 {
     if (H <= 0 || W <= 0 || !allmap || !rays_d || !rays_o || !wvt || !g || !d_allmap) return fail(-1, "dgs_regloss_backward: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr, 0};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, nullptr, 0, nullptr};
     hipLaunchKernelGGL(regloss_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, g, d_allmap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_bwd_kernel: ") + hipGetErrorString(e));
@@ -1305,7 +1308,7 @@ int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* ra
 {
     if (H <= 0 || W <= 0 || !allmap || (!rays_d && !rays_slot) || !rays_o || !wvt || !g || !d_allmap)
         return fail(-1, "dgs_regloss_backward_slot: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, write_all};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, write_all, nullptr};
     hipLaunchKernelGGL(regloss_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, g, d_allmap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_bwd_kernel: ") + hipGetErrorString(e));
@@ -1365,10 +1368,10 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
                                  exp_avg, exp_avg_sq, step_count, beta1, beta2, eps, plan, nullptr, stream);
 }
 
-int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, void* stream)
+int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, const float* loss, void* stream)
 {
     if (!step_count || !status || (host_ring && ring_len <= 0)) return fail(-1, "dgs_step_guard: bad argument");
-    hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, skip, step_count, status, host_ring, ring_len);
+    hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, skip, step_count, status, host_ring, ring_len, loss);
     return hipGetLastError() == hipSuccess ? 0 : fail(-4, "step_guard_kernel: launch failed");
 }
 
@@ -1545,21 +1548,27 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
     s.g_xyz = g_xyz; s.g_scaling_raw = g_scaling_raw; s.g_rotation_raw = g_rotation_raw; s.g_opacity_raw = g_opacity_raw;
     if (accumulate & 2) {
         // coherent variant (surfels stored by nearest node): one zeroed [M][G] table, wave-level sums, global atomics
-        const hipError_t me = hipMemsetAsync(scratch, 0, (size_t)M * G * sizeof(float), (hipStream_t)stream);
-        if (me != hipSuccess) return fail(-4, std::string("dgs_deform_backward: ") + hipGetErrorString(me));
+        // accumulate bit 2 (value 4): `scratch` is a persistent table that is zero on entry and must be zero on exit
+        const bool persistent = (accumulate & 4) != 0;
+        if (!persistent) {
+            const hipError_t me = hipMemsetAsync(scratch, 0, (size_t)M * G * sizeof(float), (hipStream_t)stream);
+            if (me != hipSuccess) return fail(-4, std::string("dgs_deform_backward: ") + hipGetErrorString(me));
+        }
         auto kern = H == 8 ? lbs_bwd_kernel<true, true, 8> : lbs_bwd_kernel<true, true, 0>;   // the trainer's hyper_dim, specialised
         hipLaunchKernelGGL(kern, dim3((N + kCohThreads - 1) / kCohThreads), dim3(kCohThreads), 0, (hipStream_t)stream, a,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1,
                            (float*)scratch, kCohThreads, s);
         hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
-                           node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1);
+                           node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1,
+                           persistent ? (float*)scratch : (float*)nullptr);
     } else {
         const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
         hipLaunchKernelGGL((lbs_bwd_kernel<true, false>), dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1, (float*)scratch,
                            chunk > 0 ? chunk : 1, s);
         hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
-                           node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, kLbsBlocks);
+                           node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, kLbsBlocks,
+                           (float*)nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("lbs_bwd_kernel<asm>: ") + hipGetErrorString(e));
@@ -1584,12 +1593,23 @@ int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, fl
     return 0;
 }
 
+int dgs_regloss_forward_partials_z(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                                   float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot,
+                                   float* zero_plane, void* stream);
+
 int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
                                  float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot, void* stream)
 {
+    return dgs_regloss_forward_partials_z(H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, partials, rays_slot, nullptr, stream);
+}
+
+int dgs_regloss_forward_partials_z(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                                   float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot,
+                                   float* zero_plane, void* stream)
+{
     if (H <= 0 || W <= 0 || !allmap || (!rays_d && !rays_slot) || !rays_o || !wvt || !partials)
         return fail(-1, "dgs_regloss_forward_partials: bad argument");
-    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, 0};
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, 0, zero_plane};
     hipLaunchKernelGGL(regloss_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, (float*)nullptr,
                        partials);
     hipError_t e = hipGetLastError();

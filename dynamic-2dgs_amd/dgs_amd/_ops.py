@@ -16,7 +16,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
-            "dgs_step_guard", "dgs_adam_step_guarded", "dgs_densify_accumulate_guarded")
+            "dgs_step_guard", "dgs_adam_step_guarded", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z")
 
 
 def _deps():
@@ -115,7 +115,9 @@ def load():
         lib.dgs_densify_accumulate.restype = ci
         lib.dgs_densify_accumulate.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp]
         lib.dgs_step_guard.restype = ci
-        lib.dgs_step_guard.argtypes = [vp, vp, vp, vp, ci, vp]
+        lib.dgs_step_guard.argtypes = [vp, vp, vp, vp, ci, vp, vp]
+        lib.dgs_regloss_forward_partials_z.restype = ci
+        lib.dgs_regloss_forward_partials_z.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         lib.dgs_adam_step_guarded.restype = ci
         lib.dgs_adam_step_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
@@ -269,6 +271,7 @@ class FlatAdam:
         # rank's rasterizer overflowed its list capacity); None = every step is applied
         self.skip = None
         self.host_ring = None    # optional pinned float tensor [ring_len, 4] the guard kernel reports into
+        self.loss = None         # optional device float: the step's loss, copied into the ring entry by the guard kernel
         dev = flat_grad.device
         n = sum(p.numel() for p in self.params)
         assert flat_grad.numel() >= n and flat_grad.is_contiguous()
@@ -327,7 +330,8 @@ class FlatAdam:
             if advance:   # one-thread kernel: t += 1 unless the step is to be skipped; bookkeeping for the host
                 ring = self.host_ring
                 _check(lib, lib.dgs_step_guard(skip, self.t.data_ptr(), self.status.data_ptr(), None if ring is None else ring.data_ptr(),
-                                               0 if ring is None else ring.shape[0], _stream(dev)), "dgs_step_guard")
+                                               0 if ring is None else ring.shape[0], None if self.loss is None else self.loss.data_ptr(),
+                                               _stream(dev)), "dgs_step_guard")
             rc = lib.dgs_adam_step_guarded(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
                                            self.grad.data_ptr(),
                                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
@@ -522,6 +526,9 @@ class DeferredNodeMLP:
         self.state = None
 
 
+_COHERENT_TABLES = {}
+
+
 class _FusedDeform(torch.autograd.Function):
     """(means3D, scales, rotations, opacity) of the deformed surfels from the raw surfel parameters, the node tables
     and the node attribute table (dgs_deform_forward / dgs_deform_backward).  sink: None or the list of the eight
@@ -564,7 +571,16 @@ class _FusedDeform(torch.autograd.Function):
         z = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()
         g_means, g_scales, g_rots, g_opac = z(g_means, xyz), z(g_scales, scaling), z(g_rots, rotation), z(g_opac, opacity)
         g_attrs = torch.empty_like(attrs) if ctx.g_attrs_out is None else ctx.g_attrs_out  # deferred node MLP: caller's buffer
-        scratch = torch.empty(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
+        persistent = 0
+        if ctx.coherent:
+            # one persistent zeroed [M][13+H+2] table per (device, M, H): the reduce kernel leaves it zeroed again
+            key = (dev, M, H)
+            scratch = _COHERENT_TABLES.get(key)
+            if scratch is None:
+                scratch = _COHERENT_TABLES[key] = torch.zeros(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
+            persistent = 4
+        else:
+            scratch = torch.empty(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
         tens = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
         if ctx.sink is not None:
             outs, ret, acc = ctx.sink, [None] * 8, 1
@@ -580,7 +596,7 @@ class _FusedDeform(torch.autograd.Function):
                 node_weight.data_ptr(), attrs.data_ptr(), None if mask is None else mask.data_ptr(), scaling.data_ptr(),
                 rotation.data_ptr(), opacity.data_ptr(), g_means.data_ptr(), g_scales.data_ptr(), g_rots.data_ptr(), g_opac.data_ptr(),
                 outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), outs[5].data_ptr(),
-                outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), acc | (2 if ctx.coherent else 0), scratch.data_ptr(), _stream(dev))
+                outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), acc | (2 if ctx.coherent else 0) | persistent, scratch.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_deform_backward")
         return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None)
 
@@ -619,17 +635,22 @@ class _FusedTrainLoss(torch.autograd.Function):
         part = torch.empty(2 * nb + nr, dtype=torch.float32, device=dev)  # per-workgroup partial sums, no zero fill needed
         maps = torch.empty((3, C, H, W), dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
+        # the backward's gradient image of the allmap: its kernel stores every plane but 5, which collects atomics and is
+        # cleared HERE by the regulariser's forward kernel (one fill launch less per step)
+        g_allmap = torch.empty_like(allmap) if torch.is_grad_enabled() or allmap.requires_grad else None
         with torch.cuda.device(dev):
             st = _stream(dev)
             _check(lib, lib.dgs_photo_forward(C, H, W, image.data_ptr(), gt.data_ptr(), part.data_ptr(), maps[0].data_ptr(),
                                               maps[1].data_ptr(), maps[2].data_ptr(), gslot, st), "dgs_photo_forward")
-            _check(lib, lib.dgs_regloss_forward_partials(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
-                                                         lam_n, lam_d, part.data_ptr() + 8 * nb, rslot, st), "dgs_regloss_forward_partials")
+            _check(lib, lib.dgs_regloss_forward_partials_z(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
+                                                           lam_n, lam_d, part.data_ptr() + 8 * nb, rslot,
+                                                           None if g_allmap is None else g_allmap[5].data_ptr(), st), "dgs_regloss_forward_partials")
             _check(lib, lib.dgs_loss_combine(part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, C * H * W, lam_dssim, loss.data_ptr(), st),
                    "dgs_loss_combine")
         ctx.save_for_backward(image, allmap, gt, rays_d, rays_o, wvt, maps)
         ctx.lam = (lam_dssim, lam_n, lam_d)
         ctx.slots = slots
+        ctx.g_allmap = g_allmap
         return loss.reshape(())
 
     @staticmethod
@@ -642,8 +663,11 @@ class _FusedTrainLoss(torch.autograd.Function):
         C, H, W = image.shape
         gd = g.reshape(1).to(torch.float32).contiguous()
         g_image = torch.empty_like(image)
-        g_allmap = torch.empty_like(allmap)   # the kernel stores everything but plane 5, which collects atomics
-        g_allmap[5].zero_()
+        g_allmap = ctx.g_allmap               # plane 5 was cleared in forward; the kernel stores every other plane
+        ctx.g_allmap = None
+        if g_allmap is None:                  # forward ran without grad mode knowledge (or backward is run twice)
+            g_allmap = torch.empty_like(allmap)
+            g_allmap[5].zero_()
         with torch.cuda.device(dev):
             st = _stream(dev)
             _check(lib, lib.dgs_photo_backward(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),

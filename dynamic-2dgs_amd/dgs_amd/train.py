@@ -201,7 +201,7 @@ class Trainer:
 
     # ---- step guard: a capacity overflow must not train anything -----------------------------------------------------
     GUARD_LAG = 2     # the host looks at the report of the step issued two steps earlier (already finished: no stall)
-    GUARD_RING = 8
+    GUARD_RING = 256  # entries of the pinned report ring (step, skipped flag, skipped so far, loss): also the loss history
 
     def _init_guard(self, old_opt=None):
         """Capacity mode has no host read inside the step, so a view whose tile lists do not fit renders as background and
@@ -226,6 +226,18 @@ class Trainer:
 
     def world_size_hint(self):
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def loss_history(self, k):
+        """Losses of the last k steps (oldest first) from the guard kernel's pinned ring -- no copy kernel per step, no
+        synchronisation inside the loop; synchronises here.  Steps that were skipped (capacity overflow) report their loss too."""
+        assert 0 < k <= min(self.GUARD_RING, self._guard_steps), "only the last GUARD_RING steps are kept"
+        torch.cuda.synchronize()
+        out = []
+        for n in range(self._guard_steps - k + 1, self._guard_steps + 1):
+            e = self._ring[n % self.GUARD_RING]
+            assert int(e[0]) == n, "ring entry overwritten"
+            out.append(float(e[3]))
+        return out
 
     def _check_guard(self):
         """Poll the report of the guarded step issued GUARD_LAG steps ago; recover if it (or, the flag being sticky, any
@@ -419,9 +431,15 @@ class Trainer:
                 self.bucket.extra[self.P:2 * self.P].copy_(vis.to(torch.float32))
                 self._radii[:self.P].copy_(torch.where(vis, pkg["radii"], torch.zeros_like(pkg["radii"])))
 
+    def _note_loss(self, loss):
+        """The guard kernel of this step copies the loss into its report (FlatAdam.loss)."""
+        if self.opt_deform is None:
+            self.opt_surfels.loss = loss.reshape(1)
+
     def _fwd_bwd(self, cam, gt):
         d = self.deform
         loss, pkg, asm, fused = self._forward(cam, gt)
+        self._note_loss(loss.detach())
         # explicit unit gradient: loss.backward() alone launches a fill for it every step
         self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
         if hasattr(d, "finish_backward"):
@@ -449,6 +467,7 @@ class Trainer:
         leaf = pkg["viewspace_points"]
         grads = self._run_backward(lambda: torch.autograd.grad(loss, list(asm) + [leaf], grad_outputs=self._unit, allow_unused=True), fused)
         leaf.grad = grads[4]
+        self._note_loss(loss.detach())
         self._half = (asm, grads[:4], pkg)
         with torch.no_grad():   # final after the forward: their MAX all-reduce starts first (the guard of the SH update needs it)
             self._radii[:self.P].copy_(pkg["radii"])   # radii are 0 for culled surfels: same as the masked copy of _statistics

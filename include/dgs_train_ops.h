@@ -109,13 +109,13 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
  * raises an int32 device flag; nothing on the host knows yet.  The kernels below read such a flag ON THE DEVICE (`skip`:
  * the rasterizer's flag itself, or -- data parallel -- a copy that went through a MAX all-reduce so that every rank sees
  * "some rank overflowed"):
- *   dgs_step_guard(skip, step_count, status, host_ring, ring_len): one thread; advances the Adam step count unless
+ *   dgs_step_guard(skip, step_count, status, host_ring, ring_len, loss): one thread; advances the Adam step count unless
  *     skip[0] != 0; status[3] = {skip flag of this step, skipped steps so far, guarded steps so far}; if host_ring (pinned,
- *     device-accessible host memory, 4 floats per entry) is given, entry (steps % ring_len) <- (steps, flag, skipped, 0) so
- *     the host can poll the outcome of step k a few steps later without synchronising,
+ *     device-accessible host memory, 4 floats per entry) is given, entry (steps % ring_len) <- (steps, flag, skipped, loss[0]
+ *     or 0) so the host can poll the outcome -- and the loss -- of step k a few steps later without synchronising,
  *   dgs_adam_step_guarded / dgs_densify_accumulate_guarded: return without changing anything when skip[0] != 0.
  * A frame that overflowed therefore trains nothing -- not the parameters, not the moments, not the statistics. */
-int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, void* stream);
+int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, const float* loss, void* stream);
 int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
                           const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                           float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
@@ -157,7 +157,8 @@ int dgs_knn_points2(int N, int M, int D1, int D2, int K, const float* x1, const 
  * (dgs_amd.train.Trainer.sort_surfels): the 64 points of a wave then share one or two nodes per neighbour slot, their
  * contributions are summed across the wave and one 23-lane global atomic per (wave, node) goes into a single [M][13+H+2]
  * table -- instead of 256 per-workgroup LDS tables of 94 KB.  Same results for any order (float summation order aside);
- * an unsorted set makes it slow, not wrong.  scratch: dgs_lbs_scratch_bytes(M, H) bytes. */
+ * an unsorted set makes it slow, not wrong.  accumulate bit 2 (value 4, coherent variant only): `scratch` is a persistent
+ * table that is all zero on entry and is left all zero (no memset launch).  scratch: dgs_lbs_scratch_bytes(M, H) bytes. */
 int dgs_deform_forward(int N, int M, int H, const float* xyz, const float* feature, int feature_stride, const long long* idx,
                        const float* nodes, const float* node_radius_raw, const float* node_weight_raw, const float* attrs,
                        const float* mask, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
@@ -190,6 +191,11 @@ int dgs_regloss_forward_partials(int H, int W, const float* allmap, const float*
 int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
                               float lambda_normal, float lambda_dist, const float* g, float* d_allmap, const float* const* rays_slot,
                               int write_all, void* stream);
+/* dgs_regloss_forward_partials that also clears zero_plane[H,W] (may be NULL): the plane of the backward's gradient image that
+ * collects atomics, cleared here so that the backward needs no fill launch */
+int dgs_regloss_forward_partials_z(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
+                                   float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot,
+                                   float* zero_plane, void* stream);
 int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
                      float lambda_dssim, float* out, void* stream);
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
