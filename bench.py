@@ -280,6 +280,7 @@ def main():
             _C.profile_enable(0)
         tr._graph = None
         _C.set_capacity(0)
+        _C.set_option(6, 0)
         _C.profile_enable(1)
         _C.profile_reset()
         eager_losses = [float(tr.step()) for _ in range(args.steps)]

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P,
 // left empty (the frame renders as background) and *overflow is raised instead of writing out of bounds.
 __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
                                                           uint32_t* total_out /*[3]: num_rendered, longest list, overflow*/,
-                                                          uint32_t cap, int* overflow, uint32_t* order /*or null*/)
+                                                          uint32_t cap, int* overflow, uint32_t* order /*or null*/, uint32_t list_hint)
 {
     __shared__ uint32_t s_wsum[4], s_wmax[4];
     __shared__ uint32_t s_hist[1024];
@@ -228,7 +228,10 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts
         const int per = (ntiles + 255) / 256;
         const int t0 = tid * per, t1 = min(ntiles, t0 + per);
         const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-        const bool over = cap > 0 && total > cap;
+        const uint32_t longest = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+        // capacity mode: the lists must fit the pre-sized buffer, and -- if the caller promised a longest list (list_hint:
+        // only the sort kernels for lists up to it were launched) -- no list may be longer than promised
+        const bool over = cap > 0 && (total > cap || (list_hint > 0 && longest > list_hint));
         uint32_t run = s_hist[tid];
         for (int w = 0; w < wave; w++) run += s_wsum[w];
         for (int t = t0; t < t1; t++) {
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts
         }
         if (tid == 0) {
             total_out[0] = total;
-            total_out[1] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+            total_out[1] = longest;
             total_out[2] = over ? 1u : 0u;
             if (over && overflow) atomicOr(overflow, 1);
         }

@@ -184,6 +184,7 @@ struct dgs_context {
     std::atomic<int> sort_regs{2};    // per-tile sort: 2 LSD radix in LDS (default), 1 bitonic network in registers, 0 bitonic in LDS
     std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
+    std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
     std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
     std::atomic<int> grid_limit_fwd{0};   // > 0 (diagnostic, key 5): same for the forward blend (the other tiles' state is zero-filled)
     std::atomic<int*> overflow{nullptr};  // device flag raised by a capacity overflow (library- or caller-owned)
@@ -310,11 +311,13 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (key == 1 && value >= 0 && value <= 3) { c->tile_order.store(value); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
+    if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
     if (key == 5 && value >= 0) { c->grid_limit_fwd.store(value); return DGS_OK; }
     if (key == 2 && value >= 0) {
         if (value > 0)
             if (int e = ensure_overflow(c)) return e;
         c->capacity.store(value);
+        if (value == 0) c->list_hint.store(0);   // the promise belongs to a capacity-mode session
         return DGS_OK;
     }
     return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_set_option: unknown key / value");
@@ -542,7 +545,8 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     const int tile_order = ctx->tile_order.load();
     hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
                        il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)capacity, overflow,
-                       tile_order == 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr);   // + the forward's dispatch order
+                       tile_order == 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr,   // + the forward's dispatch order
+                       (uint32_t)(capacity > 0 ? ctx->list_hint.load() : 0));
     DGS_STAGE("scan_tiles", debug, stream);
 
     // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285).
@@ -552,7 +556,8 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     const bool capacity_mode = capacity > 0;
     if (capacity_mode) {
         R_u = (uint32_t)capacity;
-        longest = 0xffffffffu;
+        const int hint = ctx->list_hint.load();
+        longest = hint > 0 ? (uint32_t)hint : 0xffffffffu;   // a longer list than promised raises the overflow flag (scan_tiles_kernel)
     } else {
         // one pinned word per context: concurrent forwards of the same context take turns here (other contexts do not wait)
         std::lock_guard<std::mutex> lk(ctx->stage.mu);

@@ -263,7 +263,10 @@ class Trainer:
         self._oflag.zero_()
         self._guard_events.clear()
         self.overflow_recoveries += 1
-        self._capacity = 2 * self._capacity
+        if getattr(self, "_list_hint", 0):
+            self._list_hint = 0             # first suspect: a tile list longer than promised (enable_graph re-captures without it)
+        else:
+            self._capacity = 2 * self._capacity
         self._graph = None
         self.enable_graph(self._capacity, validate=False)
 
@@ -288,6 +291,12 @@ class Trainer:
         dev = self.surfels.get_xyz.device
         self._capacity = int(capacity)
         _C.set_capacity(int(capacity))
+        # promise of the longest tile list (dgs_set_option key 6): one sort launch instead of three.  A frame that breaks it
+        # counts as an overflow: at capture time (below) and in the step guard the promise is withdrawn first, the capacity
+        # doubled only if that was not the reason
+        if not hasattr(self, "_list_hint"):
+            self._list_hint = 2048
+        _C.set_option(6, self._list_hint)
         if getattr(self, "_oflag", None) is not None:
             _C.set_overflow_flag(self._oflag)   # the captured launches keep THIS trainer's flag
         # (rays_d [H*W,3], rays_o [3]) per view and the targets stay resident: the table rows point at them
@@ -345,8 +354,13 @@ class Trainer:
         self._graph = True
         # validate: the warm-up rendered the first view -- fail now rather than let the step guard double the capacity later
         # (validate=False leaves it to the guard: every view, not just the first, is covered by it anyway)
-        if _C.read_overflow() and validate:
-            raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
+        if _C.read_overflow():
+            if self._list_hint:            # perhaps only the promised list length was exceeded: withdraw it and capture again
+                self._list_hint = 0
+                self._graph = None
+                return self.enable_graph(capacity, validate=validate)
+            if validate:
+                raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
 
     def _snapshot(self):
         sf = self.surfels

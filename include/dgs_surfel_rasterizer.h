@@ -144,6 +144,10 @@ void dgs_set_tight_rects(int on);
  *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do
  *         not fit renders as background and raises the overflow flag; value 0 restores the exact-size mode,
  * key 3 = per-tile sort: 2 LSD radix sort in LDS [default], 1 bitonic network with the keys in registers, 0 bitonic network in LDS,
+ * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
+ *         host read the library cannot know which of its per-tile sort kernels will find work and launches all three; with the
+ *         promise it launches only those for lists up to `value` (2048: one launch instead of three, ~10 us of an 800x800
+ *         forward).  A frame that breaks the promise is treated exactly like a capacity overflow: background, flag raised,
  * key 4 / key 5 = diagnostic: the backward / forward blend processes only the first `value` tiles of its dispatch order
  *         (0 = all); results are then incomplete -- for measuring how long the heaviest tiles run on an otherwise idle device.
  * Returns DGS_OK or an error. */
