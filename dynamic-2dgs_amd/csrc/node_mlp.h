@@ -4,19 +4,33 @@
 // reference: positional encodings, a 13->256->30 time net, 8 x 256 ReLU layers with a skip concat after layer 4, four
 // linear heads) which in PyTorch is ~150 launches of 3-10 us on 1024 rows per step:
 //
-//   mlp_pack_kernel   re-lays the 0.52 M weights into MFMA fragment order (once per step; the weights change every
-//                     Adam step), one copy for Z = X W^T and one for dX = dZ W.
-//   mlp_fwd_kernel    one workgroup (16 waves) = 16 nodes through ALL layers; activations stay in LDS, weights stream from L2 as
-//                     coalesced 1-KB fragments, v_mfma_f32_16x16x4_f32 (exact fp32).  Post-ReLU activations are saved.
+//   mlp_pack_kernel   re-lays the 0.52 M weights into the operand order of the two chains (once per step; the weights
+//                     change every Adam step): [k/4][column] float4 for Z = X W^T and for dX = dZ W.
+//   mlp_fwd_kernel    one workgroup (16 waves) = 8 nodes through ALL layers; activations stay in LDS, weights stream from L2
+//                     as coalesced 1-KB rows.  Post-ReLU activations are saved.
 //   mlp_bwd_kernel    the same tiling backwards: dZ_l = (dZ_{l+1} W_{l+1}) * [H_l > 0], every dZ_l saved.
 //   mlp_wgrad_kernel  all weight/bias gradients in ONE launch: dW_l = dZ_l^T X_l as 64x32 tiles over a descriptor
 //                     table, reduction over the 1024 nodes inside the workgroup (no atomics, deterministic).
 //
-// Fragment maps of v_mfma_f32_16x16x4_f32 (lane l): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
-// D[i = 4*(l>>4) + reg][j = l&15].  The reduction index inside one 16-wide K chunk is permuted (lane group q, step s
-// <-> k = 4q + s) identically for A and B, so both operands are read as one 16-byte vector per lane and chunk.
+// Why 8 nodes per workgroup and v_mfma_f32_4x4x1: a chain through all layers needs every weight (2.2 MB) in every
+// workgroup, so a workgroup is bounded by its CU's 64 B/clk L2 port (~17 us) and by fp32 MFMA issue (256 flop/clk/CU
+// whatever the tile shape).  With the 16-row tiles of v_mfma_f32_16x16x4 the 1024 nodes are 64 workgroups on a quarter of
+// the CUs and MFMA issue is the bound (27 us + latencies: measured 54 us); v_mfma_f32_4x4x1_16b computes 16 independent
+// 4x4 outer products per instruction, which with the A-block broadcast (cbsz = 4, abid = g) is D[4 rows of group g][64
+// columns] += X[4g..4g+3][k] * W[k][64 columns]: 8 nodes per workgroup fill the instruction, 128 workgroups halve the
+// MFMA time per CU, and both operand reads are vectors (A: one ds_read_b128 of 4 k for the 8 rows, B: one 16-byte load
+// per lane = 4 k of its column).  Lane maps (tools/micro/mfma4x4_probe.hip checks them on the device):
+// A[blk][i] lane 4 blk + i, B[blk][j] lane 4 blk + j, D[blk][i][j] VGPR i of lane 4 blk + j.
+//
+// A 256-wide layer is split over the 16 waves as 4 column groups of 64 x 4 quarters of K; the four partial sums of an
+// output meet in LDS, where bias + ReLU (or the ReLU mask) are applied by all 1024 threads.  Narrow layers (30, 13 or 32
+// outputs) use one column group x 16 slices of K.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#ifndef MLP_TRACE_POINT
+#define MLP_TRACE_POINT() do { } while (0)   // tools/micro/mlp_chain_bench.hip stamps the device clock here
+#endif
 
 namespace mlp {
 
@@ -30,41 +44,45 @@ constexpr int kTOut = 30;
 constexpr int kTCh = 13;       // posenc t, 6 bands
 constexpr int kTPad = 16;
 constexpr int kHeads = 13;     // local_rotation 4 | d_xyz 3 | d_rotation 4 | d_scaling 2
-constexpr int kRows = 16;      // nodes per workgroup
-constexpr int kThreads = 1024; // 16 waves, one 16-column tile each per 256-wide layer (4 waves/SIMD hide the L2 latency of the weights)
+constexpr int kRows = 8;       // nodes per workgroup: two 4-row groups of the 4x4x1 MFMA
+constexpr int kThreads = 1024; // 16 waves
 constexpr int kNL = 11;        // layer ids: 0 = T1, 1 = T2, 2..9 = L0..L7, 10 = heads
+constexpr int kXOff = 32;      // the MLP input in LDS is [time 30 | 2 zeros | posenc(xyz) 63 | 1 zero]: the time-net gradient is one column group
 
-// layer meta ------------------------------------------------------------------------------------------------------
+// layer meta (weights as PyTorch stores them, [out][in]) -------------------------------------------------------------
 __host__ __device__ constexpr int l_out(int l) { return l == 1 ? kTOut : (l == 10 ? kHeads : kW); }
 __host__ __device__ constexpr int l_in(int l) { return l == 0 ? kTCh : (l == 2 ? kIn : (l == 7 ? kIn + kW : kW)); }
-__host__ __device__ constexpr int l_inpad(int l) { return l == 0 ? kTPad : (l == 2 ? kInPad : (l == 7 ? kInPad + kW : kW)); }
-__host__ __device__ constexpr int l_outpad(int l) { return l == 1 ? 32 : (l == 10 ? 16 : kW); }
-// forward packing: tiles over out, chunks over in;  backward (dgrad) packing: tiles over in, chunks over out
-__host__ __device__ constexpr int fwd_tiles(int l) { return l_outpad(l) / 16; }
-__host__ __device__ constexpr int fwd_kc(int l) { return l_inpad(l) / 16; }
-__host__ __device__ constexpr int bwd_tiles(int l) { return l == 0 ? 0 : l_inpad(l) / 16; }   // T1 needs no input gradient
-__host__ __device__ constexpr int bwd_kc(int l) { return l_outpad(l) / 16; }
-__host__ __device__ constexpr int fwd_off(int l)
+// forward Z = X W^T: K = padded inputs, C = padded outputs;  backward dX = dZ W: K = padded outputs, C = the input columns needed
+__host__ __device__ constexpr int f_K(int l) { return l == 0 ? kTPad : (l == 2 ? kInPad : (l == 7 ? kW + kInPad : kW)); }
+__host__ __device__ constexpr int f_C(int l) { return (l == 1 || l == 10) ? 64 : kW; }
+__host__ __device__ constexpr int b_K(int l) { return l == 1 ? 32 : (l == 10 ? 16 : kW); }
+__host__ __device__ constexpr int b_C(int l) { return l == 0 ? 0 : (l == 2 ? 64 : (l == 7 ? kW + 64 : kW)); }   // L0: time columns only; L5: H4 + time
+__host__ __device__ constexpr int f_off(int l)   // in float4
 {
     int f = 0;
-    for (int i = 0; i < l; i++) f += fwd_tiles(i) * fwd_kc(i);
+    for (int i = 0; i < l; i++) f += f_K(i) / 4 * f_C(i);
     return f;
 }
-__host__ __device__ constexpr int bwd_off(int l)
+__host__ __device__ constexpr int b_off(int l)
 {
     int f = 0;
-    for (int i = 0; i < l; i++) f += bwd_tiles(i) * bwd_kc(i);
+    for (int i = 0; i < l; i++) f += b_K(i) / 4 * b_C(i);
     return f;
 }
-constexpr int kFwdChunks = fwd_off(kNL);   // 16-column x 16-k fragments (64 float4 each)
-constexpr int kBwdChunks = bwd_off(kNL);
-constexpr size_t kBiasOff = (size_t)(kFwdChunks + kBwdChunks) * 256;   // then kNL x 256 biases (zero padded)
+constexpr int kFwdVecs = f_off(kNL);
+constexpr int kBwdVecs = b_off(kNL);
+constexpr size_t kBiasOff = (size_t)(kFwdVecs + kBwdVecs) * 4;   // then kNL x 256 biases (zero padded)
 constexpr size_t kPackedFloats = kBiasOff + (size_t)kNL * kW;
 
-// padded input coordinate -> column of the weight matrix, or -1 (zero padding)
+// coordinate of a layer's input as the kernels hold it in LDS -> column of the weight matrix, or -1 (zero padding)
+__device__ __forceinline__ int inp_col(int p)
+{
+    return p < kTOut ? kXCh + p : ((p < kXOff || p >= kXOff + kXCh) ? -1 : p - kXOff);
+}
 __device__ __forceinline__ int in_col(int l, int p)
 {
-    if (l == 7) return p < kInPad ? (p < kIn ? p : -1) : p - kInPad + kIn;
+    if (l == 2) return inp_col(p);
+    if (l == 7) return p < kW ? kIn + p : inp_col(p - kW);   // LDS row = [H4 | input]; the reference concatenates [input, H4]
     return p < l_in(l) ? p : -1;
 }
 
@@ -82,7 +100,7 @@ struct Grads {
 };
 
 // saved-activation buffer layout (floats)
-__host__ __device__ inline size_t sv_inp(int M) { return 0; }                                   // [M][96]
+__host__ __device__ inline size_t sv_inp(int M) { return 0; }                                   // [M][96]: posenc(xyz) 63 | time 30 | 0
 __host__ __device__ inline size_t sv_et(int M) { return (size_t)M * kInPad; }                   // [M][16]
 __host__ __device__ inline size_t sv_t1(int M) { return sv_et(M) + (size_t)M * kTPad; }         // [M][256]
 __host__ __device__ inline size_t sv_h(int M, int l) { return sv_t1(M) + (size_t)M * kW * (1 + l); }  // L0..L7 outputs [M][256]
@@ -99,37 +117,37 @@ __device__ __forceinline__ const float* w_row(const Weights& w, int l, int n)
     return l == 10 ? w.hw[n] : w.W[l] + (size_t)n * l_in(l);
 }
 
+// one thread per float4 of the two operand arrays: forward [l][k/4][c] = W_l[c][col(4 (k/4) + s)], backward
+// [l][j/4][c] = W_l[4 (j/4) + s][col(c)]
 __global__ void __launch_bounds__(256) mlp_pack_kernel(Weights w, float4* __restrict__ packed)
 {
     int g = blockIdx.x * 256 + threadIdx.x;
-    int frag = g >> 6, lane = g & 63;
     if (g < kNL * kW) {
         int l = g >> 8, c = g & 255;
         reinterpret_cast<float*>(packed)[kBiasOff + g] = c < l_out(l) ? (l == 10 ? w.hb[c][0] : w.b[l][c]) : 0.f;
     }
-    if (frag >= kFwdChunks + kBwdChunks) return;
-    bool bwd = frag >= kFwdChunks;
-    int f = bwd ? frag - kFwdChunks : frag;
+    if (g >= kFwdVecs + kBwdVecs) return;
+    bool bwd = g >= kFwdVecs;
+    int f = bwd ? g - kFwdVecs : g;
     int l = 0;
 #pragma unroll
     for (int i = 1; i < kNL; i++)
-        if (f >= (bwd ? bwd_off(i) : fwd_off(i))) l = i;
-    int local = f - (bwd ? bwd_off(l) : fwd_off(l));
-    int kcn = bwd ? bwd_kc(l) : fwd_kc(l);
-    int t = local / kcn, kc = local - t * kcn;
+        if (f >= (bwd ? b_off(i) : f_off(i))) l = i;
+    int local = f - (bwd ? b_off(l) : f_off(l));
+    int C = bwd ? b_C(l) : f_C(l);
+    int kk = local / C, c = local - kk * C;
     float v[4];
     if (!bwd) {
-        int n = t * 16 + (lane & 15);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            int col = in_col(l, kc * 16 + 4 * (lane >> 4) + s);
-            v[s] = (n < l_out(l) && col >= 0) ? w_row(w, l, n)[col] : 0.f;
+            int col = in_col(l, 4 * kk + s);
+            v[s] = (c < l_out(l) && col >= 0) ? w_row(w, l, c)[col] : 0.f;
         }
     } else {
-        int col = in_col(l, t * 16 + (lane & 15));
+        int col = in_col(l, c);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            int j = kc * 16 + 4 * (lane >> 4) + s;
+            int j = 4 * kk + s;
             v[s] = (j < l_out(l) && col >= 0) ? w_row(w, l, j)[col] : 0.f;
         }
     }
@@ -137,36 +155,88 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(Weights w, float4* __rest
 }
 
 // ---- shared GEMM core -------------------------------------------------------------------------------------------
-// acc[u] += act[16 x (16*kc_count)] * fragment stream of NT consecutive tiles.  `wp` already points at
-// [first tile][first chunk][lane]; consecutive tiles are `tile_stride` float4 apart.
-template <int NT>
-__device__ __forceinline__ void mma_run(const float* __restrict__ act, int stride, int kc_count, const float4* __restrict__ wp,
-                                        int tile_stride, f32x4 (&acc)[NT], int lane)
+// A wave owns 64 output columns (lane = column) and a slice of K.  Its operand rows ([k/4][C] float4) arrive in CHUNKS of up to
+// 8 rows through two register buffers: while one chunk multiplies, the next one -- of this layer or of the following one, the
+// weights do not depend on the activations -- is in flight, across the barriers of the layer.  (All 16 rows of a layer in one
+// request leave the load pipe idle while they multiply and the matrix pipe idle while the next 16 arrive: 3.3 us per layer
+// against 1.9 us for 256 KB at the CU's 64 B/clk.)
+constexpr int kChunk = 8;
+
+// `p` is wave-uniform (scalar base registers: one address VGPR for all rows instead of a 64-bit pair per row)
+template <int N>
+__device__ __forceinline__ void frag_load(float4 (&b)[kChunk], const float4* __restrict__ p, int C, int lane)
 {
-    const float* arow = act + (lane & 15) * stride + 4 * (lane >> 4);
-#pragma unroll 4
-    for (int kc = 0; kc < kc_count; kc++) {
-        float4 a = *reinterpret_cast<const float4*>(arow + kc * 16);
-        float4 b[NT];
 #pragma unroll
-        for (int u = 0; u < NT; u++) b[u] = wp[(size_t)u * tile_stride + kc * 64];
-#pragma unroll
-        for (int u = 0; u < NT; u++) {
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u].x, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u].y, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u].z, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u].w, acc[u], 0, 0, 0);
-        }
-    }
+    for (int kk = 0; kk < N; kk++) b[kk] = p[kk * C + lane];
 }
 
-constexpr int kSIn = 100, kSH = 260, kST = 20, kSG = 36;   // LDS row strides (floats; = 4 mod 32: conflict-free 16-B reads)
+// acc[g][v] += X[4 g + v][k] W[k][column] over the chunk's 4 N values of k; `arow` = this lane's activation row (lane & 7) at
+// the chunk's first k
+template <int N>
+__device__ __forceinline__ void frag_mma(const float4 (&b)[kChunk], const float* __restrict__ arow, f32x4 (&acc)[2])
+{
+    // The two row groups alternate on the matrix pipe (a dependent 4x4x1 needs two wait states, the other group fills them).
+    // The empty asm statements pin that order: the intrinsics are pure, and left alone the compiler runs one group's whole chain
+    // first, keeps every activation vector alive for the second (spills; a scratch reload then waits for every weight load in
+    // flight) and pays the wait states.  "memory" on the last one keeps the LDS read of step kk + 1 inside step kk.
+#define MLP_PIN(mem) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : mem)
+    float4 a = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+    for (int kk = 0; kk < N; kk++) {
+        float4 an = a;
+        if (kk + 1 < N) an = *reinterpret_cast<const float4*>(arow + 4 * (kk + 1));
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b[kk].x, acc[0], 4, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b[kk].x, acc[1], 4, 1, 0);
+        MLP_PIN();
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b[kk].y, acc[0], 4, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b[kk].y, acc[1], 4, 1, 0);
+        MLP_PIN();
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b[kk].z, acc[0], 4, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b[kk].z, acc[1], 4, 1, 0);
+        MLP_PIN();
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b[kk].w, acc[0], 4, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b[kk].w, acc[1], 4, 1, 0);
+        MLP_PIN("memory");
+        a = an;
+    }
+#undef MLP_PIN
+}
+
+// partial sums of a wave -> LDS [wave][row = 4 g + v][lane]
+__device__ __forceinline__ void part_store(float* __restrict__ sPart, int wave, int lane, const f32x4 (&acc)[2])
+{
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) sPart[(wave * 8 + 4 * g + v) * 64 + lane] = acc[g][v];
+}
+// wide layer (wave = 4 kq + cg): output (row, column c) = the four K quarters of column group c >> 6
+__device__ __forceinline__ float part_sum_wide(const float* __restrict__ sPart, int row, int c)
+{
+    const float* p = sPart + ((c >> 6) * 8 + row) * 64 + (c & 63);
+    return (p[0] + p[4 * 8 * 64]) + (p[8 * 8 * 64] + p[12 * 8 * 64]);
+}
+// narrow layer (wave = K slice): output (row, column ln < 64) = the 16 slices
+__device__ __forceinline__ float part_sum_narrow(const float* __restrict__ sPart, int row, int ln)
+{
+    const float* p = sPart + row * 64 + ln;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) s += p[w * 8 * 64];
+    return s;
+}
+
+constexpr int kSA = 356, kST = 20, kSG = 20, kSD = 36;   // LDS row strides (floats; = 4 or 20 mod 32: the 8 rows of a 16-B read hit 8 bank groups)
+constexpr int kPartFloats = 16 * 8 * 64;
+
+template <int L> struct FOff { static constexpr int v = f_off(L); };
+template <int L> struct BOff { static constexpr int v = b_off(L); };
 
 struct FwdArgs {
     int M;
     const float* x; int x_stride;      // node positions (first 3 columns used)
     const float* t; int t_stride;      // time per node (stride 0 = broadcast)
-    const float4* wp;                  // packed forward fragments
+    const float4* wp;                  // packed forward operand
     const float* bias;                 // packed biases [kNL][256]
     float* saved;                      // sv_* layout
     float* attrs;                      // [M][13]
@@ -179,37 +249,39 @@ __device__ __forceinline__ float band(float v, int q)   // q = 2 * band + is_cos
     return (q & 1) ? cosf(a) : sinf(a);
 }
 
-// one 256-wide hidden layer: one tile per wave, ReLU, result to LDS and to the saved activations
-__device__ __forceinline__ void hidden_store(const f32x4 (&acc)[1], int wave, int lane, float* __restrict__ sdst,
-                                             float* __restrict__ gdst /* [M][256] + row0*256 */)
-{
-    int col = wave * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int row = 4 * (lane >> 4) + r;
-        float v = fmaxf(acc[0][r], 0.f);
-        sdst[row * kSH + col] = v;
-        gdst[row * kW + col] = v;
-    }
-}
-
 __global__ void __launch_bounds__(kThreads) mlp_fwd_kernel(FwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sIn[kRows * kSIn];
-    __shared__ __attribute__((aligned(16))) float sA[kRows * kSH];
-    __shared__ __attribute__((aligned(16))) float sB[kRows * kSH];
+    // activation rows [hidden 256 | MLP input 96]: the skip layer reads one contiguous K = 352
+    __shared__ __attribute__((aligned(16))) float sA[kRows * kSA];
+    __shared__ __attribute__((aligned(16))) float sB[kRows * kSA];
     __shared__ __attribute__((aligned(16))) float sT[kRows * kST];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float sPart[kPartFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, kq = wave >> 2, r8 = lane & 7;
     const int row0 = blockIdx.x * kRows, M = a.M;
+    const int fc = tid & 255, fv = tid >> 8;                 // finalize: column and row-in-group of this thread
+    // operand rows of this wave (wave-uniform pointers): a wide layer l is [K/4][256] and the wave owns rows kq * K/16 .. of column
+    // group cg; a narrow one is [64][64] and the wave owns rows 4 wave ..
+#define FW(l, row) (a.wp + (FOff<l>::v + (row) * kW + cg * 64))
+#define FN(l) (a.wp + (FOff<l>::v + wave * 4 * 64))
+    float4 q0[kChunk], q1[kChunk];
+    frag_load<1>(q0, FW(0, kq), kW, lane);                   // T1
+    frag_load<4>(q1, FN(1), 64, lane);                       // T2
+    float bias = a.bias[0 * kW + fc];
 
     for (int e = tid; e < kRows * kInPad; e += kThreads) {
-        int r = e / kInPad, c = e - r * kInPad;
+        int r = e / kInPad, p = e - r * kInPad;
+        if (p < kTOut) continue;                             // time-net outputs: written by T2 below
+        int q = p - kXOff;
         float v = 0.f;
-        if (c < kXCh) {
+        if (q >= 0 && q < kXCh) {
             const float* xr = a.x + (size_t)(row0 + r) * a.x_stride;
-            v = c < 3 ? xr[c] : band(xr[(c - 3) % 3], (c - 3) / 3);
+            v = q < 3 ? xr[q] : band(xr[(q - 3) % 3], (q - 3) / 3);
         }
-        sIn[r * kSIn + c] = v;
+        sA[r * kSA + kW + p] = v;
+        sB[r * kSA + kW + p] = v;
+        int sc = (q >= 0 && q < kXCh) ? q : (p < kXOff ? kIn + (p - kTOut) : kInPad - 1);   // the 3 zero columns 93..95
+        a.saved[sv_inp(M) + (size_t)(row0 + r) * kInPad + sc] = v;
     }
     for (int e = tid; e < kRows * kTPad; e += kThreads) {
         int r = e >> 4, c = e & 15;
@@ -218,157 +290,216 @@ __global__ void __launch_bounds__(kThreads) mlp_fwd_kernel(FwdArgs a)
         sT[r * kST + c] = v;
         a.saved[sv_et(M) + (size_t)(row0 + r) * kTPad + c] = v;
     }
+    MLP_TRACE_POINT();
     __syncthreads();
+    MLP_TRACE_POINT();
 
-    f32x4 acc[1];
-    auto init_bias = [&](int l, int tile) {
-        float bv = a.bias[l * kW + tile * 16 + (lane & 15)];
-        acc[0] = f32x4{bv, bv, bv, bv};
-    };
-    // time net layer 1: [16 x 16] -> 256, ReLU
-    init_bias(0, wave);
-    mma_run<1>(sT, kST, 1, a.wp + ((size_t)(fwd_off(0) + wave * fwd_kc(0)) * 64 + lane), 0, acc, lane);
-    hidden_store(acc, wave, lane, sA, a.saved + sv_t1(M) + (size_t)row0 * kW);
-    __syncthreads();
-    // time net layer 2: 256 -> 30 (two tiles, waves 0 and 1), no activation; lands in columns 63..92 of the MLP input
-    if (wave < 2) {
-        f32x4 c1[1];
-        int col = wave * 16 + (lane & 15);
-        float bv = a.bias[1 * kW + col];
-        c1[0] = f32x4{bv, bv, bv, bv};
-        mma_run<1>(sA, kSH, fwd_kc(1), a.wp + ((size_t)(fwd_off(1) + wave * fwd_kc(1)) * 64 + lane), 0, c1, lane);
-        if (col < kTOut)
-#pragma unroll
-            for (int r = 0; r < 4; r++) sIn[(4 * (lane >> 4) + r) * kSIn + kXCh + col] = c1[0][r];
-    }
-    __syncthreads();
-    for (int e = tid; e < kRows * kInPad; e += kThreads) {
-        int r = e / kInPad, c = e - r * kInPad;
-        a.saved[sv_inp(M) + (size_t)(row0 + r) * kInPad + c] = sIn[r * kSIn + c];
-    }
-    // L0: 96 -> 256
-    init_bias(2, wave);
-    mma_run<1>(sIn, kSIn, fwd_kc(2), a.wp + ((size_t)(fwd_off(2) + wave * fwd_kc(2)) * 64 + lane), 0, acc, lane);
-    hidden_store(acc, wave, lane, sB, a.saved + sv_h(M, 0) + (size_t)row0 * kW);
-    __syncthreads();
-    float* cur = sB;
-    float* nxt = sA;
-#pragma unroll 1
-    for (int li = 1; li < 8; li++) {
-        const int l = li + 2;
-        init_bias(l, wave);
-        if (li == 5) {   // input = [inp | H4]
-            const float4* wp = a.wp + ((size_t)(fwd_off(7) + wave * fwd_kc(7)) * 64 + lane);
-            mma_run<1>(sIn, kSIn, kInPad / 16, wp, 0, acc, lane);
-            mma_run<1>(cur, kSH, kW / 16, wp + (kInPad / 16) * 64, 0, acc, lane);
-        } else {
-            mma_run<1>(cur, kSH, kW / 16, a.wp + ((size_t)(fwd_off(l) + wave * (kW / 16)) * 64 + lane), 0, acc, lane);
-        }
-        hidden_store(acc, wave, lane, nxt, a.saved + sv_h(M, li) + (size_t)row0 * kW);
+    f32x4 acc[2];
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    // partial sums -> bias + ReLU -> LDS activation rows and the saved activations; then the next layer's bias
+    auto finish_hidden = [&](float* __restrict__ sdst, float* __restrict__ gdst /* [M][256] + row0 * 256 */, int next_bias) {
+        part_store(sPart, wave, lane, acc);
         __syncthreads();
-        float* tmp = cur; cur = nxt; nxt = tmp;
-    }
-    // heads: 256 -> 13 (one tile, wave 0)
-    if (wave == 0) {
-        f32x4 c1[1];
-        int col = lane & 15;
-        float bv = a.bias[10 * kW + col];
-        if (col < 4) bv += a.rot_bias[col];
-        c1[0] = f32x4{bv, bv, bv, bv};
-        mma_run<1>(cur, kSH, kW / 16, a.wp + ((size_t)fwd_off(10) * 64 + lane), 0, c1, lane);
-        if (col < kHeads)
 #pragma unroll
-            for (int r = 0; r < 4; r++) a.attrs[(size_t)(row0 + 4 * (lane >> 4) + r) * kHeads + col] = c1[0][r];
+        for (int g = 0; g < 2; g++) {
+            int row = 4 * g + fv;
+            float v = fmaxf(part_sum_wide(sPart, row, fc) + bias, 0.f);
+            sdst[row * kSA + fc] = v;
+            gdst[row * kW + fc] = v;
+        }
+        bias = a.bias[next_bias];
+        __syncthreads();
+        MLP_TRACE_POINT();
+        acc[0] = zero; acc[1] = zero;
+    };
+    const float* rA = sA + r8 * kSA;
+    const float* rB = sB + r8 * kSA;
+
+    // time net layer 1: [8 x 16] -> 256, ReLU
+    acc[0] = zero; acc[1] = zero;
+    frag_mma<1>(q0, sT + r8 * kST + kq * 4, acc);
+    frag_load<6>(q0, FW(2, kq * 6), kW, lane);               // L0
+    finish_hidden(sA, a.saved + sv_t1(M) + (size_t)row0 * kW, 1 * kW + (lane < kTOut ? lane : 0));
+
+    // time net layer 2: 256 -> 30, no activation; lands in the first columns of the MLP input
+    frag_mma<4>(q1, rA + wave * 16, acc);
+    frag_load<8>(q1, FW(3, kq * 16), kW, lane);              // L1, first half
+    part_store(sPart, wave, lane, acc);
+    __syncthreads();
+    if (tid < 512) {
+        int row = tid >> 6;
+        float v = lane < kTOut ? part_sum_narrow(sPart, row, lane) + bias : 0.f;
+        if (lane < kXOff) {
+            sA[row * kSA + kW + lane] = v;
+            sB[row * kSA + kW + lane] = v;
+        }
+        if (lane < kTOut) a.saved[sv_inp(M) + (size_t)(row0 + row) * kInPad + kXCh + lane] = v;
     }
+    bias = a.bias[2 * kW + fc];
+    __syncthreads();
+    MLP_TRACE_POINT();
+    acc[0] = zero; acc[1] = zero;
+
+    // L0: 96 -> 256
+    frag_mma<6>(q0, rA + kW + kq * 24, acc);
+    frag_load<8>(q0, FW(3, kq * 16 + 8), kW, lane);          // L1, second half
+    finish_hidden(sB, a.saved + sv_h(M, 0) + (size_t)row0 * kW, 3 * kW + fc);
+
+    // L1 .. L4, L6, L7: 256 -> 256.  `src` = this lane's row of the input, weights of layer id `l`; the two requests of the step
+    // are the next two chunks of the stream
+#define HIDDEN(src, dst, li, l, LOADA, LOADB)                                          \
+    frag_mma<8>(q1, (src) + kq * 64, acc);                                             \
+    LOADA;                                                                             \
+    frag_mma<8>(q0, (src) + kq * 64 + 32, acc);                                        \
+    LOADB;                                                                             \
+    finish_hidden(dst, a.saved + sv_h(M, li) + (size_t)row0 * kW, ((l) + 1) * kW + fc)
+    HIDDEN(rB, sA, 1, 3, frag_load<8>(q1, FW(4, kq * 16), kW, lane), frag_load<8>(q0, FW(4, kq * 16 + 8), kW, lane));
+    HIDDEN(rA, sB, 2, 4, frag_load<8>(q1, FW(5, kq * 16), kW, lane), frag_load<8>(q0, FW(5, kq * 16 + 8), kW, lane));
+    HIDDEN(rB, sA, 3, 5, frag_load<8>(q1, FW(6, kq * 16), kW, lane), frag_load<8>(q0, FW(6, kq * 16 + 8), kW, lane));
+    // L4; then L5 = [H4 | MLP input] -> 256: operand rows 0..63 belong to H4, 64..87 to the input, each split over the 4 kq
+    HIDDEN(rA, sB, 4, 6, frag_load<8>(q1, FW(7, kq * 16), kW, lane), frag_load<8>(q0, FW(7, kq * 16 + 8), kW, lane));
+    frag_mma<8>(q1, rB + kq * 64, acc);
+    frag_load<6>(q1, FW(7, 64 + kq * 6), kW, lane);
+    frag_mma<8>(q0, rB + kq * 64 + 32, acc);
+    frag_load<8>(q0, FW(8, kq * 16), kW, lane);              // L6, first half
+    frag_mma<6>(q1, rB + kW + kq * 24, acc);
+    frag_load<8>(q1, FW(8, kq * 16 + 8), kW, lane);
+    finish_hidden(sA, a.saved + sv_h(M, 5) + (size_t)row0 * kW, 8 * kW + fc);
+    // L6 (the buffers of the two halves are swapped from here on)
+    frag_mma<8>(q0, rA + kq * 64, acc);
+    frag_load<8>(q0, FW(9, kq * 16), kW, lane);
+    frag_mma<8>(q1, rA + kq * 64 + 32, acc);
+    frag_load<8>(q1, FW(9, kq * 16 + 8), kW, lane);
+    finish_hidden(sB, a.saved + sv_h(M, 6) + (size_t)row0 * kW, 9 * kW + fc);
+    // L7
+    frag_mma<8>(q0, rB + kq * 64, acc);
+    frag_load<4>(q0, FN(10), 64, lane);                      // heads
+    frag_mma<8>(q1, rB + kq * 64 + 32, acc);
+    finish_hidden(sA, a.saved + sv_h(M, 7) + (size_t)row0 * kW, 10 * kW + (lane < kHeads ? lane : 0));
+#undef HIDDEN
+    // heads: 256 -> 13
+    frag_mma<4>(q0, rA + wave * 16, acc);
+    part_store(sPart, wave, lane, acc);
+    __syncthreads();
+    if (tid < 512 && lane < kHeads) {
+        int row = tid >> 6;
+        float v = part_sum_narrow(sPart, row, lane) + bias;
+        if (lane < 4) v += a.rot_bias[lane];
+        a.attrs[(size_t)(row0 + row) * kHeads + lane] = v;
+    }
+    MLP_TRACE_POINT();
+#undef FW
+#undef FN
 }
 
 // ---- backward chain ---------------------------------------------------------------------------------------------
 struct BwdArgs {
     int M;
     const float* g_attrs;      // [M][13]
-    const float4* wq;          // packed dgrad fragments (= packed + kFwdChunks * 64)
+    const float4* wq;          // packed dgrad operand (= packed + kFwdVecs)
     const float* saved;
     float* scratch;            // sc_* layout
 };
 
-// dH tile -> mask with the saved post-ReLU activation -> dZ to LDS and scratch
-__device__ __forceinline__ void dz_store(const f32x4 (&acc)[1], int tile, int lane, const float* __restrict__ hsaved /* + row0*256 */,
-                                         float* __restrict__ sdst, float* __restrict__ gdst /* + row0*256 */)
-{
-    int col = tile * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int row = 4 * (lane >> 4) + r;
-        float v = hsaved[row * kW + col] > 0.f ? acc[0][r] : 0.f;
-        sdst[row * kSH + col] = v;
-        gdst[row * kW + col] = v;
-    }
-}
-
 __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sA[kRows * kSH];
-    __shared__ __attribute__((aligned(16))) float sB[kRows * kSH];
-    __shared__ __attribute__((aligned(16))) float sDin[kRows * kSIn];   // gradient of the MLP input, padded columns 48..95
-    __shared__ __attribute__((aligned(16))) float sG[kRows * kSG];      // g_attrs (16 wide), later dT2 (32 wide)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float sA[kRows * kSA];
+    __shared__ __attribute__((aligned(16))) float sB[kRows * kSA];
+    __shared__ __attribute__((aligned(16))) float sG[kRows * kSG];      // g_attrs (16 wide)
+    __shared__ __attribute__((aligned(16))) float sD[kRows * kSD];      // gradient of the time-net output (32 wide)
+    __shared__ float sPart[kPartFloats];
+    __shared__ float sPartN[kPartFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, kq = wave >> 2, r8 = lane & 7;
     const int row0 = blockIdx.x * kRows, M = a.M;
-
+    const int fc = tid & 255, fv = tid >> 8;
+    // dgrad operand of layer l: [K/4][C] with C = b_C(l); wide: rows kq * K/16 .. of column group cg; narrow: rows 4 wave .. of one group
+#define BW(l, row) (a.wq + (BOff<l>::v + (row) * b_C(l) + cg * 64))
+#define BN(l, col0) (a.wq + (BOff<l>::v + wave * 4 * b_C(l) + (col0)))
+    float4 q0[kChunk], q1[kChunk];
+    frag_load<1>(q0, BW(10, kq), kW, lane);                  // heads
+    frag_load<8>(q1, BW(9, kq * 16), kW, lane);              // L7, first half
+    // the ReLU masks are the saved post-activation values of this thread's two outputs (rows fv and 4 + fv, column fc)
+    const float* hs = a.saved + (size_t)(row0 + fv) * kW + fc;
+    float h0 = hs[sv_h(M, 7)], h1 = hs[sv_h(M, 7) + 4 * kW];
     for (int e = tid; e < kRows * 16; e += kThreads) {
         int r = e >> 4, c = e & 15;
         sG[r * kSG + c] = c < kHeads ? a.g_attrs[(size_t)(row0 + r) * kHeads + c] : 0.f;
     }
     __syncthreads();
-    f32x4 acc[1];
+
+    f32x4 acc[2];
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    // heads: dH7 = g_attrs[16 x 16] * Wh
-    acc[0] = zero;
-    mma_run<1>(sG, kSG, 1, a.wq + ((size_t)(bwd_off(10) + wave * bwd_kc(10)) * 64 + lane), 0, acc, lane);
-    dz_store(acc, wave, lane, a.saved + sv_h(M, 7) + (size_t)row0 * kW, sA, a.scratch + sc_dz(M, 7) + (size_t)row0 * kW);
-    __syncthreads();
-    float* cur = sA;
-    float* nxt = sB;
-#pragma unroll 1
-    for (int li = 7; li >= 1; li--) {   // dZ_li (cur) -> dZ_{li-1} (nxt)
-        const int l = li + 2;
-        acc[0] = zero;
-        if (li == 5) {   // tiles 0..5 belong to the MLP input (only 3..5 carry time-net gradient), 6..21 to H4
-            const float4* wq = a.wq + ((size_t)bwd_off(7) * 64 + lane);
-            mma_run<1>(cur, kSH, kW / 16, wq + (size_t)(6 + wave) * bwd_kc(7) * 64, 0, acc, lane);
-            if (wave < 3) {
-                f32x4 c1[1] = {zero};
-                mma_run<1>(cur, kSH, kW / 16, wq + (size_t)(3 + wave) * bwd_kc(7) * 64, 0, c1, lane);
-#pragma unroll
-                for (int r = 0; r < 4; r++) sDin[(4 * (lane >> 4) + r) * kSIn + (3 + wave) * 16 + (lane & 15)] = c1[0][r];
-            }
-        } else {
-            mma_run<1>(cur, kSH, kW / 16, a.wq + ((size_t)(bwd_off(l) + wave * (kW / 16)) * 64 + lane), 0, acc, lane);
-        }
-        dz_store(acc, wave, lane, a.saved + sv_h(M, li - 1) + (size_t)row0 * kW, nxt,
-                 a.scratch + sc_dz(M, li - 1) + (size_t)row0 * kW);
+    // partial sums -> ReLU mask -> dZ to LDS (when the chain goes on) and to the scratch; then the mask of the next stage
+    auto finish_dz = [&](float* __restrict__ sdst, float* __restrict__ gdst /* + row0 * 256 */, size_t next_mask) {
+        part_store(sPart, wave, lane, acc);
         __syncthreads();
-        float* tmp = cur; cur = nxt; nxt = tmp;
+        float v0 = h0 > 0.f ? part_sum_wide(sPart, fv, fc) : 0.f;
+        float v1 = h1 > 0.f ? part_sum_wide(sPart, 4 + fv, fc) : 0.f;
+        if (sdst) {
+            sdst[fv * kSA + fc] = v0;
+            sdst[(4 + fv) * kSA + fc] = v1;
+        }
+        gdst[fv * kW + fc] = v0;
+        gdst[(4 + fv) * kW + fc] = v1;
+        h0 = hs[next_mask]; h1 = hs[next_mask + 4 * kW];
+        __syncthreads();
+        acc[0] = zero; acc[1] = zero;
+    };
+    const float* rA = sA + r8 * kSA;
+    const float* rB = sB + r8 * kSA;
+
+    // heads: dZ7 = (g_attrs[8 x 16] * Wh) * [H7 > 0]
+    acc[0] = zero; acc[1] = zero;
+    frag_mma<1>(q0, sG + r8 * kSG + kq * 4, acc);
+    frag_load<8>(q0, BW(9, kq * 16 + 8), kW, lane);
+    finish_dz(sA, a.scratch + sc_dz(M, 7) + (size_t)row0 * kW, sv_h(M, 6));
+
+    // dZ_{li-1} = (dZ_li * W_li) * [H_{li-1} > 0], W_li = layer id li + 2
+#define DGRAD(src, dst, li, LOADA, LOADB, QA, QB)                                      \
+    frag_mma<8>(QA, (src) + kq * 64, acc);                                             \
+    LOADA;                                                                             \
+    frag_mma<8>(QB, (src) + kq * 64 + 32, acc);                                        \
+    LOADB;                                                                             \
+    finish_dz(dst, a.scratch + sc_dz(M, (li) - 1) + (size_t)row0 * kW, (li) >= 2 ? sv_h(M, (li) - 2) : sv_t1(M))
+    DGRAD(rA, sB, 7, frag_load<8>(q1, BW(8, kq * 16), kW, lane), frag_load<8>(q0, BW(8, kq * 16 + 8), kW, lane), q1, q0);
+    DGRAD(rB, sA, 6, frag_load<8>(q1, BW(7, kq * 16), b_C(7), lane), frag_load<8>(q0, BW(7, kq * 16 + 8), b_C(7), lane), q1, q0);
+    // L5: dZ4 from the H4 columns, and the time-net columns of the MLP input (column group 4 of the operand, K in 16 slices)
+    {
+        frag_mma<8>(q1, rA + kq * 64, acc);
+        frag_load<4>(q1, BN(7, kW), b_C(7), lane);
+        frag_mma<8>(q0, rA + kq * 64 + 32, acc);
+        frag_load<8>(q0, BW(6, kq * 16), kW, lane);          // L4, first half
+        f32x4 accn[2] = {zero, zero};
+        frag_mma<4>(q1, rA + wave * 16, accn);
+        frag_load<8>(q1, BW(6, kq * 16 + 8), kW, lane);
+        part_store(sPartN, wave, lane, accn);
+        finish_dz(sB, a.scratch + sc_dz(M, 4) + (size_t)row0 * kW, sv_h(M, 3));
+        // (sPartN is complete after the first barrier of finish_dz; sD is read two stages later)
+        if (tid < 512 && lane < 32) sD[(tid >> 6) * kSD + lane] = part_sum_narrow(sPartN, tid >> 6, lane);
     }
-    // L0: only the time-net columns (padded 48..95) of the input gradient are needed
-    if (wave < 3) {
-        f32x4 c1[1] = {zero};
-        mma_run<1>(cur, kSH, kW / 16, a.wq + ((size_t)(bwd_off(2) + (3 + wave) * bwd_kc(2)) * 64 + lane), 0, c1, lane);
-#pragma unroll
-        for (int r = 0; r < 4; r++) sDin[(4 * (lane >> 4) + r) * kSIn + (3 + wave) * 16 + (lane & 15)] += c1[0][r];
-    }
+    DGRAD(rB, sA, 4, frag_load<8>(q0, BW(5, kq * 16), kW, lane), frag_load<8>(q1, BW(5, kq * 16 + 8), kW, lane), q0, q1);
+    DGRAD(rA, sB, 3, frag_load<8>(q0, BW(4, kq * 16), kW, lane), frag_load<8>(q1, BW(4, kq * 16 + 8), kW, lane), q0, q1);
+    DGRAD(rB, sA, 2, frag_load<8>(q0, BW(3, kq * 16), kW, lane), frag_load<8>(q1, BW(3, kq * 16 + 8), kW, lane), q0, q1);
+    DGRAD(rA, sB, 1, frag_load<4>(q0, BN(2, 0), 64, lane), frag_load<2>(q1, BW(1, kq * 2), kW, lane), q0, q1);
+#undef DGRAD
+    // L0: only the time-net columns of the input gradient are needed (the node positions get no gradient here)
+    frag_mma<4>(q0, rB + wave * 16, acc);
+    part_store(sPartN, wave, lane, acc);
     __syncthreads();
-    // dT2 = input-gradient columns 63..92 -> [16 x 32]
-    for (int e = tid; e < kRows * 32; e += kThreads) {
-        int r = e >> 5, c = e & 31;
-        float v = c < kTOut ? sDin[r * kSIn + kXCh + c] : 0.f;
-        sG[r * kSG + c] = v;
-        a.scratch[sc_dt2(M) + (size_t)(row0 + r) * 32 + c] = v;
+    if (tid < 512 && lane < 32) {   // dT2 [8 x 32] (columns 30, 31: zero operand columns)
+        int row = tid >> 6;
+        float v = sD[row * kSD + lane] + part_sum_narrow(sPartN, row, lane);
+        sD[row * kSD + lane] = v;
+        a.scratch[sc_dt2(M) + (size_t)(row0 + row) * 32 + lane] = v;
     }
     __syncthreads();
     // dT1 = (dT2 * Wt2) * [T1 > 0]
-    acc[0] = zero;
-    mma_run<1>(sG, kSG, bwd_kc(1), a.wq + ((size_t)(bwd_off(1) + wave * bwd_kc(1)) * 64 + lane), 0, acc, lane);
-    dz_store(acc, wave, lane, a.saved + sv_t1(M) + (size_t)row0 * kW, nxt, a.scratch + sc_dt1(M) + (size_t)row0 * kW);
+    acc[0] = zero; acc[1] = zero;
+    frag_mma<2>(q1, sD + r8 * kSD + kq * 8, acc);
+    finish_dz(nullptr, a.scratch + sc_dt1(M) + (size_t)row0 * kW, sv_t1(M));
+#undef BW
+#undef BN
 }
 
 // ---- weight gradients -------------------------------------------------------------------------------------------

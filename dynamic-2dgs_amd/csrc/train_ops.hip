@@ -312,6 +312,12 @@ int launch_knn(int N, int M, int D, const float* x, const float* nodes, long lon
 // over all M nodes therefore needs 3 of the D coordinates (7 instead of 2*D VALU operations per node) and just records
 // the few candidates; full distances are evaluated for those only.  Any seed (stale, random, duplicated) gives the exact
 // result: a bad seed only makes T large, a full candidate list falls back to the plain scan for that point.
+//
+// The scan skips whole 32-node blocks: every block has a bounding box (built next to the staged nodes), every wave the box of
+// its points' search spheres (centre x, radius sqrt(T)); a block whose box misses the wave's cannot hold a candidate of any
+// lane, and the test is one lane per block + one ballot.  Pays when both sides are spatially coherent -- surfels stored in the
+// order of their nearest node and nodes stored along a space-filling curve (Trainer.sort_surfels / sort_nodes: 32 blocks ->
+// ~4 per wave at 200 k surfels / 1024 nodes); any order gives the same, exact result.
 constexpr int kKnnCap = 12;
 
 template <int K, int Q>
@@ -320,8 +326,10 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
 {
     extern __shared__ float4 s_dyn[];
     const int Mp = (M + 31) & ~31;                                        // rows padded to the 32-node scan blocks (zeros, masked)
+    const int nblk = Mp >> 5;
     float4* s_nodes = s_dyn;                                              // [Mp][Q]
-    int* s_list = reinterpret_cast<int*>(s_dyn + (size_t)Mp * Q);         // [256 * kKnnPts][kKnnCap]
+    float4* s_box = s_dyn + (size_t)Mp * Q;                               // [nblk][2]: min, max of the block's nodes (coordinates 0..2)
+    int* s_list = reinterpret_cast<int*>(s_box + 2 * nblk);               // [256 * kKnnPts][kKnnCap]
     for (int r0 = 0; r0 < Mp; r0 += 1024) {   // see knn_kernel: all loads of a pass in flight before the LDS stores
         float v[4][4 * Q];
 #pragma unroll
@@ -337,6 +345,17 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
 #pragma unroll
                 for (int q = 0; q < Q; q++) s_nodes[r * Q + q] = make_float4(v[i][4 * q], v[i][4 * q + 1], v[i][4 * q + 2], v[i][4 * q + 3]);
         }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+        for (int g = 0; g < 32 && b * 32 + g < M; g++) {
+            const float4 nd = s_nodes[(b * 32 + g) * Q];
+            lo.x = fminf(lo.x, nd.x); lo.y = fminf(lo.y, nd.y); lo.z = fminf(lo.z, nd.z);
+            hi.x = fmaxf(hi.x, nd.x); hi.y = fmaxf(hi.y, nd.y); hi.z = fmaxf(hi.z, nd.z);
+        }
+        s_box[2 * b] = lo;
+        s_box[2 * b + 1] = hi;
     }
     __syncthreads();
     const int p0 = (blockIdx.x * 256 + threadIdx.x) * kKnnPts;
@@ -389,7 +408,37 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
     float Tn[kKnnPts];
 #pragma unroll
     for (int u = 0; u < kKnnPts; u++) Tn[u] = -(T[u] * (1.0f + 1e-6f) + 1e-30f);   // inflated: d3 == T must stay a hit
-    for (int j0 = 0; j0 < M; j0 += 32) {
+    // box of the wave's search spheres (lanes past N have T = -1: no sphere).  |x_c - n_c| <= sqrt(d3) <= sqrt(-Tn) on every axis
+    // for a hit; the radius is rounded up generously, the box only filters
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int u = 0; u < kKnnPts; u++)
+        if (T[u] >= 0.f) {
+            const float r = sqrtf(-Tn[u]) * 1.0001f + 1e-30f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                blo[c] = fminf(blo[c], xv[u][c] - r);
+                bhi[c] = fmaxf(bhi[c], xv[u][c] + r);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            blo[c] = fminf(blo[c], __shfl_xor(blo[c], o));
+            bhi[c] = fmaxf(bhi[c], __shfl_xor(bhi[c], o));
+        }
+    const int lane = threadIdx.x & 63;
+    for (int bb = 0; bb < nblk; bb += 64) {
+    bool touch = false;
+    if (bb + lane < nblk) {
+        const float4 lo = s_box[2 * (bb + lane)], hi = s_box[2 * (bb + lane) + 1];
+        touch = lo.x <= bhi[0] && hi.x >= blo[0] && lo.y <= bhi[1] && hi.y >= blo[1] && lo.z <= bhi[2] && hi.z >= blo[2];
+    }
+    unsigned long long blocks = __ballot(touch);
+    while (blocks) {
+        const int j0 = (bb + __builtin_ctzll(blocks)) * 32;
+        blocks &= blocks - 1;
         unsigned w[kKnnPts];
 #pragma unroll
         for (int u = 0; u < kKnnPts; u++) w[u] = 0u;
@@ -420,6 +469,7 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
                 cnt[u]++;
             }
         }
+    }
     }
     // ---- candidates (ascending index, strict < on insertion: ties keep the lower index like the plain scan)
 #pragma unroll
@@ -455,7 +505,8 @@ int launch_knn_refine_q(int N, int M, int D, const float* x, const float* nodes,
                         int stride2)
 {
     const int per_block = 256 * kKnnPts;
-    const size_t lds = (size_t)((M + 31) & ~31) * Q * sizeof(float4) + (size_t)256 * kKnnPts * kKnnCap * sizeof(int);
+    const size_t lds = (size_t)((M + 31) & ~31) * Q * sizeof(float4) + (size_t)((M + 31) >> 5) * 2 * sizeof(float4) +
+                       (size_t)256 * kKnnPts * kKnnCap * sizeof(int);
     hipLaunchKernelGGL((knn_refine_kernel<K, Q>), dim3((N + per_block - 1) / per_block), dim3(256), lds, s, N, M, D, x, nodes, idx, x2, D1,
                        stride2);
     hipError_t e = hipGetLastError();
@@ -1429,7 +1480,7 @@ int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_s
         for (int k = 0; k < kHeadRows[h]; k++, r++) { w.hw[r] = params[20 + 2 * h] + (size_t)k * mlp::kW; w.hb[r] = params[21 + 2 * h] + k; }
     for (; r < 16; r++) { w.hw[r] = w.hw[0]; w.hb[r] = w.hb[0]; }
     hipStream_t s = (hipStream_t)stream;
-    int nthreads = (mlp::kFwdChunks + mlp::kBwdChunks) * 64;
+    int nthreads = mlp::kFwdVecs + mlp::kBwdVecs;   // one thread per float4 of the two operand arrays
     hipLaunchKernelGGL(mlp::mlp_pack_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<float4*>(packed));
     mlp::FwdArgs a{};
     a.M = M; a.x = x; a.x_stride = x_stride; a.t = t; a.t_stride = t_stride;
@@ -1450,7 +1501,7 @@ int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const flo
     hipStream_t s = (hipStream_t)stream;
     mlp::BwdArgs b{};
     b.M = M; b.g_attrs = g_attrs; b.saved = saved; b.scratch = scratch;
-    b.wq = reinterpret_cast<const float4*>(packed) + (size_t)mlp::kFwdChunks * 64;
+    b.wq = reinterpret_cast<const float4*>(packed) + (size_t)mlp::kFwdVecs;
     hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
 
     mlp::WgArgs g{};

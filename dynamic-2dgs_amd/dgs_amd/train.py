@@ -618,6 +618,47 @@ class Trainer:
             seed.copy_(seed[perm])
 
     @torch.no_grad()
+    def reorder_nodes(self, perm):
+        """Permute the control nodes IN PLACE (new row i <- old row perm[i]): positions + hyper coordinates, radius, weight,
+        their Adam moments; the node indices held in the neighbour-search seed are renamed.  The order of the nodes carries
+        no meaning (the MLP is evaluated per node, skinning sums over a surfel's K neighbours)."""
+        d = self.deform
+        perm = perm.to(d.nodes.device)
+        M = d.nodes.shape[0]
+        assert perm.shape == (M,)
+        for p in (d.nodes, d._node_radius, d._node_weight):
+            p.data.copy_(p.data[perm])
+            for m in self._any_moments(p):
+                if m is not None:
+                    m.copy_(m[perm])
+        seed = getattr(d, "_knn_seed", None)
+        if seed is not None:
+            new_of_old = torch.empty_like(perm)
+            new_of_old[perm] = torch.arange(M, device=perm.device)
+            ok = (seed >= 0) & (seed < M)
+            seed.copy_(torch.where(ok, new_of_old[seed.clamp(0, M - 1)], seed))
+
+    @torch.no_grad()
+    def sort_nodes(self):
+        """Store the control nodes along a Morton curve through their bounding box (padding nodes last): 32 consecutive nodes
+        then fill a small box, which is what lets dgs_knn_refine skip most 32-node blocks for a wave of neighbouring surfels."""
+        d = self.deform
+        x = d.nodes.detach()[:, :3]
+        live = d.live_nodes if hasattr(d, "live_nodes") else torch.ones(x.shape[0], dtype=torch.bool, device=x.device)
+        if callable(live):
+            live = live()
+        if not bool(live.any()):
+            return
+        lo, hi = x[live].min(0).values, x[live].max(0).values
+        q = ((x - lo) / (hi - lo).clamp_min(1e-12) * 1023.0).clamp(0, 1023).to(torch.int64)
+        code = torch.zeros(x.shape[0], dtype=torch.int64, device=x.device)
+        for b in range(10):
+            for c in range(3):
+                code |= ((q[:, c] >> b) & 1) << (3 * b + c)
+        code = torch.where(live, code, torch.full_like(code, 1 << 40))
+        self.reorder_nodes(torch.argsort(code, stable=True))
+
+    @torch.no_grad()
     def sort_surfels(self):
         """Store the surfels in the order of their nearest control node (dead slots last).  On MI355X this is what makes the
         per-surfel kernels of the deformation coherent: the 64 surfels of a wave then read the same one or two node rows
@@ -625,6 +666,7 @@ class Trainer:
         atomic per (wave, node) (dgs_deform_backward, coherent variant; 97 -> ~20 us at 200 k surfels / 1024 nodes) instead
         of building 256 LDS tables.  Call after initialisation and after densification; stale order only costs time."""
         s, d = self.surfels, self.deform
+        self.sort_nodes()
         x, nodes = s.get_xyz.detach(), d.nodes.detach()[:, :3]
         near = torch.cat([torch.cdist(x[i:i + 16384], nodes).argmin(1) for i in range(0, x.shape[0], 16384)])
         near = torch.where(s.alive, near, torch.full_like(near, nodes.shape[0]))

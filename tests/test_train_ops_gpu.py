@@ -58,6 +58,32 @@ def test_knn_refine_is_exact_for_any_seed():
         assert torch.equal(got, want), name
 
 
+def test_knn_refine_block_culling_is_exact_on_sorted_inputs():
+    """The 32-node block culling of dgs_knn_refine only fires when a wave's points and a block's nodes are spatially coherent:
+    nodes along a Morton curve, points in the order of their nearest node (the storage order of the trainer).  Same answer as
+    the plain scan, for a good seed (small search spheres, most blocks skipped), a stale one, and a node count that is not a
+    multiple of 32 (partial last block)."""
+    from dgs_amd import _ops
+    g = torch.Generator().manual_seed(21)
+    for N, M in ((40000, 1024), (20011, 1000), (5000, 77)):
+        nodes3 = torch.rand(M, 3, generator=g) * 2 - 1
+        q = ((nodes3 + 1) * 511.5).long().clamp(0, 1023)
+        code = torch.zeros(M, dtype=torch.long)
+        for b in range(10):
+            for c in range(3):
+                code |= ((q[:, c] >> b) & 1) << (3 * b + c)
+        nodes3 = nodes3[torch.argsort(code)]
+        nodes = torch.cat([nodes3, 0.01 * torch.randn(M, 8, generator=g)], 1).cuda()
+        x = torch.rand(N, 3, generator=g) * 2 - 1
+        x = x[torch.argsort(torch.cdist(x, nodes3).argmin(1), stable=True)].cuda()
+        f = (0.01 * torch.randn(N, 8, generator=g)).cuda()
+        want = _ops.knn_indices2(x, f, nodes, 3)
+        stale = _ops.knn_indices2(x + 0.02 * torch.randn(N, 3, generator=g).cuda(), f, nodes, 3)
+        for name, seed in (("exact", want.clone()), ("stale", stale), ("far", torch.flip(want, (0,)).contiguous())):
+            got = _ops.knn_indices2(x, f, nodes, 3, seed=seed)
+            assert torch.equal(got, want), (N, M, name)
+
+
 def test_graph_captured_step_matches_eager():
     """The whole-step HIP graph (rasterizer in capacity mode, no host synchronisation) must train like the eager
     step: same loss trajectory (enable_graph() warms up on a snapshot, it does not train).  Parameters are compared through the losses and a robust

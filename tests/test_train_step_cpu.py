@@ -68,6 +68,40 @@ def test_trainer_single_process_updates_everything():
     assert float(surfels.denom.sum()) > 0 and int(surfels.max_radii2D.max()) > 0
 
 
+def test_node_storage_order_is_free():
+    """Trainer.sort_nodes / reorder_nodes permute the control nodes in place (Morton order: what lets the neighbour kernel skip
+    blocks of far nodes): same deformation of every surfel, Adam moments and the neighbour seed follow their nodes."""
+    surfels, deform, cams, targets, bg = _build(nodes=64)
+    tr = Trainer(surfels, deform, cams, targets, bg)
+    tr.step(); tr.step()                                   # non-zero moments
+    t = deform.expand_time(cams[1].fid)
+    with torch.no_grad():
+        want = deform(surfels.get_xyz.detach(), t, surfels.feature, surfels.motion_mask)
+    x0 = deform.nodes.detach().clone()
+    m0 = tr._any_moments(deform.nodes)[0].clone()
+    r0 = deform._node_radius.detach().clone()
+    deform._knn_seed = torch.stack([torch.arange(surfels.get_xyz.shape[0]) % 64, torch.full((surfels.get_xyz.shape[0],), -1)], 1)
+    seed0 = deform._knn_seed.clone()
+    tr.sort_nodes()
+    x1 = deform.nodes.detach()
+    # a permutation: every old row is somewhere, with its radius and its moment
+    same = (x1[:, None, :] == x0[None, :, :]).all(-1)
+    assert bool((same.sum(1) == 1).all())
+    perm = same.float().argmax(1)
+    assert torch.equal(torch.sort(perm).values, torch.arange(64))
+    assert not torch.equal(perm, torch.arange(64))
+    assert torch.equal(deform._node_radius.detach(), r0[perm]) and torch.equal(tr._any_moments(deform.nodes)[0], m0[perm])
+    assert torch.equal(perm[deform._knn_seed[:, 0]], seed0[:, 0]) and torch.equal(deform._knn_seed[:, 1], seed0[:, 1])
+    del deform._knn_seed
+    with torch.no_grad():
+        got = deform(surfels.get_xyz.detach(), t, surfels.feature, surfels.motion_mask)
+    for k in ("d_xyz", "d_rotation", "d_scaling"):
+        assert torch.allclose(got[k], want[k], rtol=1e-5, atol=1e-7), k
+    # Morton order: consecutive nodes are close (mean step well under the mean distance of random pairs)
+    step = (x1[1:, :3] - x1[:-1, :3]).norm(dim=1).mean()
+    assert float(step) < 0.6 * float(torch.pdist(x1[:, :3]).mean())
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -20,6 +20,10 @@ ap.add_argument("--W", type=int, default=800)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--views", type=int, default=8)
 ap.add_argument("--order", type=int, default=-1)
+ap.add_argument("--scale-mul", type=float, default=1.0, help="scale of the splats (6 with --radius 2.2 and 96x96: thousands of entries per tile)")
+ap.add_argument("--radius", type=float, default=4.0, help="camera orbit radius")
+ap.add_argument("--sh-degree", type=int, default=3)
+ap.add_argument("--capacity", type=int, default=0, help="> 0: capacity mode with that many list entries (no host read; every tile picks its sort kernel on the device)")
 ap.add_argument("--grid-limit", type=int, default=0, help="diagnostic: blend kernels process only the N heaviest tiles")
 ap.add_argument("--sort-regs", type=int, default=-1, help="0: LDS bitonic network, 1: register-resident network (default of the library)")
 a = ap.parse_args()
@@ -28,7 +32,10 @@ if a.order >= 0:
     _C.set_option(1, a.order)
 if a.sort_regs >= 0:
     _C.set_option(3, a.sort_regs)
-cases = [small_case(P=a.P, H=a.H, W=a.W, seed=0, view=v * (64 // a.views), n_views=64) for v in range(a.views)]
+if a.capacity > 0:
+    _C.set_capacity(a.capacity)
+cases = [small_case(P=a.P, H=a.H, W=a.W, seed=0, view=v * (64 // a.views), n_views=64, scale_mul=a.scale_mul, radius=a.radius, sh_degree=a.sh_degree)
+         for v in range(a.views)]
 leaf = {k: cases[0][k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
 rasts = [GaussianRasterizer(settings_from_case(c, dev)) for c in cases]
 gc = torch.randn(3, a.H, a.W, device=dev)
@@ -70,6 +77,6 @@ for i in range(a.iters):
 torch.cuda.synchronize()
 tfb = (time.time() - t) / a.iters
 pr = _C.profile_read()
-print("P=%d %dx%d fwd %.3f ms, fwd+bwd %.3f ms" % (a.P, a.W, a.H, tf * 1e3, tfb * 1e3))
+print("P=%d %dx%d fwd %.3f ms, fwd+bwd %.3f ms%s" % (a.P, a.W, a.H, tf * 1e3, tfb * 1e3, " (capacity mode, overflow=%s)" % _C.read_overflow() if a.capacity > 0 else ""))
 print("blend fwd %.3f ms/launch (%d), blend bwd %.3f ms/launch (%d)" % (
     pr["fwd_ms"] / max(pr["fwd_n"], 1), pr["fwd_n"], pr["bwd_ms"] / max(pr["bwd_n"], 1), pr["bwd_n"]))
