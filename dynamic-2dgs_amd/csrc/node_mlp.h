@@ -503,13 +503,23 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
 }
 
 // ---- weight gradients -------------------------------------------------------------------------------------------
+// dW[j][i] = sum_m dZ[m][j] X[m][i] is a sum of M outer products, which is what v_mfma_f32_4x4x1 computes: with the A-block
+// broadcast (cbsz = 4, abid = g) one instruction is dZ[m][4g..4g+3] (x) X[m][64 columns], and both operands are ROWS of the
+// row-major activations -- lane l holds dZ[m][j0 + l] and X[m][i0 + l]: coalesced loads straight from global memory, no
+// transposition, no LDS staging.  A workgroup owns a 16 x 64 tile of one layer's dW (4 accumulators of 4 registers); its 8 waves
+// split the M nodes and meet in LDS (fixed order: deterministic, no atomics).  ~540 workgroups of 512 threads, up to four per
+// CU: the loop is bound by the latency of the activation rows (written by other XCDs: they come from the memory side), and
+// waves in flight are what hides it.
+// (Round 1 used 16x16x4 tiles whose operands are columns of the activations: twelve 4-byte loads with 64-byte segments per
+// 8 MFMAs, 44 us; the chip-wide MFMA time of these products is 8 us.)
 struct WgDesc {
     const float* dz; int dz_stride; int out;
     const float* x; int x_stride; int in;     // x already offset to its first column
     float* dw; int dw_stride;                 // dw already offset to its first column; nullptr = per-row pointers (heads)
     float* db;                                // nullptr = no bias gradient from this descriptor
-    int block0;                               // first workgroup of this descriptor
-    int iblocks;                              // ceil(in / 32)
+    int iblocks;                              // ceil(in / 64)
+    int ntiles;                               // ceil(out / 16) * iblocks
+    int xcd, first;                           // the descriptor's tiles are slots first .. first + ntiles - 1 of XCD `xcd` (wg_place)
 };
 constexpr int kWgDescs = 12;
 struct WgArgs {
@@ -519,77 +529,148 @@ struct WgArgs {
     float* hb[16];
 };
 
-constexpr int kWgThreads = 1024;   // 16 waves: 4 output-feature tiles x 4 quarters of the node rows (latency hiding), LDS reduce
-
-__global__ void __launch_bounds__(kWgThreads) mlp_wgrad_kernel(WgArgs a)
+// XCD placement.  Workgroups go to the 8 XCDs round-robin (blockIdx & 7), each XCD has its own 4 MB L2, and the activations of
+// all layers (19 MB) do not fit one: with tiles handed out in descriptor order every XCD streamed every layer over the fabric
+// (168 MB per launch at ~6.7 TB/s = the 25 us the kernel took whatever its inner loop looked like).  A layer's dZ and X are 2 MB
+// and its 64 tiles reuse them 16x / 4x: all tiles of a descriptor go to ONE XCD (slot = blockIdx >> 3), descriptors are spread
+// over the XCDs longest-first.  Returns the grid size.
+inline int wg_place(WgArgs& a)
 {
-    __shared__ float sRed[3][4][64][9];   // partial sums of row quarters 1..3: 8 accumulators + bias per lane
-    int di = 0;
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool done[kWgDescs] = {};
+    for (int n = 0; n < a.ndesc; n++) {
+        int best = -1;
+        for (int i = 0; i < a.ndesc; i++)
+            if (!done[i] && (best < 0 || a.d[i].ntiles > a.d[best].ntiles)) best = i;
+        int x = 0;
+        for (int k = 1; k < 8; k++)
+            if (load[k] < load[x]) x = k;
+        done[best] = true;
+        a.d[best].xcd = x;
+        a.d[best].first = load[x];
+        load[x] += a.d[best].ntiles;
+    }
+    int most = 0;
+    for (int k = 0; k < 8; k++) most = load[k] > most ? load[k] : most;
+    return 8 * most;
+}
+
+constexpr int kWgThreads = 512;   // 8 waves = 8 slices of the nodes
+constexpr int kWgTileJ = 16, kWgTileI = 64;
+constexpr int kWgG = kWgTileJ / 4;   // accumulators (4 rows of dW each) per wave
+
+#ifndef DGS_WGRAD_WAVES
+#define DGS_WGRAD_WAVES 4   // waves per SIMD the register allocation aims at (2 workgroups per CU)
+#endif
+// NB = batches of 8 rows per wave when known at compile time (M = 64 NB): the row loop is then ONE basic block and the wait
+// counters are exact -- around a loop's back edge the compiler waits for every load in flight (vmcnt(0) at the loop header),
+// which turns a 4-deep request ring into no ring at all.  NB = 0: any M, runtime loop.
+template <int NB>
+__global__ void __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu(DGS_WGRAD_WAVES, DGS_WGRAD_WAVES))) mlp_wgrad_kernel(WgArgs a)
+{
+    __shared__ float sRed[8][kWgG][4][64];   // [wave][row group g][v][lane]: 32 KB
+    __shared__ float sBias[8][kWgTileJ];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int di = -1;
 #pragma unroll
-    for (int i = 1; i < kWgDescs; i++)
-        if (i < a.ndesc && (int)blockIdx.x >= a.d[i].block0) di = i;
+    for (int i = 0; i < kWgDescs; i++)
+        if (i < a.ndesc && a.d[i].xcd == xcd && slot >= a.d[i].first && slot < a.d[i].first + a.d[i].ntiles) di = i;
+    if (di < 0) return;                              // this XCD has fewer tiles than the fullest one
     const WgDesc& d = a.d[di];
-    const int local = blockIdx.x - d.block0;
+    const int local = slot - d.first;
     const int jb = local / d.iblocks, ib = local - jb * d.iblocks;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int jt = wave & 3, part = wave >> 2;
-    const int jl = lane & 15, mq = lane >> 4;
-    const int j = jb * 64 + jt * 16 + jl;            // this lane's A row (output feature)
-    const int i0 = ib * 32 + jl;                     // this lane's B column (input feature) of tile 0; tile 1 = +16
-    const bool jv = j < d.out, iv0 = i0 < d.in, iv1 = i0 + 16 < d.in;
-    const int rows = a.M >> 2;                       // rows per quarter (M is a multiple of 64)
-    const float* pz = d.dz + (size_t)(part * rows + 4 * mq) * d.dz_stride + (jv ? j : 0);
-    const float* px = d.x + (size_t)(part * rows + 4 * mq) * d.x_stride + (iv0 ? i0 : 0);
-    const int x1 = iv1 ? 16 : 0;
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = jb * kWgTileJ + lane, i = ib * kWgTileI + lane;
+    const bool jv = lane < kWgTileJ && j < d.out, iv = i < d.in;
+    const int rows = NB > 0 ? 8 * NB : a.M >> 3;     // nodes per wave (M is a multiple of 64)
+    // wave-uniform row pointers + one lane offset: scalar base registers, no 64-bit address pair per row
+    // buffer loads: resource = the matrix, scalar offset = the row, one 32-bit lane offset for every row of the kernel (flat
+    // 64-bit addresses cost two VALU additions per load and a register pair per row in flight)
+    const int zs = d.dz_stride * 4, xs = d.x_stride * 4;   // row strides in bytes
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dz), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7fffffff, 0x00020000);
+    int zb = wave * rows * zs, xb = wave * rows * xs;
+    const unsigned zoff = (jv ? j : 0) * 4u, xoff = (iv ? i : 0) * 4u;
+    f32x4 acc[kWgG];
+#pragma unroll
+    for (int g = 0; g < kWgG; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-#pragma unroll 2
-    for (int m0 = 0; m0 < rows; m0 += 16) {
-        float av[4], b0[4], b1[4];
+    // The activation rows were written by other XCDs and come from the memory side (~2 us under load): a ring of kWgDepth
+    // batches of 8 rows keeps 3-4 batches (48-64 loads per wave) in flight; with one batch ahead the loop was a chain of
+    // rows/8 exposed latencies (34 us whatever the occupancy).
+    constexpr int kWgDepth = 4;
+    float av[kWgDepth][8], bv[kWgDepth][8];
+    auto request = [&](int s, int m0) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            av[s] = pz[(size_t)(m0 + s) * d.dz_stride];
-            b0[s] = px[(size_t)(m0 + s) * d.x_stride];
-            b1[s] = px[(size_t)(m0 + s) * d.x_stride + x1];
+        for (int r = 0; r < 8; r++) {
+            av[s][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, zoff, zb + (m0 + r) * zs, 0));
+            bv[s][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff, xb + (m0 + r) * xs, 0));
         }
+    };
+    auto multiply = [&](int s, bool jvs) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            float as = jv ? av[s] : 0.f;
-            bsum += as;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as, iv0 ? b0[s] : 0.f, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as, iv1 ? b1[s] : 0.f, acc1, 0, 0, 0);
+        for (int r = 0; r < 8; r++) {
+            const float av_ = jvs ? av[s][r] : 0.f, bv_ = iv ? bv[s][r] : 0.f;
+            bsum += av_;
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[0], 4, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[1], 4, 1, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[2], 4, 2, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[3], 4, 3, 0);
+            static_assert(kWgG == 4, "one MFMA per row group");
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < kWgDepth; s++) request(s, 8 * s < rows ? 8 * s : rows - 8);
+    if (NB > 0) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            multiply(b % kWgDepth, jv);
+            // requests stay behind the batch they follow (hoisted, they cost 26 spilled registers and every scratch reload waits
+            // for all loads in flight): their scalar offsets "depend" on the batch's last accumulator
+            asm volatile("" : "+s"(zb), "+s"(xb) : "v"(acc[3]));
+            if (b + kWgDepth < NB) request(b % kWgDepth, 8 * (b + kWgDepth));
+        }
+    } else {
+#pragma unroll 1
+        for (int m0 = 0; m0 < rows; m0 += 8 * kWgDepth) {
+#pragma unroll
+            for (int s = 0; s < kWgDepth; s++) {
+                multiply(s, jv && m0 + 8 * s < rows);    // rows / 8 need not be a multiple of the ring: a batch past the end adds zeros
+                // no branch around the request; past the end the last batch is requested again and never used
+                const int mn = m0 + 8 * (kWgDepth + s);
+                request(s, mn < rows ? mn : rows - 8);
+            }
         }
     }
-    if (part > 0) {
-        float* r = sRed[part - 1][jt][lane];
 #pragma unroll
-        for (int c = 0; c < 4; c++) { r[c] = acc0[c]; r[4 + c] = acc1[c]; }
-        r[8] = bsum;
-    }
+    for (int g = 0; g < kWgG; g++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) sRed[wave][g][v][lane] = acc[g][v];
+    if (lane < kWgTileJ) sBias[wave][lane] = bsum;
     __syncthreads();
-    if (part > 0) return;
+    // thread -> (row group g = wave & 3, half of its rows, column lane): 2 outputs dW[16 jb + 4 g + v][64 ib + lane]
+    if (iv) {
+        const int g = wave & 3;
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
-        const float* r = sRed[p][jt][lane];
+        for (int vv = 0; vv < 2; vv++) {
+            const int v = 2 * (wave >> 2) + vv;
+            const int jo = jb * kWgTileJ + 4 * g + v;
+            if (jo >= d.out) continue;
+            float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; c++) { acc0[c] += r[c]; acc1[c] += r[4 + c]; }
-        bsum += r[8];
+            for (int w = 0; w < 8; w++) sum += sRed[w][g][v][lane];
+            float* row = d.dw ? d.dw + (size_t)jo * d.dw_stride : a.hw[jo];
+            row[i] = a.accumulate ? row[i] + sum : sum;
+        }
     }
-    // D[row = 4*mq + r -> output feature][col = jl -> input feature]
+    if (ib == 0 && (d.db || !d.dw) && threadIdx.x < kWgTileJ) {
+        const int jo = jb * kWgTileJ + threadIdx.x;
+        if (jo < d.out) {
+            float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int jo = jb * 64 + jt * 16 + 4 * mq + r;
-        if (jo >= d.out) continue;
-        float* row = d.dw ? d.dw + (size_t)jo * d.dw_stride : a.hw[jo];
-        if (iv0) row[i0] = a.accumulate ? row[i0] + acc0[r] : acc0[r];
-        if (iv1) row[i0 + 16] = a.accumulate ? row[i0 + 16] + acc1[r] : acc1[r];
-    }
-    if (ib == 0 && (d.db || !d.dw)) {
-        bsum += __shfl_xor(bsum, 16);
-        bsum += __shfl_xor(bsum, 32);
-        if (mq == 0 && jv) {
-            float* p = d.dw ? d.db + j : a.hb[j];
-            *p = a.accumulate ? *p + bsum : bsum;
+            for (int w = 0; w < 8; w++) sum += sBias[w][threadIdx.x];
+            float* p = d.dw ? d.db + jo : a.hb[jo];
+            *p = a.accumulate ? *p + sum : sum;
         }
     }
 }

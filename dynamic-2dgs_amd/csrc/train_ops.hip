@@ -1164,7 +1164,8 @@ __global__ void __launch_bounds__(256) regloss_bwd_kernel(RegArgs a, const float
 
 // ---- flat Adam --------------------------------------------------------------------------------------------------
 constexpr int kAdamSeg = 64;
-constexpr int kAdamChunk = 4096;   // elements per workgroup (256 threads x 16)
+constexpr int kAdamChunk = 1024;   // elements per workgroup (256 threads x 4: every load of a thread in flight at once -- with 16 the
+                                   // update of the 0.5 M deformation parameters was four dependent memory round trips, 19 us)
 
 struct AdamSegs {
     float* p[kAdamSeg];
@@ -1228,7 +1229,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
     const unsigned period = (unsigned)sg.period[s], split = (unsigned)sg.split[s];
     float* __restrict__ p = sg.p[s];
     const long long base = sg.off[s];
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < kAdamChunk / 256; k++) {
         const long long i = (long long)pl.y + k * 256 + threadIdx.x;
         if (i < seg_len) {
@@ -1514,8 +1515,8 @@ int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const flo
     auto add = [&](const float* dz, int dzs, int out, const float* x, int xs, int in, float* dw, int dws, float* db) {
         mlp::WgDesc& d = g.d[nd++];
         d.dz = dz; d.dz_stride = dzs; d.out = out; d.x = x; d.x_stride = xs; d.in = in; d.dw = dw; d.dw_stride = dws; d.db = db;
-        d.block0 = block; d.iblocks = (in + 31) / 32;
-        block += ((out + 63) / 64) * d.iblocks;
+        d.iblocks = (in + mlp::kWgTileI - 1) / mlp::kWgTileI;
+        d.ntiles = ((out + mlp::kWgTileJ - 1) / mlp::kWgTileJ) * d.iblocks;
     };
     const int W = mlp::kW;
     auto H = [&](int l) { return saved + mlp::sv_h(M, l); };
@@ -1535,7 +1536,8 @@ int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const flo
     add(scratch + mlp::sc_dt2(M), 32, mlp::kTOut, saved + mlp::sv_t1(M), W, W, grads[2], W, grads[3]);        // time net 2
     add(scratch + mlp::sc_dt1(M), W, W, saved + mlp::sv_et(M), mlp::kTPad, mlp::kTCh, grads[0], mlp::kTCh, grads[1]);  // time net 1
     g.ndesc = nd;
-    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, s, g);
+    block = mlp::wg_place(g);
+    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<0>, dim3(block), dim3(mlp::kWgThreads), 0, s, g);
     if (hipGetLastError() != hipSuccess) return fail(-2, "dgs_mlp_backward: launch failed");
     return 0;
 }

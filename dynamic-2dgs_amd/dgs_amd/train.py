@@ -458,7 +458,12 @@ class Trainer:
         self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
         if hasattr(d, "finish_backward"):
             d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
-        self._statistics(pkg, fused)
+        if getattr(d, "_join_pending", False) and fused:
+            # single GPU: the node-MLP backward now runs on the side stream and is the longer branch; the statistics kernels
+            # (three launches, ~25 us of a mostly idle device) go behind the surfel update instead of in front of it (_finish)
+            self._late_stats = (pkg, fused)
+        else:
+            self._statistics(pkg, fused)
         return loss.detach()
 
     # ---- data parallel: the backward in two halves with the SH all-reduce in between ---------------------------------
@@ -539,14 +544,21 @@ class Trainer:
                 self._reduce()
             if self.opt_deform is None:
                 self.opt_surfels.grad_scale = 1.0 / self.world if self._fold_mean else 1.0
-            if self.rasterizer_cls is None and s.get_xyz.is_cuda:
-                from . import _ops
-                _ops.densify_accumulate(self.bucket.extra[:self.P], self.bucket.extra[self.P:2 * self.P], self._radii[:self.P], s.xyz_gradient_accum,
-                                        s.denom, s.max_radii2D, skip=self.opt_surfels.skip if self.opt_deform is None else None)
-            else:
-                s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
-                s.denom.add_(self.bucket.extra[self.P:2 * self.P, None])
-                torch.maximum(s.max_radii2D, self._radii[:self.P], out=s.max_radii2D)
+
+            def accumulate():
+                if self.rasterizer_cls is None and s.get_xyz.is_cuda:
+                    from . import _ops
+                    _ops.densify_accumulate(self.bucket.extra[:self.P], self.bucket.extra[self.P:2 * self.P], self._radii[:self.P],
+                                            s.xyz_gradient_accum, s.denom, s.max_radii2D,
+                                            skip=self.opt_surfels.skip if self.opt_deform is None else None)
+                else:
+                    s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
+                    s.denom.add_(self.bucket.extra[self.P:2 * self.P, None])
+                    torch.maximum(s.max_radii2D, self._radii[:self.P], out=s.max_radii2D)
+            late = getattr(self, "_late_stats", None)
+            self._late_stats = None
+            if late is None:
+                accumulate()
             if self.opt_deform is not None:
                 if self.lr_schedule:
                     k = self._steps_done
@@ -563,10 +575,17 @@ class Trainer:
                 # the node-MLP backward is still running on the side stream (64 workgroups): update the surfels, which do
                 # not depend on it, meanwhile; then join and update the deformation parameters
                 self.opt_surfels.step(0, self.n_surfel_params)
+                if late is not None:
+                    self._statistics(*late)
+                    accumulate()
+                    late = None
                 self.deform.join_backward()
                 self.opt_surfels.step(self.n_surfel_params, None, advance=False)
             else:
                 self.opt_surfels.step()
+            if late is not None:   # (not reached with the current branches: statistics are never dropped)
+                self._statistics(*late)
+                accumulate()
 
     # ---- adaptive density control (train_gui.py:410-423; dgs_amd/densify.py) -----------------------------------------
     def _moments(self):

@@ -40,22 +40,59 @@ int main(int argc, char** argv)
     mlp::FwdArgs a{}; a.M = M; a.x = x; a.x_stride = 3; a.t = t; a.t_stride = 1; a.wp = (const float4*)packed;
     a.bias = packed + mlp::kBiasOff; a.saved = saved; a.attrs = attrs;
     mlp::BwdArgs b{}; b.M = M; b.g_attrs = g_attrs; b.saved = saved; b.scratch = scratch; b.wq = (const float4*)packed + mlp::kFwdVecs;
+    // weight-gradient descriptors as dgs_mlp_backward builds them (csrc/train_ops.hip)
+    mlp::WgArgs g{};
+    g.M = M; g.accumulate = 1;
+    float* gw[10]; float* gb[10];
+    for (int l = 0; l < 10; l++) { gw[l] = dev((size_t)mlp::l_out(l) * mlp::l_in(l), false); gb[l] = dev(mlp::l_out(l), false); }
+    float* ghw = dev(16 * 256, false); float* ghb = dev(16, false);
+    for (int r = 0; r < 16; r++) { g.hw[r] = ghw + 256 * (r < 13 ? r : 0); g.hb[r] = ghb + (r < 13 ? r : 0); }
+    int ndesc = 0, block = 0;
+    auto add = [&](const float* dz, int dzs, int out, const float* xx, int xs, int in, float* dw, int dws, float* db) {
+        mlp::WgDesc& d = g.d[ndesc++];
+        d.dz = dz; d.dz_stride = dzs; d.out = out; d.x = xx; d.x_stride = xs; d.in = in; d.dw = dw; d.dw_stride = dws; d.db = db;
+        d.iblocks = (in + mlp::kWgTileI - 1) / mlp::kWgTileI;
+        d.ntiles = ((out + mlp::kWgTileJ - 1) / mlp::kWgTileJ) * d.iblocks;
+    };
+    const int W = mlp::kW;
+    auto H = [&](int l) { return saved + mlp::sv_h(M, l); };
+    auto dZ = [&](int l) { return scratch + mlp::sc_dz(M, l); };
+    add(g_attrs, mlp::kHeads, mlp::kHeads, H(7), W, W, nullptr, W, nullptr);
+    for (int l = 7; l >= 1; l--) {
+        if (l == 5) {
+            add(dZ(5), W, W, saved + mlp::sv_inp(M), mlp::kInPad, mlp::kIn, gw[7], mlp::kIn + W, gb[7]);
+            add(dZ(5), W, W, H(4), W, W, gw[7] + mlp::kIn, mlp::kIn + W, nullptr);
+        } else {
+            add(dZ(l), W, W, H(l - 1), W, W, gw[l + 2], W, gb[l + 2]);
+        }
+    }
+    add(dZ(0), W, W, saved + mlp::sv_inp(M), mlp::kInPad, mlp::kIn, gw[2], mlp::kIn, gb[2]);
+    add(scratch + mlp::sc_dt2(M), 32, mlp::kTOut, saved + mlp::sv_t1(M), W, W, gw[1], W, gb[1]);
+    add(scratch + mlp::sc_dt1(M), W, W, saved + mlp::sv_et(M), mlp::kTPad, mlp::kTCh, gw[0], mlp::kTCh, gb[0]);
+    g.ndesc = ndesc;
+    block = mlp::wg_place(g);
+    if (getenv("WG_GRID")) block = atoi(getenv("WG_GRID"));   // fewer workgroups: throughput- or latency-bound?
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms;
-    for (int pass = 0; pass < 2; pass++) {
+    for (int pass = 0; pass < 3; pass++) {
         for (int i = 0; i < 5; i++) {
             if (pass == 0) hipLaunchKernelGGL(mlp::mlp_fwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, a);
-            else hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, b);
+            else if (pass == 1) hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, b);
+            else if (M == 1024) hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<16>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
+            else hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<0>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
         }
         hipEventRecord(e0, 0);
         for (int i = 0; i < iters; i++) {
             if (pass == 0) hipLaunchKernelGGL(mlp::mlp_fwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, a);
-            else hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, b);
+            else if (pass == 1) hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, b);
+            else if (M == 1024) hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<16>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
+            else hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<0>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
         }
         hipEventRecord(e1, 0);
         CK(hipEventSynchronize(e1));
         hipEventElapsedTime(&ms, e0, e1);
-        printf("%s chain: %.1f us per launch (M = %d, %d workgroups)\n", pass ? "backward" : "forward", ms * 1e3 / iters, M, M / mlp::kRows);
+        printf("%s: %.1f us per launch (M = %d, %d workgroups)\n", pass == 0 ? "forward chain" : pass == 1 ? "backward chain" : "weight gradients", ms * 1e3 / iters, M,
+               pass < 2 ? M / mlp::kRows : block);
     }
 #ifdef DGS_MLP_TRACE
     int zero = 0;
