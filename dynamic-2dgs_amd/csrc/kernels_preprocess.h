@@ -605,8 +605,10 @@ struct SurfelBwdArgs {
     float* dL_drot;              // [P,4]
 };
 
-// Fused computeAABB-bwd + preprocessCUDA-bwd (backward.cu:533-649).  Outputs are caller-zeroed
-// (rasterize_points.cu:194-202); culled surfels are left untouched.
+// Fused computeAABB-bwd + preprocessCUDA-bwd (backward.cu:533-649).  The reference's outputs are caller-zeroed
+// (rasterize_points.cu:194-202) and culled surfels left untouched; here the eight per-surfel arrays are written for EVERY row
+// (zeros for culled surfels, 112 B each) so that the caller needs no 22 MB fill in front of the backward; dL_dsh keeps the
+// reference's rule (visible rows, first (D+1)^2 coefficients): it is the array callers accumulate into (gradient sinks).
 __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs a)   // 135 VGPRs; forcing 128 (full residency, 3 spills) measured 43 against 41 us: bandwidth-bound
 {
     // SH rows (192 B per surfel at degree 3) are the bulk of this kernel's traffic and one-thread-per-surfel access to
@@ -674,11 +676,24 @@ __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs 
         }
         a.dL_dmean2D[3 * idx] = g.dmean2D[0];
         a.dL_dmean2D[3 * idx + 1] = g.dmean2D[1];
+        a.dL_dmean2D[3 * idx + 2] = 0.f;
         a.dL_dopacity[idx] = acc[kAccOpacity];
         for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = g.dT[c];
         a.dL_dscale[2 * idx] = g.dscale[0];
         a.dL_dscale[2 * idx + 1] = g.dscale[1];
         reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(g.drot[0], g.drot[1], g.drot[2], g.drot[3]);
+    } else if (idx < a.P) {
+        for (int c = 0; c < 3; c++) {
+            a.dL_dmean3D[3 * idx + c] = 0.f;
+            a.dL_dcolor[3 * idx + c] = 0.f;
+            a.dL_dnormal[3 * idx + c] = 0.f;
+            a.dL_dmean2D[3 * idx + c] = 0.f;
+        }
+        a.dL_dopacity[idx] = 0.f;
+        for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = 0.f;
+        a.dL_dscale[2 * idx] = 0.f;
+        a.dL_dscale[2 * idx + 1] = 0.f;
+        reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (a.shs) {
         // only visible surfels and only the first (D+1)^2 coefficients are written, as in the reference

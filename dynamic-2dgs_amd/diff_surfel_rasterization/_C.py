@@ -288,16 +288,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
     opts = dict(dtype=torch.float32, device=dev)
-    # all nine gradient arrays from ONE zero-filled allocation (one fill launch instead of nine)
-    cols = (3, 3, 3, 3, 1, 9, 0 if dL_dsh_out is not None else 3 * M, 2, 4)
+    # the eight per-surfel arrays from ONE allocation, not filled: the library writes every row of them (zeros for culled
+    # surfels; dgs_surfel_rasterizer.h).  dL_dsh follows the reference (visible rows only): zero-filled here unless the caller
+    # provides the array it accumulates into
+    cols = (3, 3, 3, 3, 1, 9, 2, 4)
     seg = [(P * c + 63) // 64 * 64 for c in cols]  # segment starts stay 256-byte aligned
-    flat = torch.zeros(sum(seg), **opts)
+    flat = torch.empty(sum(seg), **opts) if P != 0 else torch.zeros(sum(seg), **opts)
     views, off = [], 0
     for c, n in zip(cols, seg):
         views.append(flat[off:off + P * c].view(P, c))
         off += n
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal, dL_dopacity, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations = views
-    dL_dsh = dL_dsh_out if dL_dsh_out is not None else dL_dsh.view(P, M, 3)  # caller-provided: written in place (extension)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal, dL_dopacity, dL_dtransMat, dL_dscales, dL_drotations = views
+    dL_dsh = dL_dsh_out if dL_dsh_out is not None else torch.zeros((P, M, 3), **opts)  # caller-provided: written in place (extension)
     if P != 0:
         bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
         sc, rot, tm = _f32c(scales), _f32c(rotations), _f32c(transMat_precomp)

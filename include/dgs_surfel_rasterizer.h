@@ -73,10 +73,12 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
 /* CudaRasterizer::Rasterizer::backward, rasterizer.h:59-87 / rasterizer_impl.cu:346-448.
  * R = the value forward returned.  Every dL_d* row of a VISIBLE surfel (radii > 0) is written exactly once -- stored,
  * not accumulated: the per-pixel atomics of the reference are replaced by one private 80-byte accumulator row per surfel
- * that the per-surfel kernel reads back -- and rows of culled surfels are not touched.  With caller-zeroed outputs (the
- * reference's contract, rasterize_points.cu:194-202) the results are the reference's; a caller may also pass a buffer it
- * wants only the visible rows overwritten in (diff_surfel_rasterization.set_sh_grad_sink does that for dL_dsh, of which
- * only the first (D+1)^2 coefficients are written, as in the reference).  Shapes: dL_dpix[3,H,W], dL_depths[8,H,W], dL_dmean2D[P,3],
+ * that the per-surfel kernel reads back.  The eight per-surfel arrays (everything but dL_dsh) are written for EVERY row:
+ * culled surfels get zeros, so the caller needs no fill in front of the call (22 MB at 200 k surfels); with caller-zeroed
+ * outputs (the reference's contract, rasterize_points.cu:194-202) nothing changes.  dL_dsh keeps the reference's rule --
+ * rows of visible surfels, first (D+1)^2 coefficients, everything else untouched -- because it is the array callers
+ * accumulate into: pass it zeroed, or pass the buffer the visible rows are to be overwritten in
+ * (diff_surfel_rasterization.set_sh_grad_sink).  Shapes: dL_dpix[3,H,W], dL_depths[8,H,W], dL_dmean2D[P,3],
  * dL_dnormal[P,3], dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
  * dL_dscale[P,2], dL_drot[P,4].  Returns DGS_OK or a negative dgs_status. */
 int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

@@ -133,6 +133,31 @@ def test_precomputed_colors_and_no_grad_path():
     assert rel_l2(hip["dL_dmeans3D"], og["dL_dmeans3D"]) <= 2e-4
 
 
+def test_backward_needs_no_zero_filled_outputs():
+    """The eight per-surfel gradient arrays are written for every row (culled surfels: zeros), so the binding allocates them
+    uninitialised.  Poison the allocator's free blocks with NaN first: the gradients of a scene with culled surfels must come
+    out finite, exactly zero on the culled rows (the reference: caller-zeroed arrays the kernels never touch there) and
+    identical to a second run."""
+    from gpu_utils import run_hip
+    case = small_case(P=4000, H=96, W=96, seed=31, view=5, radius=1.2)   # camera inside the cloud: a good share is culled
+    gc, go = _cot(case)
+    runs = []
+    for _ in range(2):
+        poison = [torch.full((n,), float("nan"), device="cuda:0") for n in (4000 * 28 + 4096, 4000 * 9, 4000 * 4, 4000 * 3, 1 << 22)]
+        del poison
+        runs.append(run_hip(case, gc, go, debug=False))
+    a, b = runs
+    culled = a["radii"] == 0
+    assert 0.05 < culled.mean() < 0.95, culled.mean()
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
+        assert np.isfinite(a[k]).all(), k
+        assert not a[k][culled].any(), k
+        assert a[k][~culled].any(), k
+    assert not a["dL_dmeans2D"][:, 2].any()      # the third column has no gradient (rasterize_points.cu: a [P,3] array of which 2 are used)
+    for k in ("dL_dmeans2D", "dL_dopacity"):
+        assert np.allclose(a[k], b[k], rtol=1e-3, atol=1e-6), k
+
+
 def test_edge_cases():
     """Empty scene (P == 0 short-circuit, rasterize_points.cu:106,204), everything culled (R == 0),
     argument validation messages of the reference surface, markVisible."""
