@@ -1182,6 +1182,7 @@ struct AdamSegs {
     float sched_steps[kAdamSeg];
     float sched_t0;
     float gscale;   // gradients are read as grad * gscale (data parallel: the bucket holds the SUM over ranks, gscale = 1 / world)
+    int zero_grad;  // the gradient is cleared behind the read (optimizer.step() + zero_grad() in one pass; also on a skipped step)
 };
 
 // Guard of a training step (dgs_step_guard): skip[0] != 0 means "this step must not change anything" -- a rank's rasterizer
@@ -1209,11 +1210,12 @@ __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, const float* __restrict__ grad,
+__global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step_count,
                                                    float b1, float b2, float eps, const int* __restrict__ skip)
 {
-    if (skip && skip[0] != 0) return;   // guarded step (see step_guard_kernel)
+    const bool sk = skip && skip[0] != 0;   // guarded step (see step_guard_kernel)
+    if (sk && !sg.zero_grad) return;
     const int2 pl = plan[blockIdx.x];            // (segment, first element of this block inside the segment)
     const int s = pl.x;
     const long long seg_len = sg.off[s + 1] - sg.off[s];
@@ -1234,6 +1236,8 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
         const long long i = (long long)pl.y + k * 256 + threadIdx.x;
         if (i < seg_len) {
             const float g = grad[base + i] * sg.gscale;
+            if (sg.zero_grad) grad[base + i] = 0.0f;
+            if (sk) continue;
             const float mi = b1 * m[base + i] + (1.0f - b1) * g;
             const float vi = b2 * v[base + i] + (1.0f - b2) * g * g;
             m[base + i] = mi;
@@ -1395,6 +1399,10 @@ int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offse
                           const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                           float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
                           float beta2, float eps, const void* plan, const int* skip, void* stream);
+int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                       const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                       float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
+                       float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream);
 
 int dgs_adam_step(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* grad, float* exp_avg,
                   float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
@@ -1432,6 +1440,15 @@ int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offse
                           float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
                           float beta2, float eps, const void* plan, const int* skip, void* stream)
 {
+    return dgs_adam_step_zero(nseg, params, offsets, lrs, lrs2, periods, splits, lrs_final, sched_steps, sched_t0, grad_scale,
+                              const_cast<float*>(grad), 0, exp_avg, exp_avg_sq, step_count, beta1, beta2, eps, plan, skip, stream);
+}
+
+int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                       const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                       float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
+                       float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream)
+{
     if ((lrs_final != nullptr) != (sched_steps != nullptr)) return fail(-1, "dgs_adam_step_sched: pass lrs_final and sched_steps together");
     if (nseg <= 0 || nseg > kAdamSeg || !params || !offsets || !lrs || !grad || !exp_avg || !exp_avg_sq || !step_count || !plan)
         return fail(-1, "dgs_adam_step: bad argument");
@@ -1451,6 +1468,7 @@ int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offse
     }
     sg.sched_t0 = sched_t0;
     sg.gscale = grad_scale;
+    sg.zero_grad = zero_grad ? 1 : 0;
     sg.off[nseg] = offsets[nseg];
     const long long nb = adam_blocks(nseg, offsets);
     if (nb == 0) return 0;

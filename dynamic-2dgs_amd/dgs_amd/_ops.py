@@ -16,7 +16,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
-            "dgs_step_guard", "dgs_adam_step_guarded", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z")
+            "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z")
 
 
 def _deps():
@@ -121,6 +121,9 @@ def load():
         lib.dgs_adam_step_guarded.restype = ci
         lib.dgs_adam_step_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        lib.dgs_adam_step_zero.restype = ci
+        lib.dgs_adam_step_zero.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, ci, vp, vp, vp,
+                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         lib.dgs_densify_accumulate_guarded.restype = ci
         lib.dgs_densify_accumulate_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]
         if lib.dgs_train_ops_abi_version() != 1:
@@ -270,6 +273,7 @@ class FlatAdam:
         # step guard (dgs_step_guard): `skip` = a device int32 that is non-zero when this step must not change anything (a
         # rank's rasterizer overflowed its list capacity); None = every step is applied
         self.skip = None
+        self.zero_grads = False  # clear every gradient element behind its read (step + zero_grad in one pass; also on a skipped step)
         self.host_ring = None    # optional pinned float tensor [ring_len, 4] the guard kernel reports into
         self.loss = None         # optional device float: the step's loss, copied into the ring entry by the guard kernel
         dev = flat_grad.device
@@ -332,10 +336,10 @@ class FlatAdam:
                 _check(lib, lib.dgs_step_guard(skip, self.t.data_ptr(), self.status.data_ptr(), None if ring is None else ring.data_ptr(),
                                                0 if ring is None else ring.shape[0], None if self.loss is None else self.loss.data_ptr(),
                                                _stream(dev)), "dgs_step_guard")
-            rc = lib.dgs_adam_step_guarded(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
-                                           self.grad.data_ptr(),
-                                           self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
-                                           self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
+            rc = lib.dgs_adam_step_zero(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
+                                        self.grad.data_ptr(), 1 if self.zero_grads else 0,
+                                        self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
+                                        self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
         _check(lib, rc, "dgs_adam_step")
 
 

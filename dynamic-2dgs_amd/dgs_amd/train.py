@@ -191,6 +191,8 @@ class Trainer:
             self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat, patterns=patterns,
                                              schedules=schedules, sched_t0=float(self._steps_done))
             self.opt_deform = None
+            self.opt_surfels.zero_grads = True   # step + zero_grad in one pass: see _forward
+            self._bucket_clean = False
             self._init_guard(old)
         else:
             assert not getattr(surfels, "packed_sh", False), "packed SH needs the flat Adam kernel (two rates inside one parameter)"
@@ -386,7 +388,12 @@ class Trainer:
 
     def _forward(self, cam, gt):
         s, d = self.surfels, self.deform
-        self.bucket.zero()
+        # the flat Adam kernel clears the gradients behind its reads (FlatAdam.zero_grads): after a complete update the bucket
+        # is clean and the 57 MB fill in front of the step is not launched.  _bucket_clean is host state evaluated when a step
+        # is BUILT (eagerly, or once at graph capture): every path that dirties the bucket ends in a complete update
+        if not (getattr(self, "_bucket_clean", False) and self.opt_deform is None and self.opt_surfels.zero_grads):
+            self.bucket.zero()
+        self._bucket_clean = False
         t = d.expand_time(cam.fid)
         fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
         asm = None
@@ -586,6 +593,8 @@ class Trainer:
             if late is not None:   # (not reached with the current branches: statistics are never dropped)
                 self._statistics(*late)
                 accumulate()
+            # every branch above ran the update over ALL parameters of the bucket (with _finish_sh in the split step)
+            self._bucket_clean = self.opt_deform is None and bool(getattr(self.opt_surfels, "zero_grads", False))
 
     # ---- adaptive density control (train_gui.py:410-423; dgs_amd/densify.py) -----------------------------------------
     def _moments(self):

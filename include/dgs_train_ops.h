@@ -120,6 +120,13 @@ int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offse
                           const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                           float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
                           float beta2, float eps, const void* plan, const int* skip, void* stream);
+/* optimizer.step() and zero_grad() in one pass (train_gui.py:427-431 calls them back to back): with zero_grad != 0 every gradient
+ * element the launch reads is cleared behind the read -- on a skipped step too, or the next step would add to a stale buffer --
+ * so the trainer needs no 57 MB fill in front of the next backward.  zero_grad = 0: dgs_adam_step_guarded. */
+int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                       const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                       float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
+                       float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream);
 
 /* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:
  * posenc(xyz,10) | timenet(posenc(t,6)): 13->256->30, 8 x 256 ReLU layers, skip concat after layer 4, heads

@@ -553,3 +553,40 @@ def test_flat_adam_grad_scale_is_the_mean_of_a_summed_bucket():
         ob.step()
     for p, q in zip(a, b):
         assert torch.equal(p, q)     # 4 g * 0.25 is exact in binary floating point
+
+
+def test_flat_adam_clears_the_gradients_behind_its_reads():
+    """FlatAdam.zero_grads (dgs_adam_step_zero): optimizer.step() + zero_grad() in one pass -- same update, every gradient element
+    of the launched range zero afterwards, the others untouched; on a guarded step that is skipped the gradients are cleared
+    too (the next backward must not add to a stale buffer) while parameters, moments and the step count stay."""
+    from dgs_amd import _ops
+    from dgs_amd.train import FlatGradBucket
+    torch.manual_seed(4)
+    shapes = [(700, 16, 3), (700, 3), (1030,)]
+    a = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ba, bb = FlatGradBucket(a, extra=64), FlatGradBucket(b, extra=64)
+    oa = _ops.FlatAdam(a, [1e-3] * 3, ba.flat)
+    ob = _ops.FlatAdam(b, [1e-3] * 3, bb.flat)
+    oa.zero_grads = True
+    skip = torch.zeros(1, dtype=torch.int32, device="cuda")
+    oa.skip = skip
+    for it in range(3):
+        g = torch.randn(ba.flat.numel(), generator=torch.Generator().manual_seed(it)).cuda()
+        ba.flat.copy_(g)
+        bb.flat.copy_(g)
+        oa.step(0, 1)
+        assert not a[0].grad.any() and torch.equal(a[1].grad, b[1].grad) and torch.equal(a[2].grad, b[2].grad)
+        oa.step(1, None, advance=False)
+        ob.step()
+        assert not ba.flat[:ba.n_grad].any() and torch.equal(ba.extra, g[ba.n_grad:])   # the tail is not a gradient
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    before = [p.detach().clone() for p in a], oa.exp_avg.clone(), oa.exp_avg_sq.clone(), float(oa.t)
+    skip.fill_(1)
+    ba.flat.copy_(torch.randn(ba.flat.numel(), generator=torch.Generator().manual_seed(9)).cuda())
+    oa.step()
+    torch.cuda.synchronize()
+    assert not ba.flat[:ba.n_grad].any()
+    assert all(torch.equal(p, q) for p, q in zip(a, before[0])) and torch.equal(oa.exp_avg, before[1]) and torch.equal(oa.exp_avg_sq, before[2])
+    assert float(oa.t) == before[3]
