@@ -555,21 +555,28 @@ inline int wg_place(WgArgs& a)
     return 8 * most;
 }
 
-constexpr int kWgThreads = 512;   // 8 waves = 8 slices of the nodes
+constexpr int kWgWaves = 4;       // slices of the nodes
+constexpr int kWgThreads = 64 * kWgWaves;
 constexpr int kWgTileJ = 16, kWgTileI = 64;
 constexpr int kWgG = kWgTileJ / 4;   // accumulators (4 rows of dW each) per wave
+constexpr int kWgPhase = 32;         // rows per register set
 
-#ifndef DGS_WGRAD_WAVES
-#define DGS_WGRAD_WAVES 4   // waves per SIMD the register allocation aims at (2 workgroups per CU)
-#endif
-// NB = batches of 8 rows per wave when known at compile time (M = 64 NB): the row loop is then ONE basic block and the wait
-// counters are exact -- around a loop's back edge the compiler waits for every load in flight (vmcnt(0) at the loop header),
-// which turns a 4-deep request ring into no ring at all.  NB = 0: any M, runtime loop.
-template <int NB>
-__global__ void __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu(DGS_WGRAD_WAVES, DGS_WGRAD_WAVES))) mlp_wgrad_kernel(WgArgs a)
+// Three things bound this kernel before its matrix instructions do (measured one by one, tools/micro/mlp_chain_bench.hip):
+//  * a 4-byte-per-lane load occupies the CU's address unit as long as a 16-byte one: 256 B per 16 clocks = a quarter of the
+//    64 B/clk the L1 can take, and with 830 KB of operands per CU that alone was 25 us.  So every lane loads 16 bytes -- four
+//    ROWS of the tile per instruction (lane l: row l / 16, columns 4 (l % 16) ..) -- and the wave turns them into the
+//    lane = column layout of the MFMA operands through 1.3 KB of its own LDS (no barrier: nobody else touches it);
+//  * the rows were written by other XCDs and come from the memory side (~2 us under load): two register sets of 32 rows, one
+//    multiplies (128 MFMAs) while the 16 loads of the other are in flight;
+//  * around a loop's back edge the compiler waits for EVERY load in flight (s_waitcnt vmcnt(0) at the loop header), which
+//    turns a ring of small batches into one exposed latency per trip; with two sets the only wait is "all of the other set",
+//    which is what vmcnt(0) means at that point anyway.
+__global__ void __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) mlp_wgrad_kernel(WgArgs a)
 {
-    __shared__ float sRed[8][kWgG][4][64];   // [wave][row group g][v][lane]: 32 KB
-    __shared__ float sBias[8][kWgTileJ];
+    __shared__ float sRed[kWgWaves][kWgG][4][64];   // [wave][row group g][v][lane]: 16 KB
+    __shared__ float sBias[kWgWaves][kWgTileJ];
+    __shared__ __attribute__((aligned(16))) float sX[kWgWaves][2][4 * kWgTileI];   // per wave: 4 rows x 64 columns, double-buffered
+    __shared__ __attribute__((aligned(16))) float sZ[kWgWaves][2][16 * kWgTileJ];              // per wave: 16 rows x 16 columns, double-buffered
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int di = -1;
 #pragma unroll
@@ -582,65 +589,80 @@ __global__ void __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = jb * kWgTileJ + lane, i = ib * kWgTileI + lane;
     const bool jv = lane < kWgTileJ && j < d.out, iv = i < d.in;
-    const int rows = NB > 0 ? 8 * NB : a.M >> 3;     // nodes per wave (M is a multiple of 64)
-    // wave-uniform row pointers + one lane offset: scalar base registers, no 64-bit address pair per row
-    // buffer loads: resource = the matrix, scalar offset = the row, one 32-bit lane offset for every row of the kernel (flat
-    // 64-bit addresses cost two VALU additions per load and a register pair per row in flight)
+    const int rows = a.M / kWgWaves;                 // nodes per wave (M is a multiple of 64: rows of 16)
+    // buffer loads: resource = the matrix (reads past its end return 0: a 16-byte load of the last columns of a 13-wide row runs
+    // into the next row, and past the buffer on the last one), scalar offset = the row, one 32-bit lane offset for the whole kernel
     const int zs = d.dz_stride * 4, xs = d.x_stride * 4;   // row strides in bytes
-    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dz), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7fffffff, 0x00020000);
-    int zb = wave * rows * zs, xb = wave * rows * xs;
-    const unsigned zoff = (jv ? j : 0) * 4u, xoff = (iv ? i : 0) * 4u;
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dz), 0, a.M * zs, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.M * xs, 0x00020000);
+    const int zb = wave * rows * zs, xb = wave * rows * xs;
+    // lane -> (row, 4 columns) of one load: X 4 rows (row l / 16, columns 4 (l % 16)); dZ 16 rows (row l / 4, columns 4 (l % 4))
+    const unsigned xoff = (unsigned)(lane >> 4) * xs + (unsigned)(ib * kWgTileI + 4 * (lane & 15)) * 4u;
+    const unsigned zoff = (unsigned)(lane >> 2) * zs + (unsigned)(jb * kWgTileJ + 4 * (lane & 3)) * 4u;
     f32x4 acc[kWgG];
 #pragma unroll
     for (int g = 0; g < kWgG; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    // The activation rows were written by other XCDs and come from the memory side (~2 us under load): a ring of kWgDepth
-    // batches of 8 rows keeps 3-4 batches (48-64 loads per wave) in flight; with one batch ahead the loop was a chain of
-    // rows/8 exposed latencies (34 us whatever the occupancy).
-    constexpr int kWgDepth = 4;
-    float av[kWgDepth][8], bv[kWgDepth][8];
-    auto request = [&](int s, int m0) {
+    constexpr int kGroups = kWgPhase / 4;
+    float4 xq[2][kGroups], zq[2][kWgPhase / 16];   // (a third set, two phases in flight, spills at 168 registers: 40 us)
+    auto request = [&](int s, int m0) {   // groups past the end: the last group again (never used)
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            av[s][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, zoff, zb + (m0 + r) * zs, 0));
-            bv[s][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff, xb + (m0 + r) * xs, 0));
+        for (int g = 0; g < kGroups; g++) {
+            const int m = m0 + 4 * g < rows ? m0 + 4 * g : rows - 4;
+            xq[s][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, xb + m * xs, 0));
+        }
+#pragma unroll
+        for (int h = 0; h < kWgPhase / 16; h++) {
+            const int m = m0 + 16 * h < rows ? m0 + 16 * h : rows - 16;
+            zq[s][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rz, zoff, zb + m * zs, 0));
         }
     };
-    auto multiply = [&](int s, bool jvs) {
+    float* const wx = &sX[wave][0][(lane >> 4) * kWgTileI + 4 * (lane & 15)];
+    float* const wz = &sZ[wave][0][(lane >> 2) * kWgTileJ + 4 * (lane & 3)];
+    const float* const rxp = &sX[wave][0][lane];
+    const float* const rzp = &sZ[wave][0][lane & 15];
+    // one set of 32 rows = 8 groups of 4: group g + 2 is written to LDS and group g + 1 read back while group g multiplies (a
+    // wave's LDS operations complete in order; without the overlap the write -> read -> multiply chain of a group is ~450 clocks)
+    auto put = [&](int s, int g) {
+        *reinterpret_cast<float4*>(wx + (g & 1) * 4 * kWgTileI) = xq[s][g];
+        if ((g & 3) == 0) *reinterpret_cast<float4*>(wz + ((g >> 2) & 1) * 16 * kWgTileJ) = zq[s][g >> 2];
+    };
+    auto get = [&](int g, float (&av)[4], float (&bvv)[4]) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const float av_ = jvs ? av[s][r] : 0.f, bv_ = iv ? bv[s][r] : 0.f;
-            bsum += av_;
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[0], 4, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[1], 4, 1, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[2], 4, 2, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[3], 4, 3, 0);
-            static_assert(kWgG == 4, "one MFMA per row group");
+        for (int r = 0; r < 4; r++) {
+            av[r] = rzp[((g >> 2) & 1) * 16 * kWgTileJ + (4 * (g & 3) + r) * kWgTileJ];
+            bvv[r] = rxp[(g & 1) * 4 * kWgTileI + r * kWgTileI];
         }
     };
+    auto multiply = [&](int s, int m0) {
+        float av[2][4], bvv[2][4];
+        put(s, 0);
+        put(s, 1);
+        get(0, av[0], bvv[0]);
 #pragma unroll
-    for (int s = 0; s < kWgDepth; s++) request(s, 8 * s < rows ? 8 * s : rows - 8);
-    if (NB > 0) {
+        for (int g = 0; g < kGroups; g++) {
+            if (g + 1 < kGroups) get(g + 1, av[(g + 1) & 1], bvv[(g + 1) & 1]);
+            const bool jvs = jv && m0 + 4 * g < rows;
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            multiply(b % kWgDepth, jv);
-            // requests stay behind the batch they follow (hoisted, they cost 26 spilled registers and every scratch reload waits
-            // for all loads in flight): their scalar offsets "depend" on the batch's last accumulator
-            asm volatile("" : "+s"(zb), "+s"(xb) : "v"(acc[3]));
-            if (b + kWgDepth < NB) request(b % kWgDepth, 8 * (b + kWgDepth));
-        }
-    } else {
-#pragma unroll 1
-        for (int m0 = 0; m0 < rows; m0 += 8 * kWgDepth) {
-#pragma unroll
-            for (int s = 0; s < kWgDepth; s++) {
-                multiply(s, jv && m0 + 8 * s < rows);    // rows / 8 need not be a multiple of the ring: a batch past the end adds zeros
-                // no branch around the request; past the end the last batch is requested again and never used
-                const int mn = m0 + 8 * (kWgDepth + s);
-                request(s, mn < rows ? mn : rows - 8);
+            for (int r = 0; r < 4; r++) {
+                const float av_ = jvs ? av[g & 1][r] : 0.f, bv_ = iv ? bvv[g & 1][r] : 0.f;
+                bsum += av_;
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[0], 4, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[1], 4, 1, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[2], 4, 2, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av_, bv_, acc[3], 4, 3, 0);
+                static_assert(kWgG == 4, "one MFMA per row group");
             }
+            if (g + 2 < kGroups) put(s, g + 2);
         }
+    };
+    request(0, 0);
+#pragma unroll 1
+    for (int m0 = 0; m0 < rows; m0 += 2 * kWgPhase) {
+        request(1, m0 + kWgPhase);
+        multiply(0, m0);
+        request(0, m0 + 2 * kWgPhase);
+        multiply(1, m0 + kWgPhase);
     }
 #pragma unroll
     for (int g = 0; g < kWgG; g++)
@@ -648,17 +670,15 @@ __global__ void __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu
         for (int v = 0; v < 4; v++) sRed[wave][g][v][lane] = acc[g][v];
     if (lane < kWgTileJ) sBias[wave][lane] = bsum;
     __syncthreads();
-    // thread -> (row group g = wave & 3, half of its rows, column lane): 2 outputs dW[16 jb + 4 g + v][64 ib + lane]
+    // thread -> (row group g = wave, column lane): 4 outputs dW[16 jb + 4 g + v][64 ib + lane]
     if (iv) {
-        const int g = wave & 3;
 #pragma unroll
-        for (int vv = 0; vv < 2; vv++) {
-            const int v = 2 * (wave >> 2) + vv;
-            const int jo = jb * kWgTileJ + 4 * g + v;
+        for (int v = 0; v < 4; v++) {
+            const int jo = jb * kWgTileJ + 4 * wave + v;
             if (jo >= d.out) continue;
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; w++) sum += sRed[w][g][v][lane];
+            for (int w = 0; w < kWgWaves; w++) sum += sRed[w][wave][v][lane];
             float* row = d.dw ? d.dw + (size_t)jo * d.dw_stride : a.hw[jo];
             row[i] = a.accumulate ? row[i] + sum : sum;
         }
@@ -668,7 +688,7 @@ __global__ void __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu
         if (jo < d.out) {
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; w++) sum += sBias[w][threadIdx.x];
+            for (int w = 0; w < kWgWaves; w++) sum += sBias[w][threadIdx.x];
             float* p = d.dw ? d.db + jo : a.hb[jo];
             *p = a.accumulate ? *p + sum : sum;
         }

@@ -1555,7 +1555,7 @@ int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const flo
     add(scratch + mlp::sc_dt1(M), W, W, saved + mlp::sv_et(M), mlp::kTPad, mlp::kTCh, grads[0], mlp::kTCh, grads[1]);  // time net 1
     g.ndesc = nd;
     block = mlp::wg_place(g);
-    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<0>, dim3(block), dim3(mlp::kWgThreads), 0, s, g);
+    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, s, g);
     if (hipGetLastError() != hipSuccess) return fail(-2, "dgs_mlp_backward: launch failed");
     return 0;
 }

@@ -79,10 +79,9 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
         assert tr.world == world and tr.view_for(0) == rank
-        tr.opt_surfels.zero_grads = False   # keep the reduced gradients of the step for the comparison below (normally the
-        tr.step()                           # update clears them behind its reads)
+        tr.opt_surfels.zero_grads = False   # keep the reduced gradients of the step for the comparison below (the update can
+        tr.step()                           # clear them behind its reads)
         flat_after = tr.bucket.flat.detach().cpu().numpy().copy()
-        tr.opt_surfels.zero_grads = True
         tr.step()
         torch.cuda.synchronize()
         params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()

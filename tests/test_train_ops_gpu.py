@@ -590,3 +590,23 @@ def test_flat_adam_clears_the_gradients_behind_its_reads():
     assert not ba.flat[:ba.n_grad].any()
     assert all(torch.equal(p, q) for p, q in zip(a, before[0])) and torch.equal(oa.exp_avg, before[1]) and torch.equal(oa.exp_avg_sq, before[2])
     assert float(oa.t) == before[3]
+
+
+def test_trainer_without_the_bucket_fill_trains_the_same():
+    """Trainer with FlatAdam.zero_grads: the update clears the gradients, no fill is launched in front of the next step
+    (Trainer._bucket_clean) -- same training as with the fill (default: on its own stream, joined before the backward)."""
+    import bench
+    dev = torch.device("cuda:0")
+    res = {}
+    for fused_zero in (False, True):
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2)
+        tr.opt_surfels.zero_grads = fused_zero
+        losses = [float(tr.step()) for _ in range(4)]
+        torch.cuda.synchronize()
+        assert tr._bucket_clean == fused_zero
+        if fused_zero:
+            assert not tr.bucket.flat[:tr.bucket.n_grad].any()
+        res[fused_zero] = (losses, torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu())
+    for x, y in zip(res[False][0], res[True][0]):
+        assert abs(x - y) <= 1e-4 * abs(x), (res[False][0], res[True][0])
+    assert float((res[False][1] - res[True][1]).abs().median()) < 1e-6

@@ -78,15 +78,15 @@ int main(int argc, char** argv)
         for (int i = 0; i < 5; i++) {
             if (pass == 0) hipLaunchKernelGGL(mlp::mlp_fwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, a);
             else if (pass == 1) hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, b);
-            else if (M == 1024) hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<16>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
-            else hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<0>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
+            else if (M == 1024) hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
+            else hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
         }
         hipEventRecord(e0, 0);
         for (int i = 0; i < iters; i++) {
             if (pass == 0) hipLaunchKernelGGL(mlp::mlp_fwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, a);
             else if (pass == 1) hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, 0, b);
-            else if (M == 1024) hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<16>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
-            else hipLaunchKernelGGL(mlp::mlp_wgrad_kernel<0>, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
+            else if (M == 1024) hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
+            else hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, 0, g);
         }
         hipEventRecord(e1, 0);
         CK(hipEventSynchronize(e1));
