@@ -354,8 +354,16 @@ class Trainer:
             with torch.cuda.graph(self._g2, pool=self._g1.pool(), **mode):
                 self._finish(reduce=False, sh_done=self._split)
         self._graph = True
-        # validate: the warm-up rendered the first view -- fail now rather than let the step guard double the capacity later
-        # (validate=False leaves it to the guard: every view, not just the first, is covered by it anyway)
+        # validate: render EVERY view once (forward only, nothing trains; ~0.3 ms each) -- a view whose tile lists break the
+        # capacity or the promised list length is found now, not by the step guard in the middle of a run (which would skip
+        # that step, double / withdraw and re-capture).  validate=False leaves it to the guard.
+        if validate:
+            with torch.no_grad():
+                for v in range(len(self.cameras)):
+                    self._scam.load(self._vtab[v])
+                    self._forward(self._scam, self._sgt)
+            self._scam.load(self._vtab[0])
+            torch.cuda.synchronize()
         if _C.read_overflow():
             if self._list_hint:            # perhaps only the promised list length was exceeded: withdraw it and capture again
                 self._list_hint = 0
