@@ -396,24 +396,14 @@ class Trainer:
 
     def _forward(self, cam, gt):
         s, d = self.surfels, self.deform
-        # Clearing the gradient bucket (57 MB, 10 us) is not on the step's critical path: nothing touches the bucket before the
-        # backward, so on the GPU the fill runs on its own stream next to the neighbour search / node MLP and is joined in
-        # _run_backward.  (The flat Adam kernel can also clear the gradients behind its reads -- FlatAdam.zero_grads, then the
-        # bucket is clean after every complete update and no fill is launched -- but that adds 57 MB of writes to the SH
-        # update, which is the longer branch of the step's tail: measured 84 -> 101 us there.  _bucket_clean is host state
-        # evaluated when a step is BUILT, eagerly or once at graph capture.)
+        # The gradient bucket (57 MB) is cleared by a fill in front of the step (10 us).  Two alternatives were built and measured
+        # on the replayed step: (a) the flat Adam kernel clears the gradients behind its reads (FlatAdam.zero_grads; the bucket
+        # is then clean after every complete update and no fill is launched: _bucket_clean, host state evaluated when a step is
+        # BUILT) -- but the 57 MB of extra writes land in the SH update, the longer branch of the step's tail (84 -> 101 us);
+        # (b) the fill on its own stream next to the neighbour search, joined before the backward -- a cross-stream dependency
+        # inside a replayed graph costs 5-10 us of idle device at the fork AND at the join, more than the fill.
         if not (getattr(self, "_bucket_clean", False) and self.opt_deform is None and self.opt_surfels.zero_grads):
-            if self.bucket.flat.is_cuda and self.rasterizer_cls is None:
-                cur = torch.cuda.current_stream(self.bucket.flat.device)
-                zs = getattr(self, "_zero_stream", None)
-                if zs is None:
-                    zs = self._zero_stream = torch.cuda.Stream(self.bucket.flat.device)
-                zs.wait_stream(cur)          # behind the previous step's update, which reads the gradients
-                with torch.cuda.stream(zs):
-                    self.bucket.zero()
-                self._zero_pending = True
-            else:
-                self.bucket.zero()
+            self.bucket.zero()
         self._bucket_clean = False
         t = d.expand_time(cam.fid)
         fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
@@ -441,9 +431,6 @@ class Trainer:
         """fn() under the SH gradient sink when it applies (the rasterizer's backward then writes dL/dSH straight into the
         bucket view of the packed parameter)."""
         s = self.surfels
-        if getattr(self, "_zero_pending", False):   # the bucket's fill (see _forward) must be done before the first gradient lands
-            torch.cuda.current_stream(self.bucket.flat.device).wait_stream(self._zero_stream)
-            self._zero_pending = False
         if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink:
             import diff_surfel_rasterization as dsr
             dsr.set_sh_grad_sink(s._features.grad)

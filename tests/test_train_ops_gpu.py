@@ -594,7 +594,7 @@ def test_flat_adam_clears_the_gradients_behind_its_reads():
 
 def test_trainer_without_the_bucket_fill_trains_the_same():
     """Trainer with FlatAdam.zero_grads: the update clears the gradients, no fill is launched in front of the next step
-    (Trainer._bucket_clean) -- same training as with the fill (default: on its own stream, joined before the backward)."""
+    (Trainer._bucket_clean) -- same training as with the fill in front of the step (the default)."""
     import bench
     dev = torch.device("cuda:0")
     res = {}
