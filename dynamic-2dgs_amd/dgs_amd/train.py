@@ -590,7 +590,7 @@ class Trainer:
             elif sh_done:
                 self.opt_surfels.step(1, None, advance=False)
             elif getattr(self.deform, "_join_pending", False):
-                # the node-MLP backward is still running on the side stream (64 workgroups): update the surfels, which do
+                # the node-MLP backward is still running on the side stream: update the surfels, which do
                 # not depend on it, meanwhile; then join and update the deformation parameters
                 self.opt_surfels.step(0, self.n_surfel_params)
                 if late is not None:

@@ -135,7 +135,8 @@ int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets,
  *                   local_rotation, gaussian_warp, gaussian_rotation, gaussian_scaling  (torch Linear layout [out][in])
  *   x[M, x_stride] node positions (first 3 columns), t[M * t_stride] time per node (t_stride 0 = one shared value)
  *   attrs[M,13] = [local_rotation + rot_bias(4, host) | d_xyz 3 | d_rotation 4 | d_scaling 2]  (dgs_lbs_forward's table)
- *   packed: dgs_mlp_packed_floats() floats, written by forward, read by backward (weights re-laid in MFMA order)
+ *   packed: dgs_mlp_packed_floats() floats, written by forward, read by backward (weights re-laid as [k/4][column] float4
+ *           operands of the two chains: csrc/node_mlp.h)
  *   saved : dgs_mlp_saved_floats(M) floats of activations, written by forward, read by backward
  *   scratch: dgs_mlp_scratch_floats(M) floats
  * backward writes (accumulate = 0) or adds to (accumulate = 1) every gradient tensor.  M must be a multiple of 64. */
@@ -222,7 +223,9 @@ int dgs_densify_accumulate_guarded(int P, const float* grad_norm, const float* v
 /* Exact K nearest neighbours seeded with a previous answer: idx[N,K] holds any earlier result on entry (typically last
  * step's; stale, random or invalid entries only cost time) and the exact answer of dgs_knn_points2 on exit.  The scan over
  * the M <= 2048 nodes uses only coordinates 0..2 (D1 >= 3: a lower bound of the full squared distance) against the bound
- * the seed gives; full distances are evaluated for the few survivors.  D2 may be 0 (x2 unused). */
+ * the seed gives; full distances are evaluated for the few survivors.  Whole 32-node blocks are skipped when the bounding box
+ * of a wave's search spheres misses the block's: this pays when consecutive points are neighbours in space and consecutive
+ * nodes are too (Trainer.sort_surfels / sort_nodes); any order gives the same, exact result.  D2 may be 0 (x2 unused). */
 int dgs_knn_refine(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
                    long long* idx, void* stream);
 
