@@ -21,9 +21,9 @@ namespace {
 thread_local std::string g_err;
 int fail(int code, const std::string& m) { g_err = m; return code; }
 
-constexpr int kT = 16;          // output tile edge
+constexpr int kT = 32;          // output tile edge
 constexpr int kR = 5;           // window radius (11 taps)
-constexpr int kIn = kT + 2 * kR;  // 26
+constexpr int kIn = kT + 2 * kR;  // 42
 
 struct Gauss { float w[11]; };
 
@@ -39,6 +39,13 @@ Gauss make_gauss()
 
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
+// Both SSIM kernels: one 32 x 32 output tile per 256-thread workgroup (42 x 42 inputs: 1.7x halo; the 16 x 16 tiles of round 1
+// re-read 2.6x), separable 11-tap window through LDS, and every thread computes FOUR adjacent outputs of a pass from one run of 14
+// inputs held in registers (11 taps x 4 outputs = 44 LDS reads become 14; the passes were LDS-read bound: 91 reads per pixel).
+// Same sums in the same order as before (and as the reference's conv2d would give up to fp32 summation order).
+constexpr int kPer = 4;           // outputs per thread along the filtered direction
+static_assert(kT == 32 && kT % kPer == 0, "thread maps below assume a 32 x 32 tile");
+
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                        Gauss g, float* __restrict__ ssim_sum, float* __restrict__ dm_dmu1,
                                                        float* __restrict__ dm_ds11, float* __restrict__ dm_ds12,
@@ -49,7 +56,7 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float
     __shared__ float s_a[kIn][kIn + 1], s_b[kIn][kIn + 1];
     __shared__ float s_h[5][kIn][kT + 1];
     __shared__ float s_red[8];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
     const size_t plane = (size_t)blockIdx.z * H * W;
     for (int i = tid; i < kIn * kIn; i += 256) {
@@ -60,39 +67,60 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float
         s_b[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < kIn * kT; i += 256) {  // horizontal pass: 26 rows x 16 columns
-        const int r = i / kT, c = i - r * kT;
-        float m1 = 0.f, m2 = 0.f, q11 = 0.f, q22 = 0.f, q12 = 0.f;
+    for (int it = tid; it < kIn * (kT / kPer); it += 256) {  // horizontal pass: 42 rows x 8 groups of 4 columns
+        const int r = it / (kT / kPer), c0 = (it - r * (kT / kPer)) * kPer;
+        float a[kPer + 10], b[kPer + 10];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float a = s_a[r][c + k], b = s_b[r][c + k], w = g.w[k];
-            m1 += w * a; m2 += w * b; q11 += w * a * a; q22 += w * b * b; q12 += w * a * b;
+        for (int j = 0; j < kPer + 10; j++) { a[j] = s_a[r][c0 + j]; b[j] = s_b[r][c0 + j]; }
+#pragma unroll
+        for (int o = 0; o < kPer; o++) {
+            float m1 = 0.f, m2 = 0.f, q11 = 0.f, q22 = 0.f, q12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float av = a[o + k], bv = b[o + k], w = g.w[k];
+                m1 += w * av; m2 += w * bv; q11 += w * av * av; q22 += w * bv * bv; q12 += w * av * bv;
+            }
+            s_h[0][r][c0 + o] = m1; s_h[1][r][c0 + o] = m2; s_h[2][r][c0 + o] = q11; s_h[3][r][c0 + o] = q22; s_h[4][r][c0 + o] = q12;
         }
-        s_h[0][r][c] = m1; s_h[1][r][c] = m2; s_h[2][r][c] = q11; s_h[3][r][c] = q22; s_h[4][r][c] = q12;
     }
     __syncthreads();
-    float mu1 = 0.f, mu2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    // vertical pass: thread -> column lx, rows ry .. ry + 3
+    const int lx = tid & 31, ry = (tid >> 5) * kPer;
+    float res[5][kPer];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = g.w[k];
-        mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx];
-        s11 += w * s_h[2][ly + k][lx]; s22 += w * s_h[3][ly + k][lx]; s12 += w * s_h[4][ly + k][lx];
+    for (int q = 0; q < 5; q++) {
+        float v[kPer + 10];
+#pragma unroll
+        for (int j = 0; j < kPer + 10; j++) v[j] = s_h[q][ry + j][lx];
+#pragma unroll
+        for (int o = 0; o < kPer; o++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) t += g.w[k] * v[o + k];
+            res[q][o] = t;
+        }
     }
-    const int x = x0 + lx, y = y0 + ly;
+    const int x = x0 + lx;
     float val = 0.f, l1 = 0.f;
-    if (x < W && y < H) {
-        l1 = fabsf(s_a[ly + kR][lx + kR] - s_b[ly + kR][lx + kR]);
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float sg1 = s11 - mu1_sq, sg2 = s22 - mu2_sq, sg12 = s12 - mu12;
-        const float A = 2.f * mu12 + kC1, B = 2.f * sg12 + kC2, Cc = mu1_sq + mu2_sq + kC1, D = sg1 + sg2 + kC2;
-        const float inv_cd = 1.0f / (Cc * D);
-        val = A * B * inv_cd;
-        if (dm_dmu1) {
-            // map = A B / (Cc D) with sigma1^2 = s11 - mu1^2, sigma12 = s12 - mu1 mu2 (loss_utils.py:59-71)
-            const size_t o = plane + (size_t)y * W + x;
-            dm_dmu1[o] = (2.f * mu2 * B - 2.f * mu2 * A) * inv_cd - val * (2.f * mu1 / Cc - 2.f * mu1 / D);
-            dm_ds11[o] = -val / D;
-            dm_ds12[o] = 2.f * A * inv_cd;
+#pragma unroll
+    for (int o = 0; o < kPer; o++) {
+        const int y = y0 + ry + o;
+        if (x < W && y < H) {
+            const float mu1 = res[0][o], mu2 = res[1][o], s11 = res[2][o], s22 = res[3][o], s12 = res[4][o];
+            l1 += fabsf(s_a[ry + o + kR][lx + kR] - s_b[ry + o + kR][lx + kR]);
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sg1 = s11 - mu1_sq, sg2 = s22 - mu2_sq, sg12 = s12 - mu12;
+            const float A = 2.f * mu12 + kC1, B = 2.f * sg12 + kC2, Cc = mu1_sq + mu2_sq + kC1, D = sg1 + sg2 + kC2;
+            const float inv_cd = 1.0f / (Cc * D);
+            const float m = A * B * inv_cd;
+            val += m;
+            if (dm_dmu1) {
+                // map = A B / (Cc D) with sigma1^2 = s11 - mu1^2, sigma12 = s12 - mu1 mu2 (loss_utils.py:59-71)
+                const size_t oo = plane + (size_t)y * W + x;
+                dm_dmu1[oo] = (2.f * mu2 * B - 2.f * mu2 * A) * inv_cd - m * (2.f * mu1 / Cc - 2.f * mu1 / D);
+                dm_ds11[oo] = -m / D;
+                dm_ds12[oo] = 2.f * A * inv_cd;
+            }
         }
     }
     for (int d = 32; d >= 1; d >>= 1) { val += __shfl_xor(val, d, 64); l1 += __shfl_xor(l1, d, 64); }
@@ -123,7 +151,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n
     if (img2_slot) img2 = *img2_slot;
     __shared__ float s_in[3][kIn][kIn + 1];
     __shared__ float s_h[3][kIn][kT + 1];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
     const size_t plane = (size_t)blockIdx.z * H * W;
     for (int i = tid; i < kIn * kIn; i += 256) {
@@ -136,31 +164,52 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n
         s_in[2][r][c] = in ? dm_ds12[o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < kIn * kT; i += 256) {
-        const int r = i / kT, c = i - r * kT;
-        float a = 0.f, b = 0.f, d = 0.f;
+    for (int it = tid; it < kIn * (kT / kPer); it += 256) {
+        const int r = it / (kT / kPer), c0 = (it - r * (kT / kPer)) * kPer;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = g.w[k];
-            a += w * s_in[0][r][c + k]; b += w * s_in[1][r][c + k]; d += w * s_in[2][r][c + k];
+        for (int q = 0; q < 3; q++) {
+            float v[kPer + 10];
+#pragma unroll
+            for (int j = 0; j < kPer + 10; j++) v[j] = s_in[q][r][c0 + j];
+#pragma unroll
+            for (int o = 0; o < kPer; o++) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) t += g.w[k] * v[o + k];
+                s_h[q][r][c0 + o] = t;
+            }
         }
-        s_h[0][r][c] = a; s_h[1][r][c] = b; s_h[2][r][c] = d;
     }
     __syncthreads();
-    float a = 0.f, b = 0.f, d = 0.f;
+    const int lx = tid & 31, ry = (tid >> 5) * kPer;
+    float res[3][kPer];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = g.w[k];
-        a += w * s_h[0][ly + k][lx]; b += w * s_h[1][ly + k][lx]; d += w * s_h[2][ly + k][lx];
+    for (int q = 0; q < 3; q++) {
+        float v[kPer + 10];
+#pragma unroll
+        for (int j = 0; j < kPer + 10; j++) v[j] = s_h[q][ry + j][lx];
+#pragma unroll
+        for (int o = 0; o < kPer; o++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) t += g.w[k] * v[o + k];
+            res[q][o] = t;
+        }
     }
-    const int x = x0 + lx, y = y0 + ly;
-    if (x < W && y < H) {
-        const size_t o = plane + (size_t)y * W + x;
-        // the zero-padded symmetric window is its own adjoint
-        // inv_n scales the SSIM-map adjoint, l1_coef the sign(img1 - img2) of an optional mean-|.| term
-        const float df = img1[o] - img2[o];
-        const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-        dL_dimg1[o] = ((a + 2.f * img1[o] * b + img2[o] * d) * inv_n + l1_coef * sg) * dL_dmean[0];
+    const int x = x0 + lx;
+    const float gm = dL_dmean[0];
+#pragma unroll
+    for (int o = 0; o < kPer; o++) {
+        const int y = y0 + ry + o;
+        if (x < W && y < H) {
+            const size_t oo = plane + (size_t)y * W + x;
+            // the zero-padded symmetric window is its own adjoint
+            // inv_n scales the SSIM-map adjoint, l1_coef the sign(img1 - img2) of an optional mean-|.| term
+            const float i1 = img1[oo], i2 = img2[oo];
+            const float df = i1 - i2;
+            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            dL_dimg1[oo] = ((res[0][o] + 2.f * i1 * res[1][o] + i2 * res[2][o]) * inv_n + l1_coef * sg) * gm;
+        }
     }
 }
 
