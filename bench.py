@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-legs", action="store_true",
                     help="skip the extra kernel-timing passes after the timed region (PMC runs of tools/pmc_kernels.sh use this)")
+    ap.add_argument("--tile-order", type=int, default=None,
+                    help="dispatch order of the blend tiles (dgs_set_option(1, m): 3 longest first, 4 XCD-local groups): A/B runs only")
     ap.add_argument("--densify-every", type=int, default=0,
                     help="also run the in-place densification every N timed steps (off by default: the metric is the plain step)")
     ap.add_argument("--slots-factor", type=float, default=1.5, help="surfel slots per initial surfel when --densify-every is on")
@@ -208,6 +210,8 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
 
     from diff_surfel_rasterization import _C
+    if args.tile_order is not None:
+        _C.set_option(1, args.tile_order)
     P, H, W = WORKLOADS[args.workload]
     if args.workload == "c2":
         if world > 1:

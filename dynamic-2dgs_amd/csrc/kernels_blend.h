@@ -49,11 +49,14 @@ struct BlendFwdArgs {
 //      dense centre -- go to one XCD: load imbalance),
 //   2  row-interleaved: XCD x gets tile rows r with r % 8 == x, walked left to right (horizontal neighbours
 //      share an L2, every XCD samples the whole image height).
+//   4  XCD-local groups, longest first inside an XCD: the image is cut into 4 x 4-tile groups (a surfel's tiles mostly fall
+//      into one), the groups are dealt to the 8 XCDs heaviest-first in snake order (balanced sums), and XCD x walks ITS
+//      tiles in descending length: order[8 k + x] = its k-th tile (tile_order_body; empty slots hold `ntiles`).
 __device__ __forceinline__ int tile_for_block(int bid, int tiles_x, int tiles_y, int mode)
 {
     constexpr int kXcd = 8;
     const int ntiles = tiles_x * tiles_y;
-    if (mode == 0 || mode == 3) return bid;  // mode 3 indexes the sorted order[] with it
+    if (mode == 0 || mode >= 3) return bid;  // modes 3, 4 index the sorted order[] with it
     const int xcd = bid % kXcd, k = bid / kXcd;
     if (mode == 1) {
         const int per = (ntiles + kXcd - 1) / kXcd;
@@ -70,6 +73,17 @@ __device__ __forceinline__ int tile_for_block(int bid, int tiles_x, int tiles_y,
 // whichever SIMD drew the heaviest tiles last.  Dispatching tiles in descending list length (counting sort below)
 // puts the long tiles first and lets the short ones fill the tail.
 constexpr int kOrderBins = 1024;
+constexpr int kOrderGroup = 4;      // mode 4: tiles per group edge
+constexpr int kOrderMaxGroups = 1024;
+// mode 4: slots of the order array = 8 x (most tiles one XCD can get): every XCD gets at most ceil(G / 8) + 1 groups of 16 tiles
+__host__ __device__ inline int order_groups(int tiles_x, int tiles_y)
+{
+    return ((tiles_x + kOrderGroup - 1) / kOrderGroup) * ((tiles_y + kOrderGroup - 1) / kOrderGroup);
+}
+__host__ __device__ inline int order_slots(int tiles_x, int tiles_y)
+{
+    return 8 * kOrderGroup * kOrderGroup * ((order_groups(tiles_x, tiles_y) + 7) / 8 + 1);
+}
 
 // body shared by tile_order_kernel and scan_tiles_kernel (which orders the forward's tiles right after it has scanned their
 // counts: one launch less in the step); all 1024 threads of the workgroup must call it
@@ -110,11 +124,120 @@ __device__ __forceinline__ void tile_order_body(const uint2* ranges, const uint3
     }
 }
 
-__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, const uint32_t* weights, int ntiles, uint32_t* order)
+// exclusive scan of s[0 .. 1024) in place, one element per thread of the 1024-thread workgroup
+__device__ __forceinline__ void scan1024(uint32_t* s, uint32_t* s_wsum /*[16]*/)
 {
-    __shared__ uint32_t s_hist[kOrderBins];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t v = s[tid];
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += n;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wsum[w];
+    __syncthreads();
+    s[tid] = base + inc - v;
+    __syncthreads();
+}
+
+// Mode 4 (see tile_for_block).  s_hist: [8][kOrderBins]; s_gw, s_gx: [kOrderMaxGroups].  All 1024 threads must call it.
+// group_xcd [kOrderMaxGroups] (global): the group -> XCD map.  The forward (deal = true) deals the groups by list length and
+// stores the map; the backward reuses it (its weights, the traversed lengths, follow the list lengths, and the records a
+// group's tiles share should meet the L2 that already holds them): no second ranking.
+__device__ __forceinline__ void tile_order_xcd_body(const uint2* ranges, const uint32_t* weights, int tiles_x, int tiles_y, uint32_t* order,
+                                                    uint32_t* group_xcd, bool deal, uint32_t* s_hist, uint32_t* s_gw, uint32_t* s_gx,
+                                                    uint32_t* s_wsum)
+{
+    const int tid = threadIdx.x;
+    const int ntiles = tiles_x * tiles_y, gtx = (tiles_x + kOrderGroup - 1) / kOrderGroup, ngroups = order_groups(tiles_x, tiles_y);
+    const int slots = order_slots(tiles_x, tiles_y);
+    // a thread's tiles are tid, tid + 1024, ..: weight and group of the first kKeep stay in registers (800 x 800: 3 per thread)
+    constexpr int kKeep = 4;
+    uint32_t wk[kKeep], gk[kKeep];
+    auto weight = [&](int t) { return weights ? weights[t] : (ranges[t].y - ranges[t].x); };
+    auto group = [&](int t) { return (uint32_t)(((t / tiles_x) / kOrderGroup) * gtx + (t % tiles_x) / kOrderGroup); };
+#pragma unroll
+    for (int i = 0; i < kKeep; i++) {
+        const int t = tid + 1024 * i;
+        wk[i] = t < ntiles ? weight(t) : 0u;
+        gk[i] = t < ntiles ? group(t) : 0u;
+    }
+    auto wt = [&](int i, int t) { return i < kKeep ? wk[i] : weight(t); };
+    auto gr = [&](int i, int t) { return i < kKeep ? gk[i] : group(t); };
+    s_gw[tid] = 0;
+    for (int i = tid; i < 8 * kOrderBins; i += 1024) s_hist[i] = 0;
+    for (int i = tid; i < slots; i += 1024) order[i] = (uint32_t)ntiles;   // empty slot
+    if (!deal && tid < ngroups) s_gx[tid] = group_xcd[tid] & 7u;   // (& 7: a forward under another tile order left no map -- any map is valid)
+    __syncthreads();
+    if (deal) {
+        for (int i = 0, t = tid; t < ntiles; i++, t += 1024) atomicAdd(&s_gw[gr(i, t)], wt(i, t));
+        __syncthreads();
+        // rank of every group by weight (descending; 64 entries per bin, ties in any order) -> its XCD in snake order
+        const uint32_t gwt = tid < ngroups ? s_gw[tid] : 0u;
+        const uint32_t gbin = kOrderBins - 1 - min(gwt >> 6, (uint32_t)(kOrderBins - 1));
+        if (tid < ngroups) atomicAdd(&s_hist[gbin], 1u);
+        __syncthreads();
+        scan1024(s_hist, s_wsum);
+        if (tid < ngroups) {
+            const uint32_t r = atomicAdd(&s_hist[gbin], 1u);
+            const uint32_t x = (r >> 3) & 1u ? 7u - (r & 7u) : (r & 7u);
+            s_gx[tid] = x;
+            group_xcd[tid] = x;
+        }
+        __syncthreads();
+        s_hist[tid] = 0;
+        __syncthreads();
+    }
+    // per XCD: counting sort of its tiles by weight, heaviest first
+    for (int i = 0, t = tid; t < ntiles; i++, t += 1024) {
+        const uint32_t bin = kOrderBins - 1 - min(wt(i, t) >> 2, (uint32_t)(kOrderBins - 1));
+        atomicAdd(&s_hist[s_gx[gr(i, t)] * kOrderBins + bin], 1u);
+    }
+    __syncthreads();
+    {   // the 8 exclusive scans at once: thread <-> bin, one shuffle network carrying 8 values
+        const int lane = tid & 63, wave = tid >> 6;
+        uint32_t v[8], inc[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) { v[x] = s_hist[x * kOrderBins + tid]; inc[x] = v[x]; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                const uint32_t n = __shfl_up(inc[x], d, 64);
+                if (lane >= d) inc[x] += n;
+            }
+        if (lane == 63)
+#pragma unroll
+            for (int x = 0; x < 8; x++) s_gw[x * 16 + wave] = inc[x];   // the group weights are no longer needed
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            uint32_t base = 0;
+            for (int w = 0; w < wave; w++) base += s_gw[x * 16 + w];
+            s_hist[x * kOrderBins + tid] = base + inc[x] - v[x];
+        }
+        __syncthreads();
+    }
+    for (int i = 0, t = tid; t < ntiles; i++, t += 1024) {
+        const uint32_t x = s_gx[gr(i, t)];
+        const uint32_t bin = kOrderBins - 1 - min(wt(i, t) >> 2, (uint32_t)(kOrderBins - 1));
+        const uint32_t pos = atomicAdd(&s_hist[x * kOrderBins + bin], 1u);
+        order[8u * pos + x] = (uint32_t)t;
+    }
+}
+
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, const uint32_t* weights, int tiles_x, int tiles_y, int mode,
+                                                          uint32_t* order, uint32_t* group_xcd)
+{
+    __shared__ uint32_t s_hist[8 * kOrderBins];
+    __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
     __shared__ uint32_t s_wsum[16];
-    tile_order_body(ranges, weights, ntiles, order, s_hist, s_wsum);
+    if (mode == 4) tile_order_xcd_body(ranges, weights, tiles_x, tiles_y, order, group_xcd, false, s_hist, s_gw, s_gx, s_wsum);
+    else tile_order_body(ranges, weights, tiles_x * tiles_y, order, s_hist, s_wsum);
 }
 
 // grid size that covers every tile under `mode`
@@ -122,6 +245,7 @@ inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
 {
     const int ntiles = tiles_x * tiles_y;
     if (mode == 0 || mode == 3) return ntiles;
+    if (mode == 4) return order_slots(tiles_x, tiles_y);
     if (mode == 1) return ((ntiles + 7) / 8) * 8;
     return ((tiles_y + 7) / 8) * tiles_x * 8;
 }
@@ -135,8 +259,9 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
 
     const int ntiles = a.tiles_x * a.tiles_y;
     int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
-    if (tile >= ntiles) return;
-    if (a.mode == 3) tile = (int)a.order[tile];
+    if (a.mode < 3 && tile >= ntiles) return;
+    if (a.mode >= 3) tile = (int)a.order[tile];
+    if (tile >= ntiles) return;   // mode 4: empty slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     int lx_, ly_;
@@ -412,8 +537,9 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
 
     const int ntiles = a.tiles_x * a.tiles_y;
     int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
-    if (tile >= ntiles) return;
-    if (a.mode == 3) tile = (int)a.order[tile];
+    if (a.mode < 3 && tile >= ntiles) return;
+    if (a.mode >= 3) tile = (int)a.order[tile];
+    if (tile >= ntiles) return;   // mode 4: empty slot
     const int L = (int)a.tile_last[tile];  // entries [0, L) can contribute to some pixel of the tile
     if (L == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -200,10 +200,12 @@ __global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P,
 // left empty (the frame renders as background) and *overflow is raised instead of writing out of bounds.
 __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
                                                           uint32_t* total_out /*[3]: num_rendered, longest list, overflow*/,
-                                                          uint32_t cap, int* overflow, uint32_t* order /*or null*/, uint32_t list_hint)
+                                                          uint32_t cap, int* overflow, uint32_t* order /*or null*/, uint32_t list_hint,
+                                                          int tiles_x, int tiles_y, int order_mode, uint32_t* group_xcd)
 {
     __shared__ uint32_t s_wsum[4], s_wmax[4];
-    __shared__ uint32_t s_hist[1024];
+    __shared__ uint32_t s_hist[8 * kOrderBins];
+    __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
     __shared__ uint32_t s_osum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 256) {   // the scan proper: 256 threads, `per` consecutive tiles each
@@ -253,7 +255,8 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts
         // workgroup, visible to all of its threads after the fence + barrier
         __threadfence_block();
         __syncthreads();
-        tile_order_body(ranges, nullptr, ntiles, order, s_hist, s_osum);
+        if (order_mode == 4) tile_order_xcd_body(ranges, nullptr, tiles_x, tiles_y, order, group_xcd, true, s_hist, s_gw, s_gx, s_osum);
+        else tile_order_body(ranges, nullptr, ntiles, order, s_hist, s_osum);
     }
 }
 

@@ -73,7 +73,7 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, tile_last, order_fwd, order_bwd, tile_counts, cursor, bytes;
+    size_t final_T, n_contrib, ranges, tile_last, order_fwd, order_bwd, group_xcd, tile_counts, cursor, bytes;
     bool lds_bins;  // per-workgroup LDS histograms fit (T * 4 bytes <= 144 KB)
     int tiles_x, tiles_y, ntiles;
     ImageLayout(int W, int H)
@@ -87,8 +87,10 @@ struct ImageLayout {
         n_contrib = c.take(2 * plane * 4);
         ranges = c.take((size_t)ntiles * 8);
         tile_last = c.take((size_t)ntiles * 4);
-        order_fwd = c.take((size_t)ntiles * 4);
-        order_bwd = c.take((size_t)ntiles * 4);
+        const size_t order_len = (size_t)std::max(ntiles, dgs::order_slots(tiles_x, tiles_y));   // tile order 4 has empty slots
+        order_fwd = c.take(order_len * 4);
+        order_bwd = c.take(order_len * 4);
+        group_xcd = c.take((size_t)dgs::kOrderMaxGroups * 4);   // tile order 4: the forward's group -> XCD map, reused by the backward
         tile_counts = c.take((size_t)ntiles * 4);
         lds_bins = (size_t)ntiles * 4 <= 144 * 1024;
         // LDS path: G x T matrix of per-workgroup counts / cursors; fallback: T global cursors
@@ -308,7 +310,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
 {
     if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
     if (key == 0) { c->tight_rects.store(value != 0); return DGS_OK; }
-    if (key == 1 && value >= 0 && value <= 3) { c->tile_order.store(value); return DGS_OK; }
+    if (key == 1 && value >= 0 && value <= 4) { c->tile_order.store(value); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
@@ -542,11 +544,13 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     const int capacity = ctx->capacity.load();
     int* overflow = ctx->overflow.load();
     // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
-    const int tile_order = ctx->tile_order.load();
+    int tile_order = ctx->tile_order.load();
+    if (tile_order == 4 && dgs::order_groups(il.tiles_x, il.tiles_y) > dgs::kOrderMaxGroups) tile_order = 3;   // > 128 x 128 tiles
     hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
                        il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)capacity, overflow,
-                       tile_order == 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr,   // + the forward's dispatch order
-                       (uint32_t)(capacity > 0 ? ctx->list_hint.load() : 0));
+                       tile_order >= 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr,   // + the forward's dispatch order
+                       (uint32_t)(capacity > 0 ? ctx->list_hint.load() : 0), il.tiles_x, il.tiles_y, tile_order,
+                       (uint32_t*)(img + il.group_xcd));
     DGS_STAGE("scan_tiles", debug, stream);
 
     // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285).
@@ -693,9 +697,11 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         ba.rec = (const float4*)(geom_buffer + gl.rec);
         ba.W = width; ba.H = height; ba.tiles_x = il.tiles_x; ba.tiles_y = il.tiles_y; ba.mode = ctx->tile_order.load();
         ba.order = (const uint32_t*)(img_buffer + il.order_bwd);
-        if (ba.mode == 3) {  // by the traversed length the forward measured
+        if (ba.mode == 4 && dgs::order_groups(il.tiles_x, il.tiles_y) > dgs::kOrderMaxGroups) ba.mode = 3;
+        if (ba.mode >= 3) {  // by the traversed length the forward measured
             hipLaunchKernelGGL(dgs::tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint2*)nullptr,
-                               (const uint32_t*)(img_buffer + il.tile_last), il.ntiles, (uint32_t*)(img_buffer + il.order_bwd));
+                               (const uint32_t*)(img_buffer + il.tile_last), il.tiles_x, il.tiles_y, ba.mode,
+                               (uint32_t*)(img_buffer + il.order_bwd), (uint32_t*)(img_buffer + il.group_xcd));
             DGS_STAGE("tile_order_bwd", debug, stream);
         }
         ba.bg = background;

@@ -140,7 +140,8 @@ int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* off
 void dgs_set_tight_rects(int on);
 
 /* Knobs (default context of the current device; defaults are the tuned values): key 0 = tight rects (0/1),
- * key 1 = blend tile order (0 row-major, 1 XCD-contiguous, 2 XCD row-interleaved, 3 longest-list-first [default]),
+ * key 1 = blend tile order (0 row-major, 1 XCD-contiguous, 2 XCD row-interleaved, 3 longest-list-first [default], 4 XCD-local
+ *         groups of 4 x 4 tiles, longest first inside an XCD: half the record re-fetches of 3 for ~15 us of extra ordering work),
  * key 2 = capacity mode: value > 0 sizes the binning buffer for `value` list entries and removes the one
  *         device->host read of the forward (rasterizer_impl.cu:281-282), which makes forward + backward legal inside
  *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do

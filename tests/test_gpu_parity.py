@@ -133,6 +133,33 @@ def test_precomputed_colors_and_no_grad_path():
     assert rel_l2(hip["dL_dmeans3D"], og["dL_dmeans3D"]) <= 2e-4
 
 
+@pytest.mark.parametrize("shape", [(96, 80), (200, 136)])
+def test_every_tile_order_renders_the_same(shape):
+    """dgs_set_option(1, m): the dispatch order of the blend tiles (row-major, two static XCD maps, longest-first, XCD-local
+    groups longest-first with empty slots) changes which workgroup renders a tile, never what it renders: bit-identical forward,
+    backward equal up to the order of its atomic sums."""
+    from diff_surfel_rasterization import _C
+    from gpu_utils import run_hip
+    H, W = shape
+    case = small_case(P=6000, H=H, W=W, seed=17, view=2, scale_mul=1.5)
+    gc, go = _cot(case)
+    outs = {}
+    try:
+        for mode in (3, 0, 1, 2, 4):
+            _C.set_option(1, mode)
+            outs[mode] = run_hip(case, gc, go, debug=False)
+    finally:
+        _C.set_option(1, 3)
+    ref = outs[3]
+    for mode in (0, 1, 2, 4):
+        o = outs[mode]
+        assert np.array_equal(o["color"], ref["color"]) and np.array_equal(o["allmap"], ref["allmap"]), mode
+        assert np.array_equal(o["radii"], ref["radii"]), mode
+        for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh", "dL_dmeans2D"):
+            scale = np.abs(ref[k]).max()
+            assert np.abs(o[k] - ref[k]).max() <= 2e-4 * scale + 1e-12, (mode, k)
+
+
 def test_backward_needs_no_zero_filled_outputs():
     """The eight per-surfel gradient arrays are written for every row (culled surfels: zeros), so the binding allocates them
     uninitialised.  Poison the allocator's free blocks with NaN first: the gradients of a scene with culled surfels must come
