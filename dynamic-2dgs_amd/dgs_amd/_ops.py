@@ -322,6 +322,20 @@ class FlatAdam:
         return None, None
 
     @torch.no_grad()
+    def guard(self):
+        """The step's one-thread guard kernel alone: t += 1 unless the step is to be skipped, bookkeeping for the host.  step()
+        launches it when advance=True; a caller that spreads the update over streams launches it first and orders the
+        update launches (advance=False) behind it."""
+        lib = load()
+        dev = self.grad.device
+        skip = None if self.skip is None else self.skip.data_ptr()
+        ring = self.host_ring
+        with torch.cuda.device(dev):
+            _check(lib, lib.dgs_step_guard(skip, self.t.data_ptr(), self.status.data_ptr(), None if ring is None else ring.data_ptr(),
+                                           0 if ring is None else ring.shape[0], None if self.loss is None else self.loss.data_ptr(),
+                                           _stream(dev)), "dgs_step_guard")
+
+    @torch.no_grad()
     def step(self, first=0, last=None, advance=True):
         """Adam update of parameters [first, last) (default: all).  advance=False reuses the step count of the previous
         call: a step split over several launches advances the counter on its first launch only."""
@@ -331,11 +345,8 @@ class FlatAdam:
         k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, plan = self._range(first, last)
         skip = None if self.skip is None else self.skip.data_ptr()
         with torch.cuda.device(dev):
-            if advance:   # one-thread kernel: t += 1 unless the step is to be skipped; bookkeeping for the host
-                ring = self.host_ring
-                _check(lib, lib.dgs_step_guard(skip, self.t.data_ptr(), self.status.data_ptr(), None if ring is None else ring.data_ptr(),
-                                               0 if ring is None else ring.shape[0], None if self.loss is None else self.loss.data_ptr(),
-                                               _stream(dev)), "dgs_step_guard")
+            if advance:
+                self.guard()
             rc = lib.dgs_adam_step_zero(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
                                         self.grad.data_ptr(), 1 if self.zero_grads else 0,
                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
