@@ -406,6 +406,7 @@ struct BlendBwdArgs {
     const float* dL_dpix;     // [3,H,W]
     const float* dL_dothers;  // [8,H,W]
     float* acc;               // [P, kAccFloats], zeroed
+    float* det_part;          // deterministic variant only: [num_rendered][4 waves][kAccFloats], zeroed (see det_reduce_kernel)
 };
 
 // ---- wave reduction of the 16 per-surfel partials of one (wave, entry) visit --------------------------------------------
@@ -529,6 +530,10 @@ __device__ __forceinline__ float wave_sum(float v)
 #ifndef DGS_BWD_MINWAVES
 #define DGS_BWD_MINWAVES 4
 #endif
+// DET = false: the per-(wave, entry) sums go into the surfel's accumulator row with hardware float atomics (order of arrival:
+// results differ at the rounding level from run to run, like the reference's).  DET = true (dgs_set_option(7, 1), tests): every
+// (list entry, wave) owns a row of det_part and stores its sums there; det_reduce_kernel adds the rows of a surfel in a fixed order.
+template <bool DET>
 __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
 {
     __shared__ float4 s_rec[kStagedQuads][kBatch];
@@ -623,13 +628,20 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
                 float out[16], out2d[2];
                 pixbwd_step(st, ev, ok, e, pfx, pfy, as_quad(q1), as_quad(q2), as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]), out, out2d);
                 // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
-                float* dst = a.acc + (size_t)__builtin_amdgcn_readfirstlane(s_id[jc]) * kAccFloats;
+                float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * 4 + wave) * kAccFloats
+                                 : a.acc + (size_t)__builtin_amdgcn_readfirstlane(s_id[jc]) * kAccFloats;
                 const float tot = wave_reduce16(out, lane);
-                if (rslot >= 0) atomicAdd(dst + rslot, tot);
+                if (rslot >= 0) {
+                    if (DET) dst[rslot] = tot;
+                    else atomicAdd(dst + rslot, tot);
+                }
                 if (__ballot(ok && !ev.use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
                     const float mx = wave_sum(out2d[0]);
                     const float my = wave_sum(out2d[1]);
-                    if (lane == 0) { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                    if (lane == 0) {
+                        if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
+                        else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                    }
                 }
             };
             int ja = c * 64 + __builtin_ctzll(m), jb = 0;
@@ -653,6 +665,36 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
             }
         }
     }
+}
+
+// Deterministic reduction of the backward blend (test option): one thread per surfel walks the tiles of its rectangle in
+// row-major order, finds its entry in the tile's sorted list and adds the four waves' rows in order 0..3.  Same sums as the
+// atomics in ONE fixed order: two runs give bit-identical gradients.  Slow by design (linear search of the lists).
+__global__ void __launch_bounds__(256) det_reduce_kernel(int P, const int* radii, const uint2* rects, int tiles_x, const uint2* ranges,
+                                                         const uint32_t* point_list, const float* part, float* acc)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || !(radii[idx] > 0)) return;
+    const uint2 r = rects[idx];
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    float sum[kAccFloats];
+#pragma unroll
+    for (int k = 0; k < kAccFloats; k++) sum[k] = 0.f;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const uint2 rg = ranges[y * tiles_x + x];
+            for (uint32_t pos = rg.x; pos < rg.y; pos++) {
+                if (point_list[pos] != (uint32_t)idx) continue;
+                for (int w = 0; w < 4; w++) {
+                    const float* row = part + ((size_t)pos * 4 + w) * kAccFloats;
+#pragma unroll
+                    for (int k = 0; k < kAccFloats; k++) sum[k] += row[k];
+                }
+                break;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < kAccFloats; k++) acc[(size_t)idx * kAccFloats + k] = sum[k];
 }
 
 }  // namespace dgs

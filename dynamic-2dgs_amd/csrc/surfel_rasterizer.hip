@@ -185,6 +185,7 @@ struct dgs_context {
     std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
     std::atomic<int> sort_regs{2};    // per-tile sort: 2 LSD radix in LDS (default), 1 bitonic network in registers, 0 bitonic in LDS
     std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
+    std::atomic<int> deterministic{0};   // key 7: backward blend without atomics, fixed summation order (tests)
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
     std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
@@ -311,6 +312,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
     if (key == 0) { c->tight_rects.store(value != 0); return DGS_OK; }
     if (key == 1 && value >= 0 && value <= 4) { c->tile_order.store(value); return DGS_OK; }
+    if (key == 7) { c->deterministic.store(value != 0); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
@@ -715,7 +717,22 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         if (const int lim = ctx->grid_limit_bwd.load()) grid = lim < grid ? lim : grid;
         Prof::Pair pp;
         const bool timed = prof_begin(ctx, 1, stream, pp);
-        hipLaunchKernelGGL(dgs::blend_bwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+        if (ctx->deterministic.load()) {
+            // test option: every (list entry, wave) stores its sums in a row of its own, a per-surfel kernel adds them in a fixed
+            // order.  R x 320 bytes of scratch from the stream-ordered allocator (not capturable: tests run eagerly)
+            float* part = nullptr;
+            const size_t bytes = (size_t)R * 4 * dgs::kAccFloats * sizeof(float);
+            DGS_HIP(hipMallocAsync((void**)&part, bytes, stream));
+            DGS_HIP(hipMemsetAsync(part, 0, bytes, stream));
+            ba.det_part = part;
+            hipLaunchKernelGGL(dgs::blend_bwd_kernel<true>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+            hipLaunchKernelGGL(dgs::det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, radii,
+                               (const uint2*)(geom_buffer + gl.rects), il.tiles_x, ba.ranges, ba.point_list, (const float*)part, acc);
+            DGS_HIP(hipFreeAsync(part, stream));
+        } else {
+            ba.det_part = nullptr;
+            hipLaunchKernelGGL(dgs::blend_bwd_kernel<false>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+        }
         if (timed) prof_end(ctx, stream, pp, ba.tile_last, il.ntiles);
         DGS_STAGE("blend_bwd", debug, stream);
     }

@@ -147,6 +147,9 @@ void dgs_set_tight_rects(int on);
  *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do
  *         not fit renders as background and raises the overflow flag; value 0 restores the exact-size mode,
  * key 3 = per-tile sort: 2 LSD radix sort in LDS [default], 1 bitonic network with the keys in registers, 0 bitonic network in LDS,
+ * key 7 = deterministic backward (0 [default] / 1): the backward blend stores its per-(list entry, wave) sums instead of adding them
+ *         with float atomics and a per-surfel kernel adds them in a fixed order -- bit-identical gradients from run to run.  For
+ *         tests: R x 320 bytes of scratch from hipMallocAsync (not capturable), a linear search per (surfel, tile).
  * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
  *         host read the library cannot know which of its per-tile sort kernels will find work and launches all three; with the
  *         promise it launches only those for lists up to `value` (2048: one launch instead of three, ~10 us of an 800x800

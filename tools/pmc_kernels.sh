@@ -32,6 +32,7 @@ for p in ("p1","p2","p3","p4","p5"):
     if not f: print(p, "no counter file"); continue
     for r in csv.DictReader(open(f[0])):
         k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
+        k = re.sub(r"<.*>$", "", k)   # template arguments (blend_bwd_kernel<false>) are not part of the key
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 kern = {}
 for k, d in sorted(acc.items()):
