@@ -368,9 +368,15 @@ int launch_knn(int N, int M, int D, const float* x, const float* nodes, long lon
 // order of their nearest node and nodes stored along a space-filling curve (Trainer.sort_surfels / sort_nodes: 32 blocks ->
 // ~4 per wave at 200 k surfels / 1024 nodes); any order gives the same, exact result.
 constexpr int kKnnCap = 12;
+// 512 threads x 1 point: 200k points are 3125 waves (3 per SIMD) instead of the 1563 of 256 threads x 2 points -- the scan is
+// bound by the latency of its LDS broadcasts, not by its instruction count (a filter that cut the node tests to a third changed
+// nothing) -- and the node table (48 KB) is shared by twice the points per workgroup, so two workgroups still fit a CU.
+constexpr int kRefThreads = 512;
+constexpr int kRefPts = 1;
+constexpr int kRefGrp = 4;   // nodes per group of LDS broadcasts in flight (8: no change)
 
 template <int K, int Q>
-__global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
+__global__ void __launch_bounds__(kRefThreads) knn_refine_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
                                                          long long* __restrict__ idx, const float* __restrict__ x2, int D1, int stride2)
 {
     extern __shared__ float4 s_dyn[];
@@ -378,25 +384,25 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
     const int nblk = Mp >> 5;
     float4* s_nodes = s_dyn;                                              // [Mp][Q]
     float4* s_box = s_dyn + (size_t)Mp * Q;                               // [nblk][2]: min, max of the block's nodes (coordinates 0..2)
-    int* s_list = reinterpret_cast<int*>(s_box + 2 * nblk);               // [256 * kKnnPts][kKnnCap]
-    for (int r0 = 0; r0 < Mp; r0 += 1024) {   // see knn_kernel: all loads of a pass in flight before the LDS stores
+    int* s_list = reinterpret_cast<int*>(s_box + 2 * nblk);               // [kRefThreads * kRefPts][kKnnCap]
+    for (int r0 = 0; r0 < Mp; r0 += 4 * kRefThreads) {   // see knn_kernel: all loads of a pass in flight before the LDS stores
         float v[4][4 * Q];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int r = r0 + i * 256 + threadIdx.x;
+            const int r = r0 + i * kRefThreads + threadIdx.x;
 #pragma unroll
             for (int d = 0; d < 4 * Q; d++) v[i][d] = (r < M && d < D) ? nodes[(size_t)r * D + d] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int r = r0 + i * 256 + threadIdx.x;
+            const int r = r0 + i * kRefThreads + threadIdx.x;
             if (r < Mp)
 #pragma unroll
                 for (int q = 0; q < Q; q++) s_nodes[r * Q + q] = make_float4(v[i][4 * q], v[i][4 * q + 1], v[i][4 * q + 2], v[i][4 * q + 3]);
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nblk; b += 256) {
+    for (int b = threadIdx.x; b < nblk; b += kRefThreads) {
         float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
         for (int g = 0; g < 32 && b * 32 + g < M; g++) {
             const float4 nd = s_nodes[(b * 32 + g) * Q];
@@ -407,10 +413,10 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
         s_box[2 * b + 1] = hi;
     }
     __syncthreads();
-    const int p0 = (blockIdx.x * 256 + threadIdx.x) * kKnnPts;
-    float xv[kKnnPts][4 * Q];
-    float T[kKnnPts];
-    int cnt[kKnnPts];
+    const int p0 = (blockIdx.x * kRefThreads + threadIdx.x) * kRefPts;
+    float xv[kRefPts][4 * Q];
+    float T[kRefPts];
+    int cnt[kRefPts];
     auto full_dist = [&](int u, int j) {
         float a = 0.f;
 #pragma unroll
@@ -425,7 +431,7 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
         return a;
     };
 #pragma unroll
-    for (int u = 0; u < kKnnPts; u++) {
+    for (int u = 0; u < kRefPts; u++) {
         const bool in = p0 + u < N;
 #pragma unroll
         for (int d = 0; d < 4 * Q; d++) {
@@ -454,14 +460,14 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
     }
     // ---- scan: 3-D lower bound only.  Branch-free inner loop: the sign of d3 - T' is shifted into a 32-node hit word
     // (v_alignbit), 7 VALU operations per (node, point); the words are drained once per 32 nodes.
-    float Tn[kKnnPts];
+    float Tn[kRefPts];
 #pragma unroll
-    for (int u = 0; u < kKnnPts; u++) Tn[u] = -(T[u] * (1.0f + 1e-6f) + 1e-30f);   // inflated: d3 == T must stay a hit
+    for (int u = 0; u < kRefPts; u++) Tn[u] = -(T[u] * (1.0f + 1e-6f) + 1e-30f);   // inflated: d3 == T must stay a hit
     // box of the wave's search spheres (lanes past N have T = -1: no sphere).  |x_c - n_c| <= sqrt(d3) <= sqrt(-Tn) on every axis
     // for a hit; the radius is rounded up generously, the box only filters
     float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int u = 0; u < kKnnPts; u++)
+    for (int u = 0; u < kRefPts; u++)
         if (T[u] >= 0.f) {
             const float r = sqrtf(-Tn[u]) * 1.0001f + 1e-30f;
 #pragma unroll
@@ -470,36 +476,50 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
                 bhi[c] = fmaxf(bhi[c], xv[u][c] + r);
             }
         }
+    // FOUR boxes per wave, one per 16 lanes: where consecutive points change their nearest node across a jump of the node order,
+    // one box over all 64 lanes spans the jump and touches most of the blocks (mean 8 of 32 but up to 23: those waves set the
+    // kernel's time); the union of four tight boxes does not
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
+        for (int o = 8; o >= 1; o >>= 1) {
             blo[c] = fminf(blo[c], __shfl_xor(blo[c], o));
             bhi[c] = fmaxf(bhi[c], __shfl_xor(bhi[c], o));
         }
     const int lane = threadIdx.x & 63;
+    float qlo[4][3], qhi[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            qlo[q][c] = __shfl(blo[c], 16 * q);
+            qhi[q][c] = __shfl(bhi[c], 16 * q);
+        }
     for (int bb = 0; bb < nblk; bb += 64) {
     bool touch = false;
     if (bb + lane < nblk) {
         const float4 lo = s_box[2 * (bb + lane)], hi = s_box[2 * (bb + lane) + 1];
-        touch = lo.x <= bhi[0] && hi.x >= blo[0] && lo.y <= bhi[1] && hi.y >= blo[1] && lo.z <= bhi[2] && hi.z >= blo[2];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            touch = touch || (lo.x <= qhi[q][0] && hi.x >= qlo[q][0] && lo.y <= qhi[q][1] && hi.y >= qlo[q][1] && lo.z <= qhi[q][2] &&
+                              hi.z >= qlo[q][2]);
     }
     unsigned long long blocks = __ballot(touch);
     while (blocks) {
         const int j0 = (bb + __builtin_ctzll(blocks)) * 32;
         blocks &= blocks - 1;
-        unsigned w[kKnnPts];
+        unsigned w[kRefPts];
 #pragma unroll
-        for (int u = 0; u < kKnnPts; u++) w[u] = 0u;
+        for (int u = 0; u < kRefPts; u++) w[u] = 0u;
 #pragma unroll
-        for (int g0 = 0; g0 < 32; g0 += kKnnGrp) {
-            float4 nd[kKnnGrp];
+        for (int g0 = 0; g0 < 32; g0 += kRefGrp) {
+            float4 nd[kRefGrp];
 #pragma unroll
-            for (int g = 0; g < kKnnGrp; g++) nd[g] = s_nodes[(j0 + g0 + g) * Q];   // wave-uniform: LDS broadcast
+            for (int g = 0; g < kRefGrp; g++) nd[g] = s_nodes[(j0 + g0 + g) * Q];   // wave-uniform: LDS broadcast
 #pragma unroll
-            for (int g = 0; g < kKnnGrp; g++)
+            for (int g = 0; g < kRefGrp; g++)
 #pragma unroll
-                for (int u = 0; u < kKnnPts; u++) {
+                for (int u = 0; u < kRefPts; u++) {
                     float t, a;
                     t = xv[u][0] - nd[g].x; a = fmaf(t, t, Tn[u]);
                     t = xv[u][1] - nd[g].y; a = fmaf(t, t, a);
@@ -509,12 +529,12 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
         }
         const unsigned valid = (M - j0) >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (M - j0));   // node j0 + g <-> bit 31 - g
 #pragma unroll
-        for (int u = 0; u < kKnnPts; u++) {
+        for (int u = 0; u < kRefPts; u++) {
             unsigned ww = w[u] & valid;
             while (ww) {
                 const int lz = __clz(ww);
                 ww &= ~(0x80000000u >> lz);
-                if (cnt[u] < kKnnCap) s_list[(threadIdx.x * kKnnPts + u) * kKnnCap + cnt[u]] = j0 + lz;
+                if (cnt[u] < kKnnCap) s_list[(threadIdx.x * kRefPts + u) * kKnnCap + cnt[u]] = j0 + lz;
                 cnt[u]++;
             }
         }
@@ -522,7 +542,7 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
     }
     // ---- candidates (ascending index, strict < on insertion: ties keep the lower index like the plain scan)
 #pragma unroll
-    for (int u = 0; u < kKnnPts; u++) {
+    for (int u = 0; u < kRefPts; u++) {
         if (p0 + u >= N) continue;
         float bd[K];
         int bi[K];
@@ -531,7 +551,7 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(int N, int M, int D, co
         const bool listed = cnt[u] <= kKnnCap;
         const int n = listed ? cnt[u] : M;
         for (int c = 0; c < n; c++) {
-            const int j = listed ? s_list[(threadIdx.x * kKnnPts + u) * kKnnCap + c] : c;
+            const int j = listed ? s_list[(threadIdx.x * kRefPts + u) * kKnnCap + c] : c;
             const float dj = full_dist(u, j);
             if (dj < bd[K - 1]) {
                 bd[K - 1] = dj; bi[K - 1] = j;
@@ -553,10 +573,10 @@ template <int K, int Q>
 int launch_knn_refine_q(int N, int M, int D, const float* x, const float* nodes, long long* idx, hipStream_t s, const float* x2, int D1,
                         int stride2)
 {
-    const int per_block = 256 * kKnnPts;
+    const int per_block = kRefThreads * kRefPts;
     const size_t lds = (size_t)((M + 31) & ~31) * Q * sizeof(float4) + (size_t)((M + 31) >> 5) * 2 * sizeof(float4) +
-                       (size_t)256 * kKnnPts * kKnnCap * sizeof(int);
-    hipLaunchKernelGGL((knn_refine_kernel<K, Q>), dim3((N + per_block - 1) / per_block), dim3(256), lds, s, N, M, D, x, nodes, idx, x2, D1,
+                       (size_t)kRefThreads * kRefPts * kKnnCap * sizeof(int);
+    hipLaunchKernelGGL((knn_refine_kernel<K, Q>), dim3((N + per_block - 1) / per_block), dim3(kRefThreads), lds, s, N, M, D, x, nodes, idx, x2, D1,
                        stride2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("knn_refine_kernel: ") + hipGetErrorString(e));

@@ -46,3 +46,18 @@ blo, bhi = nb.min(1).values, nb.max(1).values
 touch = ((blo[None] <= hi[:, None]) & (bhi[None] >= lo[:, None])).all(-1).sum(1)
 print("32-node blocks touched per wave (of %d): mean %.1f  p50 %d  p99 %d  max %d" % (M // 32, touch.float().mean(), touch.median(),
                                                                                       touch.float().quantile(0.99), touch.max()))
+# would a per-node neighbour list certify the seed?  a = the seed nearest in 3-D, r = sqrt(T); every candidate n has
+# |n - a| <= r + |x - a|, so if that is below R_a (3-D distance from a to the first node NOT in its list of L nearest nodes) the
+# list holds all candidates
+n3 = nodes[:, :3]
+dn = torch.cdist(n3.double(), n3.double())
+dn_sorted = dn.sort(1).values
+d3seed = torch.stack([(x - n3[seed[:, k]]).norm(dim=1) for k in range(3)], 1)
+a = seed.gather(1, d3seed.argmin(1, keepdim=True)).squeeze(1)
+need = r + d3seed.min(1).values
+for L in (32, 48, 64, 96):
+    Ra = dn_sorted[:, L].float()[a]
+    ok = need < Ra
+    wave_ok = ok[:N // 128 * 128].view(-1, 128).all(1)
+    print("list of %3d nodes: certifies %.2f %% of the points, %.2f %% of the waves (mean R_a %.3f, mean need %.3f)" % (
+        L, 100 * ok.float().mean(), 100 * wave_ok.float().mean(), Ra.mean(), need.mean()))
