@@ -368,9 +368,8 @@ int launch_knn(int N, int M, int D, const float* x, const float* nodes, long lon
 // order of their nearest node and nodes stored along a space-filling curve (Trainer.sort_surfels / sort_nodes: 32 blocks ->
 // ~4 per wave at 200 k surfels / 1024 nodes); any order gives the same, exact result.
 constexpr int kKnnCap = 12;
-// 512 threads x 1 point: 200k points are 3125 waves (3 per SIMD) instead of the 1563 of 256 threads x 2 points -- the scan is
-// bound by the latency of its LDS broadcasts, not by its instruction count (a filter that cut the node tests to a third changed
-// nothing) -- and the node table (48 KB) is shared by twice the points per workgroup, so two workgroups still fit a CU.
+// 512 threads x 1 point: 200k points are 3125 waves (3 per SIMD) instead of the 1563 of 256 threads x 2 points, and the node
+// table (48 KB) is shared by twice the points per workgroup, so two workgroups still fit a CU.
 constexpr int kRefThreads = 512;
 constexpr int kRefPts = 1;
 constexpr int kRefGrp = 4;   // nodes per group of LDS broadcasts in flight (8: no change)
@@ -479,22 +478,26 @@ __global__ void __launch_bounds__(kRefThreads) knn_refine_kernel(int N, int M, i
     // FOUR boxes per wave, one per 16 lanes: where consecutive points change their nearest node across a jump of the node order,
     // one box over all 64 lanes spans the jump and touches most of the blocks (mean 8 of 32 but up to 23: those waves set the
     // kernel's time); the union of four tight boxes does not
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) {
-            blo[c] = fminf(blo[c], __shfl_xor(blo[c], o));
-            bhi[c] = fmaxf(bhi[c], __shfl_xor(bhi[c], o));
-        }
+    // min / max over each row of 16 lanes with DPP row shifts (lane 15 of a row ends up with the row's result; a lane without a
+    // source keeps its own value), then the four results to scalar registers: no LDS traffic (48 ds_bpermute before)
     const int lane = threadIdx.x & 63;
     float qlo[4][3], qhi[4][3];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int c = 0; c < 3; c++) {
+        float lo = blo[c], hi = bhi[c];
+#define KNN_ROW_STEP(n)                                                                                                                   \
+        lo = fminf(lo, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lo), __builtin_bit_cast(int, lo),   \
+                                                                             0x110 + (n), 0xf, 0xf, false)));                             \
+        hi = fmaxf(hi, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, hi), __builtin_bit_cast(int, hi),   \
+                                                                             0x110 + (n), 0xf, 0xf, false)))
+        KNN_ROW_STEP(1); KNN_ROW_STEP(2); KNN_ROW_STEP(4); KNN_ROW_STEP(8);
+#undef KNN_ROW_STEP
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            qlo[q][c] = __shfl(blo[c], 16 * q);
-            qhi[q][c] = __shfl(bhi[c], 16 * q);
+        for (int q = 0; q < 4; q++) {
+            qlo[q][c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 16 * q + 15));
+            qhi[q][c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 16 * q + 15));
         }
+    }
     for (int bb = 0; bb < nblk; bb += 64) {
     bool touch = false;
     if (bb + lane < nblk) {
@@ -508,34 +511,50 @@ __global__ void __launch_bounds__(kRefThreads) knn_refine_kernel(int N, int M, i
     while (blocks) {
         const int j0 = (bb + __builtin_ctzll(blocks)) * 32;
         blocks &= blocks - 1;
+        // ONE LDS read per block: lane g fetches node j0 + g (a wave-wide broadcast read of a node occupies the LDS pipe like any
+        // other 1-KB read, and 32 of them per block were what bounded the scan: 28 us whatever the instruction count).  Lane g also
+        // tests its node against the wave's boxes once for all lanes; the survivors (a third of a touched block) go to scalar
+        // registers (v_readlane) and are tested per point
+        float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool inb = false;
+        if (lane < 32 && j0 + lane < M) {
+            mine = s_nodes[(j0 + lane) * Q];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                inb = inb || (mine.x >= qlo[q][0] && mine.x <= qhi[q][0] && mine.y >= qlo[q][1] && mine.y <= qhi[q][1] &&
+                              mine.z >= qlo[q][2] && mine.z <= qhi[q][2]);
+        }
+        const unsigned sv = (unsigned)__ballot(inb);   // bit g <-> node j0 + g
+        if (sv == 0u) continue;
+        const int ns = __builtin_popcount(sv);
         unsigned w[kRefPts];
 #pragma unroll
         for (int u = 0; u < kRefPts; u++) w[u] = 0u;
+        for (unsigned m = sv; m; m &= m - 1) {
+            const int g = __builtin_ctz(m);
+            const float nx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), g));
+            const float ny = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), g));
+            const float nz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), g));
 #pragma unroll
-        for (int g0 = 0; g0 < 32; g0 += kRefGrp) {
-            float4 nd[kRefGrp];
-#pragma unroll
-            for (int g = 0; g < kRefGrp; g++) nd[g] = s_nodes[(j0 + g0 + g) * Q];   // wave-uniform: LDS broadcast
-#pragma unroll
-            for (int g = 0; g < kRefGrp; g++)
-#pragma unroll
-                for (int u = 0; u < kRefPts; u++) {
-                    float t, a;
-                    t = xv[u][0] - nd[g].x; a = fmaf(t, t, Tn[u]);
-                    t = xv[u][1] - nd[g].y; a = fmaf(t, t, a);
-                    t = xv[u][2] - nd[g].z; a = fmaf(t, t, a);
-                    w[u] = __builtin_amdgcn_alignbit(w[u], __float_as_uint(a), 31);   // (w << 1) | sign(a)
-                }
+            for (int u = 0; u < kRefPts; u++) {
+                float t, a;
+                t = xv[u][0] - nx; a = fmaf(t, t, Tn[u]);
+                t = xv[u][1] - ny; a = fmaf(t, t, a);
+                t = xv[u][2] - nz; a = fmaf(t, t, a);
+                w[u] = __builtin_amdgcn_alignbit(w[u], __float_as_uint(a), 31);   // (w << 1) | sign(a): k-th survivor -> bit ns - 1 - k
+            }
         }
-        const unsigned valid = (M - j0) >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (M - j0));   // node j0 + g <-> bit 31 - g
 #pragma unroll
         for (int u = 0; u < kRefPts; u++) {
-            unsigned ww = w[u] & valid;
-            while (ww) {
-                const int lz = __clz(ww);
-                ww &= ~(0x80000000u >> lz);
-                if (cnt[u] < kKnnCap) s_list[(threadIdx.x * kRefPts + u) * kKnnCap + cnt[u]] = j0 + lz;
-                cnt[u]++;
+            if (w[u] == 0u) continue;
+            unsigned mm = sv;
+            for (int k = ns - 1; mm; k--) {
+                const int g = __builtin_ctz(mm);
+                mm &= mm - 1;
+                if ((w[u] >> k) & 1u) {
+                    if (cnt[u] < kKnnCap) s_list[(threadIdx.x * kRefPts + u) * kKnnCap + cnt[u]] = j0 + g;
+                    cnt[u]++;
+                }
             }
         }
     }
