@@ -526,10 +526,6 @@ __global__ void __launch_bounds__(kRefThreads) knn_refine_kernel(int N, int M, i
         }
         const unsigned sv = (unsigned)__ballot(inb);   // bit g <-> node j0 + g
         if (sv == 0u) continue;
-        const int ns = __builtin_popcount(sv);
-        unsigned w[kRefPts];
-#pragma unroll
-        for (int u = 0; u < kRefPts; u++) w[u] = 0u;
         for (unsigned m = sv; m; m &= m - 1) {
             const int g = __builtin_ctz(m);
             const float nx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), g));
@@ -541,17 +537,7 @@ __global__ void __launch_bounds__(kRefThreads) knn_refine_kernel(int N, int M, i
                 t = xv[u][0] - nx; a = fmaf(t, t, Tn[u]);
                 t = xv[u][1] - ny; a = fmaf(t, t, a);
                 t = xv[u][2] - nz; a = fmaf(t, t, a);
-                w[u] = __builtin_amdgcn_alignbit(w[u], __float_as_uint(a), 31);   // (w << 1) | sign(a): k-th survivor -> bit ns - 1 - k
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kRefPts; u++) {
-            if (w[u] == 0u) continue;
-            unsigned mm = sv;
-            for (int k = ns - 1; mm; k--) {
-                const int g = __builtin_ctz(mm);
-                mm &= mm - 1;
-                if ((w[u] >> k) & 1u) {
+                if (a < 0.f) {   // a candidate of this point (3 per point on average: the branch is skipped by most waves)
                     if (cnt[u] < kKnnCap) s_list[(threadIdx.x * kRefPts + u) * kKnnCap + cnt[u]] = j0 + g;
                     cnt[u]++;
                 }
