@@ -384,20 +384,36 @@ __global__ void __launch_bounds__(kRefThreads) knn_refine_kernel(int N, int M, i
     float4* s_nodes = s_dyn;                                              // [Mp][Q]
     float4* s_box = s_dyn + (size_t)Mp * Q;                               // [nblk][2]: min, max of the block's nodes (coordinates 0..2)
     int* s_list = reinterpret_cast<int*>(s_box + 2 * nblk);               // [kRefThreads * kRefPts][kKnnCap]
-    for (int r0 = 0; r0 < Mp; r0 += 4 * kRefThreads) {   // see knn_kernel: all loads of a pass in flight before the LDS stores
-        float v[4][4 * Q];
+    // node table -> LDS rows of 4 Q floats (zero padded).  The table is read as a flat stream of 16-byte vectors (a 4-byte load
+    // occupies the address unit as long as a 16-byte one: 24 loads per thread became 6) and scattered into the padded rows
+    {
+        float* s_f = reinterpret_cast<float*>(s_nodes);
+        const int F = M * D, nvec = (reinterpret_cast<size_t>(nodes) & 15) == 0 ? F >> 2 : 0;
+        for (int r = threadIdx.x; r < Mp; r += kRefThreads)
+            for (int c = (r < M ? D : 0); c < 4 * Q; c++) s_f[r * 4 * Q + c] = 0.f;
+        for (int base = 0; base < nvec; base += 8 * kRefThreads) {
+            float4 q[8];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r = r0 + i * kRefThreads + threadIdx.x;
+            for (int i = 0; i < 8; i++) {
+                const int v = base + i * kRefThreads + threadIdx.x;
+                q[i] = v < nvec ? reinterpret_cast<const float4*>(nodes)[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-            for (int d = 0; d < 4 * Q; d++) v[i][d] = (r < M && d < D) ? nodes[(size_t)r * D + d] : 0.f;
+            for (int i = 0; i < 8; i++) {
+                const int v = base + i * kRefThreads + threadIdx.x;
+                if (v >= nvec) continue;
+                int r = (4 * v) / D, c = 4 * v - r * D;
+                const float e[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    s_f[r * 4 * Q + c] = e[k];
+                    if (++c == D) { c = 0; r++; }
+                }
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r = r0 + i * kRefThreads + threadIdx.x;
-            if (r < Mp)
-#pragma unroll
-                for (int q = 0; q < Q; q++) s_nodes[r * Q + q] = make_float4(v[i][4 * q], v[i][4 * q + 1], v[i][4 * q + 2], v[i][4 * q + 3]);
+        for (int e = 4 * nvec + threadIdx.x; e < F; e += kRefThreads) {   // the last F % 4 elements, or all of an unaligned table
+            const int r = e / D, c = e - r * D;
+            s_f[r * 4 * Q + c] = nodes[e];
         }
     }
     __syncthreads();
