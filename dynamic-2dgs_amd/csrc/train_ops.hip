@@ -417,15 +417,33 @@ __global__ void __launch_bounds__(kRefThreads) knn_refine_kernel(int N, int M, i
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nblk; b += kRefThreads) {
-        float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
-        for (int g = 0; g < 32 && b * 32 + g < M; g++) {
-            const float4 nd = s_nodes[(b * 32 + g) * Q];
-            lo.x = fminf(lo.x, nd.x); lo.y = fminf(lo.y, nd.y); lo.z = fminf(lo.z, nd.z);
-            hi.x = fmaxf(hi.x, nd.x); hi.y = fmaxf(hi.y, nd.y); hi.z = fmaxf(hi.z, nd.z);
+    // bounding boxes of the 32-node blocks: 16 lanes per block, two nodes each, min / max over the row of 16 with DPP shifts
+    // (32 threads walking 32 nodes each left the other 480 waiting at the barrier)
+    for (int b = threadIdx.x >> 4; b < nblk; b += kRefThreads >> 4) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = b * 32 + 2 * (threadIdx.x & 15) + h;
+            if (j < M) {
+                const float4 nd = s_nodes[j * Q];
+                lo[0] = fminf(lo[0], nd.x); lo[1] = fminf(lo[1], nd.y); lo[2] = fminf(lo[2], nd.z);
+                hi[0] = fmaxf(hi[0], nd.x); hi[1] = fmaxf(hi[1], nd.y); hi[2] = fmaxf(hi[2], nd.z);
+            }
         }
-        s_box[2 * b] = lo;
-        s_box[2 * b + 1] = hi;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#define KNN_ROW_STEP(n)                                                                                                                         \
+            lo[c] = fminf(lo[c], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lo[c]), __builtin_bit_cast(int, lo[c]), \
+                                                                                       0x110 + (n), 0xf, 0xf, false)));                         \
+            hi[c] = fmaxf(hi[c], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, hi[c]), __builtin_bit_cast(int, hi[c]), \
+                                                                                       0x110 + (n), 0xf, 0xf, false)))
+            KNN_ROW_STEP(1); KNN_ROW_STEP(2); KNN_ROW_STEP(4); KNN_ROW_STEP(8);
+#undef KNN_ROW_STEP
+        }
+        if ((threadIdx.x & 15) == 15) {
+            s_box[2 * b] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            s_box[2 * b + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
     }
     __syncthreads();
     const int p0 = (blockIdx.x * kRefThreads + threadIdx.x) * kRefPts;
