@@ -1,6 +1,8 @@
+# Bench lines (metric with CPU baseline, C2-C4), kernel stats, per-step summary and timeline of the final code -> gpurun_out/r02_c_*
+# (PMC=1: also the counter passes of the C5 workload; the metric's are taken by tools/round_artifacts.sh)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=r02_c
 cd $R
-bash tools/pmc_kernels.sh r02_blend_c5 "dgs::blend" c5 2>&1 | tail -2
+[ "$PMC" = "1" ] && bash tools/pmc_kernels.sh r02_blend_c5 "dgs::blend" c5 2>&1 | tail -2   # only when the rasterizer library changed
 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; tail -c 200 $O/${TAG}_bench_line.json; echo
 for w in c2 c3 c4; do timeout 300 python bench.py --workload $w --no-cpu-baseline > $O/${TAG}_bench_line_$w.json 2>/dev/null; done
 cd /tmp && export TMPDIR=/tmp
