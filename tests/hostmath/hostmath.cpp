@@ -173,13 +173,14 @@ static inline bool wave_sees(int w, const float* r, float px0, float py0)
     const float yf = py0 + 4.0f * w + 0.5f;
     return r[21] >= px0 + 0.5f && r[20] <= px0 + 15.5f && r[23] >= yf && r[22] <= yf + 3.0f;
 }
-extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*12*/)
+extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*16*/)
 {
     // per (tile, entry, 16x4 strip) with the wave still alive: visited = the entry's pixel box touches the strip (what the
     // kernels evaluate); any = some pixel passes the alpha test; blend = some live pixel blends it
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     double S = 0, strip_pairs = 0, strip_any = 0, pix_pairs = 0, pix_pass = 0, pix_blend = 0, strip_blend_any = 0;
     double visited = 0, visited_any = 0, visited_blend = 0, visited_pix_blend = 0, missed = 0;
+    double sub44 = 0, sub84 = 0, sub44_pass = 0;   // 4x4 / 8x4 sub-blocks of a blending (wave, entry) visit that hold a blending (passing) pixel
     for (int ty = 0; ty < tiles_y; ty++)
         for (int tx = 0; tx < tiles_x; tx++) {
             const int tile = ty * tiles_x + tx;
@@ -197,6 +198,7 @@ extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint3
                     strip_pairs += 1;
                     const bool vis = wave_sees(w, r, (float)(tx * 16), (float)(ty * 16));
                     int any = 0, anyb = 0, nb = 0;
+                    unsigned m44 = 0, m84 = 0, m44p = 0;
                     for (int k = 0; k < 64; k++) {
                         const int i = lane_of(w, k);
                         if (!inside[i]) continue;
@@ -204,11 +206,13 @@ extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint3
                         PairEval ev;
                         const float pfx = tx * 16 + (i & 15) + 0.5f, pfy = ty * 16 + (i >> 4) + 0.5f;
                         bool ok = pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev);
-                        if (ok) { pix_pass += 1; any = 1; }
+                        if (ok) { pix_pass += 1; any = 1; m44p |= 1u << (((k >> 3) >> 2) * 2 + ((k & 7) >> 2)); }
+                        if (ok && !done[i]) { m44 |= 1u << (((k >> 3) >> 2) * 2 + ((k & 7) >> 2)); m84 |= 1u << ((k >> 3) >> 2); }
                         if (ok && !done[i]) { anyb = 1; nb++; pix_blend += 1; st[i].contributor = e - r0 + 1; if (!pixfwd_blend(st[i], ev, Q(r, 3), Q(r, 4))) done[i] = true; }
                     }
                     strip_any += any; strip_blend_any += anyb;
-                    if (vis) { visited += 1; visited_any += any; visited_blend += anyb; visited_pix_blend += nb; }
+                    if (vis) { visited += 1; visited_any += any; visited_blend += anyb; visited_pix_blend += nb;
+                               sub44 += __builtin_popcount(m44); sub84 += __builtin_popcount(m84); sub44_pass += __builtin_popcount(m44p); }
                     else if (anyb) missed += 1;
                 }
             }
@@ -216,4 +220,5 @@ extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint3
         }
     out[0] = S; out[1] = strip_pairs; out[2] = strip_any; out[3] = pix_pairs; out[4] = pix_pass; out[5] = pix_blend; out[6] = strip_blend_any;
     out[7] = visited; out[8] = visited_any; out[9] = visited_blend; out[10] = visited_pix_blend; out[11] = missed;
+    out[12] = sub44; out[13] = sub84; out[14] = sub44_pass;
 }

@@ -21,10 +21,13 @@ ranges, plist = orc.field("ranges"), orc.field("point_list")
 print("mean radius %.1f px, R(ref lists) %d" % (radii[radii > 0].mean(), orc.num_rendered))
 for shape, name in ((0, "16x4 strips, box"), (2, "8x8 quadrants, box"), (1, "8x8 quadrants, box + conic (the kernels)")):
   hm.hm_set_shape(shape)
-  out = np.zeros(12)
+  out = np.zeros(16)
   hm.hm_blend_stats(W, H, p(np.ascontiguousarray(ranges)), p(np.ascontiguousarray(plist)), p(rec), p(out))
-  S, sp, sa, pp, ppass, pb, sba, vis, visany, visb, vispb, missed = out
+  S, sp, sa, pp, ppass, pb, sba, vis, visany, visb, vispb, missed = out[:12]
   print("---- wave shape", name, " S", S)
   print("strip pairs (alive) %d ; visited by mask %d (%.1f%%) ; of visited: any pixel passes %.1f%%, some live pixel blends %.1f%% ; missed %d"
       % (sp, vis, 100 * vis / sp, 100 * visany / vis, 100 * visb / vis, missed))
   print("lanes blending per blending (strip,entry): %.1f of 64 ; blending (strip,entry) pairs %d" % (vispb / max(visb, 1), visb))
+  if g_shape_is_quadrant := (shape >= 1):
+      print("of the 4 4x4 sub-blocks of a visited quadrant: %.2f hold a blending pixel (%.2f a passing one); of the 2 8x4 halves: %.2f"
+            % (out[12] / max(vis, 1), out[14] / max(vis, 1), out[13] / max(vis, 1)))
