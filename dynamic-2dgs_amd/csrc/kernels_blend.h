@@ -2,22 +2,31 @@
 //
 // One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 8x8 pixel quadrant (w & 1, w >> 1) of the
 // tile (surfel_math.h lane_pixel), so all 64 lanes of a wave consume the same staged surfel at the same time.
-// The tile's depth-sorted list is consumed in batches of 256 entries whose packed 96-B records are gathered
-// into LDS as five float4 planes (20 KB; the sixth quad, the surfel's exact pixel bounding box, is consumed at
-// staging time: each entry is tested against the four 8x8 quadrants and the four per-quadrant ballots become 64-bit
-// masks, so a wave only visits the entries whose box touches its quadrant).  The inner loop reads the planes with
-// wave-uniform addresses (LDS broadcast, conflict free).  Replaces renderCUDA of forward.cu:265-463 and
-// backward.cu:143-449.
+// The tile's depth-sorted list is consumed in batches of 256 entries.  The thread that stages an entry gathers its packed
+// 96-B record and turns it into the entry's AFFINE image for this tile (surfel_math.h tile_affine: p = A + dxs B + dys C
+// around the projected centre -- 6 FMAs per pixel instead of 12 operations) -- three float4 planes for the alpha test, then
+// Tw, normal and colour planes that are only read when some pixel blends the entry (22.5 KB forward, 27.5 KB backward).  The
+// record's sixth quad, the surfel's exact pixel bounding box, is consumed at staging time: each entry is tested against the
+// four 8x8 quadrants and the four per-quadrant ballots become 64-bit masks, so a wave only visits the entries whose footprint
+// touches its quadrant.  The inner loop reads the planes with wave-uniform addresses (LDS broadcast, conflict free).
+// Replaces renderCUDA of forward.cu:265-463 and backward.cu:143-449.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "surfel_math.h"
 #include "wave_reduce.h"
 
 namespace dgs {
 
+#ifndef DGS_FWD_MINWAVES
+#define DGS_FWD_MINWAVES 1
+#endif
+#ifndef DGS_PIN_PREFETCH
+#define DGS_PIN_PREFETCH 1
+#endif
 constexpr int kBatch = 256;
-constexpr int kStagedQuads = 5;  // q0..q4 go to LDS, q5 (bounding box) is consumed while staging
 
 __device__ __forceinline__ Quad as_quad(const float4& v) { return Quad{v.x, v.y, v.z, v.w}; }
 
@@ -250,9 +259,18 @@ inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
     return ((tiles_y + 7) / 8) * tiles_x * 8;
 }
 
-__global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
+// What the instruction mix of the loop below costs on gfx950 (tools/micro/valu_issue_bench, profiles/r03_valu_issue_gfx950.txt):
+// FMA / mul / add with VGPR operands 2.5 cycles per wave, anything with an SGPR operand, comparisons, min/max, selects 4.4-4.8,
+// v_rcp / v_exp 8.5-12.7, and every scalar instruction takes one of the CU's ~1 per cycle scalar issue slots.  So the visit is
+// built from plain FMAs on VGPR operands (entry constants arrive through LDS broadcasts, not SGPRs), one comparison decides the
+// alpha test (alpha_affine), finished and outside pixels are poisoned with NaN coordinates instead of being masked, and the
+// median bookkeeping is skipped once no pixel of the wave has T > 0.5.
+__global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(BlendFwdArgs a)
 {
-    __shared__ float4 s_rec[kStagedQuads][kBatch];
+    __shared__ float4 s_a[3][kBatch];   // alpha part of the entry's affine image (tile_affine)
+    __shared__ float4 s_tw[kBatch];     // (Tw.x Tw.y Tw.z -)
+    __shared__ float4 s_q3[kBatch];     // (n.x n.y n.z r)
+    __shared__ float2 s_q4[kBatch];     // (g b)
     __shared__ unsigned long long s_bits[4][4];  // [quadrant][chunk of 64 entries]
     __shared__ int s_flag[4];
     __shared__ uint32_t s_max[4];
@@ -268,8 +286,11 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
     lane_pixel(tid, lx_, ly_);
     const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
     const bool inside = px < a.W && py < a.H;
-    const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
     const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
+    const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
+    // sqrt2 x (pixel - tile centre); NaN = this pixel takes no further entry (outside the image, or saturated)
+    float us = inside ? kSqrt2 * ((float)lx_ - 7.5f) : __builtin_nanf("");
+    const float vs = kSqrt2 * ((float)ly_ - 7.5f);
 
     const uint2 range = a.ranges[tile];
     int todo = (int)(range.y - range.x);
@@ -277,11 +298,11 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
 
     PixFwd st;
     pixfwd_init(st);
-    bool done = !inside;
+    unsigned long long alive = __ballot(inside);   // lanes that still take entries (wave-uniform)
 
     for (int b = 0; b < rounds; b++, todo -= kBatch) {
         // workgroup vote: leave when all four waves have finished (forward.cu:334-336)
-        const bool wave_done = (__ballot(!done) == 0ull);
+        const bool wave_done = alive == 0ull;
         if (lane == 0) s_flag[wave] = wave_done ? 1 : 0;
         __syncthreads();  // also fences the previous batch's LDS reads
         if (s_flag[0] & s_flag[1] & s_flag[2] & s_flag[3]) break;
@@ -291,14 +312,16 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
         if (tid < n) {
             const uint32_t id = a.point_list[range.x + (uint32_t)(b * kBatch + tid)];
             const float4* src = a.rec + (size_t)id * kRecQuads;
-            float4 q[kStagedQuads];
-#pragma unroll
-            for (int c = 0; c < kStagedQuads; c++) q[c] = src[c];
-            const float4 bx = src[5];
-#pragma unroll
-            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = q[c];
+            const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
+            const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+            s_a[0][tid] = make_float4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+            s_a[1][tid] = make_float4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+            s_a[2][tid] = make_float4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+            s_tw[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
+            s_q3[tid] = q3;
+            s_q4[tid] = make_float2(q4.x, q4.y);
             // which of the tile's four 8x8 quadrants can this entry touch: bounding box, refined by the exact footprint
-            smask = quad_mask_conic(as_quad(q[0]), as_quad(q[1]), as_quad(q[2]), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
+            smask = quad_mask_conic(as_quad(q0), as_quad(q1), as_quad(q2), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -308,45 +331,61 @@ __global__ void __launch_bounds__(kTilePix) blend_fwd_kernel(BlendFwdArgs a)
         __syncthreads();
 
         if (!wave_done) {
-            // Visit, in list order, only the entries whose box touches this wave's quadrant.  The alpha part (q0..q2) of
-            // the next visited entry is prefetched while the current one is evaluated branch-free for all 64 lanes;
-            // a single wave-uniform branch skips the blend when no lane passes.
-            const uint32_t base = (uint32_t)(b * kBatch);
-            bool stop = false;
-            for (int c = 0; c < 4 && !stop; c++) {
-                unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
-                if (m == 0ull) continue;
-                // Two register sets (a*, b*) alternate as "current" and "prefetched": a single set would be rotated with
-                // six 64-bit moves per entry (8 % of the loop's VALU work).
-                auto visit = [&](const float4& q0, const float4& q1, const float4& q2, int jc) -> bool {
-                    PairEval e;
-                    const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), e) && !done;
-                    if (__ballot(ok) == 0ull) return false;
-                    if (ok) {
-                        st.contributor = base + (uint32_t)jc + 1u;  // 1-based list position (forward.cu:356)
-                        if (!pixfwd_blend(st, e, as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]))) done = true;
-                    }
-                    return __ballot(!done) == 0ull;  // wave-level early out
-                };
-                int ja = c * 64 + __builtin_ctzll(m), jb = 0;
-                float4 a0 = s_rec[0][ja], a1 = s_rec[1][ja], a2 = s_rec[2][ja], b0, b1, b2;
-                b0 = b1 = b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            // Visit, in list order, only the entries whose footprint touches this wave's quadrant.
+            const uint32_t base = (uint32_t)(b * kBatch) + 1u;   // 1-based list position of batch entry 0 (forward.cu:356)
+            auto chunk = [&](auto track_median, int c, unsigned long long m) {
+                int j = c * 64 + __builtin_ctzll(m);
+                float4 a0 = s_a[0][j], a1 = s_a[1][j], a2 = s_a[2][j];
                 while (true) {
+                    AlphaEval e;
+                    bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
+                    // The next visited entry's alpha part is requested as soon as this one's has been consumed, INTO THE SAME
+                    // registers (the empty asm pins the order: without it the compiler hoists the loads above the evaluation,
+                    // needs a second register set and pays twelve moves per visit to rotate it).
+#if DGS_PIN_PREFETCH
+                    asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");
+#endif
+                    const int jc = j;
                     m &= m - 1ull;
-                    if (m != 0ull) {
-                        jb = c * 64 + __builtin_ctzll(m);
-                        b0 = s_rec[0][jb]; b1 = s_rec[1][jb]; b2 = s_rec[2][jb];
+                    const bool more = m != 0ull;
+                    if (more) {
+                        j = c * 64 + __builtin_ctzll(m);
+                        a0 = s_a[0][j]; a1 = s_a[1][j]; a2 = s_a[2][j];
                     }
-                    if (visit(a0, a1, a2, ja)) { stop = true; break; }
-                    if (m == 0ull) break;
-                    m &= m - 1ull;
-                    if (m != 0ull) {
-                        ja = c * 64 + __builtin_ctzll(m);
-                        a0 = s_rec[0][ja]; a1 = s_rec[1][ja]; a2 = s_rec[2][ja];
+                    const unsigned long long okm = __ballot(ok);
+                    if (okm != 0ull) {
+                        const float4 tw = s_tw[jc];
+                        bool use3d;
+                        const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
+                        float w, test_T;
+                        pixfwd_weight(st, e.alpha, w, test_T);
+                        const bool near_ok = depth >= kNear;      // forward.cu:388 (float 0.2f: same set as (double)depth < 0.2)
+                        const bool sat_t = test_T < kTmin;
+                        ok = ok & near_ok;
+                        const bool blend = ok & !sat_t;
+                        if (blend) {
+                            st.contributor = base + (uint32_t)jc;
+                            const float4 q3 = s_q3[jc];
+                            const float2 q4 = s_q4[jc];
+                            pixfwd_accumulate<decltype(track_median)::value>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
+                        }
+                        // (ballots of the three comparisons themselves: a ballot of their conjunction goes through a VGPR)
+                        const unsigned long long satm = okm & __ballot(near_ok) & __ballot(sat_t);
+                        if (satm != 0ull) {   // some pixel saturated (forward.cu:402-406): it takes no further entry; wave-level early out
+                            if (ok & !blend) us = __builtin_nanf("");
+                            alive &= ~satm;
+                            if (alive == 0ull) break;
+                        }
                     }
-                    if (visit(b0, b1, b2, jb)) { stop = true; break; }
-                    if (m == 0ull) break;
+                    if (!more) break;
                 }
+            };
+            for (int c = 0; c < 4 && alive != 0ull; c++) {
+                const unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
+                if (m == 0ull) continue;
+                // median bookkeeping (forward.cu:421-425) only while some pixel of the wave still has T > 0.5
+                if (__ballot(st.T > 0.5f && us == us) != 0ull) chunk(std::true_type{}, c, m);
+                else chunk(std::false_type{}, c, m);
             }
         }
     }
@@ -536,7 +575,11 @@ __device__ __forceinline__ float wave_sum(float v)
 template <bool DET>
 __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
 {
-    __shared__ float4 s_rec[kStagedQuads][kBatch];
+    __shared__ float4 s_a[3][kBatch];   // alpha part of the entry's affine image (tile_affine)
+    __shared__ float4 s_tw[kBatch];     // (Tw.x Tw.y Tw.z opacity)
+    __shared__ float4 s_tuv[kBatch];    // (Tu.x Tu.y Tv.x Tv.y): k.xy, l.xy of a pixel are rebuilt from them
+    __shared__ float4 s_q3[kBatch];     // (n.x n.y n.z r)
+    __shared__ float2 s_q4[kBatch];     // (g b)
     __shared__ uint32_t s_id[kBatch];
     __shared__ unsigned long long s_bits[4][4];
 
@@ -555,11 +598,13 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
     const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
+    const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
+    const float us = kSqrt2 * ((float)lx_ - 7.5f), vs = kSqrt2 * ((float)ly_ - 7.5f);
     const uint2 range = a.ranges[tile];
 
     const size_t plane = (size_t)ntiles * kTilePix;
     const size_t slot = (size_t)tile * kTilePix + tid;
-    PixBwd st;
+    PixBwdA st;
     {
         float gpix[3] = {0.f, 0.f, 0.f}, goth[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (inside) {
@@ -572,8 +617,8 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
         }
         const int last = inside ? (int)a.n_contrib[slot] : 0;
         const int medc = inside ? (int)a.n_contrib[plane + slot] : 0;
-        pixbwd_init(st, inside ? a.final_T[slot] : 0.f, a.final_T[plane + slot], a.final_T[2 * plane + slot], last, medc, gpix,
-                    goth, a.bg);
+        pixbwd_init_affine(st, inside ? a.final_T[slot] : 0.f, a.final_T[plane + slot], a.final_T[2 * plane + slot], last, medc, gpix,
+                           goth, a.bg);
     }
     // highest entry any lane of this wave needs
     int wave_last = st.last_contributor;
@@ -595,14 +640,17 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
             const uint32_t id = a.point_list[range.x + (uint32_t)e_mine];
             s_id[tid] = id;
             const float4* src = a.rec + (size_t)id * kRecQuads;
-            float4 q[kStagedQuads];
-#pragma unroll
-            for (int c = 0; c < kStagedQuads; c++) q[c] = src[c];
-            const float4 bx = src[5];
-#pragma unroll
-            for (int c = 0; c < kStagedQuads; c++) s_rec[c][tid] = q[c];
+            const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
+            const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+            s_a[0][tid] = make_float4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+            s_a[1][tid] = make_float4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+            s_a[2][tid] = make_float4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+            s_tw[tid] = make_float4(q1.z, q1.w, q2.x, q2.w);
+            s_tuv[tid] = make_float4(q0.x, q0.y, q0.w, q1.x);
+            s_q3[tid] = q3;
+            s_q4[tid] = make_float2(q4.x, q4.y);
             // which of the tile's four 8x8 quadrants can this entry touch: bounding box, refined by the exact footprint
-            smask = quad_mask_conic(as_quad(q[0]), as_quad(q[1]), as_quad(q[2]), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
+            smask = quad_mask_conic(as_quad(q0), as_quad(q1), as_quad(q2), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -618,50 +666,52 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
             unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
             if (j0 > c * 64) m &= ~((1ull << (j0 - c * 64)) - 1ull);
             if (m == 0ull) continue;
-            // two alternating register sets for the current / prefetched entry (see blend_fwd_kernel)
-            auto visit = [&](const float4& q0, const float4& q1, const float4& q2, int jc) {
-                const int e = L - 1 - (b * kBatch + jc);  // 0-based list index == the reference's `contributor`
-                PairEval ev;
-                const bool ok = pair_eval_bf(pfx, pfy, as_quad(q0), as_quad(q1), as_quad(q2), ev) && (e < st.last_contributor);
-                if (__ballot(ok) == 0ull) return;
-                // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step)
-                float out[16], out2d[2];
-                pixbwd_step(st, ev, ok, e, pfx, pfy, as_quad(q1), as_quad(q2), as_quad(s_rec[3][jc]), as_quad(s_rec[4][jc]), out, out2d);
-                // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
-                float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * 4 + wave) * kAccFloats
-                                 : a.acc + (size_t)__builtin_amdgcn_readfirstlane(s_id[jc]) * kAccFloats;
-                const float tot = wave_reduce16(out, lane);
-                if (rslot >= 0) {
-                    if (DET) dst[rslot] = tot;
-                    else atomicAdd(dst + rslot, tot);
+            int j = c * 64 + __builtin_ctzll(m);
+            float4 a0 = s_a[0][j], a1 = s_a[1][j], a2 = s_a[2][j];
+            while (true) {
+                AlphaEval ev;
+                bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
+#if DGS_PIN_PREFETCH
+                asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: the loads below reuse a0..a2
+#endif
+                const int jc = j;
+                m &= m - 1ull;
+                const bool more = m != 0ull;
+                if (more) {   // the next visited entry's alpha part is requested as soon as this one's has been consumed
+                    j = c * 64 + __builtin_ctzll(m);
+                    a0 = s_a[0][j]; a1 = s_a[1][j]; a2 = s_a[2][j];
                 }
-                if (__ballot(ok && !ev.use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
-                    const float mx = wave_sum(out2d[0]);
-                    const float my = wave_sum(out2d[1]);
-                    if (lane == 0) {
-                        if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
-                        else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                const int e = L - 1 - (b * kBatch + jc);  // 0-based list index == the reference's `contributor`
+                ok = ok & (e < st.last_contributor);
+                if (__ballot(ok) != 0ull) {
+                    const float4 tw = s_tw[jc];
+                    bool use3d;
+                    const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
+                    ok = ok & (depth >= kNear);
+                    // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step_affine)
+                    const float4 tuv = s_tuv[jc], q3 = s_q3[jc];
+                    const float2 q4 = s_q4[jc];
+                    float out[16], out2d[2];
+                    pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
+                                       Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
+                    // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
+                    float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * 4 + wave) * kAccFloats
+                                     : a.acc + (size_t)__builtin_amdgcn_readfirstlane(s_id[jc]) * kAccFloats;
+                    const float tot = wave_reduce16(out, lane);
+                    if (rslot >= 0) {
+                        if (DET) dst[rslot] = tot;
+                        else atomicAdd(dst + rslot, tot);
+                    }
+                    if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                        const float mx = wave_sum(out2d[0]);
+                        const float my = wave_sum(out2d[1]);
+                        if (lane == 0) {
+                            if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
+                            else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                        }
                     }
                 }
-            };
-            int ja = c * 64 + __builtin_ctzll(m), jb = 0;
-            float4 a0 = s_rec[0][ja], a1 = s_rec[1][ja], a2 = s_rec[2][ja], b0, b1, b2;
-            b0 = b1 = b2 = make_float4(0.f, 0.f, 0.f, 0.f);
-            while (true) {
-                m &= m - 1ull;
-                if (m != 0ull) {
-                    jb = c * 64 + __builtin_ctzll(m);
-                    b0 = s_rec[0][jb]; b1 = s_rec[1][jb]; b2 = s_rec[2][jb];
-                }
-                visit(a0, a1, a2, ja);
-                if (m == 0ull) break;
-                m &= m - 1ull;
-                if (m != 0ull) {
-                    ja = c * 64 + __builtin_ctzll(m);
-                    a0 = s_rec[0][ja]; a1 = s_rec[1][ja]; a2 = s_rec[2][ja];
-                }
-                visit(b0, b1, b2, jb);
-                if (m == 0ull) break;
+                if (!more) break;
             }
         }
     }

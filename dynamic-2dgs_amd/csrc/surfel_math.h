@@ -417,6 +417,98 @@ DGS_HD bool pair_eval_bf(float pfx, float pfy, const Quad& q0, const Quad& q1, c
     return (e.pz != 0.0f) & (e.depth >= kNear) & !(power > 0.0f) & (e.alpha >= kAlphaMin);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Affine form of the same evaluation around the splat's projected centre -- what the blend kernels run since round 3.
+//
+// forward.cu:359-368 builds, per (pixel, entry), the planes k = x Tw - Tu, l = y Tw - Tv and their cross product
+// p = k x l: 6 FMAs + 6 products.  p is AFFINE in the pixel: with c = (cx, cy) the entry's projected centre (its `xy`),
+//     kc = cx Tw - Tu,  lc = cy Tw - Tv            (the reference's own planes, taken at the centre)
+//     p(x, y) = (kc + (x - cx) Tw) x (lc + (y - cy) Tw) = kc x lc + (x - cx) (Tw x lc) + (y - cy) (kc x Tw)
+// so nine constants are computed ONCE per (tile, entry) by the thread that stages the entry and a pixel pays 6 FMAs.  The
+// expansion point matters: p.xy vanishes at the centre of the splat, so around the centre no term is larger than the result
+// (around the tile centre, 8 px away, a sub-pixel splat's terms cancel to 1/100 of their size and the error of a gradient-free
+// constant lands on every pixel; the global form Tu x Tv + x (Tv x Tw) + y (Tw x Tu) is worse still).  The pixel offset is
+// already there: the low-pass term (auxiliary.h:20-21, FilterInvSquare = 2) needs d = c - pixel, carried pre-scaled
+// (ds = sqrt2 d, from tile-relative operands: cs = sqrt2 (c - tile centre), us = sqrt2 (pixel - tile centre)) so that
+// rho2d = dxs^2 + dys^2 needs no doubling, and p = A + dxs B + dys C with B = -(Tw x lc) / sqrt2, C = -(kc x Tw) / sqrt2.
+// Staged image of an entry (floats):
+//   a0 = (A.x A.y A.z B.x)  a1 = (B.y B.z C.x C.y)  a2 = (C.z cxs cys opacity)       <- alpha part, read for every visit
+//   Tw, normal, colour: the record's own q1/q2 (Tw), q3, q4                         <- read when some pixel blends the entry
+constexpr float kSqrt2 = 1.41421356237309505f;
+constexpr float kInvSqrt2 = 0.70710678118654752f;
+constexpr float kNegHalfLog2e = -0.72134752044448170f;   // G = exp(-rho/2) = 2^(rho * this)
+constexpr float kDepthC1 = 100.0f / 99.8f;               // mapped depth (FAR d - FAR NEAR) / ((FAR - NEAR) d) = C1 - C2 / d, forward.cu:412
+constexpr float kDepthC2 = 20.0f / 99.8f;
+
+DGS_HD float fast_exp2(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DGS_PRECISE_MATH)
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return exp2f(x);
+#endif
+}
+
+struct TileAffine {
+    Quad a0, a1, a2;
+    float kcx, kcy, lcx, lcy;   // x, y of the centre planes: the backward rebuilds k.xy, l.xy of a pixel from them
+};
+
+// X0, Y0: pixel-centre coordinates of the tile's centre (tile origin + 8; pixel centres are X0 + u, u = -7.5 .. 7.5)
+DGS_HD TileAffine tile_affine(const Quad& q0, const Quad& q1, const Quad& q2, float X0, float Y0)
+{
+    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y, Twx = q1.z, Twy = q1.w, Twz = q2.x;
+    const float cx = q2.y, cy = q2.z;
+    const float kx = cx * Twx - Tux, ky = cx * Twy - Tuy, kz = cx * Twz - Tuz;
+    const float lx = cy * Twx - Tvx, ly = cy * Twy - Tvy, lz = cy * Twz - Tvz;
+    TileAffine t;
+    t.kcx = kx; t.kcy = ky; t.lcx = lx; t.lcy = ly;
+    t.a0.x = ky * lz - kz * ly;   t.a0.y = kz * lx - kx * lz;   t.a0.z = kx * ly - ky * lx;                       // A = kc x lc
+    t.a0.w = -kInvSqrt2 * (Twy * lz - Twz * ly); t.a1.x = -kInvSqrt2 * (Twz * lx - Twx * lz); t.a1.y = -kInvSqrt2 * (Twx * ly - Twy * lx);   // B
+    t.a1.z = -kInvSqrt2 * (ky * Twz - kz * Twy); t.a1.w = -kInvSqrt2 * (kz * Twx - kx * Twz); t.a2.x = -kInvSqrt2 * (kx * Twy - ky * Twx);   // C
+    t.a2.y = kSqrt2 * (cx - X0); t.a2.z = kSqrt2 * (cy - Y0); t.a2.w = q2.w;
+    return t;
+}
+
+struct AlphaEval {
+    float pz, inv_pz, sx, sy;      // p.z, its reciprocal, the intersection in splat space
+    float dxs, dys;                // sqrt2 * (projected centre - pixel)
+    float rho3d, rho2d;
+    float G, a, alpha;             // Gaussian weight, opacity * G before and after the 0.99 clamp (forward.cu:397)
+};
+
+// (us, vs) = sqrt2 (pixel - tile centre).  Returns whether the pixel passes the alpha test of forward.cu:369-399 EXCEPT the
+// near-plane test on the depth (alpha_depth below), which needs Tw and is evaluated only when some pixel of the wave passes
+// here.  One comparison decides: everything that makes the reference skip the pair turns `a` into something that fails
+// `a >= 1/255` --
+//   * p.z == 0 (forward.cu:368): 1/p.z = inf, rho3d = inf or NaN, and `0 * rho3d` poisons rho with NaN (the only departure: a
+//     rho3d that OVERFLOWS, |s| > 1.8e19, is skipped too, where the reference would fall back to the low-pass disc);
+//   * a lane that is done or outside the image carries us = NaN: every quantity below is NaN for it.
+DGS_HD bool alpha_affine(float us, float vs, const Quad& a0, const Quad& a1, const Quad& a2, AlphaEval& e)
+{
+    e.dxs = a2.y - us; e.dys = a2.z - vs;
+    const float px = e.dys * a1.z + (e.dxs * a0.w + a0.x);
+    const float py = e.dys * a1.w + (e.dxs * a1.x + a0.y);
+    e.pz = e.dys * a2.x + (e.dxs * a1.y + a0.z);
+    e.inv_pz = fast_rcp(e.pz);
+    e.sx = px * e.inv_pz; e.sy = py * e.inv_pz;
+    e.rho3d = e.sy * e.sy + e.sx * e.sx;
+    e.rho2d = e.dys * e.dys + e.dxs * e.dxs;
+    const float rho = e.rho3d * 0.0f + fminf(e.rho3d, e.rho2d);
+    e.G = fast_exp2(rho * kNegHalfLog2e);
+    e.a = a2.w * e.G;
+    e.alpha = fminf(e.a, kAlphaMax);
+    return e.a >= kAlphaMin;
+}
+
+// depth of the pair (forward.cu:385-387: the intersection's when the 3-D distance is the smaller one, the centre's otherwise)
+DGS_HD float alpha_depth(const AlphaEval& e, float Twx, float Twy, float Twz, bool& use3d)
+{
+    use3d = e.rho3d <= e.rho2d;
+    const float d3 = e.sy * Twy + (e.sx * Twx + Twz);
+    return use3d ? d3 : Twz;
+}
+
 // (FAR*d - FAR*NEAR) / ((FAR-NEAR)*d), forward.cu:412, through one reciprocal (v_rcp_f32, 1 ulp) that the
 // backward reuses for d(mapped)/d(depth) = FAR*NEAR / ((FAR-NEAR) d^2), backward.cu:352
 DGS_HD float mapped_depth_r(float depth, float rd /* = fast_rcp(depth) */)
@@ -462,6 +554,36 @@ DGS_HD bool pixfwd_blend(PixFwd& s, const PairEval& e, const Quad& q3, const Qua
     s.T = test_T;
     s.last = s.contributor;
     return true;
+}
+
+// forward.cu:400-438 for one contributing entry, in two parts so that the kernel can evaluate the saturation test for the whole
+// wave before it narrows the execution mask once.  w = alpha T and test_T = T - w replace T (1 - alpha): one rounding less on the
+// same value.  pixfwd_weight: the pixel saturates (forward.cu:402-406: the entry is NOT blended) when test_T < 1e-4.
+DGS_HD void pixfwd_weight(const PixFwd& s, float alpha, float& w, float& test_T)
+{
+    w = alpha * s.T;
+    test_T = s.T - w;
+}
+
+// TRACK_MEDIAN = false: no pixel of the wave has T > 0.5 any more (forward.cu:421-425 would not fire)
+template <bool TRACK_MEDIAN>
+DGS_HD void pixfwd_accumulate(PixFwd& s, float w, float test_T, float depth, const Quad& q3, const Quad& q4)
+{
+    const float A = 1.f - s.T;
+    const float m = kDepthC1 - kDepthC2 * fast_rcp(depth);
+    const float mm = m * m;
+    const float err = (mm * A + s.dist2) - (m + m) * s.dist1;
+    s.distortion += err * w;
+    if (TRACK_MEDIAN) {
+        if (s.T > 0.5f) { s.med_d = depth; s.med_w = w; s.med_c = s.contributor; }
+    }
+    s.N[0] += q3.x * w; s.N[1] += q3.y * w; s.N[2] += q3.z * w;
+    s.D += depth * w;
+    s.dist1 += m * w;
+    s.dist2 += mm * w;
+    s.C[0] += q3.w * w; s.C[1] += q4.x * w; s.C[2] += q4.y * w;
+    s.T = test_T;
+    s.last = s.contributor;
 }
 
 // Running per-pixel state of the backward blend (backward.cu:191-247), reduced to what the recurrences need.
@@ -546,6 +668,79 @@ DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, bool ok, int contributor, 
     out[kAccT + 6] = m3w * sx; out[kAccT + 7] = m3w * sy; out[kAccT + 8] = m3w;
     const float f2 = (ok & !e.use3d) ? 2.0f * nGdG : 0.f;   // dL_dG * (-G * FilterInvSquare), backward.cu:436-443
     out2d[0] = f2 * e.dx; out2d[1] = f2 * e.dy;
+}
+
+// Backward of one list entry in the affine form (blend_bwd_kernel since round 3).  Same contract as pixbwd_step: branch-free, a
+// pixel that does not blend the entry (`ok` false) runs on neutral values and contributes exact zeros.  Differences:
+//   * the alpha part comes from alpha_affine (e: s, 1/p.z, G, a, ds) and the pair's depth from alpha_depth;
+//   * k.xy, l.xy of the pixel (needed for dL_dk.z, dL_dl.z) are rebuilt from Tu.xy, Tv.xy, Tw.xy: 4 FMAs, only here;
+//   * the distortion terms use the per-pixel products gA = g_dist A, gD = g_dist D, gD2 = g_dist D2 (pixbwd_init_affine):
+//         dL_dweight = g_dist (D2 + m^2 A - 2 m D) = gD2 + m (tz - gD),  tz = m gA - gD
+//         dL_dz      = w (2 tz dm/dd + g_depth)
+//   * u is one FMA chain; 1 / (1 - alpha) needs no select (alpha = 0 gives exactly 1).
+struct PixBwdA {
+    float T, T_final, acc;
+    float gA, gD, gD2;            // g_dist * (final_A, final_D, final_D2)
+    float g_pix[3], g_depth, g_alpha, g_normal[3], g_meddepth, g_medw, bg_dot;
+    int last_contributor, med_c;
+};
+
+DGS_HD void pixbwd_init_affine(PixBwdA& s, float T_final, float dist1, float dist2, int last, int med_c, const float* gpix,
+                               const float* gothers /*8*/, const float* bg)
+{
+    s.T = s.T_final = T_final;
+    s.acc = 0.f;
+    for (int c = 0; c < 3; c++) s.g_pix[c] = gpix[c];
+    const float g_dist = gothers[6];
+    s.gA = g_dist * (1.f - T_final); s.gD = g_dist * dist1; s.gD2 = g_dist * dist2;
+    s.g_depth = gothers[0]; s.g_alpha = gothers[1];
+    s.g_normal[0] = gothers[2]; s.g_normal[1] = gothers[3]; s.g_normal[2] = gothers[4];
+    s.g_meddepth = gothers[5]; s.g_medw = gothers[7];
+    s.bg_dot = bg[0] * gpix[0] + bg[1] * gpix[1] + bg[2] * gpix[2];
+    s.last_contributor = last; s.med_c = med_c;
+}
+
+// tuv = (Tu.x, Tu.y, Tv.x, Tv.y); (pfx, pfy) absolute pixel centre.  out[16] in AccSlot order, out2d = dL_dmean2D (rare branch).
+DGS_HD void pixbwd_step_affine(PixBwdA& s, const AlphaEval& e, bool ok, bool use3d, float depth, int contributor, float pfx, float pfy,
+                               float Twx, float Twy, const Quad& tuv, float opacity, const Quad& q3, const Quad& q4, float* out /*[16]*/,
+                               float* out2d /*[2]*/)
+{
+    const bool m3 = ok & use3d;
+    const float alpha = ok ? e.alpha : 0.f;
+    const float G = ok ? e.G : 0.f;
+    const float c_d = ok ? depth : 1.f;
+    const float sx = m3 ? e.sx : 0.f, sy = m3 ? e.sy : 0.f, inv_pz = m3 ? e.inv_pz : 0.f;
+    const float inv_1ma = fast_rcp(1.f - alpha);   // alpha <= 0.99: well conditioned; alpha = 0 gives exactly 1
+    s.T = s.T * inv_1ma;
+    const float w = alpha * s.T;
+    const float r_d = fast_rcp(c_d);
+    const float m_d = kDepthC1 - kDepthC2 * r_d;
+    const float dmd2 = (2.0f * kDepthC2) * (r_d * r_d);     // 2 d(mapped)/d(depth), backward.cu:352
+    const bool is_med = ok & (contributor == s.med_c - 1);
+    const float tz = m_d * s.gA - s.gD;
+    float u = s.gD2 + m_d * (tz - s.gD) + s.g_alpha;
+    u += is_med ? s.g_medw : 0.f;
+    u = q3.w * s.g_pix[0] + (q4.x * s.g_pix[1] + (q4.y * s.g_pix[2] + (q3.x * s.g_normal[0] + (q3.y * s.g_normal[1] + (q3.z * s.g_normal[2] + (c_d * s.g_depth + u))))));
+    const float d = u - s.acc;
+    const float dL_dalpha = d * s.T - (s.T_final * inv_1ma) * s.bg_dot;
+    s.acc += alpha * d;
+    float dL_dz = w * (tz * dmd2 + s.g_depth);
+    dL_dz += is_med ? s.g_meddepth : 0.f;
+    out[kAccColor + 0] = w * s.g_pix[0]; out[kAccColor + 1] = w * s.g_pix[1]; out[kAccColor + 2] = w * s.g_pix[2];
+    out[kAccNormal + 0] = w * s.g_normal[0]; out[kAccNormal + 1] = w * s.g_normal[1]; out[kAccNormal + 2] = w * s.g_normal[2];
+    out[kAccOpacity] = G * dL_dalpha;
+    const float nGdG = -(G * (opacity * dL_dalpha));   // -G dL_dG
+    const float dsx = nGdG * sx + dL_dz * Twx, dsy = nGdG * sy + dL_dz * Twy;
+    const float ax = dsx * inv_pz, ay = dsy * inv_pz;   // dL_dp.xy; dL_dp.z = -(ax s.x + ay s.y)
+    const float kx = pfx * Twx - tuv.x, ky = pfx * Twy - tuv.y, lx = pfy * Twx - tuv.z, ly = pfy * Twy - tuv.w;
+    const float n1 = ly * ax - lx * ay;             // -dL_dk.z
+    const float n2 = ay * kx - ax * ky;             // -dL_dl.z
+    const float m3w = dL_dz - (pfx * n1 + pfy * n2);
+    out[kAccT + 0] = n1 * sx; out[kAccT + 1] = n1 * sy; out[kAccT + 2] = n1;
+    out[kAccT + 3] = n2 * sx; out[kAccT + 4] = n2 * sy; out[kAccT + 5] = n2;
+    out[kAccT + 6] = m3w * sx; out[kAccT + 7] = m3w * sy; out[kAccT + 8] = m3w;
+    const float f2 = (ok & !use3d) ? (2.0f * kInvSqrt2) * nGdG : 0.f;   // dL_dG * (-G * FilterInvSquare) * d, d = ds / sqrt2 (backward.cu:436-443)
+    out2d[0] = f2 * e.dxs; out2d[1] = f2 * e.dys;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 // HIP kernels inline against the oracle without a GPU.  Test infrastructure only: the shipped library
 // never runs this; control flow of the kernels (LDS staging, wave reductions, atomics) is NOT covered
 // here and is checked by the -m gpu tests.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -68,23 +69,34 @@ int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
     return any | ((int)mask << 4) | ((int)box << 8);
 }
 
-// planar [c,H,W] outputs like the reference's image state
+// planar [c,H,W] outputs like the reference's image state.  Follows blend_fwd_kernel: per tile, every entry is turned into its
+// tile-relative affine image (tile_affine) and the pixels evaluate alpha_affine / alpha_depth / pixfwd_blend_affine; a pixel that
+// saturates is poisoned with NaN coordinates, as in the kernel.
 void hm_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, const float* bg,
                   float* out_color, float* out_others, float* final_T, uint32_t* n_contrib)
 {
     const int tiles_x = (W + 15) / 16, HW = W * H;
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
-            const int tile = (py / 16) * tiles_x + px / 16;
-            const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+            const int tx = px / 16, ty = py / 16, tile = ty * tiles_x + tx;
+            const float X0 = (float)(tx * 16) + 8.0f, Y0 = (float)(ty * 16) + 8.0f;
+            float u = (float)(px - tx * 16) - 7.5f, v = (float)(py - ty * 16) - 7.5f;
+            float us = kSqrt2 * u, vs = kSqrt2 * v;
             PixFwd st;
             pixfwd_init(st);
             for (uint32_t e = ranges[2 * tile]; e < ranges[2 * tile + 1]; e++) {
                 const float* r = rec + (size_t)point_list[e] * kRecFloats;
                 st.contributor++;
-                PairEval ev;
-                if (!pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev)) continue;
-                if (!pixfwd_blend(st, ev, Q(r, 3), Q(r, 4))) break;
+                const TileAffine ta = tile_affine(Q(r, 0), Q(r, 1), Q(r, 2), X0, Y0);
+                AlphaEval ev;
+                if (!alpha_affine(us, vs, ta.a0, ta.a1, ta.a2, ev)) continue;
+                bool use3d;
+                const float depth = alpha_depth(ev, r[6], r[7], r[8], use3d);
+                if (!(depth >= kNear)) continue;
+                float w, test_T;
+                pixfwd_weight(st, ev.alpha, w, test_T);
+                if (test_T < kTmin) { us = NAN; continue; }
+                pixfwd_accumulate<true>(st, w, test_T, depth, Q(r, 3), Q(r, 4));
             }
             const int pix = py * W + px;
             final_T[pix] = st.T; final_T[HW + pix] = st.dist1; final_T[2 * HW + pix] = st.dist2;
@@ -105,23 +117,29 @@ long hm_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* p
     long bad = 0;   // non-zero (or NaN) outputs from a pixel that does not blend the entry
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
-            const int tile = (py / 16) * tiles_x + px / 16;
+            const int tx = px / 16, ty = py / 16, tile = ty * tiles_x + tx;
             const int pix = py * W + px;
+            const float X0 = (float)(tx * 16) + 8.0f, Y0 = (float)(ty * 16) + 8.0f;
             const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+            const float us = kSqrt2 * ((float)(px - tx * 16) - 7.5f), vs = kSqrt2 * ((float)(py - ty * 16) - 7.5f);
             float gp[3], go[8];
             for (int c = 0; c < 3; c++) gp[c] = dL_dpix[c * HW + pix];
             for (int c = 0; c < 8; c++) go[c] = dL_dothers[c * HW + pix];
-            PixBwd st;
-            pixbwd_init(st, final_T[pix], final_T[HW + pix], final_T[2 * HW + pix], (int)n_contrib[pix], (int)n_contrib[HW + pix], gp, go, bg);
+            PixBwdA st;
+            pixbwd_init_affine(st, final_T[pix], final_T[HW + pix], final_T[2 * HW + pix], (int)n_contrib[pix], (int)n_contrib[HW + pix], gp, go, bg);
             const uint32_t r0 = ranges[2 * tile];
             for (int e = st.last_contributor - 1; e >= 0; e--) {
                 const uint32_t id = point_list[r0 + (uint32_t)e];
                 const float* r = rec + (size_t)id * kRecFloats;
-                PairEval ev;
+                const TileAffine ta = tile_affine(Q(r, 0), Q(r, 1), Q(r, 2), X0, Y0);
+                AlphaEval ev;
                 // like the kernel: entries the pixel does not blend go through the same step with ok = false
-                const bool ok = pair_eval_bf(pfx, pfy, Q(r, 0), Q(r, 1), Q(r, 2), ev);
+                bool ok = alpha_affine(us, vs, ta.a0, ta.a1, ta.a2, ev);
+                bool use3d;
+                const float depth = alpha_depth(ev, r[6], r[7], r[8], use3d);
+                ok = ok & (depth >= kNear);
                 float out[16], out2d[2];
-                pixbwd_step(st, ev, ok, e, pfx, pfy, Q(r, 1), Q(r, 2), Q(r, 3), Q(r, 4), out, out2d);
+                pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, r[6], r[7], Quad{r[0], r[1], r[3], r[4]}, r[11], Q(r, 3), Q(r, 4), out, out2d);
                 for (int c = 0; c < 16; c++) dacc[(size_t)id * kAccFloats + c] += out[c];
                 dacc[(size_t)id * kAccFloats + kAccMean2D] += out2d[0];
                 dacc[(size_t)id * kAccFloats + kAccMean2D + 1] += out2d[1];
