@@ -2,13 +2,18 @@
 //
 // One 16x16 screen tile per 256-thread workgroup = 4 wave64; wave w owns the 8x8 pixel quadrant (w & 1, w >> 1) of the
 // tile (surfel_math.h lane_pixel), so all 64 lanes of a wave consume the same staged surfel at the same time.
-// The tile's depth-sorted list is consumed in batches of 256 entries.  The thread that stages an entry gathers its packed
-// 96-B record and turns it into the entry's AFFINE image for this tile (surfel_math.h tile_affine: p = A + dxs B + dys C
-// around the projected centre -- 6 FMAs per pixel instead of 12 operations) -- three float4 planes for the alpha test, then
-// Tw, normal and colour planes that are only read when some pixel blends the entry (22.5 KB forward, 27.5 KB backward).  The
-// record's sixth quad, the surfel's exact pixel bounding box, is consumed at staging time: each entry is tested against the
-// four 8x8 quadrants and the four per-quadrant ballots become 64-bit masks, so a wave only visits the entries whose footprint
-// touches its quadrant.  The inner loop reads the planes with wave-uniform addresses (LDS broadcast, conflict free).
+//
+// Since round 3 the four waves of a tile run AUTONOMOUSLY: each walks the tile's depth-sorted list in chunks of 64 entries, one
+// entry per lane.  The lane gathers the entry's packed 96-B record, turns it into the entry's AFFINE image for this tile
+// (surfel_math.h tile_affine: p = A + dxs B + dys C around the projected centre -- 6 FMAs per pixel instead of 12 operations),
+// tests it against the wave's own quadrant (exact pixel box of the record, then the exact footprint: block_hit_affine) and, if it
+// can touch the quadrant, stages it in the WAVE'S OWN slice of LDS: three float4 planes for the alpha test, then Tw, normal and
+// colour planes that are only read when some pixel blends the entry.  One ballot gives the chunk's 64-bit visit mask; the inner
+// loop walks its set bits and reads the planes with wave-uniform addresses (LDS broadcast, conflict free).  No workgroup barrier
+// inside the list loop: with the shared 256-entry batches of rounds 1-2 a wave spent 30-40 % of its cycles parked at the two
+// barriers per batch waiting for its three siblings (SQ_WAIT_ANY, profiles/r02_pmc_blend_metric.json), and a tile ran as long
+// as its slowest quadrant TWICE over (once per barrier).  The price: a record is fetched and its affine image computed by up to
+// four waves instead of one (staging is ~100 VALU instructions per 64 entries against ~1300 for their visits).
 // Replaces renderCUDA of forward.cu:265-463 and backward.cu:143-449.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,9 +31,17 @@ namespace dgs {
 #ifndef DGS_PIN_PREFETCH
 #define DGS_PIN_PREFETCH 1
 #endif
-constexpr int kBatch = 256;
+constexpr int kChunk = 64;   // list entries staged per wave and step: one per lane
 
 __device__ __forceinline__ Quad as_quad(const float4& v) { return Quad{v.x, v.y, v.z, v.w}; }
+
+// Staged planes are read as native 4-vectors and pinned as such (an empty asm that takes the whole vector): the loop-carried
+// float4 of a software-pipelined read is otherwise split by the compiler into four ds_read_b32 with an address register each.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Quad as_quad(const f32x4& v) { return Quad{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ f32x4 mk4(float x, float y, float z, float w) { return f32x4{x, y, z, w}; }
+__device__ __forceinline__ f32x4 mk4(const float4& v) { return f32x4{v.x, v.y, v.z, v.w}; }
+#define DGS_PIN4(v) asm volatile("" : "+v"(v))
 
 __device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long long v)
 {
@@ -265,14 +278,28 @@ inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
 // built from plain FMAs on VGPR operands (entry constants arrive through LDS broadcasts, not SGPRs), one comparison decides the
 // alpha test (alpha_affine), finished and outside pixels are poisoned with NaN coordinates instead of being masked, and the
 // median bookkeeping is skipped once no pixel of the wave has T > 0.5.
+struct FwdStage {            // one wave's staging slice: the chunk's visited entries, compacted (+1: the visit loop reads one slot ahead)
+    f32x4 a[3][kChunk + 1];  // alpha part of the entry's affine image (tile_affine)
+    f32x4 tw[kChunk + 1];    // (Tw.x Tw.y Tw.z, 1-based list position as bits)
+    f32x4 q3[kChunk + 1];    // (n.x n.y n.z r)
+    f32x4 q4[kChunk + 1];    // (g b - -): a 16-byte plane like the others, so one address register serves all six
+};
+
+// does the record's exact pixel box (q5) reach a pixel centre of the 8x8 block whose first pixel is (qx, qy)?
+__device__ __forceinline__ bool block_box_hit(const float4& bx, float qx, float qy)
+{
+    return (bx.y >= qx + 0.5f) & (bx.x <= qx + 7.5f) & (bx.w >= qy + 0.5f) & (bx.z <= qy + 7.5f);
+}
+
+// slot of this lane among the set bits of m (number of set bits below the lane)
+__device__ __forceinline__ int lane_rank(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(BlendFwdArgs a)
 {
-    __shared__ float4 s_a[3][kBatch];   // alpha part of the entry's affine image (tile_affine)
-    __shared__ float4 s_tw[kBatch];     // (Tw.x Tw.y Tw.z -)
-    __shared__ float4 s_q3[kBatch];     // (n.x n.y n.z r)
-    __shared__ float2 s_q4[kBatch];     // (g b)
-    __shared__ unsigned long long s_bits[4][4];  // [quadrant][chunk of 64 entries]
-    __shared__ int s_flag[4];
+    __shared__ FwdStage s_stage[4];
     __shared__ uint32_t s_max[4];
 
     const int ntiles = a.tiles_x * a.tiles_y;
@@ -288,106 +315,89 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(B
     const bool inside = px < a.W && py < a.H;
     const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
     const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
+    // this wave's quadrant: first pixel, and its span in the scaled tile-relative coordinates of the affine form
+    const float qx = tpx + (float)(8 * (wave & 1)), qy = tpy + (float)(8 * (wave >> 1));
+    const float qus0 = kSqrt2 * ((wave & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((wave & 2) ? 0.5f : -7.5f);
     // sqrt2 x (pixel - tile centre); NaN = this pixel takes no further entry (outside the image, or saturated)
     float us = inside ? kSqrt2 * ((float)lx_ - 7.5f) : __builtin_nanf("");
     const float vs = kSqrt2 * ((float)ly_ - 7.5f);
 
     const uint2 range = a.ranges[tile];
-    int todo = (int)(range.y - range.x);
-    const int rounds = (todo + kBatch - 1) / kBatch;
+    const uint32_t len = range.y - range.x;
+    FwdStage& S = s_stage[wave];
 
     PixFwd st;
     pixfwd_init(st);
-    unsigned long long alive = __ballot(inside);   // lanes that still take entries (wave-uniform)
 
-    for (int b = 0; b < rounds; b++, todo -= kBatch) {
-        // workgroup vote: leave when all four waves have finished (forward.cu:334-336)
-        const bool wave_done = alive == 0ull;
-        if (lane == 0) s_flag[wave] = wave_done ? 1 : 0;
-        __syncthreads();  // also fences the previous batch's LDS reads
-        if (s_flag[0] & s_flag[1] & s_flag[2] & s_flag[3]) break;
-
-        const int n = todo < kBatch ? todo : kBatch;
-        uint32_t smask = 0;
-        if (tid < n) {
-            const uint32_t id = a.point_list[range.x + (uint32_t)(b * kBatch + tid)];
-            const float4* src = a.rec + (size_t)id * kRecQuads;
-            const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
-            const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
-            s_a[0][tid] = make_float4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
-            s_a[1][tid] = make_float4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
-            s_a[2][tid] = make_float4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
-            s_tw[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
-            s_q3[tid] = q3;
-            s_q4[tid] = make_float2(q4.x, q4.y);
-            // which of the tile's four 8x8 quadrants can this entry touch: bounding box, refined by the exact footprint
-            smask = quad_mask_conic(as_quad(q0), as_quad(q1), as_quad(q2), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
-        }
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const unsigned long long bal = __ballot((smask >> w) & 1u);
-            if (lane == 0) s_bits[w][wave] = bal;  // this wave staged entries 64*wave .. 64*wave+63
-        }
-        __syncthreads();
-
-        if (!wave_done) {
-            // Visit, in list order, only the entries whose footprint touches this wave's quadrant.
-            const uint32_t base = (uint32_t)(b * kBatch) + 1u;   // 1-based list position of batch entry 0 (forward.cu:356)
-            auto chunk = [&](auto track_median, int c, unsigned long long m) {
-                int j = c * 64 + __builtin_ctzll(m);
-                float4 a0 = s_a[0][j], a1 = s_a[1][j], a2 = s_a[2][j];
-                while (true) {
-                    AlphaEval e;
-                    bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
-                    // The next visited entry's alpha part is requested as soon as this one's has been consumed, INTO THE SAME
-                    // registers (the empty asm pins the order: without it the compiler hoists the loads above the evaluation,
-                    // needs a second register set and pays twelve moves per visit to rotate it).
+    // Visit, in list order, the nhit entries the wave has staged.  Every instruction of this loop is issued once per (wave, entry)
+    // visit, scalar ones included (the CU's scalar unit issues ~1 instruction per cycle for all four SIMDs: 25 scalar
+    // instructions per visit -- bit-scan of a visit mask, saturation ballots, early-out tests -- cost as much issue time as the
+    // arithmetic).  Hence: the staged entries are COMPACTED (a counted loop over consecutive slots), a pixel that saturates
+    // (forward.cu:402-406: it blends neither this entry nor any later one) is poisoned with one select, and whether the wave
+    // still has live pixels is tested per chunk, not per visit.
+    auto visit = [&](auto track_median, int nhit) {
+        f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
+        f32x4 tw = S.tw[0], q3 = S.q3[0], q4 = S.q4[0];
+        for (int i = 0; i < nhit; i++) {
+            AlphaEval e;
+            const bool pass = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
+            // Software pipeline over the visited entries with ONE register set: the next entry's alpha part is requested as soon
+            // as this one's has been consumed, its Tw / normal / colour at the end of the visit -- each INTO THE SAME registers,
+            // a good hundred cycles before it is needed.  The empty asm statements pin the order: left alone the compiler hoists
+            // the loads above the evaluation, needs a second register set and pays twelve moves per visit to rotate it.
 #if DGS_PIN_PREFETCH
-                    asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");
+            asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");
 #endif
-                    const int jc = j;
-                    m &= m - 1ull;
-                    const bool more = m != 0ull;
-                    if (more) {
-                        j = c * 64 + __builtin_ctzll(m);
-                        a0 = s_a[0][j]; a1 = s_a[1][j]; a2 = s_a[2][j];
-                    }
-                    const unsigned long long okm = __ballot(ok);
-                    if (okm != 0ull) {
-                        const float4 tw = s_tw[jc];
-                        bool use3d;
-                        const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
-                        float w, test_T;
-                        pixfwd_weight(st, e.alpha, w, test_T);
-                        const bool near_ok = depth >= kNear;      // forward.cu:388 (float 0.2f: same set as (double)depth < 0.2)
-                        const bool sat_t = test_T < kTmin;
-                        ok = ok & near_ok;
-                        const bool blend = ok & !sat_t;
-                        if (blend) {
-                            st.contributor = base + (uint32_t)jc;
-                            const float4 q3 = s_q3[jc];
-                            const float2 q4 = s_q4[jc];
-                            pixfwd_accumulate<decltype(track_median)::value>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
-                        }
-                        // (ballots of the three comparisons themselves: a ballot of their conjunction goes through a VGPR)
-                        const unsigned long long satm = okm & __ballot(near_ok) & __ballot(sat_t);
-                        if (satm != 0ull) {   // some pixel saturated (forward.cu:402-406): it takes no further entry; wave-level early out
-                            if (ok & !blend) us = __builtin_nanf("");
-                            alive &= ~satm;
-                            if (alive == 0ull) break;
-                        }
-                    }
-                    if (!more) break;
-                }
-            };
-            for (int c = 0; c < 4 && alive != 0ull; c++) {
-                const unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
-                if (m == 0ull) continue;
-                // median bookkeeping (forward.cu:421-425) only while some pixel of the wave still has T > 0.5
-                if (__ballot(st.T > 0.5f && us == us) != 0ull) chunk(std::true_type{}, c, m);
-                else chunk(std::false_type{}, c, m);
+            a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
+            bool use3d;
+            const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
+            float w, test_T;
+            pixfwd_weight(st, e.alpha, w, test_T);
+            const bool ok = pass & (depth >= kNear);      // forward.cu:388 (float 0.2f: same set as (double)depth < 0.2)
+            const bool blend = ok & !(test_T < kTmin);
+            if (blend) {
+                st.contributor = __float_as_uint(tw.w);   // 1-based list position (forward.cu:356)
+                pixfwd_accumulate<decltype(track_median)::value>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
             }
+            us = (ok ^ blend) ? __builtin_nanf("") : us;   // passed but saturated: the pixel is finished
+#if DGS_PIN_PREFETCH
+            asm volatile("" : "+v"(st.T), "+v"(us) : : "memory");
+#endif
+            tw = S.tw[i + 1]; q3 = S.q3[i + 1]; q4 = S.q4[i + 1];
         }
+    };
+
+    uint32_t id_next = lane < len ? a.point_list[range.x + lane] : 0u;
+    unsigned long long alive = __ballot(inside);   // lanes that still take entries (wave-uniform)
+    for (uint32_t base = 0; base < len && alive != 0ull; base += kChunk) {
+        const uint32_t e_mine = base + (uint32_t)lane;
+        const uint32_t id = id_next;   // (lanes beyond the end of the list hold id 0: a valid record, masked out below)
+        // Straight-line staging: all six quads of the record are requested at once and every lane runs the whole test (a
+        // conditional ladder -- list end, box, footprint -- makes the compiler sink each load behind the test before it:
+        // five dependent trips to memory per chunk).  Entries that can touch the quadrant are compacted: slot = rank among them.
+        const float4* src = a.rec + (size_t)id * kRecQuads;
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
+        // the id of the lane's next entry travels while this chunk is visited (the record loads of the next step then start at once)
+        id_next = e_mine + kChunk < len ? a.point_list[range.x + e_mine + kChunk] : 0u;
+        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+        const bool hit = (e_mine < len) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        if (hit) {
+            const int slot = lane_rank(m);
+            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+            S.tw[slot] = mk4(q1.z, q1.w, q2.x, __uint_as_float(e_mine + 1u));
+            S.q3[slot] = mk4(q3);
+            S.q4[slot] = mk4(q4);
+        }
+        __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
+        // median bookkeeping (forward.cu:421-425) only while some pixel of the wave still has T > 0.5
+        if (__ballot(st.T > 0.5f && us == us) != 0ull) visit(std::true_type{}, __builtin_popcountll(m));
+        else visit(std::false_type{}, __builtin_popcountll(m));
+        __builtin_amdgcn_wave_barrier();
+        alive = __ballot(us == us);   // wave-level early out (forward.cu:334-336 votes per block)
     }
 
     // per-tile maximum of the last contributor: the backward starts there instead of walking the
@@ -572,24 +582,25 @@ __device__ __forceinline__ float wave_sum(float v)
 // DET = false: the per-(wave, entry) sums go into the surfel's accumulator row with hardware float atomics (order of arrival:
 // results differ at the rounding level from run to run, like the reference's).  DET = true (dgs_set_option(7, 1), tests): every
 // (list entry, wave) owns a row of det_part and stores its sums there; det_reduce_kernel adds the rows of a surfel in a fixed order.
+struct BwdStage {            // one wave's staging slice: the chunk's visited entries, compacted (+1: the visit loop reads one slot ahead)
+    f32x4 a[3][kChunk + 1];  // alpha part of the entry's affine image (tile_affine)
+    f32x4 tw[kChunk + 1];    // (Tw.x Tw.y Tw.z opacity)
+    f32x4 tuv[kChunk + 1];   // (Tu.x Tu.y Tv.x Tv.y): k.xy, l.xy of a pixel are rebuilt from them
+    f32x4 q3[kChunk + 1];    // (n.x n.y n.z r)
+    f32x4 q4[kChunk + 1];    // (g b, 0-based list index as bits, surfel id as bits)
+};
+
 template <bool DET>
 __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
 {
-    __shared__ float4 s_a[3][kBatch];   // alpha part of the entry's affine image (tile_affine)
-    __shared__ float4 s_tw[kBatch];     // (Tw.x Tw.y Tw.z opacity)
-    __shared__ float4 s_tuv[kBatch];    // (Tu.x Tu.y Tv.x Tv.y): k.xy, l.xy of a pixel are rebuilt from them
-    __shared__ float4 s_q3[kBatch];     // (n.x n.y n.z r)
-    __shared__ float2 s_q4[kBatch];     // (g b)
-    __shared__ uint32_t s_id[kBatch];
-    __shared__ unsigned long long s_bits[4][4];
+    __shared__ BwdStage s_stage[4];
 
     const int ntiles = a.tiles_x * a.tiles_y;
     int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
     if (a.mode < 3 && tile >= ntiles) return;
     if (a.mode >= 3) tile = (int)a.order[tile];
     if (tile >= ntiles) return;   // mode 4: empty slot
-    const int L = (int)a.tile_last[tile];  // entries [0, L) can contribute to some pixel of the tile
-    if (L == 0) return;
+    if (a.tile_last[tile] == 0u) return;   // no pixel of the tile blended anything
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     int lx_, ly_;
@@ -599,11 +610,14 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
     const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
     const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
+    const float qx = tpx + (float)(8 * (wave & 1)), qy = tpy + (float)(8 * (wave >> 1));
+    const float qus0 = kSqrt2 * ((wave & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((wave & 2) ? 0.5f : -7.5f);
     const float us = kSqrt2 * ((float)lx_ - 7.5f), vs = kSqrt2 * ((float)ly_ - 7.5f);
     const uint2 range = a.ranges[tile];
+    BwdStage& S = s_stage[wave];
 
     const size_t plane = (size_t)ntiles * kTilePix;
-    const size_t slot = (size_t)tile * kTilePix + tid;
+    const size_t slot_px = (size_t)tile * kTilePix + tid;
     PixBwdA st;
     {
         float gpix[3] = {0.f, 0.f, 0.f}, goth[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -615,105 +629,91 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
 #pragma unroll
             for (int c = 0; c < 8; c++) goth[c] = a.dL_dothers[c * HW + pix];
         }
-        const int last = inside ? (int)a.n_contrib[slot] : 0;
-        const int medc = inside ? (int)a.n_contrib[plane + slot] : 0;
-        pixbwd_init_affine(st, inside ? a.final_T[slot] : 0.f, a.final_T[plane + slot], a.final_T[2 * plane + slot], last, medc, gpix,
+        const int last = inside ? (int)a.n_contrib[slot_px] : 0;
+        const int medc = inside ? (int)a.n_contrib[plane + slot_px] : 0;
+        pixbwd_init_affine(st, inside ? a.final_T[slot_px] : 0.f, a.final_T[plane + slot_px], a.final_T[2 * plane + slot_px], last, medc, gpix,
                            goth, a.bg);
     }
-    // highest entry any lane of this wave needs
+    // highest entry any lane of this wave needs: the wave walks the list back to front from there (backward.cu:276-279 skips the
+    // entries behind a pixel's last contributor one by one)
     int wave_last = st.last_contributor;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         int o = __shfl_xor(wave_last, d, 64);
         wave_last = o > wave_last ? o : wave_last;
     }
-    wave_last = __builtin_amdgcn_readfirstlane(wave_last);  // uniform by construction: keeps the entry masks below in SGPRs
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);  // uniform by construction
     const int rslot = reduce16_slot(lane);
 
-    const int rounds = (L + kBatch - 1) / kBatch;
-    for (int b = 0; b < rounds; b++) {
-        __syncthreads();
-        // back to front: batch entry j holds list entry e = L-1 - (b*256 + j)
-        const int e_mine = L - 1 - (b * kBatch + tid);
-        uint32_t smask = 0;
-        if (e_mine >= 0) {
-            const uint32_t id = a.point_list[range.x + (uint32_t)e_mine];
-            s_id[tid] = id;
-            const float4* src = a.rec + (size_t)id * kRecQuads;
-            const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
-            const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
-            s_a[0][tid] = make_float4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
-            s_a[1][tid] = make_float4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
-            s_a[2][tid] = make_float4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
-            s_tw[tid] = make_float4(q1.z, q1.w, q2.x, q2.w);
-            s_tuv[tid] = make_float4(q0.x, q0.y, q0.w, q1.x);
-            s_q3[tid] = q3;
-            s_q4[tid] = make_float2(q4.x, q4.y);
-            // which of the tile's four 8x8 quadrants can this entry touch: bounding box, refined by the exact footprint
-            smask = quad_mask_conic(as_quad(q0), as_quad(q1), as_quad(q2), quad_mask(bx.x, bx.y, bx.z, bx.w, tpx, tpy), tpx, tpy);
+    // chunk lane l holds list entry e = top - l; the entries that can touch the quadrant are compacted in that (back to front) order
+    uint32_t id_next = wave_last - 1 - lane >= 0 ? a.point_list[range.x + (uint32_t)(wave_last - 1 - lane)] : 0u;
+    for (int top = wave_last - 1; top >= 0; top -= kChunk) {
+        const int e_mine = top - lane;
+        const uint32_t id = id_next;   // (lanes beyond the front of the list hold id 0: a valid record, masked out below)
+        // straight-line staging, see blend_fwd_kernel
+        const float4* src = a.rec + (size_t)id * kRecQuads;
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3s = src[3], q4s = src[4], bx = src[5];
+        id_next = e_mine - kChunk >= 0 ? a.point_list[range.x + (uint32_t)(e_mine - kChunk)] : 0u;
+        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+        const bool hit = (e_mine >= 0) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        if (hit) {
+            const int slot = lane_rank(m);
+            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+            S.tw[slot] = mk4(q1.z, q1.w, q2.x, q2.w);
+            S.tuv[slot] = mk4(q0.x, q0.y, q0.w, q1.x);
+            S.q3[slot] = mk4(q3s);
+            S.q4[slot] = mk4(q4s.x, q4s.y, __int_as_float(e_mine), __uint_as_float(id));
         }
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const unsigned long long bal = __ballot((smask >> w) & 1u);
-            if (lane == 0) s_bits[w][wave] = bal;
-        }
-        __syncthreads();
-        // entries j < j0 lie behind everything this wave blended (wave-uniform)
-        int j0 = (L - 1 - b * kBatch) - (wave_last - 1);
-        j0 = j0 < 0 ? 0 : j0;
-        for (int c = 0; c < 4; c++) {
-            if (c * 64 + 63 < j0) continue;
-            unsigned long long m = wave_uniform_u64(s_bits[wave][c]);
-            if (j0 > c * 64) m &= ~((1ull << (j0 - c * 64)) - 1ull);
-            if (m == 0ull) continue;
-            int j = c * 64 + __builtin_ctzll(m);
-            float4 a0 = s_a[0][j], a1 = s_a[1][j], a2 = s_a[2][j];
-            while (true) {
-                AlphaEval ev;
-                bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
+        __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
+        const int nhit = __builtin_popcountll(m);
+        f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
+        f32x4 tw = S.tw[0], tuv = S.tuv[0], q3 = S.q3[0], q4 = S.q4[0];
+        for (int i = 0; i < nhit; i++) {
+            AlphaEval ev;
+            bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
 #if DGS_PIN_PREFETCH
-                asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: the loads below reuse a0..a2
+            asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
 #endif
-                const int jc = j;
-                m &= m - 1ull;
-                const bool more = m != 0ull;
-                if (more) {   // the next visited entry's alpha part is requested as soon as this one's has been consumed
-                    j = c * 64 + __builtin_ctzll(m);
-                    a0 = s_a[0][j]; a1 = s_a[1][j]; a2 = s_a[2][j];
+            a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
+            DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
+            const int e = __builtin_amdgcn_readfirstlane(__float_as_int(q4.z));  // 0-based list index == the reference's `contributor`
+            ok = ok & (e < st.last_contributor);
+            if (__ballot(ok) != 0ull) {
+                bool use3d;
+                const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
+                ok = ok & (depth >= kNear);
+                // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step_affine)
+                float out[16], out2d[2];
+                pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
+                                   Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
+                // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
+                float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * 4 + wave) * kAccFloats
+                                 : a.acc + (size_t)__builtin_amdgcn_readfirstlane(__float_as_uint(q4.w)) * kAccFloats;
+                const float tot = wave_reduce16(out, lane);
+                if (rslot >= 0) {
+                    if (DET) dst[rslot] = tot;
+                    else atomicAdd(dst + rslot, tot);
                 }
-                const int e = L - 1 - (b * kBatch + jc);  // 0-based list index == the reference's `contributor`
-                ok = ok & (e < st.last_contributor);
-                if (__ballot(ok) != 0ull) {
-                    const float4 tw = s_tw[jc];
-                    bool use3d;
-                    const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
-                    ok = ok & (depth >= kNear);
-                    // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step_affine)
-                    const float4 tuv = s_tuv[jc], q3 = s_q3[jc];
-                    const float2 q4 = s_q4[jc];
-                    float out[16], out2d[2];
-                    pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
-                                       Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
-                    // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
-                    float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * 4 + wave) * kAccFloats
-                                     : a.acc + (size_t)__builtin_amdgcn_readfirstlane(s_id[jc]) * kAccFloats;
-                    const float tot = wave_reduce16(out, lane);
-                    if (rslot >= 0) {
-                        if (DET) dst[rslot] = tot;
-                        else atomicAdd(dst + rslot, tot);
-                    }
-                    if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
-                        const float mx = wave_sum(out2d[0]);
-                        const float my = wave_sum(out2d[1]);
-                        if (lane == 0) {
-                            if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
-                            else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
-                        }
+                if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                    const float mx = wave_sum(out2d[0]);
+                    const float my = wave_sum(out2d[1]);
+                    if (lane == 0) {
+                        if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
+                        else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
                     }
                 }
-                if (!more) break;
             }
+#if DGS_PIN_PREFETCH
+            asm volatile("" : "+v"(st.T) : : "memory");
+#endif
+            tw = S.tw[i + 1]; tuv = S.tuv[i + 1]; q3 = S.q3[i + 1]; q4 = S.q4[i + 1];
+            DGS_PIN4(tw); DGS_PIN4(tuv); DGS_PIN4(q3); DGS_PIN4(q4);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -470,6 +470,50 @@ DGS_HD TileAffine tile_affine(const Quad& q0, const Quad& q1, const Quad& q2, fl
     return t;
 }
 
+// Can the entry reach alpha >= 1/255 on the block of pixels whose scaled tile-relative coordinates span [us0, us1] x [vs0, vs1]
+// (an 8x8 quadrant: us1 = us0 + 7 sqrt2)?  Same test as quad_mask_conic -- the footprint is the union of the conic
+// |P.xy|^2 - tau P.z^2 <= 0 and the low-pass disc rho2d <= tau, tau = 2 ln(255 o) -- written in the variables of the affine form
+// (x, y) = (dxs, dys) = cs - (us, vs), where P = A + x B + y C and rho2d = x^2 + y^2, so it costs no cross products of its own and
+// inherits the conditioning of the centre expansion.  tau is inflated by 1 % + 0.01; anything that is not a proper ellipse
+// counts as a hit.  tests/hostmath proves on the test scenes that no block with a passing pixel is ever dropped.
+DGS_HD bool block_hit_affine(const TileAffine& t, float us0, float us1, float vs0, float vs1)
+{
+    const float tau = 2.0f * logf(255.0f * t.a2.w) * 1.01f + 0.01f;
+    const bool can_pass = tau > 0.0f;                    // false: opacity below 1/255 (or not a number), no pixel can pass
+    const float Ax = t.a0.x, Ay = t.a0.y, Az = t.a0.z, Bx = t.a0.w, By = t.a1.x, Bz = t.a1.y, Cx = t.a1.z, Cy = t.a1.w, Cz = t.a2.x;
+    const float x0 = t.a2.y - us1, x1 = t.a2.y - us0, y0 = t.a2.z - vs1, y1 = t.a2.z - vs0;   // the block in (dxs, dys)
+    // low-pass disc: distance from the centre (x = y = 0) to the block
+    const float gx = fmaxf(fmaxf(x0, -x1), 0.0f), gy = fmaxf(fmaxf(y0, -y1), 0.0f);
+    bool hit = gx * gx + gy * gy <= tau * 1.0001f;
+    // Q(x, y) = a x^2 + 2 c x y + b y^2 + 2 d x + 2 e y + f
+    const float a = Bx * Bx + By * By - tau * Bz * Bz, b = Cx * Cx + Cy * Cy - tau * Cz * Cz;
+    const float c = Bx * Cx + By * Cy - tau * Bz * Cz;
+    const float d = Ax * Bx + Ay * By - tau * Az * Bz, e = Ax * Cx + Ay * Cy - tau * Az * Cz;
+    const float f = Ax * Ax + Ay * Ay - tau * Az * Az;
+    const float det = a * b - c * c;
+    const bool no_ellipse = !((a > 0.0f) & (b > 0.0f) & (det > 1e-6f * a * b));   // not a bounded, well-conditioned ellipse: a hit
+    const float inv_det = 1.0f / det, inv_a = 1.0f / a, inv_b = 1.0f / b;
+    const float xc = (c * e - b * d) * inv_det, yc = (c * d - a * e) * inv_det;
+    const float X = fmaxf(fabsf(x0), fabsf(x1)), Y = fmaxf(fabsf(y0), fabsf(y1));
+    const float tol = 2e-6f * (a * X * X + b * Y * Y + 2.0f * (fabsf(c) * X * Y + fabsf(d) * X + fabsf(e) * Y) + fabsf(f));
+    hit |= (xc >= x0) & (xc <= x1) & (yc >= y0) & (yc <= y1);
+    auto Qf = [&](float x, float y) { return x * (a * x + 2.0f * (c * y + d)) + y * (b * y + 2.0f * e) + f; };
+    auto clampf = [](float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); };
+    float qm = Qf(x0, clampf(-(c * x0 + e) * inv_b, y0, y1));
+    qm = fminf(qm, Qf(x1, clampf(-(c * x1 + e) * inv_b, y0, y1)));
+    qm = fminf(qm, Qf(clampf(-(c * y0 + d) * inv_a, x0, x1), y0));
+    qm = fminf(qm, Qf(clampf(-(c * y1 + d) * inv_a, x0, x1), y1));
+    hit |= qm <= tol;
+    return can_pass & (hit | no_ellipse);
+}
+
+// quadrant w of the tile: us in [us_lo(w), us_lo(w) + 7 sqrt2]
+DGS_HD bool quad_hit_affine(const TileAffine& t, int w)
+{
+    const float us0 = kSqrt2 * ((w & 1) ? 0.5f : -7.5f), vs0 = kSqrt2 * ((w & 2) ? 0.5f : -7.5f);
+    return block_hit_affine(t, us0, us0 + 7.0f * kSqrt2, vs0, vs0 + 7.0f * kSqrt2);
+}
+
 struct AlphaEval {
     float pz, inv_pz, sx, sy;      // p.z, its reciprocal, the intersection in splat space
     float dxs, dys;                // sqrt2 * (projected centre - pixel)

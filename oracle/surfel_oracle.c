@@ -390,6 +390,54 @@ static void render_fwd(OracleState* st, const real* feat, const real* bg, real* 
     }
 }
 
+/* Test aid: replay render_fwd for ONE pixel and list the entries it blends -- 1-based contributor index, then (depth, weight
+ * alpha*T, T before the blend) per entry.  The two median channels of the allmap are the depth / weight of the LAST entry
+ * blended while T > 0.5 (forward.cu:421-425), a discontinuous pick: a pixel whose T sits on 0.5 to rounding takes the
+ * neighbouring contributor under any other fp32 evaluation order.  The parity tests use this trace to show that a median
+ * that differs from the oracle's is exactly that (tests/gpu_utils.py median_flips).  Same arithmetic as render_fwd. */
+int oracle_pixel_trace(const OracleState* st, int pxi, int pyi, int cap, uint32_t* out_contrib, real* out_vals /* [cap][3] */)
+{
+    if (pxi < 0 || pyi < 0 || pxi >= st->W || pyi >= st->H) return -1;
+    const int tile = (pyi / BLOCK_Y) * st->tiles_x + pxi / BLOCK_X;
+    const uint32_t r0 = st->ranges[2 * tile], r1 = st->ranges[2 * tile + 1];
+    const real pfx = (real)pxi + (real)0.5, pfy = (real)pyi + (real)0.5;
+    real T = 1;
+    uint32_t contributor = 0;
+    int n = 0;
+    for (uint32_t e = r0; e < r1; e++) {
+        contributor++;
+        const uint32_t id = st->point_list[e];
+        const real* Tm = st->transMat + 9 * id;
+        const real* Tu = Tm; const real* Tv = Tm + 3; const real* Tw = Tm + 6;
+        real k[3] = {-Tu[0] + pfx * Tw[0], -Tu[1] + pfx * Tw[1], -Tu[2] + pfx * Tw[2]};
+        real l[3] = {-Tv[0] + pfy * Tw[0], -Tv[1] + pfy * Tw[1], -Tv[2] + pfy * Tw[2]};
+        real p[3];
+        cross3(k, l, p);
+        if (p[2] == 0) continue;
+        real sx = p[0] / p[2], sy = p[1] / p[2];
+        real rho3d = sx * sx + sy * sy;
+        real dx = st->means2D[2 * id] - pfx, dy = st->means2D[2 * id + 1] - pfy;
+        real rho2d = (real)(FILTER_INV_SQUARE * (double)(dx * dx + dy * dy));
+        real rho = rho3d < rho2d ? rho3d : rho2d;
+        real depth = (rho3d <= rho2d) ? (sx * Tw[0] + sy * Tw[1]) + Tw[2] : Tw[2];
+        if ((double)depth < NEAR_PLANE) continue;
+        real power = (real)-0.5 * rho;
+        if (power > 0) continue;
+        real alpha = st->normal_opacity[4 * id + 3] * R_EXP(power);
+        if (alpha > (real)0.99) alpha = (real)0.99;
+        if (alpha < (real)1 / (real)255) continue;
+        real test_T = T * (1 - alpha);
+        if (test_T < (real)0.0001) break;
+        if (n < cap) {
+            out_contrib[n] = contributor;
+            out_vals[3 * n] = depth; out_vals[3 * n + 1] = alpha * T; out_vals[3 * n + 2] = T;
+        }
+        n++;
+        T = test_T;
+    }
+    return n;
+}
+
 /* Gradient accumulators are double even in the f32 build: the reference sums fp32 atomics in a
  * non-deterministic order (backward.cu:345-446); the order-free double sum is the centre of that
  * noise band. */

@@ -70,6 +70,8 @@ def _lib(dtype):
         lib.oracle_get_ptr.argtypes = [vp, ctypes.c_int]
         lib.oracle_set_threads.restype = ctypes.c_int
         lib.oracle_set_threads.argtypes = [ctypes.c_int]
+        lib.oracle_pixel_trace.restype = ctypes.c_int
+        lib.oracle_pixel_trace.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
         lib.oracle_mark_visible.restype = None
         lib.oracle_mark_visible.argtypes = [ctypes.c_int, vp, vp, vp]
         _LIBS[key] = lib
@@ -147,6 +149,15 @@ class OracleRaster:
         ptr = self.lib.oracle_get_ptr(self.state, _PTR_FIELDS[name])
         buf = (ctypes.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
         return np.frombuffer(buf, dtype=dt).reshape(shape).copy()
+
+    def pixel_trace(self, px, py, cap=4096):
+        """Entries pixel (px, py) blends, in list order: (1-based contributor index [n], (depth, weight, T before) [n,3]).  Test aid
+        for the discontinuous median channels (oracle_pixel_trace)."""
+        contrib = np.zeros(cap, np.uint32)
+        vals = np.zeros((cap, 3), self.dtype)
+        n = self.lib.oracle_pixel_trace(self.state, int(px), int(py), cap, contrib.ctypes.data_as(ctypes.c_void_p), _p(vals))
+        assert 0 <= n <= cap, n
+        return contrib[:n], vals[:n]
 
     def backward(self, dL_dcolor, dL_dallmap):
         """Returns a dict with the 8 gradients of rasterize_points.cu:239 plus dL_dnormal."""

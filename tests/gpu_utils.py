@@ -122,3 +122,50 @@ def grad_close(a, b, name, tol_trim=2e-4, tol_all=5e-3, trim_frac=1e-3):
     trimmed = float(np.linalg.norm(np.sort(e)[:e.shape[0] - k]) / denom) if e.shape[0] > k else 0.0
     assert trimmed <= tol_trim, "%s: trimmed rel-L2 %.3e" % (name, trimmed)
     assert full <= tol_all, "%s: rel-L2 %.3e" % (name, full)
+
+
+def hip_median_contrib(case, dev="cuda:0"):
+    """[H,W] 1-based list position of the entry the kernel picked as the median contributor (0: none), in the numbering of the
+    REFERENCE's lists: the forward is re-run with the reference's tile rectangles (the default lists omit pairs that cannot reach
+    alpha >= 1/255 -- same pixels, same picks, other positions)."""
+    _C.set_tight_rects(False)
+    try:
+        return run_hip_raw(case, dev)["n_contrib"][1]
+    finally:
+        _C.set_tight_rects(True)
+
+
+def median_flips(med_contrib, orc, max_frac=2e-4, tie_tol=2.5e-3):
+    """The two median channels of the allmap (5: depth, 7: weight alpha*T of the LAST entry blended while T > 0.5,
+    forward.cu:421-425) are a discontinuous pick: a pixel whose T sits on 0.5 to rounding takes a neighbouring contributor under
+    any other fp32 evaluation order.  `med_contrib` [H,W] is the 1-based list position of the pick (0: none) as the kernel
+    stores it for its backward (n_contrib plane 1; run_hip_raw) or as another oracle build computed it.  Returns the boolean mask
+    of pixels whose pick differs from the oracle's, after PROVING for each of them, with the oracle's own per-pixel trace, that
+    it is exactly a tie:
+      * the entry the kernel picked is one the oracle blends for this pixel as well, and
+      * every entry between the two picks was blended at a T within tie_tol of 0.5: the picks can only differ across ties.  tie_tol
+        is what ONE contributor on the 1/255 alpha threshold upstream moves T by at T = 0.5 (0.5 / 255 = 2e-3; seen at 1 M surfels:
+        T = 0.49976) plus rounding; such threshold flips are themselves bounded by the callers' pixel-fraction tolerances.
+    Everywhere else the callers hold channels 5 and 7 to the tolerance of the summed channels.  At most max_frac of the pixels
+    (never fewer than 2 allowed) may flip.  Gradient comparisons zero the cotangent of channels 5 and 7 on the returned mask: the
+    derivative of a different entry's depth is not comparable, everything else is."""
+    mc = np.asarray(med_contrib).astype(np.int64)
+    diff = mc != orc.field("n_contrib")[1].astype(np.int64)
+    ys, xs = np.nonzero(diff)
+    assert len(ys) <= max(2, int(max_frac * diff.size)), "%d pixels with a different median contributor" % len(ys)
+    for y, x in zip(ys, xs):
+        contrib, vals = orc.pixel_trace(int(x), int(y))
+        vals = np.asarray(vals, np.float64)
+        above = np.nonzero(vals[:, 2] > 0.5)[0]
+        i_orc = int(above[-1]) if len(above) else -1                     # the oracle's pick (-1: none)
+        if mc[y, x] == 0:
+            i_hip = -1
+        else:
+            at = np.nonzero(contrib == mc[y, x])[0]
+            assert len(at) == 1, "pixel (%d,%d): median contributor %d is not an entry the oracle blends" % (x, y, mc[y, x])
+            i_hip = int(at[0])
+        lo, hi = min(i_hip, i_orc), max(i_hip, i_orc)
+        # the picks differ across entries lo+1 .. hi: each of those was blended with T on the threshold
+        ties = vals[lo + 1:hi + 1, 2]
+        assert len(ties) and np.all(np.abs(ties - 0.5) <= tie_tol), "pixel (%d,%d): median differs without a tie at T = 0.5 (T = %s)" % (x, y, ties)
+    return diff

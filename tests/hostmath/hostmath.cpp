@@ -45,13 +45,16 @@ void hm_preprocess(int P, int D, int M, const float* means3D, const float* scale
     }
 }
 
-// Bit w of the result: some pixel of quadrant w (8x8, lane_pixel) of tile (tx,ty) passes the alpha test for this record.
-// Bits 4..7: the quadrant mask the blend kernels use (box test refined by quad_mask_conic); bits 8..11: the box test alone.
-// -1: the branchy and branch-free evaluations disagree; -2 / -3: a quadrant is reachable although the record's
+// Bit w of the result: some pixel of quadrant w (8x8, lane_pixel) of tile (tx,ty) passes the alpha test for this record -- in the
+// reference's form (pair_eval) OR in the affine form the kernels evaluate (alpha_affine + alpha_depth).
+// Bits 4..7: the quadrant mask the blend kernels use (box test refined by quad_hit_affine); bits 8..11: the box test alone.
+// -1: the branchy and branch-free reference-form evaluations disagree; -2 / -3: a quadrant is reachable although the record's
 // bounding box (q5) / the conic refinement says it is not (quadrant culling of the blend kernels would be wrong).
 int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
 {
     int any = 0;
+    const float X0 = (float)(tx * 16) + 8.0f, Y0 = (float)(ty * 16) + 8.0f;
+    const TileAffine ta = tile_affine(Q(r, 0), Q(r, 1), Q(r, 2), X0, Y0);
     for (int ly = 0; ly < 16; ly++)
         for (int lx = 0; lx < 16; lx++) {
             const int px = tx * 16 + lx, py = ty * 16 + ly;
@@ -60,10 +63,15 @@ int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
             const bool ka = pair_eval((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), a);
             const bool kb = pair_eval_bf((float)px + 0.5f, (float)py + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), b);
             if (ka != kb) return -1;
-            any |= ka ? (1 << ((ly >> 3) * 2 + (lx >> 3))) : 0;
+            AlphaEval ev;
+            bool kc = alpha_affine(kSqrt2 * ((float)lx - 7.5f), kSqrt2 * ((float)ly - 7.5f), ta.a0, ta.a1, ta.a2, ev);
+            bool use3d;
+            kc = kc && alpha_depth(ev, r[6], r[7], r[8], use3d) >= kNear;
+            any |= (ka || kc) ? (1 << ((ly >> 3) * 2 + (lx >> 3))) : 0;
         }
     const uint32_t box = quad_mask(r[20], r[21], r[22], r[23], (float)(tx * 16), (float)(ty * 16));
-    const uint32_t mask = quad_mask_conic(Q(r, 0), Q(r, 1), Q(r, 2), box, (float)(tx * 16), (float)(ty * 16));
+    uint32_t mask = 0;
+    for (int w = 0; w < 4; w++) mask |= (((box >> w) & 1u) && quad_hit_affine(ta, w)) ? (1u << w) : 0u;
     if (any & ~(int)box) return -2;
     if (any & ~(int)mask) return -3;   // the conic refinement dropped a quadrant that holds a passing pixel
     return any | ((int)mask << 4) | ((int)box << 8);
@@ -183,7 +191,7 @@ static inline int lane_of(int w, int k)   // pixel index (y*16 + x) of lane k of
 }
 static inline bool wave_sees(int w, const float* r, float px0, float py0)
 {
-    if (g_shape == 1) return (quad_mask_conic(Q(r, 0), Q(r, 1), Q(r, 2), quad_mask(r[20], r[21], r[22], r[23], px0, py0), px0, py0) >> w) & 1u;
+    if (g_shape == 1) return ((quad_mask(r[20], r[21], r[22], r[23], px0, py0) >> w) & 1u) && quad_hit_affine(tile_affine(Q(r, 0), Q(r, 1), Q(r, 2), px0 + 8.0f, py0 + 8.0f), w);
     if (g_shape == 2) {   // 8x8 quadrants, bounding box only (before the conic refinement)
         const float xf = px0 + 8.0f * (w & 1) + 0.5f, yf = py0 + 8.0f * (w >> 1) + 0.5f;
         return r[21] >= xf && r[20] <= xf + 7.0f && r[23] >= yf && r[22] <= yf + 7.0f;

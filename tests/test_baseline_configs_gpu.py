@@ -26,7 +26,7 @@ def _cot(H, W, seed=5):
 
 @pytest.mark.parametrize("name", ["c3", "c4", "c5"])
 def test_config_matches_oracle_and_properties(name):
-    from gpu_utils import frac_close, grad_close, rel_l2, run_hip
+    from gpu_utils import frac_close, grad_close, median_flips, rel_l2, run_hip, hip_median_contrib
     cfg = CONFIGS[name]
     case = small_case(P=cfg["P"], H=cfg["H"], W=cfg["W"], seed=0, view=cfg["view"], n_views=64)
     gc, go = _cot(cfg["H"], cfg["W"])
@@ -50,12 +50,15 @@ def test_config_matches_oracle_and_properties(name):
     assert float((a["radii"] != orc.radii).mean()) <= 1e-4
     frac_close(a["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
     # Channels 5 and 7 (median depth, median weight) are the depth / weight of ONE contributor, the last one blended while
-    # T > 0.5 (forward.cu:416-420): a pixel whose T sits on 0.5 to rounding picks the neighbouring contributor and jumps by
-    # the difference between the two (seen at 1 M / 1600x1600: weight 0.500001 vs 0.028) -- no cap on the size of the jump
-    # applies, only on how many pixels do it.  Every other channel is a sum whose threshold flips are bounded.
+    # T > 0.5 (forward.cu:416-420): a pixel whose T sits on 0.5 to rounding picks a neighbouring contributor and jumps by the
+    # difference between the two (seen at 1 M / 1600x1600: weight 0.500001 vs 0.028).  median_flips proves, pixel by pixel
+    # from the oracle's own trace, that every pixel whose pick differs reports an entry the oracle blends too and differs
+    # from the oracle's pick only across entries blended at T = 0.5 +- 2e-4; all other pixels are held to the tolerance of
+    # the summed channels.
     sums, medians = [0, 1, 2, 3, 4, 6], [5, 7]
     frac_close(a["allmap"][sums], orc.allmap[sums], 1e-4, 5e-5, 1e-4, 2e-1, "allmap")
-    frac_close(a["allmap"][medians], orc.allmap[medians], 1e-4, 5e-5, 1e-4, float(orc.allmap[0].max()) + 1.0, "median depth / weight")
+    flips = median_flips(hip_median_contrib(case), orc)
+    frac_close(a["allmap"][medians][:, ~flips], orc.allmap[medians][:, ~flips], 1e-4, 5e-5, 1e-4, 2e-1, "median depth / weight")
     mse = float(((a["color"] - orc.color) ** 2).mean())
     assert mse < 1e-9                                                     # PSNR > 90 dB for a [0, 1] image
     og = orc.backward(gc, go)

@@ -28,6 +28,7 @@ def test_gradients_meet_survey_tolerance_with_fast_and_precise_math():
     assert os.path.exists(_C.PRECISE_LIB_PATH), "build it with __graft_entry__.build()"
     fast, precise = _probe(_C.LIB_PATH), _probe(_C.PRECISE_LIB_PATH)
     report = {}
+    print("pixels with a tied median pick (no cotangent on the median channels there):", {sc: (fast[sc]["median_flips"], precise[sc]["median_flips"]) for sc in fast})
     for scene in fast:
         for k in fast[scene]["grads_vs_f32"]:
             report[(scene, k)] = (fast[scene]["grads_vs_f32"][k], precise[scene]["grads_vs_f32"][k], fast[scene]["grads_vs_f64"][k],
