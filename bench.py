@@ -29,6 +29,10 @@ import time
 # zero-fill out of order (an L1 term of exactly 0, or 1e18 gradients, depending on host timing).  The runtime knob
 # below selects the regular graph launch path; it must be in the environment before the HIP runtime initialises.
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL, CUDA-tensor sharing): also read when the HIP runtime starts, so it
+# is set here, before torch is imported, and not next to init_process_group
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
@@ -200,12 +204,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the surfel rasterizer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (tests: two ranks on the one GPU of the test box) ranks share devices
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL ("nccl") is the product path; DGS_DIST_BACKEND=gloo is for the multi-rank test of THIS file on a one-GPU box
+        # (RCCL refuses two ranks on one device)
+        backend = os.environ.get("DGS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
 

@@ -138,6 +138,11 @@ class Trainer:
         self.iteration = 0
         self._graph = None
         self.overlap_allreduce = True  # DP: all-reduce the SH gradients while the deformation backward runs
+        # DP, third split (off by default until an N > 1 RCCL run says it pays): the per-surfel non-SH gradients (xyz, scaling,
+        # rotation, opacity, feature: 18 floats per surfel) are final after the skinning backward and start their all-reduce
+        # there, under the node-MLP backward + weight gradients; only the deformation parameters and the statistics wait for
+        # the end of the backward.  Costs two more graph replays per step.
+        self.split3 = False
         self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
         self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
         # step guard (capacity mode): see _init_guard / _check_guard
@@ -337,22 +342,34 @@ class Trainer:
             with torch.cuda.graph(self._g1, **mode):
                 self._sloss = self._fwd_bwd_a(self._scam, self._sgt)
             self._g1b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g1b, pool=self._g1.pool(), **mode):
-                self._fwd_bwd_b()
+            self._g1c = None
+            if self.split3:
+                with torch.cuda.graph(self._g1b, pool=self._g1.pool(), **mode):
+                    self._fwd_bwd_b1()
+                self._g1c = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g1c, pool=self._g1.pool(), **mode):
+                    self._fwd_bwd_b2()
+            else:
+                with torch.cuda.graph(self._g1b, pool=self._g1.pool(), **mode):
+                    self._fwd_bwd_b()
         else:
             with torch.cuda.graph(self._g1, **mode):
                 self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
                 if self.world == 1:
                     self._finish()
-        self._g2 = self._g2a = None
+        self._g2 = self._g2a = self._g2b = None
         if self.world > 1:
             if self._split:
                 self._g2a = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._g2a, pool=self._g1.pool(), **mode):
                     self._finish_sh()
+                if self.split3:
+                    self._g2b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._g2b, pool=self._g1.pool(), **mode):
+                        self._finish_mid()
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g2, pool=self._g1.pool(), **mode):
-                self._finish(reduce=False, sh_done=self._split)
+                self._finish(reduce=False, sh_done=self._split, mid_done=self._split and self.split3)
         self._graph = True
         # validate: render EVERY view once (forward only, nothing trains; ~0.3 ms each) -- a view whose tile lists break the
         # capacity or the promised list length is found now, not by the step guard in the middle of a run (which would skip
@@ -513,12 +530,37 @@ class Trainer:
 
     def _fwd_bwd_b(self):
         """The rest of the backward: skinning / activations, node MLP, statistics."""
+        self._fwd_bwd_b1()
+        self._fwd_bwd_b2()
+
+    def _fwd_bwd_b1(self):
+        """Skinning / activation backward: afterwards every per-surfel gradient is final (second bucket segment)."""
         asm, g_asm, pkg = self._half
         keep = [(a, g) for a, g in zip(asm, g_asm) if g is not None]
         torch.autograd.backward([a for a, _ in keep], [g for _, g in keep])
+
+    def _fwd_bwd_b2(self):
+        """Node-MLP backward + weight gradients, statistics: the deformation parameters and the bucket tail are final."""
+        _, _, pkg = self._half
         self.deform.finish_backward(join=True)
         self._statistics(pkg, True, early_radii=True)
         self._half = None
+
+    def _n_mid(self):
+        """Elements of the second bucket segment: the surfel parameters behind the SH coefficients."""
+        return sum(p.numel() for p in self.bucket.params[1:self.n_surfel_params])
+
+    def _reduce_mid_start(self):
+        return dist.all_reduce(self.bucket.flat[self.n_sh:self.n_sh + self._n_mid()], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _reduce_tail_start(self):
+        return [dist.all_reduce(self.bucket.flat[self.n_sh + self._n_mid():], op=dist.ReduceOp.SUM, async_op=True)]
+
+    def _finish_mid(self):
+        """Third split: the surfel parameters behind the SH coefficients, as soon as THEIR all-reduce is in."""
+        with torch.no_grad():
+            self.opt_surfels.grad_scale = 1.0 / self.world
+            self.opt_surfels.step(1, self.n_surfel_params, advance=False)
 
     def _reduce_sh_start(self):
         return dist.all_reduce(self.bucket.flat[:self.n_sh], op=dist.ReduceOp.SUM, async_op=True)
@@ -536,7 +578,11 @@ class Trainer:
         n_flat = self.bucket.flat.numel()
         n_radii = self.P + 4
         sh = self.n_sh if self._split_ok() else 0
-        return {"sh": 4 * sh, "rest": 4 * (n_flat - sh), "radii": 4 * n_radii, "total": 4 * (n_flat + n_radii)}
+        out = {"sh": 4 * sh, "rest": 4 * (n_flat - sh), "radii": 4 * n_radii, "total": 4 * (n_flat + n_radii)}
+        if sh and self.split3:   # 'mid' leaves when the skinning backward is done, 'rest' (deformation parameters + statistics) last
+            out["mid"] = 4 * self._n_mid()
+            out["rest"] -= out["mid"]
+        return out
 
     @property
     def _fold_mean(self):
@@ -555,7 +601,7 @@ class Trainer:
             self.opt_surfels.grad_scale = 1.0 / self.world
             self.opt_surfels.step(0, 1)
 
-    def _finish(self, reduce=True, sh_done=False):
+    def _finish(self, reduce=True, sh_done=False, mid_done=False):
         s = self.surfels
         with torch.no_grad():
             if reduce:
@@ -588,7 +634,7 @@ class Trainer:
                 self.opt_surfels.step()
                 self.opt_deform.step()
             elif sh_done:
-                self.opt_surfels.step(1, None, advance=False)
+                self.opt_surfels.step(self.n_surfel_params if mid_done else 1, None, advance=False)
             elif getattr(self.deform, "_join_pending", False):
                 # the node-MLP backward is still running on the side stream: update the surfels, which do
                 # not depend on it, meanwhile; then join and update the deformation parameters
@@ -869,10 +915,19 @@ class Trainer:
                 rwork = self._reduce_radii_start()   # radii + overflow flag (small): first, the SH update's guard reads it
                 work = self._reduce_sh_start()   # runs on the collective's stream while graph 1b replays
                 self._g1b.replay()
-                rest = self._reduce_rest_start()
+                mid = None
+                if self._g1c is not None:        # third split: per-surfel gradients leave under the node-MLP backward
+                    mid = self._reduce_mid_start()
+                    self._g1c.replay()
+                    rest = self._reduce_tail_start()
+                else:
+                    rest = self._reduce_rest_start()
                 rwork.wait()
                 work.wait()
                 self._g2a.replay()               # SH update while the rest of the bucket is on the wire
+                if mid is not None:
+                    mid.wait()
+                    self._g2b.replay()
                 for w in rest:
                     w.wait()
                 self._g2.replay()
@@ -893,12 +948,22 @@ class Trainer:
         loss = self._fwd_bwd_a(cam, gt)
         rwork = self._reduce_radii_start()
         work = self._reduce_sh_start()
-        self._fwd_bwd_b()
-        rest = self._reduce_rest_start()
+        mid = None
+        if self.split3:
+            self._fwd_bwd_b1()
+            mid = self._reduce_mid_start()
+            self._fwd_bwd_b2()
+            rest = self._reduce_tail_start()
+        else:
+            self._fwd_bwd_b()
+            rest = self._reduce_rest_start()
         rwork.wait()
         work.wait()
         self._finish_sh()
+        if mid is not None:
+            mid.wait()
+            self._finish_mid()
         for w in rest:
             w.wait()
-        self._finish(reduce=False, sh_done=True)
+        self._finish(reduce=False, sh_done=True, mid_done=mid is not None)
         return loss

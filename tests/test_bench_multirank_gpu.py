@@ -1,0 +1,43 @@
+"""-m gpu: bench.py's OWN multi-rank path (process-group set-up, barriers, the MIN / MAX all-reduces around the timed region,
+the rank-0 JSON line), run as two processes.  The test box has one GPU and RCCL refuses two ranks on one device, so the
+collectives go over gloo (DGS_DIST_BACKEND) with both ranks on cuda:0 -- everything else is the code the driver's
+`torch.distributed.run --nproc-per-node N bench.py --gpus N` executes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_prints_one_valid_line():
+    world, port = 2, _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DGS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
+                                       "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")], "exactly one JSON line, from rank 0"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 2 and r["scaling"] == "weak" and r["unit"] == "views/s"
+    assert r["config"]["views_per_step"] == 2 and r["config"]["parallelism"].startswith("dp2")
+    assert r["value"] > 0 and abs(r["value"] - 2 * 1e3 / r["ms_per_step"]) <= 1e-2 * r["value"]   # whole-job rate = world views per step
+    assert r["roofline"] and r["roofline"]["kernel"] == "blend_bwd_kernel" and 0 < r["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in r   # rank 0 at N = 1 only

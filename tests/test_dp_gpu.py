@@ -173,3 +173,69 @@ def test_split_step_over_rccl_single_rank():
     assert proc.exitcode == 0
     for a, b in zip(eager, graph):
         assert 0.0 < a < 10.0 and abs(a - b) <= 1e-3 * abs(a), (eager, graph)
+
+
+def _split3_worker(rank, world, port, q, graph):
+    """Third split of the data-parallel step (Trainer.split3): per-surfel non-SH gradients leave after the skinning backward."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from diff_surfel_rasterization import _C
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        out = {}
+        for key, split3 in (("base", False), ("again", False), ("split3", True)):   # the same run twice: the yardstick for run-to-run noise
+            tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
+            tr.split3 = split3
+            assert tr._split_ok()
+            wire = tr.wire_bytes_per_step()
+            if graph:
+                tr.enable_graph(capacity=40 * 20000)
+                assert (tr._g1c is not None) == split3 and (tr._g2b is not None) == split3
+            losses = [float(tr.step()) for _ in range(4)]
+            torch.cuda.synchronize()
+            assert not _C.read_overflow()
+            _C.set_capacity(0)
+            params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
+            gp = [torch.zeros_like(params) for _ in range(world)]
+            dist.all_gather(gp, params)
+            out[key] = (all(torch.equal(gp[0], g) for g in gp), losses, params, wire, tr.P, tr.bucket.flat.numel())
+        if rank == 0:
+            q.put({k: (v[0], v[1], v[2].numpy(), v[3], v[4], v[5]) for k, v in out.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_third_split_keeps_replicas_identical_and_moves_the_wire_bytes(graph):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split3_worker, args=(r, world, port, q, graph)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    (same2, l2, p2, w2, P, nflat), (same3, l3, p3, w3, _, _), (same2b, _, p2b, _, _, _) = res["base"], res["split3"], res["again"]
+    assert same2 and same3 and same2b                                   # replicas bit-identical with and without the third split
+    # same training run either way (float atomics in the rasterizer's backward: equal to rounding, not bitwise)
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l2, l3)), (l2, l3)
+    # ... and the same parameters, up to what the order of the float atomics (rasterizer and skinning backward) does to a
+    # gradient that is zero to rounding: Adam turns its sign into a full step, so some elements move by ~lr per step from one
+    # run to the next.  The yardstick is the same configuration run twice.
+    import numpy as np
+    scale = float(np.abs(p2).max())
+    d, noise = np.abs(p2 - p3), np.abs(p2 - p2b)
+    assert float(np.median(d)) <= 1e-7 * scale
+    for qt in (0.99, 0.999, 1.0):
+        assert float(np.quantile(d, qt)) <= 2.0 * float(np.quantile(noise, qt)) + 1e-6 * scale, (qt, float(np.quantile(d, qt)), float(np.quantile(noise, qt)))
+    # what leaves when: 48 SH floats per surfel first, then (third split) the 18 other per-surfel floats, then the rest
+    assert w2["sh"] == w3["sh"] == 4 * 48 * P and "mid" not in w2
+    assert w3["mid"] == 4 * (3 + 2 + 4 + 1 + 8) * P and w3["rest"] == w2["rest"] - w3["mid"] and w3["total"] == w2["total"] == 4 * (nflat + P + 4)
