@@ -22,9 +22,11 @@ from .train import Trainer
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
-        arap=False):
+        arap=False, warm_up=3000, regularize_from=8000, on_iteration=None):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
-    list_capacity: rasterizer list entries for the captured step (default 96 per slot)."""
+    list_capacity: rasterizer list entries for the captured step (default 96 per slot).  warm_up / regularize_from: the
+    reference's stages (train_gui.py:282-285: deformation detached while iteration < opt.warm_up; :292-293: normal and
+    distortion regularisers off until iteration 8000).  on_iteration(it, trainer): optional hook after every iteration."""
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
@@ -44,17 +46,34 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
         graph = on_gpu
     if on_gpu:
         tr.sort_surfels()
-    tr.arap_from = 3000                                                # opt.warm_up (arguments/__init__.py:102)
+    tr.arap_from = warm_up                                             # opt.warm_up (arguments/__init__.py:102)
+    tr.set_regime(warmup=1 < warm_up, lambda_normal=0.0 if 1 <= regularize_from else 0.02, lambda_dist=0.0 if 1 <= regularize_from else 1000.0)
     from .arap import LAMBDA_ARAP_STEPS
     graph_from = LAMBDA_ARAP_STEPS[-1] if (arap and graph) else 0      # the regulariser runs eagerly while its weight is non-zero
     if graph and not graph_from:
         tr.enable_graph(int(list_capacity or 96 * slots))
     extent = float(data["normalization"]["radius"])
     losses = []
+    # A captured step returns the SAME device tensor every time (it lives in the graph's pool and is rewritten by every replay), so
+    # the history comes from the step guard's pinned ring instead (Trainer.loss_history: no copy kernel per step, one
+    # synchronisation per RING/2 iterations); the eager CPU path returns a fresh tensor per step.
+    ring = tr.opt_deform is None and getattr(tr, "_oflag", None) is not None
+    pending = 0
     for it in range(1, iterations + 1):
         if oneup_sh_degree_step and it % oneup_sh_degree_step == 0:                # train_gui.py:233-235
             tr.oneup_sh_degree()
-        losses.append(tr.step())
+        on = it > regularize_from                                                  # train_gui.py:292-293
+        tr.set_regime(warmup=it < warm_up, lambda_normal=0.02 if on else 0.0, lambda_dist=1000.0 if on else 0.0)
+        loss = tr.step()
+        if ring:
+            pending += 1
+            if pending == tr.GUARD_RING // 2 or it == iterations:
+                losses += tr.loss_history(pending)
+                pending = 0
+        else:
+            losses.append(float(loss))
+        if on_iteration is not None:
+            on_iteration(it, tr)
         if graph_from and it == graph_from - 1:
             tr.enable_graph(int(list_capacity or 96 * tr.P))
         if it < densify_until:                                                     # train_gui.py:410-423
@@ -72,7 +91,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
             if it % opacity_reset_interval == 0 or (white_background and it == densify_from):
                 tr.reset_opacity()
     save(tr, model_path, iterations)
-    return tr, [float(l) for l in losses]
+    return tr, losses
 
 
 def save(trainer, model_path, iteration):

@@ -145,6 +145,13 @@ class Trainer:
         self.split3 = False
         self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
         self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
+        # Regime of the reference step (train_gui.py:282-285,292-293).  Defaults = its late regime (iteration > 8000), which is what
+        # the benchmark times; fit() walks through the schedule with set_regime():
+        #   warmup (iteration < opt.warm_up = 3000): the deformation is applied but DETACHED -- nothing behind d_xyz / d_rotation /
+        #     d_scaling receives a gradient: the node parameters, the network and the surfels' hyper coordinates stay untouched;
+        #   lambda_normal / lambda_dist: 0 until iteration 8000, then 0.02 / 1000.
+        self.warmup = False
+        self.lambda_normal, self.lambda_dist = 0.02, 1000.0
         # step guard (capacity mode): see _init_guard / _check_guard
         self._guard_steps = 0
         self._guard_events = {}
@@ -430,9 +437,12 @@ class Trainer:
             pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
         else:
             dv = d(s.get_xyz.detach(), t, s.feature, s.motion_mask)
+            if self.warmup:
+                dv = {k: v.detach() for k, v in dv.items()}
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
                          postprocess=not fused)
-        loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt) if fused else training_loss(pkg, gt)
+        lam = dict(lambda_normal=self.lambda_normal, lambda_dist=self.lambda_dist)
+        loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, **lam) if fused else training_loss(pkg, gt, **lam)
         if self.arap:
             from . import arap
             lam = arap.lambda_arap(self.iteration)       # train_gui.py:315-316, utils/time_utils.py:1228-1232
@@ -491,7 +501,7 @@ class Trainer:
         self._note_loss(loss.detach())
         # explicit unit gradient: loss.backward() alone launches a fill for it every step
         self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
-        if hasattr(d, "finish_backward"):
+        if hasattr(d, "finish_backward") and not self.warmup:   # (warm-up: nothing behind the deformation's outputs trains)
             d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
         if getattr(d, "_join_pending", False) and fused:
             # single GPU: the node-MLP backward now runs on the side stream and is the longer branch; the statistics kernels
@@ -542,7 +552,8 @@ class Trainer:
     def _fwd_bwd_b2(self):
         """Node-MLP backward + weight gradients, statistics: the deformation parameters and the bucket tail are final."""
         _, _, pkg = self._half
-        self.deform.finish_backward(join=True)
+        if not self.warmup:
+            self.deform.finish_backward(join=True)
         self._statistics(pkg, True, early_radii=True)
         self._half = None
 
@@ -560,7 +571,7 @@ class Trainer:
         """Third split: the surfel parameters behind the SH coefficients, as soon as THEIR all-reduce is in."""
         with torch.no_grad():
             self.opt_surfels.grad_scale = 1.0 / self.world
-            self.opt_surfels.step(1, self.n_surfel_params, advance=False)
+            self.opt_surfels.step(1, self.n_surfel_params - 1 if self.warmup else self.n_surfel_params, advance=False)
 
     def _reduce_sh_start(self):
         return dist.all_reduce(self.bucket.flat[:self.n_sh], op=dist.ReduceOp.SUM, async_op=True)
@@ -623,7 +634,10 @@ class Trainer:
             self._late_stats = None
             if late is None:
                 accumulate()
+            n_train = self.n_surfel_params - 1 if self.warmup else None   # warm-up: everything up to (not including) `feature`
             if self.opt_deform is not None:
+                if self.warmup:   # torch Adam skips parameters without a gradient, like the reference's detached deformation
+                    s.feature.grad = None
                 if self.lr_schedule:
                     k = self._steps_done
                     for g in self.opt_surfels.param_groups:
@@ -632,9 +646,16 @@ class Trainer:
                     self.opt_deform.param_groups[0]["lr"] = expon_lr(k, *self.SCHED_DEFORM)
                 self._steps_done += 1
                 self.opt_surfels.step()
-                self.opt_deform.step()
+                if not self.warmup:
+                    self.opt_deform.step()
+                elif s.feature.grad is None:   # the flat bucket's view comes back for the next step
+                    s.feature.grad = self.bucket.flat[sum(p.numel() for p in self.bucket.params[:self.n_surfel_params - 1]):][:s.feature.numel()].view_as(s.feature)
             elif sh_done:
-                self.opt_surfels.step(self.n_surfel_params if mid_done else 1, None, advance=False)
+                first = self.n_surfel_params if mid_done else 1
+                if n_train is None or first < n_train:
+                    self.opt_surfels.step(first, n_train, advance=False)
+            elif self.warmup:
+                self.opt_surfels.step(0, n_train)
             elif getattr(self.deform, "_join_pending", False):
                 # the node-MLP backward is still running on the side stream: update the surfels, which do
                 # not depend on it, meanwhile; then join and update the deformation parameters
@@ -757,6 +778,19 @@ class Trainer:
         near = torch.where(s.alive, near, torch.full_like(near, nodes.shape[0]))
         self.reorder_surfels(torch.argsort(near, stable=True))
         d.coherent_surfels = bool(x.is_cuda and self.rasterizer_cls is None)
+
+    def set_regime(self, warmup=None, lambda_normal=None, lambda_dist=None):
+        """Move to another stage of the reference's schedule (see __init__).  The regime is part of the captured step (kernel
+        arguments, which launches exist): a change re-captures, two or three times per run.  Returns whether anything changed."""
+        new = (self.warmup if warmup is None else bool(warmup), self.lambda_normal if lambda_normal is None else float(lambda_normal),
+               self.lambda_dist if lambda_dist is None else float(lambda_dist))
+        if new == (self.warmup, self.lambda_normal, self.lambda_dist):
+            return False
+        self.warmup, self.lambda_normal, self.lambda_dist = new
+        if self._graph:
+            self._graph = None
+            self.enable_graph(self._capacity)
+        return True
 
     def oneup_sh_degree(self):
         """GaussianModel.oneupSHdegree (gaussian_model.py:139-141).  The active degree is an argument of the rasterizer
