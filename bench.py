@@ -12,11 +12,21 @@ Inputs (scene S(200k,800,800,seed 0)) are resident in HBM 
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  "roofline"     : achieved algorithmic HBM GB/s of the dominant kernel (the backward blend), timed with HIP
-                   events on the launch stream inside the timed region, against the 8 TB/s HBM3E peak;
-  "roofline_fwd" : the same for the forward blend;
-  "cpu_baseline" : the CPU port (C oracle rasterizer with OpenMP + PyTorch-CPU deformation/loss/Adam) timed on
-                   this box's host cores for a bounded sample of the same workload (rank 0, N=1 only).
+  "roofline"        : achieved algorithmic HBM GB/s of the dominant kernel (the backward blend) against the 8 TB/s HBM3E peak.
+                      Timed AFTER the headline region, on the scene state the region ended with (snapshot / restore), with
+                      device timestamps inside the replayed whole-step graph -- the launch mode of the headline -- and, as a
+                      cross-check, with HIP events around eager launches;
+  "roofline_fwd"    : the same for the forward blend;
+  "roofline_valu"   : the two blend kernels against what actually bounds them -- VALU issue: wave instructions per launch (PMC)
+                      / duration against 0.5 instructions per cycle per SIMD (MI355X_MICROARCH.md: 2 cycles per wave64 op);
+  "roofline_kernels": preprocess_fwd, binning (count + scan + scatter + per-tile sort) and surfel_bwd with the bytes SURVEY.md
+                      section 8(d) defines for them (B2, B4-6, B10), same clocks;
+  "twin"            : the graph-replayed steps and the eager steps of the roofline legs start from the SAME snapshot and render
+                      the same views: their per-step losses must agree (1e-5 relative over the first steps, 1e-3 over all), or the result is invalid;
+  "drift"           : the scene trains on noise targets while it is timed and its splats grow: ms/step of a second window 100
+                      steps after the headline window, and the mean screen radius at both (the headline is the FIRST window);
+  "cpu_baseline"    : the CPU port (C oracle rasterizer with OpenMP + PyTorch-CPU deformation/loss/Adam) timed on
+                      this box's host cores for a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -52,6 +62,10 @@ WORKLOADS = {
     "c5": (1_000_000, 1600, 1600),
     "c2": (50_000, 800, 800),          # BASELINE.json configs[1]: static canonical render, FORWARD ONLY, no deformation
     "tiny": (5_000, 128, 128),
+    # a scene WITH structure: dgs_amd.synthetic.DynamicTruth rendered at 800x800, fitted from 100k random points with densification
+    # and the reference's stages (compressed: see trained_trainer) before the timed region -- surfels crowd onto two surfaces, so
+    # the tile lists have the statistics of a trained scene (long lists in few tiles) instead of the uniform cloud of "metric"
+    "trained": (100_000, 800, 800),
 }
 
 
@@ -135,6 +149,42 @@ def cpu_baseline(P, H, W, budget_s=25.0):
             "sample": "%d full train steps (views) of the same %dk-surfel %dx%d workload, %.1f s" % (n, P // 1000, W, H, dt)}
 
 
+def trained_trainer(P, H, W, device, pre_iterations):
+    """--workload trained: fit() on the synthetic D-NeRF-format dataset for `pre_iterations` (warm-up 1/3, regularisers from 2/3 of
+    them: the reference's three stages compressed; densification every 100 iterations from 500, opacity reset at 3000), then the
+    caller times the full late-regime step on what that produced."""
+    import shutil
+    import tempfile
+    from dgs_amd.fit import fit
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    tmp = tempfile.mkdtemp(prefix="dgs_trained_")
+    try:
+        write_dynamic_dnerf(os.path.join(tmp, "scene"), n_train=48, n_test=2, H=H, W=W, device=device)
+        tr, losses = fit(os.path.join(tmp, "scene"), os.path.join(tmp, "model"), iterations=pre_iterations, device=device, num_pts=P, node_num=512,
+                         seed=0, warm_up=pre_iterations // 3, regularize_from=2 * pre_iterations // 3, node_densify_at=10 ** 9)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return tr, losses
+
+
+def kernel_bytes(kind, P, Pv, R, M, ntiles):
+    """Algorithmic bytes per launch as SURVEY.md section 8(d) defines them for the reference's algorithm (P surfels, Pv visible,
+    R = num_rendered, M SH coefficients per channel), and the bytes THIS implementation's layout moves for the same work."""
+    if kind == "preprocess_fwd":   # B2
+        return {"survey": (12 + 8 + 16 + 4 + 12 * M) * P + 91 * Pv, "own": (12 + 8 + 16 + 4 + 12 * M) * P + 104 * Pv,
+                "formula": "B2 = (12+8+16+4+12 M) P + 91 Pv; own: 96-B record + 8-B rectangle per visible surfel"}
+    if kind == "binning":          # B4-6: 44-bit LSD radix sort of (tile | depth) keys = 6 passes over 12-byte pairs
+        bits = max(1, (ntiles - 1).bit_length())
+        passes = -(-(32 + bits) // 8)
+        return {"survey": 12 * R + 2 * 12 * R * passes + 8 * R, "own": 12 * R + 12 * R + 4 * R + 8 * ntiles,
+                "formula": "B4-6 = 12 R + 2*12 R ceil((32+bits)/8) + 8 R (%d radix passes); own: keys written once into tile buckets "
+                           "(12 R), read once by the per-tile LDS sort (12 R), 4 R sorted ids out" % passes}
+    if kind == "surfel_bwd":       # B10
+        return {"survey": (232 + 96) * Pv + (12 + 8 + 16 + 12 * M) * Pv, "own": (96 + 80 + 12 + 8 + 16 + 12 * M) * Pv + (36 + 12 * M + 12 + 12 + 12 + 4 + 8 + 16) * Pv,
+                "formula": "B10 = (232+96) Pv + (12+8+16+12 M) Pv; own: 96-B record + 80-B accumulator row + inputs in, gradient rows out"}
+    raise KeyError(kind)
+
+
 def forward_only(args, P, H, W, device):
     """configs[1] of BASELINE.json: static canonical surfels rendered forward-only through the operator surface
     (GaussianRasterizer), one view per step, eager launches.  Same JSON contract; the roofline object is the forward blend."""
@@ -183,6 +233,36 @@ def forward_only(args, P, H, W, device):
     print(json.dumps(out), flush=True)
 
 
+def mean_radius(tr):
+    """Mean screen radius (px) of the surfels the last step rendered (radii of this rank's view; single-GPU runs keep them raw)."""
+    r = tr._radii[:tr.P].float()
+    vis = r > 0
+    return round(float(r[vis].mean()), 2) if bool(vis.any()) else None
+
+
+def timed_steps(tr, k, world, densify_every=0, densify_log=None):
+    """Exactly k steps between barrier + synchronize on both sides; returns seconds (this rank's clock)."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(k):
+        tr.step()   # the loss of every step lands in the trainer's pinned report ring (guard kernel): no copy kernel, no sync here;
+                    # the reference reads loss.item() -- a host synchronisation -- every step
+        if densify_every and (i + 1) % densify_every == 0:
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            # reference thresholds (arguments/__init__.py:115-122); extent = radius of the camera orbit
+            counts = tr.densify_and_prune(0.0002, 0.01, 4.0, 20)
+            torch.cuda.synchronize()
+            densify_log.append(((time.perf_counter() - td) * 1e3, counts))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +277,10 @@ def main():
     ap.add_argument("--densify-every", type=int, default=0,
                     help="also run the in-place densification every N timed steps (off by default: the metric is the plain step)")
     ap.add_argument("--slots-factor", type=float, default=1.5, help="surfel slots per initial surfel when --densify-every is on")
+    ap.add_argument("--pre-iterations", type=int, default=3000, help="--workload trained: fit() iterations before the timed region")
+    ap.add_argument("--drift-gap", type=int, default=100, help="steps between the headline window and the second (drift) window; 0: skip")
     args = ap.parse_args()
+    assert args.steps <= 128, "the per-step losses of the timed steps come from a 256-entry ring"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -235,12 +318,22 @@ def main():
         _a = (_a @ _a).clamp_(-1, 1)
     torch.cuda.synchronize()
     del _a
-    tr = build_trainer(P, H, W, device, slots=int(args.slots_factor * P) if args.densify_every else None)
     use_graph = os.environ.get("DGS_NO_GRAPHS", "0") != "1"
-    if use_graph:
-        # whole-step HIP graphs: the rasterizer runs in capacity mode (no device->host read), 24 list entries per
-        # surfel is ~3x what this scene needs
-        tr.enable_graph(capacity=24 * P)
+    pre_losses = None
+    if args.workload == "trained":
+        if world > 1:
+            raise SystemExit("--workload trained is a single-GPU workload (its preparation is not sharded)")
+        tr, pre_losses = trained_trainer(P, H, W, device, args.pre_iterations)
+        tr.set_regime(warmup=False, lambda_normal=0.02, lambda_dist=1000.0)   # the timed step is the late-regime step, like "metric"
+        if use_graph and not tr._graph:
+            tr.enable_graph(capacity=96 * tr.P)
+        P = tr.P
+    else:
+        tr = build_trainer(P, H, W, device, slots=int(args.slots_factor * P) if args.densify_every else None)
+        if use_graph:
+            # whole-step HIP graphs: the rasterizer runs in capacity mode (no device->host read), 24 list entries per
+            # surfel is ~3x what this scene needs
+            tr.enable_graph(capacity=24 * P)
     # W untimed steps, then exactly K timed ones.  The scene trains while it is timed (Adam moves every log-scale by ~lr per
     # step on the noise targets: the splats grow by ~10 % in screen radius over 50 steps), so a long run can outgrow what graph
     # capture promised the rasterizer (longest tile list, list capacity): the trainer's step guard then skips that step,
@@ -252,26 +345,8 @@ def main():
         recoveries = tr.overflow_recoveries
         for _ in range(args.warmup):
             tr.step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        densify_ms, densify_counts = [], []
-        for i in range(args.steps):
-            tr.step()   # the loss of every step lands in the trainer's pinned report ring (guard kernel): no copy kernel, no sync here;
-                        # the reference reads loss.item() -- a host synchronisation -- every step
-            if args.densify_every and (i + 1) % args.densify_every == 0:
-                torch.cuda.synchronize()
-                td = time.perf_counter()
-                # reference thresholds (arguments/__init__.py:115-122); extent = radius of the camera orbit
-                densify_counts.append(tr.densify_and_prune(0.0002, 0.01, 4.0, 20))
-                torch.cuda.synchronize()
-                densify_ms.append((time.perf_counter() - td) * 1e3)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        densify_log = []
+        dt = timed_steps(tr, args.steps, world, args.densify_every, densify_log)
         clean = not use_graph or (tr.overflow_recoveries == recoveries and not bool(tr._oflag.item() if getattr(tr, "_oflag", None) is not None else 0))
         if world > 1:   # one verdict for all ranks (a rank that overflowed in the last steps knows before the others)
             c = torch.tensor([1 if clean else 0], dtype=torch.int32, device=device)
@@ -291,17 +366,41 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    radius_headline = mean_radius(tr)
 
-    # ---- roofline legs (after the timed region; the headline value above is not affected) -------------------------------
-    # (1) in-graph: the step is re-captured with the library's device-timestamp hook on (one-thread kernels before and after
-    #     each blend launch append the 100 MHz device counter to a ring -- legal inside a captured graph, where HIP events
-    #     are not) and the same K steps are replayed: the blend kernels are timed in the launch mode the headline uses;
-    # (2) eager: the same K steps launched one by one with HIP events around the blend launches -- the classic clock, kept
-    #     as a cross-check (the device idles between eager launches and the kernels run a few % faster there).
+    # ---- everything below is measured AFTER the headline and does not change it --------------------------------------------
+    # The scene state the headline window ended with is kept: the drift leg trains on, the roofline legs and the twin check
+    # are run from this snapshot again.
+    snap, it0 = tr._snapshot(), tr.iteration
+    drift = None
+    if args.drift_gap > 0 and not args.no_roofline_legs and not args.densify_every:
+        recoveries = tr.overflow_recoveries
+        for _ in range(args.drift_gap):
+            tr.step()
+        dt2 = timed_steps(tr, args.steps, world)
+        if world > 1:
+            t2 = torch.tensor([dt2], dtype=torch.float64, device=device)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            dt2 = float(t2.item())
+        drift = {"steps_between_windows": args.drift_gap, "ms_per_step_second_window": round(dt2 / args.steps * 1e3, 4),
+                 "mean_screen_radius_px": [radius_headline, mean_radius(tr)], "recaptured_in_between": tr.overflow_recoveries != recoveries,
+                 "note": "noise targets: Adam grows every splat by ~lr per step; the headline is the first window of the run"}
+
+    # ---- roofline legs = the twin check.  From the snapshot: K graph-replayed steps with the library's device-timestamp hook on
+    # (one-thread kernels before and after each timed launch append the 100 MHz device counter to a ring -- legal inside a captured
+    # graph, where HIP events are not); from the snapshot again: the same K steps launched eagerly with HIP events around the
+    # launches.  Same parameters, same Adam state, same views: the two loss series must agree step by step.
     prof_graph = prof = None
-    eager_losses = []
-    if not args.no_roofline_legs:
+    twin = None
+    if not args.no_roofline_legs and not args.densify_every:
+        def rewind():
+            tr._restore(snap)
+            tr.iteration = it0
+            if getattr(tr, "_oflag", None) is not None:
+                tr._oflag.zero_()
+        replay_losses = None
         if use_graph:
+            rewind()
             _C.profile_enable(2)
             tr._graph = None
             tr.enable_graph(capacity=tr._capacity)
@@ -309,9 +408,10 @@ def main():
             _C.profile_reset()      # drop the stamps of the capture's warm-up launches: only replays are counted
             for _ in range(args.steps):
                 tr.step()
-            torch.cuda.synchronize()
+            replay_losses = tr.loss_history(args.steps)
             prof_graph = _C.profile_read()
             _C.profile_enable(0)
+        rewind()
         tr._graph = None
         _C.set_capacity(0)
         _C.set_option(6, 0)
@@ -321,50 +421,100 @@ def main():
         torch.cuda.synchronize()
         prof = _C.profile_read()
         _C.profile_enable(0)
-        # self-check of the graph replay: the eager steps continue the same training run, so the two loss series must agree
-        ref = sum(eager_losses) / len(eager_losses)
-        if not all(l == l and 0.8 * ref <= l <= 1.25 * ref for l in timed_losses):
-            raise SystemExit("graph-replayed steps disagree with eager steps (losses %s vs eager mean %.5f): result invalid"
-                             % (["%.4f" % l for l in timed_losses], ref))
+        if replay_losses is not None:
+            rels = [abs(a - b) / max(abs(b), 1e-12) for a, b in zip(replay_losses, eager_losses)]
+            rel, rel_first = max(rels), max(rels[:3])
+            # the two runs differ in the order of the float atomics of the backward only: identical to ~1e-6 at first, then the two
+            # trajectories drift apart (Adam turns the sign of a gradient that is zero to rounding into a full step) -- 2e-6 after 20
+            # steps on the metric workload, 2e-4 on the fast-moving "trained" one.  A replay that mis-orders a node is off by O(1)
+            twin = {"steps": args.steps, "max_rel_loss_difference": float("%.3g" % rel), "max_rel_loss_difference_first_3_steps": float("%.3g" % rel_first),
+                    "tolerance": {"first_3_steps": 1e-5, "all_steps": 1e-3},
+                    "what": "graph-replayed vs eager steps from the same snapshot (parameters, Adam state, views); float atomics in the backward are the only difference"}
+            if not (rel <= 1e-3 and rel_first <= 1e-5) or any(l != l for l in replay_losses + timed_losses):
+                raise SystemExit("graph-replayed steps disagree with their eager twin (max relative loss difference %.3g; replay %s, eager %s): result invalid"
+                                 % (rel, ["%.6f" % l for l in replay_losses], ["%.6f" % l for l in eager_losses]))
 
     if rank == 0:
         ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+        M = 16
 
-        # HBM traffic per launch from the committed PMC passes (tools/pmc_kernels.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # in separate runs of THIS command, corrected as MI355X_MICROARCH.md prescribes).  Reported only when the file was
-        # taken on this workload AND on the library sources that are loaded now (hash of sources + flags).
-        traffic, traffic_src = {}, None
-        pmc_path = os.path.join("profiles", "r02_pmc_blend_%s.json" % args.workload)
+        # HBM traffic and instruction counts per launch from the committed PMC passes (tools/pmc_kernels.sh: separate rocprofv3
+        # --pmc runs of THIS command, corrected as MI355X_MICROARCH.md prescribes).  Reported only when the file was taken on this
+        # workload AND on the library sources that are loaded now (hash of sources + flags).
+        pmc, pmc_src = {}, None
+        pmc_path = os.path.join("profiles", "r03_pmc_%s.json" % args.workload)
         try:
             with open(os.path.join(ROOT, pmc_path)) as f:
-                pmc = json.load(f)
-            if pmc.get("workload") == args.workload and pmc.get("library_source_hash") == _C.source_hash():
-                traffic = {"fwd": pmc["kernels"]["dgs::blend_fwd_kernel"]["hbm_traffic_bytes_per_launch"],
-                           "bwd": pmc["kernels"]["dgs::blend_bwd_kernel"]["hbm_traffic_bytes_per_launch"]}
-                traffic_src = "%s (bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes of this command; library sources %s)" % (
-                    pmc_path, pmc["library_source_hash"])
+                pj = json.load(f)
+            if pj.get("workload") == args.workload and pj.get("library_source_hash") == _C.source_hash():
+                pmc = pj["kernels"]
+                pmc_src = "%s (bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes of this command; library sources %s)" % (
+                    pmc_path, pj["library_source_hash"])
             else:
-                traffic_src = "%s is for workload %s / library sources %s, loaded library is %s: not reported" % (
-                    pmc_path, pmc.get("workload"), pmc.get("library_source_hash"), _C.source_hash())
+                pmc_src = "%s is for workload %s / library sources %s, loaded library is %s: not reported" % (
+                    pmc_path, pj.get("workload"), pj.get("library_source_hash"), _C.source_hash())
         except Exception as ex:
-            traffic_src = "no PMC profile for this workload (%s)" % type(ex).__name__
+            pmc_src = "no PMC profile for this workload (%s)" % type(ex).__name__
+
+        def pmc_of(kernel, counter):
+            return pmc.get("dgs::" + kernel, {}).get(counter)
+
+        def duration(key):
+            """(average ms per launch, launches, which clock) from the in-graph leg when there is one, else the eager leg"""
+            for src, label in ((prof_graph, "device timestamps (100 MHz counter) around the kernel inside the replayed whole-step graph"),
+                               (prof, "HIP events on the launch stream, eager launches")):
+                if src and src[key + "_n"] and src[key + "_ms"] > 0:
+                    return src[key + "_ms"] / src[key + "_n"], src[key + "_n"], src, label
+            return None
 
         def roof(kind):
-            # the fraction is computed from the in-graph duration when the step is graph-replayed (the headline's launch mode)
-            main, other = (prof_graph, prof) if prof_graph and prof_graph[kind + "_n"] else (prof, None)
-            if not main or main[kind + "_n"] == 0 or main[kind + "_ms"] <= 0:
+            d = duration(kind)
+            if not d:
                 return None
-            n, ms, S = main[kind + "_n"], main[kind + "_ms"], main[kind + "_S"]
-            bytes_per = blend_bytes(S / n, ntiles, H * W, backward=(kind == "bwd"))
-            gbs = bytes_per / (ms / n * 1e-3) / 1e9
+            ms, n, src, label = d
+            S = src[kind + "_S"] / n
+            bytes_per = blend_bytes(S, ntiles, H * W, backward=(kind == "bwd"))
+            gbs = bytes_per / (ms * 1e-3) / 1e9
             r = {"bound": "hbm", "kernel": "blend_%s_kernel" % kind, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(kind), "traffic_source": traffic_src,
-                 "timing": ("device timestamps (100 MHz counter) around the kernel inside the replayed whole-step graph, %d launches" % n)
-                 if main is prof_graph else ("HIP events on the launch stream, eager launches, %d launches" % n),
-                 "avg_kernel_ms": round(ms / n, 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S / n)}
-            if other and other[kind + "_n"]:
-                r["avg_kernel_ms_eager_events"] = round(other[kind + "_ms"] / other[kind + "_n"], 4)
+                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": pmc_of("blend_%s_kernel" % kind, "hbm_traffic_bytes_per_launch"),
+                 "traffic_source": pmc_src, "timing": "%s, %d launches" % (label, n),
+                 "avg_kernel_ms": round(ms, 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S)}
+            if src is prof_graph and prof and prof[kind + "_n"]:
+                r["avg_kernel_ms_eager_events"] = round(prof[kind + "_ms"] / prof[kind + "_n"], 4)
             return r
+
+        def roof_valu(kind):
+            d = duration(kind)
+            insts = pmc_of("blend_%s_kernel" % kind, "SQ_INSTS_VALU")
+            if not d or not insts:
+                return None
+            ms = d[0]
+            peak = 0.5 * 1024 * 2.4e9   # MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles on a SIMD-32; 1024 SIMDs; 2.4 GHz
+            ach = insts / (ms * 1e-3)
+            return {"bound": "valu_issue", "kernel": "blend_%s_kernel" % kind, "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
+                    "unit": "G wave64 VALU instructions/s", "frac": round(ach / peak, 4), "valu_instructions_per_launch": insts,
+                    "salu_instructions_per_launch": pmc_of("blend_%s_kernel" % kind, "SQ_INSTS_SALU"), "avg_kernel_ms": round(ms, 4),
+                    "cycles_per_instruction_per_simd": round(1024 * 2.4e9 * ms * 1e-3 / insts, 2),
+                    "measured_issue_ceiling": "2.5 cycles per plain FMA / mul / add, 4.4-4.8 with an SGPR operand, for comparisons, min/max, "
+                                              "selects, DPP; 8.5-12.7 for v_rcp / v_exp (profiles/r03_valu_issue_gfx950.txt)",
+                    "source": pmc_src}
+
+        def roof_kernel(name, key):
+            d = duration(key)
+            if not d:
+                return None
+            ms, n, src, label = d
+            R, Pv = src["R"] / max(src["pre_n"], 1), src["Pv"] / max(src["pre_n"], 1)
+            b = kernel_bytes(name, P, Pv, R, M, ntiles)
+            gbs = b["survey"] / (ms * 1e-3) / 1e9
+            kernels = {"preprocess_fwd": ["preprocess_fwd_kernel"], "surfel_bwd": ["surfel_bwd_kernel"],
+                       "binning": ["count_tiles_lds_kernel", "column_pass_kernel", "scan_tiles_kernel", "scatter_keys_lds_kernel", "sort_tiles_radix_kernel"]}[name]
+            traffic = [pmc_of(k, "hbm_traffic_bytes_per_launch") for k in kernels]
+            return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                    "traffic": None if any(t is None for t in traffic) else int(sum(t * (2 if k == "column_pass_kernel" else 1) for t, k in zip(traffic, kernels))),
+                    "avg_ms": round(ms, 4), "alg_bytes_per_launch": round(b["survey"]), "own_bytes_per_launch": round(b["own"]),
+                    "own_GBs": round(b["own"] / (ms * 1e-3) / 1e9, 2), "formula": b["formula"], "R": round(R), "P_visible": round(Pv),
+                    "timing": "%s, %d launches" % (label, n)}
 
         out = {
             "metric": "train views/sec (fwd+bwd), 800x800, 200k surfels" if args.workload == "metric"
@@ -372,16 +522,27 @@ def main():
             "value": round(world * args.steps / dt, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: synthetic scene S(%d surfels, %dx%d, seed 0), full train step (node deform + surfel "
-                                   "raster fwd/bwd + L1/D-SSIM/normal/distortion loss + Adam), 1 view per GPU per step" % (args.workload, P, W, H),
-                       "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "control_nodes": 1024,
+            "config": {"workload": ("%s: synthetic scene S(%d surfels, %dx%d, seed 0), full train step (node deform + surfel "
+                                    "raster fwd/bwd + L1/D-SSIM/normal/distortion loss + Adam), 1 view per GPU per step" % (args.workload, P, W, H))
+                       if args.workload != "trained" else
+                       ("trained: DynamicTruth (bobbing sphere + swinging plate) rendered to a D-NeRF-format dataset at %dx%d and fitted for %d "
+                        "iterations from 100k random points with densification (%d surfels in %d slots now); the timed step is the "
+                        "same full late-regime train step as 'metric'" % (W, H, args.pre_iterations, tr.surfels.num_surfels, tr.P)),
+                       "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "control_nodes": int(tr.deform.node_num),
                        "views_per_step": world, "parallelism": "dp%d (views sharded, one flat all-reduce)" % world,
                        "launch": "whole-step HIP graph replay" if use_graph else "eager"},
             "roofline": roof("bwd"), "roofline_fwd": roof("fwd"),
+            "roofline_valu": {"bwd": roof_valu("bwd"), "fwd": roof_valu("fwd")},
+            "roofline_kernels": {"preprocess_fwd": roof_kernel("preprocess_fwd", "pre"), "binning": roof_kernel("binning", "bin"),
+                                 "surfel_bwd": roof_kernel("surfel_bwd", "sbw")},
+            "twin": twin, "drift": drift,
         }
+        if pre_losses is not None:
+            k = max(len(pre_losses) // 10, 1)
+            out["config"]["pre_training_loss"] = {"first_tenth_mean": round(sum(pre_losses[:k]) / k, 5), "last_tenth_mean": round(sum(pre_losses[-k:]) / k, 5)}
         if args.densify_every:
-            out["densify"] = {"every": args.densify_every, "calls": len(densify_ms), "ms_per_call": [round(m, 3) for m in densify_ms],
-                              "cloned_split_pruned": [list(map(int, c)) for c in densify_counts], "slots": tr.P,
+            out["densify"] = {"every": args.densify_every, "calls": len(densify_log), "ms_per_call": [round(m, 3) for m, _ in densify_log],
+                              "cloned_split_pruned": [list(map(int, c)) for _, c in densify_log], "slots": tr.P,
                               "surfels_after": tr.surfels.num_surfels, "recaptured": tr.P != int(args.slots_factor * P)}
         try:
             ceil = measured_hbm_ceiling(device)
@@ -391,7 +552,7 @@ def main():
                                                  "method": "torch d2d copy / triad over 1 GiB fp32 buffers, 20 iterations, HIP events"}
         except Exception as ex:   # never lose the result line over the side measurement
             print("warning: HBM ceiling measurement failed: %r" % (ex,), file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "trained":
             del tr
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(P, H, W)

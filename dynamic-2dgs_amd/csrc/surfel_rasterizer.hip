@@ -131,6 +131,17 @@ dgs::Camera make_camera(const float* view_dev, const float* campos_dev, int W, i
 }
 
 // ---- optional kernel timing (bench.py roofline leg) ------------------------------------------------
+// per timed forward: R = num_rendered and the number of visible surfels, the units of the preprocess / binning / per-surfel
+// backward byte formulas
+__global__ void sum_forward_units_kernel(const uint32_t* total, const int* radii, int P, unsigned long long* dst_R, unsigned long long* dst_Pv)
+{
+    unsigned long long vis = 0;
+    for (int i = threadIdx.x; i < P; i += 256) vis += radii[i] > 0 ? 1u : 0u;
+    for (int d = 32; d >= 1; d >>= 1) vis += __shfl_xor(vis, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst_Pv, vis);
+    if (threadIdx.x == 0) atomicAdd(dst_R, (unsigned long long)total[0]);
+}
+
 __global__ void sum_tile_last_kernel(const uint32_t* tile_last, int n, unsigned long long* dst)
 {
     unsigned long long acc = 0;
@@ -151,17 +162,19 @@ __global__ void stamp_kernel(unsigned long long* ring, unsigned* count, unsigned
     ring[2 * (i % kStampCap) + 1] = tag;
 }
 
+constexpr int kProfKinds = 5;   // 0 forward blend, 1 backward blend, 2 preprocess_fwd, 3 binning (count .. sort), 4 surfel_bwd
 struct Prof {
     std::atomic<int> mode{0};                // 0 off, 1 HIP events (eager launches), 2 device timestamps (capturable)
-    unsigned long long* counters = nullptr;  // device: [0] sum of S over timed fwd launches, [1] over bwd launches
+    unsigned long long* counters = nullptr;  // device: [0] sum of S over timed fwd launches, [1] over bwd launches, [2] sum of
+                                             // num_rendered, [3] sum of visible surfels (radii > 0) over timed forwards
     unsigned long long* ring = nullptr;      // device: kStampCap x (timestamp, tag)
     unsigned* ring_count = nullptr;          // device
     std::mutex mu;
     struct Pair { hipEvent_t a, b; int kind; };
     std::vector<Pair> pending;
     std::vector<Pair> pool;
-    double ms[2] = {0, 0};
-    long n[2] = {0, 0};
+    double ms[kProfKinds] = {0, 0, 0, 0, 0};
+    long n[kProfKinds] = {0, 0, 0, 0, 0};
 };
 
 // Small pinned staging word for num_rendered (the one device->host read of the forward).
@@ -251,7 +264,7 @@ bool prof_begin(dgs_context* c, int kind, hipStream_t s, Prof::Pair& p)
     return true;
 }
 
-void prof_end(dgs_context* c, hipStream_t s, Prof::Pair& p, const uint32_t* tile_last, int ntiles)
+void prof_mark_end(dgs_context* c, hipStream_t s, Prof::Pair& p)
 {
     Prof& pr = c->prof;
     if (pr.mode.load() == 2) {
@@ -261,7 +274,13 @@ void prof_end(dgs_context* c, hipStream_t s, Prof::Pair& p, const uint32_t* tile
         std::lock_guard<std::mutex> lk(pr.mu);
         pr.pending.push_back(p);
     }
+}
+
+void prof_end(dgs_context* c, hipStream_t s, Prof::Pair& p, const uint32_t* tile_last, int ntiles)
+{
+    prof_mark_end(c, s, p);
     // S = sum over tiles of the list length actually traversed, for the roofline
+    Prof& pr = c->prof;
     if (pr.counters) hipLaunchKernelGGL(sum_tile_last_kernel, dim3(1), dim3(256), 0, s, tile_last, ntiles, pr.counters + p.kind);
 }
 
@@ -357,8 +376,8 @@ int dgs_context_profile_enable(dgs_context* c, int mode)
     if (mode != 0) {   // allocate now: nothing may be allocated later, while a stream capture is in progress
         std::lock_guard<std::mutex> lk(pr.mu);
         if (!pr.counters) {
-            DGS_HIP(hipMalloc((void**)&pr.counters, 16));
-            DGS_HIP(hipMemset(pr.counters, 0, 16));
+            DGS_HIP(hipMalloc((void**)&pr.counters, 32));
+            DGS_HIP(hipMemset(pr.counters, 0, 32));
         }
         if (mode == 2 && !pr.ring) {
             DGS_HIP(hipMalloc((void**)&pr.ring, (size_t)kStampCap * 16));
@@ -377,9 +396,8 @@ void dgs_context_profile_reset(dgs_context* c)
     std::lock_guard<std::mutex> lk(pr.mu);
     for (auto& p : pr.pending) pr.pool.push_back(p);
     pr.pending.clear();
-    pr.ms[0] = pr.ms[1] = 0;
-    pr.n[0] = pr.n[1] = 0;
-    if (pr.counters) (void)hipMemset(pr.counters, 0, 16);
+    for (int k = 0; k < kProfKinds; k++) { pr.ms[k] = 0; pr.n[k] = 0; }
+    if (pr.counters) (void)hipMemset(pr.counters, 0, 32);
     if (pr.ring_count) (void)hipMemset(pr.ring_count, 0, 4);
 }
 
@@ -406,13 +424,14 @@ int dgs_context_profile_read(dgs_context* c, double* out, int cap)
             const unsigned n = cnt < kStampCap ? cnt : kStampCap;
             std::vector<unsigned long long> h(2 * (size_t)kStampCap);
             (void)hipMemcpy(h.data(), pr.ring, (size_t)kStampCap * 16, hipMemcpyDeviceToHost);
-            unsigned long long open_t[2] = {0, 0};
-            bool open[2] = {false, false};
+            unsigned long long open_t[kProfKinds] = {0, 0, 0, 0, 0};
+            bool open[kProfKinds] = {false, false, false, false, false};
             const unsigned first = cnt <= kStampCap ? 0u : cnt % kStampCap;   // oldest entry still in the ring
             for (unsigned k = 0; k < n; k++) {
                 const unsigned i = (first + k) % kStampCap;
                 const unsigned tag = (unsigned)h[2 * i + 1];
-                const int kind = (int)(tag >> 1) & 1;
+                const int kind = (int)(tag >> 1);
+                if (kind >= kProfKinds) continue;
                 if ((tag & 1u) == 0) { open_t[kind] = h[2 * i]; open[kind] = true; }
                 else if (open[kind]) {
                     pr.ms[kind] += (double)(h[2 * i] - open_t[kind]) * 1e-5;   // 100 MHz ticks -> ms
@@ -423,10 +442,11 @@ int dgs_context_profile_read(dgs_context* c, double* out, int cap)
             (void)hipMemset(pr.ring_count, 0, 4);
         }
     }
-    unsigned long long cntS[2] = {0, 0};
-    if (pr.counters) (void)hipMemcpy(cntS, pr.counters, 16, hipMemcpyDeviceToHost);
-    const double v[6] = {pr.ms[0], (double)pr.n[0], pr.ms[1], (double)pr.n[1], (double)cntS[0], (double)cntS[1]};
-    int k = cap < 6 ? cap : 6;
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    if (pr.counters) (void)hipMemcpy(cnt, pr.counters, 32, hipMemcpyDeviceToHost);
+    const double v[14] = {pr.ms[0], (double)pr.n[0], pr.ms[1], (double)pr.n[1], (double)cnt[0], (double)cnt[1],
+                          pr.ms[2], (double)pr.n[2], pr.ms[3], (double)pr.n[3], pr.ms[4], (double)pr.n[4], (double)cnt[2], (double)cnt[3]};
+    int k = cap < 14 ? cap : 14;
     for (int i = 0; i < k; i++) out[i] = v[i];
     return k;
 }
@@ -525,8 +545,13 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         pa.row_inv = (unsigned)(0xFFFFFFFFu / (unsigned)(M * 3)) + 1u;
         sh_lds = (size_t)dgs::kSurfelBlock * (M * 3 + 1) * sizeof(float);
     }
+    Prof::Pair pp2;
+    const bool timed2 = prof_begin(ctx, 2, stream, pp2);
     hipLaunchKernelGGL(dgs::preprocess_fwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), sh_lds, stream, pa);
+    if (timed2) prof_mark_end(ctx, stream, pp2);
     DGS_STAGE("preprocess_fwd", debug, stream);
+    Prof::Pair pp3;
+    const bool timed3 = prof_begin(ctx, 3, stream, pp3);   // binning: count, column pass, scan, column pass, scatter, sort
     // ---- K3 per-tile entry counts
     dgs::BinArgs ba_;
     ba_.P = P; ba_.ntiles = il.ntiles; ba_.tiles_x = il.tiles_x; ba_.chunk = (P + dgs::kBinGroups - 1) / dgs::kBinGroups;
@@ -630,6 +655,12 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
                                    (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, capacity_mode ? 2048 : 16384);
         }
         DGS_STAGE("sort_tiles", debug, stream);
+    }
+    if (timed3) {
+        prof_mark_end(ctx, stream, pp3);
+        if (ctx->prof.counters)
+            hipLaunchKernelGGL(sum_forward_units_kernel, dim3(1), dim3(256), 0, stream, (const uint32_t*)(geom + gl.total), (const int*)radii, P,
+                               ctx->prof.counters + 2, ctx->prof.counters + 3);
     }
 
     // ---- K7 forward blend
@@ -754,7 +785,10 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         sa.row_inv = (unsigned)(0xFFFFFFFFu / (unsigned)(M * 3)) + 1u;
         sh_lds = (size_t)dgs::kSurfelBlock * (M * 3 + 1) * sizeof(float);
     }
+    Prof::Pair pp4;
+    const bool timed4 = prof_begin(ctx, 4, stream, pp4);
     hipLaunchKernelGGL(dgs::surfel_bwd_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), sh_lds, stream, sa);
+    if (timed4) prof_mark_end(ctx, stream, pp4);
     DGS_STAGE("surfel_bwd", debug, stream);
     return DGS_OK;
 }

@@ -262,7 +262,14 @@ class Trainer:
             return
         ev.synchronize()
         e = self._ring[k % self.GUARD_RING]
-        if int(e[0]) == k and float(e[1]) > 0:
+        if int(e[0]) != k:
+            # the device's step counter and the host's disagree (something advanced FlatAdam outside step()): resynchronise
+            # and look at the flag itself -- silently ignoring the report would hide an overflow for good
+            self._resync_guard()
+            if bool(self._oflag.item()) or float(self.opt_surfels.status[0].item()) > 0:
+                self._recover_overflow()
+            return
+        if float(e[1]) > 0:
             self._recover_overflow()
 
     def _recover_overflow(self):
@@ -417,6 +424,16 @@ class Trainer:
         sf.xyz_gradient_accum.copy_(stats[0])
         sf.denom.copy_(stats[1])
         sf.max_radii2D.copy_(stats[2])
+        self._resync_guard()
+
+    def _resync_guard(self):
+        """The guard kernel numbers its reports with the DEVICE step counter (status[2]); whoever moves that counter behind the
+        trainer's back -- a restored snapshot, a tool that drives FlatAdam.step directly -- must bring the host's copy along, or
+        no report would ever match its ring slot again (and a sticky overflow would freeze training unnoticed)."""
+        if getattr(self, "opt_deform", 1) is None and hasattr(self.opt_surfels, "status"):
+            torch.cuda.synchronize()
+            self._guard_steps = int(self.opt_surfels.status[2].item())
+            self._guard_events.clear()
 
     def _forward(self, cam, gt):
         s, d = self.surfels, self.deform

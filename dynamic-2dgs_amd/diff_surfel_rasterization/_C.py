@@ -397,7 +397,11 @@ def profile_reset():
 
 
 def profile_read():
-    """{'fwd_ms', 'fwd_n', 'bwd_ms', 'bwd_n', 'fwd_S', 'bwd_S'} accumulated over timed blend-kernel launches."""
-    out = (ctypes.c_double * 6)()
-    load().dgs_profile_read(out, 6)
-    return {"fwd_ms": out[0], "fwd_n": int(out[1]), "bwd_ms": out[2], "bwd_n": int(out[3]), "fwd_S": out[4], "bwd_S": out[5]}
+    """Accumulated over the timed launches: blend kernels {'fwd_ms', 'fwd_n', 'bwd_ms', 'bwd_n', 'fwd_S', 'bwd_S'}, and
+    {'pre_ms', 'pre_n'} preprocess_fwd, {'bin_ms', 'bin_n'} binning (count + scan + scatter + per-tile sort), {'sbw_ms', 'sbw_n'}
+    surfel_bwd, 'R' = sum of num_rendered, 'Pv' = sum of visible surfels over the timed forwards."""
+    out = (ctypes.c_double * 14)()
+    load().dgs_profile_read(out, 14)
+    return {"fwd_ms": out[0], "fwd_n": int(out[1]), "bwd_ms": out[2], "bwd_n": int(out[3]), "fwd_S": out[4], "bwd_S": out[5],
+            "pre_ms": out[6], "pre_n": int(out[7]), "bin_ms": out[8], "bin_n": int(out[9]), "sbw_ms": out[10], "sbw_n": int(out[11]),
+            "R": out[12], "Pv": out[13]}

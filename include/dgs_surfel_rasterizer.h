@@ -167,12 +167,14 @@ int dgs_set_overflow_flag(int* device_flag);
 /* 1 if a capacity overflow happened since the last reset (blocking device read; call it outside hot loops). */
 int dgs_read_overflow(int reset);
 
-/* Kernel timing hook for bench.py.  mode 1: the library brackets the forward and backward blend kernels with HIP events on
- * the launch stream (eager launches only); mode 2: with one-thread kernels that append the device's constant-rate
- * (100 MHz) counter to a ring -- legal inside a captured graph, so the kernels are timed in the launch mode the replayed
- * step uses; mode 0: off.  dgs_profile_read returns accumulated milliseconds and launch counts since the last reset:
+/* Kernel timing hook for bench.py.  mode 1: the library brackets its kernels with HIP events on the launch stream (eager
+ * launches only); mode 2: with one-thread kernels that append the device's constant-rate (100 MHz) counter to a ring --
+ * legal inside a captured graph, so the kernels are timed in the launch mode the replayed step uses; mode 0: off.
+ * dgs_profile_read returns accumulated milliseconds and launch counts since the last reset (up to 14 values):
  * out[0..1] fwd blend (ms, n), out[2..3] bwd blend (ms, n), out[4], out[5] = sum over the timed fwd / bwd launches of
- * S = sum_tiles(entries traversed), the unit of the algorithmic-bytes formula. */
+ * S = sum_tiles(entries traversed), the unit of the blend kernels' algorithmic-bytes formula;
+ * out[6..7] preprocess_fwd (ms, n), out[8..9] binning = count + scan + scatter + per-tile sort (ms, n), out[10..11] surfel_bwd
+ * (ms, n), out[12] = sum of num_rendered, out[13] = sum of visible surfels (radii > 0) over the timed forwards. */
 void dgs_profile_enable(int mode);
 void dgs_profile_reset(void);
 int dgs_profile_read(double* out, int cap);
