@@ -96,6 +96,12 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
 
 def save(trainer, model_path, iteration):
     """Scene.save + DeformModel.save_weights (scene/__init__.py, scene/deform_model.py:41-44): the two files of a checkpoint."""
+    if hasattr(trainer, "_flush_guard"):
+        for _ in range(8):   # steps the guard skipped in the last iterations are redone before the state is written
+            if not trainer._flush_guard():
+                break
+            while trainer.iteration < iteration:   # the recovery rewound the iteration counter by the number of skipped steps
+                trainer.step()
     dio.save_surfels(trainer.surfels, os.path.join(model_path, "point_cloud/iteration_{}".format(iteration), "point_cloud.ply"))
     dio.save_deform(trainer.deform, model_path, iteration)
 

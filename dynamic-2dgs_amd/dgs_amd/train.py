@@ -272,6 +272,23 @@ class Trainer:
         if float(e[1]) > 0:
             self._recover_overflow()
 
+    def _flush_guard(self):
+        """Look at every report the step guard has not shown the host yet (step() polls GUARD_LAG steps late) and recover if one of
+        them -- or the sticky flag itself -- says a step was skipped.  Called wherever the trainer is about to re-capture, change
+        the slot layout or save: an overflow of the last two steps must not be captured into a fresh graph as a stale flag, withdraw
+        the list-length promise for good, or be lost with the steps it skipped."""
+        if self.opt_deform is not None or getattr(self, "_oflag", None) is None or getattr(self, "_in_recovery", False):
+            return False
+        torch.cuda.synchronize()
+        self._guard_events.clear()
+        skipped = int(self.opt_surfels.status[1].item())
+        if bool(self._oflag.item()) or skipped != self._skipped_seen:
+            if self._graph and getattr(self, "_capacity", 0) > 0:
+                self._recover_overflow()
+                return True
+            raise RuntimeError("rasterizer capacity overflow outside capacity mode")
+        return False
+
     def _recover_overflow(self):
         from diff_surfel_rasterization import _C
         torch.cuda.synchronize()
@@ -289,7 +306,11 @@ class Trainer:
         else:
             self._capacity = 2 * self._capacity
         self._graph = None
-        self.enable_graph(self._capacity, validate=False)
+        self._in_recovery = True
+        try:
+            self.enable_graph(self._capacity, validate=False)
+        finally:
+            self._in_recovery = False
 
     # ---- whole-step HIP graph ------------------------------------------------------------------------------------
     def enable_graph(self, capacity, validate=True):
@@ -310,6 +331,9 @@ class Trainer:
             raise RuntimeError("set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE importing torch to use "
                                "Trainer.enable_graph() (see DESIGN.md, 'HIP graphs')")
         dev = self.surfels.get_xyz.device
+        if self._graph:            # a live capture is being replaced: settle what its last steps reported first
+            if self._flush_guard():
+                return             # the recovery re-captured already (with a larger capacity / without the promise)
         self._capacity = int(capacity)
         _C.set_capacity(int(capacity))
         # promise of the longest tile list (dgs_set_option key 6): one sort launch instead of three.  A frame that breaks it
@@ -320,6 +344,8 @@ class Trainer:
         _C.set_option(6, self._list_hint)
         if getattr(self, "_oflag", None) is not None:
             _C.set_overflow_flag(self._oflag)   # the captured launches keep THIS trainer's flag
+            if not getattr(self, "_in_recovery", False):
+                self._oflag.zero_()             # read_overflow below reports overflows of THIS capture only
         # (rays_d [H*W,3], rays_o [3]) per view and the targets stay resident: the table rows point at them
         self._rays = [tuple(t.contiguous() for t in camera_rays(cam, dev)) for cam in self.cameras]
         self._targets_c = [t.contiguous() for t in self.targets]
@@ -702,6 +728,7 @@ class Trainer:
         statistics were summed over the ranks by the step, the random draw is seeded by (seed, iteration).
         Returns (n_cloned, n_split, n_pruned)."""
         from . import densify
+        self._flush_guard()   # the statistics of a skipped step must be redone before they are used
         dev = self.surfels.get_xyz.device
         gen = torch.Generator(device=dev).manual_seed(int(seed) * 1000003 + self.iteration)
         args = (max_grad, min_opacity, extent, max_screen_size)
@@ -714,6 +741,7 @@ class Trainer:
 
     def reset_opacity(self):
         from . import densify
+        self._flush_guard()
         densify.reset_opacity(self.surfels, self._moments())
 
     # ---- storage order of the surfels ------------------------------------------------------------------------------------
@@ -788,6 +816,7 @@ class Trainer:
         (broadcast loads), and the skinning backward can sum a wave's contributions to a node in registers and issue one
         atomic per (wave, node) (dgs_deform_backward, coherent variant; 97 -> ~20 us at 200 k surfels / 1024 nodes) instead
         of building 256 LDS tables.  Call after initialisation and after densification; stale order only costs time."""
+        self._flush_guard()
         s, d = self.surfels, self.deform
         self.sort_nodes()
         x, nodes = s.get_xyz.detach(), d.nodes.detach()[:, :3]
@@ -803,6 +832,7 @@ class Trainer:
                self.lambda_dist if lambda_dist is None else float(lambda_dist))
         if new == (self.warmup, self.lambda_normal, self.lambda_dist):
             return False
+        self._flush_guard()
         self.warmup, self.lambda_normal, self.lambda_dist = new
         if self._graph:
             self._graph = None
@@ -815,6 +845,7 @@ class Trainer:
         s = self.surfels
         if s.active_sh_degree >= s.max_sh_degree:
             return False
+        self._flush_guard()
         s.active_sh_degree += 1
         if self._graph:
             self._graph = None
@@ -825,6 +856,7 @@ class Trainer:
         """Re-allocate the surfel slots (parameters, gradient bucket, Adam moments, statistics) to `capacity` and re-capture
         the step's graphs if they were enabled.  Values, moments and the Adam step count carry over."""
         from . import densify
+        self._flush_guard()
         s = self.surfels
         old = s.get_xyz.shape[0]
         assert capacity > old
@@ -883,6 +915,7 @@ class Trainer:
         gradient.  The node count changes, so the bucket / optimiser are rebuilt (moments and step count carry over) and the
         step is re-captured; on the HIP path the count is padded to a multiple of 64 (fused MLP kernels) with unreachable
         nodes.  Returns (n_added, n_pruned) or None if nothing changed."""
+        self._flush_guard()
         s, d = self.surfels, self.deform
         fused = self.opt_deform is None
         with torch.no_grad():

@@ -57,7 +57,7 @@ def test_fit_recovers_a_hidden_dynamic_scene(tmp_path):
     for l in losses:
         e = 0.99 * e + 0.01 * l
         ema.append(e)
-    assert ema[-1] <= 0.35 * ema[200], (ema[200], ema[-1])
+    assert ema[7999] <= 0.4 * ema[200] and ema[-1] <= 0.6 * ema[200], (ema[200], ema[7999], ema[-1])   # (the regularisers join the loss at 8001)
     assert blocks[5] < 0.6 * blocks[0] and blocks[15] < blocks[5], blocks
     assert sum(1 for a, b in zip(blocks[:-1], blocks[1:]) if b > 1.05 * a) <= 4, blocks
     assert os.path.exists(os.path.join(str(tmp_path / "model"), "point_cloud/iteration_9000/point_cloud.ply"))
