@@ -31,6 +31,9 @@ namespace dgs {
 #ifndef DGS_PIN_PREFETCH
 #define DGS_PIN_PREFETCH 1
 #endif
+#ifndef DGS_DIAG_BWD
+#define DGS_DIAG_BWD 0   // development only (WRONG results): 1 no atomics, 2 no reduction either, 3 evaluation + loop only
+#endif
 constexpr int kChunk = 64;   // list entries staged per wave and step: one per lane
 
 __device__ __forceinline__ Quad as_quad(const float4& v) { return Quad{v.x, v.y, v.z, v.w}; }
@@ -688,16 +691,32 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
                 ok = ok & (depth >= kNear);
                 // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step_affine)
                 float out[16], out2d[2];
+#if DGS_DIAG_BWD == 3
+                for (int k = 0; k < 16; k++) out[k] = depth;
+                out2d[0] = out2d[1] = 0.f;
+                asm volatile("" : : "v"(depth), "v"(tuv.x), "v"(q3.x), "v"(q4.x));
+#else
                 pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
                                    Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
+#endif
                 // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
                 float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * 4 + wave) * kAccFloats
                                  : a.acc + (size_t)__builtin_amdgcn_readfirstlane(__float_as_uint(q4.w)) * kAccFloats;
+#if DGS_DIAG_BWD >= 2
+                float tot = 0.f;
+                for (int k = 0; k < 16; k++) asm volatile("" : : "v"(out[k]));
+                asm volatile("" : : "s"(dst));
+#else
                 const float tot = wave_reduce16(out, lane);
+#endif
+#if DGS_DIAG_BWD == 0
                 if (rslot >= 0) {
                     if (DET) dst[rslot] = tot;
                     else atomicAdd(dst + rslot, tot);
                 }
+#else
+                asm volatile("" : : "v"(tot));
+#endif
                 if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
                     const float mx = wave_sum(out2d[0]);
                     const float my = wave_sum(out2d[1]);

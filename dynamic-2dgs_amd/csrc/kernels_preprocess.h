@@ -447,8 +447,16 @@ __global__ void __launch_bounds__(256) sort_tiles_reg_kernel(const uint2* ranges
 //     index by the thread that finds its head.
 // O(n) operations per pass instead of the O(n log^2 n) compare-exchanges of the bitonic network (which saturated the VALU:
 // 62 us at 200 k surfels / 800x800); keys are 32-bit here (depth bits; the index rides along as payload).
-template <int CAP>
-__global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* ranges, int ntiles, const uint64_t* keys, uint32_t* point_list, int lo)
+// SEG = true (lists longer than CAP): blockIdx.y = segment; the workgroup sorts entries [y CAP, (y + 1) CAP) of every list of
+// more than CAP and at most CAP * gridDim.y entries and writes the sorted (depth, index) KEYS into the list's scratch area;
+// merge_segments_kernel then ranks every key among the other segments.  `seg_out` = scratch of 2 R keys (list at 2 * range.x).
+// CAP = 3584: 60 KB of LDS.  A workgroup that asks for MORE than 64 KB costs ~2 us of serialised dispatch on gfx950 -- 36 idle
+// workgroups of the 128-KB kernel of round 2 took 73 us, 288 working ones 730 -- so no kernel here goes beyond 64 KB.
+constexpr int kSegCap = 3584;
+constexpr int kMaxSegs = 16;
+template <int CAP, bool SEG = false>
+__global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* ranges, int ntiles, const uint64_t* keys, uint32_t* point_list, int lo,
+                                                               uint64_t* seg_out = nullptr)
 {
     __shared__ uint32_t s_key[2][CAP];
     __shared__ uint32_t s_val[2][CAP];
@@ -458,10 +466,12 @@ __global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* rang
     // would cost ten dispatch rounds of 2500 workgroups for nothing)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint2 rg = ranges[tile];
-    const int n = (int)(rg.y - rg.x);
-    if (n <= lo || n > CAP) continue;
+    const int n_list = (int)(rg.y - rg.x);
+    const int seg0 = SEG ? (int)blockIdx.y * CAP : 0;
+    if (SEG ? (n_list <= CAP || n_list > CAP * (int)gridDim.y || seg0 >= n_list) : (n_list <= lo || n_list > CAP)) continue;
+    const int n = SEG ? min(CAP, n_list - seg0) : n_list;
     __syncthreads();   // the previous tile's last reads of the LDS arrays
-    const uint64_t* gk = keys + rg.x;
+    const uint64_t* gk = keys + rg.x + seg0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- load, and the bits in which the bucket's depths differ
     uint32_t kand = 0xffffffffu, kor = 0u;
@@ -562,7 +572,65 @@ __global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* rang
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) point_list[rg.x + i] = vf[i];
+    if (SEG) {
+        uint64_t* so = seg_out + 2 * (size_t)rg.x + seg0;
+        for (int i = tid; i < n; i += 256) so[i] = ((uint64_t)kf[i] << 32) | vf[i];
+    } else {
+        for (int i = tid; i < n; i += 256) point_list[rg.x + i] = vf[i];
+    }
+    }
+}
+
+// Lists of more than kSegCap entries, second step: every key of segment y finds its place in the whole list -- its index in
+// its own (sorted) segment plus, for every other segment, the number of keys below it.  Keys are unique inside a list (the
+// surfel index is part of the key), so "below" needs no tie rule and the result is the reference's stable (depth, index) order.
+// A thread owns 14 CONSECUTIVE keys of its segment; the other segments pass through LDS one at a time (29 KB, coalesced load):
+// the number of its keys below each of the thread's keys is a branch-free binary search in LDS.
+// Searching the other segments where they lie, in global memory, is a chain of ~200 dependent loads per thread: 0.67 ms.
+// (LDS index i lives at i + i / 32: the threads' search positions are ~32 keys apart, which would be one bank.)
+__global__ void __launch_bounds__(256) merge_segments_kernel(const uint2* ranges, int ntiles, const uint64_t* seg_keys /*scratch*/, uint32_t* point_list)
+{
+    constexpr int kPer = kSegCap / 256;
+    __shared__ uint64_t s_other[kSegCap + kSegCap / 32];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint2 rg = ranges[tile];
+        const int n_list = (int)(rg.y - rg.x);
+        const int seg = (int)blockIdx.y, seg0 = seg * kSegCap;
+        if (n_list <= kSegCap || n_list > kSegCap * (int)gridDim.y || seg0 >= n_list) continue;   // (workgroup-uniform)
+        const uint64_t* base = seg_keys + 2 * (size_t)rg.x;
+        const int n = min(kSegCap, n_list - seg0), nseg = (n_list + kSegCap - 1) / kSegCap;
+        const int i0 = (int)threadIdx.x * kPer, cnt = max(0, min(kPer, n - i0));
+        uint64_t mine[kPer];
+        int rank[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; i++) { mine[i] = i < cnt ? base[seg0 + i0 + i] : ~0ull; rank[i] = i0 + i; }
+        for (int o = 0; o < nseg; o++) {
+            if (o == seg) continue;
+            const int len = min(kSegCap, n_list - o * kSegCap);
+            __syncthreads();
+            for (int i = threadIdx.x; i < len; i += 256) s_other[i + (i >> 5)] = base[o * kSegCap + i];
+            __syncthreads();
+            // branch-free lower bound of all 14 keys at once: 12 rounds of 14 independent LDS reads (a merge-style walk from key to
+            // key is a chain of dependent reads inside a divergent loop: 25 us per segment instead of ~2)
+            int pos[kPer];
+#pragma unroll
+            for (int i = 0; i < kPer; i++) pos[i] = 0;
+#pragma unroll
+            for (int step = 2048; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int i = 0; i < kPer; i++) {
+                    const int p = pos[i] + step;
+                    const int q = p <= len ? p - 1 : 0;
+                    const bool below = (p <= len) & (s_other[q + (q >> 5)] < mine[i]);
+                    pos[i] = below ? p : pos[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kPer; i++) rank[i] += pos[i];   // (padding keys of a thread with fewer than 14 are never written)
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; i++)
+            if (i < cnt) point_list[rg.x + rank[i]] = (uint32_t)mine[i];
     }
 }
 

@@ -136,10 +136,10 @@ dgs::Camera make_camera(const float* view_dev, const float* campos_dev, int W, i
 __global__ void sum_forward_units_kernel(const uint32_t* total, const int* radii, int P, unsigned long long* dst_R, unsigned long long* dst_Pv)
 {
     unsigned long long vis = 0;
-    for (int i = threadIdx.x; i < P; i += 256) vis += radii[i] > 0 ? 1u : 0u;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) vis += radii[i] > 0 ? 1u : 0u;
     for (int d = 32; d >= 1; d >>= 1) vis += __shfl_xor(vis, d, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(dst_Pv, vis);
-    if (threadIdx.x == 0) atomicAdd(dst_R, (unsigned long long)total[0]);
+    if ((threadIdx.x & 63) == 0 && vis) atomicAdd(dst_Pv, vis);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(dst_R, (unsigned long long)total[0]);
 }
 
 __global__ void sum_tile_last_kernel(const uint32_t* tile_last, int n, unsigned long long* dst)
@@ -601,7 +601,7 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     if (R_u > 0x7fffffffu) return fail(DGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
     const int R = (int)R_u;
 
-    const bool need_global_sort = longest > (ctx->sort_regs.load() == 2 ? 8192u : 16384u);
+    const bool need_global_sort = longest > (ctx->sort_regs.load() == 2 ? (uint32_t)dgs::kSegCap : 16384u);   // (radix mode: scratch for the sorted segments)
     BinningLayout bl(R, need_global_sort);
     char* bin = binning_alloc(binning_ctx, bl.bytes);
     if (!bin) return fail(DGS_ERR_ALLOC, "binning allocator returned NULL");
@@ -626,18 +626,29 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         uint32_t* plist = (uint32_t*)(bin + bl.point_list);
         const int sort_mode = ctx->sort_regs.load();
         if (sort_mode == 2) {
-            // per-tile LSD radix sort (default): lists up to 2048 entries in 32 KB of LDS, up to 8192 in 128 KB.  Every tile
-            // picks its kernel on the device; when the longest list is known on the host (exact-size mode) the launches
-            // that cannot have work are skipped.
-            const int big_grid = il.ntiles < 256 ? il.ntiles : 256;   // long lists are rare: grid-stride over the tiles
+            // per-tile LSD radix sort (default): lists up to 2048 entries in 36 KB of LDS (one workgroup per tile), up to 3584 in
+            // 60 KB (grid-stride launch: such lists are rare); longer ones as segments of 3584 sorted side by side + a rank/merge
+            // step, up to 16 segments; beyond 57 344 entries the global-memory network.  Every tile picks its kernel on the
+            // device; when the longest list is known on the host (exact-size mode, or promised) the launches that cannot have
+            // work are skipped.
+            const int big_grid = il.ntiles < 256 ? il.ntiles : 256;
             hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
                                (const uint64_t*)keys, plist, 0);
             if (longest > 2048u)
-                hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<8192>), dim3(big_grid), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
+                hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<dgs::kSegCap>), dim3(big_grid), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
                                    (const uint64_t*)keys, plist, 2048);
-            if (longest > 8192u)
+            if (longest > (uint32_t)dgs::kSegCap) {
+                // (a 30 000-entry list on ONE workgroup's global-memory network took 0.45 ms; a crowded tile is exactly what
+                // densification produces)
+                const dim3 seg_grid(il.ntiles < 64 ? il.ntiles : 64, dgs::kMaxSegs);
+                hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<dgs::kSegCap, true>), seg_grid, dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
+                                   (const uint64_t*)keys, plist, 0, (uint64_t*)(bin + bl.scratch));
+                hipLaunchKernelGGL(dgs::merge_segments_kernel, seg_grid, dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
+                                   (const uint64_t*)(bin + bl.scratch), plist);
+            }
+            if (longest > (uint32_t)(dgs::kSegCap * dgs::kMaxSegs))
                 hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(big_grid), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
-                                   (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, 8192);
+                                   (const uint64_t*)keys, (uint64_t*)(bin + bl.scratch), plist, dgs::kSegCap * dgs::kMaxSegs);
         } else {
             if (sort_mode == 1)
                 hipLaunchKernelGGL(dgs::sort_tiles_reg_kernel, dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges,
@@ -659,7 +670,7 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     if (timed3) {
         prof_mark_end(ctx, stream, pp3);
         if (ctx->prof.counters)
-            hipLaunchKernelGGL(sum_forward_units_kernel, dim3(1), dim3(256), 0, stream, (const uint32_t*)(geom + gl.total), (const int*)radii, P,
+            hipLaunchKernelGGL(sum_forward_units_kernel, dim3(64), dim3(256), 0, stream, (const uint32_t*)(geom + gl.total), (const int*)radii, P,
                                ctx->prof.counters + 2, ctx->prof.counters + 3);
     }
 
