@@ -450,8 +450,10 @@ __global__ void __launch_bounds__(256) sort_tiles_reg_kernel(const uint2* ranges
 // SEG = true (lists longer than CAP): blockIdx.y = segment; the workgroup sorts entries [y CAP, (y + 1) CAP) of every list of
 // more than CAP and at most CAP * gridDim.y entries and writes the sorted (depth, index) KEYS into the list's scratch area;
 // merge_segments_kernel then ranks every key among the other segments.  `seg_out` = scratch of 2 R keys (list at 2 * range.x).
-// CAP = 3584: 60 KB of LDS.  A workgroup that asks for MORE than 64 KB costs ~2 us of serialised dispatch on gfx950 -- 36 idle
-// workgroups of the 128-KB kernel of round 2 took 73 us, 288 working ones 730 -- so no kernel here goes beyond 64 KB.
+// CAP = 3584: 60 KB of LDS.  The 8192-entry / 132-KB instantiation of this kernel that round 2 used for lists of 2 k - 8 k entries
+// never took less than ~73 us per launch, with or without work (36 workgroups that find nothing to sort: 73 us; this one: 2 us).
+// The cause was not isolated -- bare allocations of 16 .. 160 KB launch in 2.5 us whatever their size
+// (tools/micro/lds_launch_bench.hip) -- but the 60-KB instantiation does not show it, and its segments run side by side.
 constexpr int kSegCap = 3584;
 constexpr int kMaxSegs = 16;
 template <int CAP, bool SEG = false>
