@@ -588,8 +588,10 @@ class _FusedDeform(torch.autograd.Function):
         g_attrs = torch.empty_like(attrs) if ctx.g_attrs_out is None else ctx.g_attrs_out  # deferred node MLP: caller's buffer
         persistent = 0
         if ctx.coherent:
-            # one persistent zeroed [M][13+H+2] table per (device, M, H): the reduce kernel leaves it zeroed again
-            key = (dev, M, H)
+            # one persistent zeroed [M][13+H+2] table per (device, M, H, stream): the reduce kernel leaves it zeroed again.  Keyed
+            # by the stream as well: two backward passes on different streams must not add into one table (created during the
+            # warm-up steps that precede a capture, never inside one)
+            key = (dev, M, H, int(torch.cuda.current_stream(dev).cuda_stream))
             scratch = _COHERENT_TABLES.get(key)
             if scratch is None:
                 scratch = _COHERENT_TABLES[key] = torch.zeros(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)

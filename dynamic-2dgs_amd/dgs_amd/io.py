@@ -161,8 +161,10 @@ def save_deform(deform, model_path, iteration):
     return os.path.join(out, "deform.pth")
 
 
-def load_deform(deform, model_path, iteration=-1):
-    """DeformModel.load_weights (scene/deform_model.py:46-56): False if there is nothing to load."""
+def load_deform(deform, model_path, iteration=-1, pad_to=1):
+    """DeformModel.load_weights (scene/deform_model.py:46-56): False if there is nothing to load.  pad_to = 64 re-creates the
+    padding nodes save_deform strips (the fused MLP kernels need a node count that is a multiple of 64; without them a resumed
+    run would silently fall back to the PyTorch formulation)."""
     it = search_for_max_iteration(os.path.join(model_path, "deform")) if iteration == -1 else iteration
     path = os.path.join(model_path, "deform/iteration_{}/deform.pth".format(it))
     if not os.path.exists(path):
@@ -175,6 +177,9 @@ def load_deform(deform, model_path, iteration=-1):
     # used by the reference's node-rendering warm-up, which is not part of this path: they and any other key this model does
     # not own are skipped; an own key the file lacks is an error (a silently half-loaded network would be worse).
     skipped = [k for k in state if k not in own and k != "inited"]
+    foreign = [k for k in skipped if not k.startswith("gs_")]
+    if foreign:
+        raise KeyError("deform.pth holds entries this model does not know and the reference does not write: %s" % foreign)
     missing = [k for k in own if k not in state]
     if missing:
         raise KeyError("deform.pth lacks %s (file has %d entries, %d of them not owned by this model)" % (missing, len(state), len(skipped)))
@@ -184,6 +189,8 @@ def load_deform(deform, model_path, iteration=-1):
                 getattr(deform, k).data = torch.empty_like(state[k], device=own[k].device)
     deform.load_state_dict({k: v for k, v in state.items() if k in own})
     load_deform.skipped_keys = skipped
+    if pad_to > 1 and hasattr(deform, "pad_nodes"):
+        deform.pad_nodes(pad_to)
     return True
 
 

@@ -335,13 +335,13 @@ class Trainer:
             if self._flush_guard():
                 return             # the recovery re-captured already (with a larger capacity / without the promise)
         self._capacity = int(capacity)
-        _C.set_capacity(int(capacity))
+        _C.set_capacity(int(capacity), device=dev)   # (the context of THIS trainer's device, whatever the caller's current device is)
         # promise of the longest tile list (dgs_set_option key 6): one sort launch instead of three.  A frame that breaks it
         # counts as an overflow: at capture time (below) and in the step guard the promise is withdrawn first, the capacity
         # doubled only if that was not the reason
         if not hasattr(self, "_list_hint"):
             self._list_hint = 2048
-        _C.set_option(6, self._list_hint)
+        _C.set_option(6, self._list_hint, device=dev)
         if getattr(self, "_oflag", None) is not None:
             _C.set_overflow_flag(self._oflag)   # the captured launches keep THIS trainer's flag
             if not getattr(self, "_in_recovery", False):
@@ -421,7 +421,7 @@ class Trainer:
                     self._forward(self._scam, self._sgt)
             self._scam.load(self._vtab[0])
             torch.cuda.synchronize()
-        if _C.read_overflow():
+        if _C.read_overflow(device=dev):
             if self._list_hint:            # perhaps only the promised list length was exceeded: withdraw it and capture again
                 self._list_hint = 0
                 self._graph = None

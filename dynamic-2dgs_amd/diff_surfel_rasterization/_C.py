@@ -346,62 +346,89 @@ def debug_layout(which, P=0, width=1, height=1, R=0):
     return [int(buf[i]) for i in range(n)]
 
 
-def set_tight_rects(on=True):
+import contextlib
+
+
+@contextlib.contextmanager
+def _on(device):
+    """The reference-shaped C entry points act on the DEFAULT CONTEXT OF THE CALLING THREAD'S CURRENT DEVICE.  Every wrapper below
+    takes `device` (a torch device, an index, or a tensor's .device) and makes it current around the call, so that a trainer on
+    cuda:1 configures cuda:1's context whatever the caller's current device is; None keeps the current device."""
+    if device is None:
+        yield
+    else:
+        with torch.cuda.device(device):
+            yield
+
+
+def set_tight_rects(on=True, device=None):
     """Tile-list policy (see dgs_set_tight_rects): False reproduces the reference's lists entry for entry."""
-    load().dgs_set_tight_rects(1 if on else 0)
+    with _on(device):
+        load().dgs_set_tight_rects(1 if on else 0)
 
 
-def set_option(key, value):
+def set_option(key, value, device=None):
     lib = load()
-    rc = lib.dgs_set_option(int(key), int(value))
+    with _on(device):
+        rc = lib.dgs_set_option(int(key), int(value))
     if rc < 0:
         _raise(lib, rc, "set_option")
 
 
-def set_capacity(n_entries):
+def set_capacity(n_entries, device=None):
     """Capacity mode (dgs_set_option key 2): > 0 makes forward/backward free of host synchronisation, 0 restores it."""
-    set_option(2, int(n_entries))
+    set_option(2, int(n_entries), device)
 
 
-def read_overflow(reset=True):
-    return bool(load().dgs_read_overflow(1 if reset else 0))
+def read_overflow(reset=True, device=None):
+    with _on(device):
+        return bool(load().dgs_read_overflow(1 if reset else 0))
 
 
-_OVERFLOW_FLAG = None
+_OVERFLOW_FLAGS = {}   # device index -> the caller-owned flag tensor its default context points at (kept alive here)
 
 
-def set_overflow_flag(tensor):
+def set_overflow_flag(tensor, device=None):
     """Hand the default context of the tensor's device a caller-owned int32[1] overflow flag (dgs_set_overflow_flag), so that
-    the caller's own kernels can read it on the device; None returns to the library-owned flag."""
-    global _OVERFLOW_FLAG
+    the caller's own kernels can read it on the device; None (+ `device`) returns that device's context to the library-owned flag."""
     lib = load()
     if tensor is not None:
         assert tensor.dtype == torch.int32 and tensor.numel() == 1 and tensor.is_cuda
-        with torch.cuda.device(tensor.device):
+        device = tensor.device
+        with torch.cuda.device(device):
             rc = lib.dgs_set_overflow_flag(tensor.data_ptr())
     else:
-        rc = lib.dgs_set_overflow_flag(None)
+        with _on(device):
+            rc = lib.dgs_set_overflow_flag(None)
     if rc < 0:
         _raise(lib, rc, "set_overflow_flag")
-    _OVERFLOW_FLAG = tensor   # keep it alive while the library points at it
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if tensor is None:
+        _OVERFLOW_FLAGS.pop(idx, None)
+    else:
+        _OVERFLOW_FLAGS[idx] = tensor   # keep it alive while the library points at it
 
 
-def profile_enable(mode=True):
-    """0 / False: off; 1 / True: HIP events around the blend kernels (eager launches); 2: device timestamps, legal inside a
+def profile_enable(mode=True, device=None):
+    """0 / False: off; 1 / True: HIP events around the timed kernels (eager launches); 2: device timestamps, legal inside a
     captured graph (see dgs_profile_enable)."""
-    load().dgs_profile_enable(int(mode))
+    with _on(device):
+        load().dgs_profile_enable(int(mode))
 
 
-def profile_reset():
-    load().dgs_profile_reset()
+def profile_reset(device=None):
+    with _on(device):
+        load().dgs_profile_reset()
 
 
-def profile_read():
+def profile_read(device=None):
     """Accumulated over the timed launches: blend kernels {'fwd_ms', 'fwd_n', 'bwd_ms', 'bwd_n', 'fwd_S', 'bwd_S'}, and
     {'pre_ms', 'pre_n'} preprocess_fwd, {'bin_ms', 'bin_n'} binning (count + scan + scatter + per-tile sort), {'sbw_ms', 'sbw_n'}
     surfel_bwd, 'R' = sum of num_rendered, 'Pv' = sum of visible surfels over the timed forwards."""
     out = (ctypes.c_double * 14)()
-    load().dgs_profile_read(out, 14)
+    with _on(device):
+        load().dgs_profile_read(out, 14)
     return {"fwd_ms": out[0], "fwd_n": int(out[1]), "bwd_ms": out[2], "bwd_n": int(out[3]), "fwd_S": out[4], "bwd_S": out[5],
             "pre_ms": out[6], "pre_n": int(out[7]), "bin_ms": out[8], "bin_n": int(out[9]), "sbw_ms": out[10], "sbw_n": int(out[11]),
             "R": out[12], "Pv": out[13]}

@@ -60,16 +60,31 @@ def _guarded(fn, args, debug, dump_name, what):
         raise
 
 
-_SH_GRAD_SINK = None
+import threading
+
+_SINKS = {}                   # device index -> sink tensor
+_SINKS_LOCK = threading.Lock()
 
 
-def set_sh_grad_sink(tensor):
-    """Extension (not in the reference): while set to a contiguous fp32 [P,M,3] tensor, backward passes write dL/dSH of
-    the visible surfels directly into it (the kernel stores, it does not accumulate; rows of culled surfels are left as
-    they are) and return no gradient for `shs`.  For trainers that keep gradients in one pre-zeroed flat buffer; pass
-    None to restore the reference behaviour."""
-    global _SH_GRAD_SINK
-    _SH_GRAD_SINK = tensor
+def set_sh_grad_sink(tensor, device=None):
+    """Extension (not in the reference): while set to a contiguous fp32 [P,M,3] tensor, backward passes ON THE TENSOR'S DEVICE write
+    dL/dSH of the visible surfels directly into it (the kernel stores, it does not accumulate; rows of culled surfels are left as
+    they are) and return no gradient for `shs`.  For trainers that keep gradients in one pre-zeroed flat buffer.  None restores
+    the reference behaviour (for `device`, or for every device when no device is given).  The state is per DEVICE, like the
+    library's default contexts: two trainers on two devices do not see each other's sink.  It cannot be per thread: autograd runs
+    the backward of a HIP device on that device's own worker thread, not on the thread that called backward()."""
+    with _SINKS_LOCK:
+        if tensor is not None:
+            _SINKS[tensor.device.index] = tensor
+        elif device is None:
+            _SINKS.clear()
+        else:
+            _SINKS.pop(torch.device(device).index, None)
+
+
+def _sink_for(dev):
+    with _SINKS_LOCK:
+        return _SINKS.get(dev.index)
 
 
 class _SurfelRasterFn(torch.autograd.Function):
@@ -98,13 +113,13 @@ class _SurfelRasterFn(torch.autograd.Function):
         call = (cfg.bg, means3D, radii, colors_precomp, scales, rotations, cfg.scale_modifier, cov3Ds_precomp,
                 cfg.viewmatrix, cfg.projmatrix, cfg.tanfovx, cfg.tanfovy, g_color, g_allmap, sh, cfg.sh_degree, cfg.campos,
                 geom, ctx.n_rendered, binning, img, cfg.debug)
-        sink = _SH_GRAD_SINK
+        sink = _sink_for(means3D.device)
         if sink is not None and not (sink.shape == sh.shape and sink.dtype == torch.float32 and sink.is_contiguous()
                                      and sink.device == sh.device):
             raise RuntimeError("set_sh_grad_sink: the sink must be a contiguous fp32 tensor of the shape of shs")
         if sink is not None:
-            (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _C.rasterize_gaussians_backward(
-                *call, dL_dsh_out=sink)
+            (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
+                lambda *a: _C.rasterize_gaussians_backward(*a, dL_dsh_out=sink), call, cfg.debug, "snapshot_bw.dump", "backward")
             g_sh = None
         else:
             (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(

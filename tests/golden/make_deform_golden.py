@@ -51,10 +51,11 @@ def import_reference():
     return tu
 
 
-def main():
+def main(node_num=48, N=300, out_name="deform_golden.npz"):
+    """(48 nodes, 300 Gaussians): the small fixture; (512, 5000): BASELINE.json config 1 at its stated size (`deform_golden_c1.npz`;
+    512 nodes is also the configuration the fused gfx950 kernels cover: node count a multiple of 64)."""
     tu = import_reference()
     torch.manual_seed(0)
-    node_num, N = 48, 300
     ref = tu.ControlNodeWarp(is_blender=True, node_num=node_num, K=3, hyper_dim=8, local_frame=True, d_rot_as_res=True,
                              with_arap_loss=False, with_node_weight=True)
     fill_params(ref)
@@ -72,7 +73,7 @@ def main():
         w, d, idx = ref.cal_nn_weight(x=x, feature=feature)
         net = ref.network(ref.nodes[..., :3], t)
     np.savez_compressed(
-        os.path.join(HERE, "deform_golden.npz"),
+        os.path.join(HERE, out_name),
         x=x.numpy(), feature=feature.numpy(), t=t.numpy(), motion_mask=motion_mask.numpy(),
         nodes=ref.nodes.data.numpy(), node_radius=ref._node_radius.data.numpy(), node_weight=ref._node_weight.data.numpy(),
         d_xyz=out["d_xyz"].numpy(), d_rotation=out["d_rotation"].numpy(), d_scaling=out["d_scaling"].numpy(),
@@ -80,8 +81,9 @@ def main():
         net_d_xyz=net["d_xyz"].numpy(), net_d_rotation=net["d_rotation"].numpy(), net_d_scaling=net["d_scaling"].numpy(),
         net_local_rotation=net["local_rotation"].numpy(),
         n_params=np.array(sum(p.numel() for p in ref.network.parameters())))
-    print("wrote deform_golden.npz; network params:", sum(p.numel() for p in ref.network.parameters()))
+    print("wrote %s; network params:" % out_name, sum(p.numel() for p in ref.network.parameters()))
 
 
 if __name__ == "__main__":
     main()
+    main(512, 5000, "deform_golden_c1.npz")

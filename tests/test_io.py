@@ -146,6 +146,29 @@ def test_deform_weights_file_is_the_reference_layout(tmp_path):
     torch.save(full, tmp_path / "deform" / "iteration_42000" / "deform.pth")
     with pytest.raises(KeyError):
         dio.load_deform(deform, str(tmp_path))
+    # ... and so is an entry neither this model nor the reference's writer knows (only the `gs_*` family is skipped)
+    odd = dict(ref_state, surprise=torch.zeros(3))
+    os.makedirs(tmp_path / "deform" / "iteration_43000")
+    torch.save(odd, tmp_path / "deform" / "iteration_43000" / "deform.pth")
+    with pytest.raises(KeyError):
+        dio.load_deform(deform, str(tmp_path))
+
+
+def test_padding_nodes_are_stripped_on_save_and_restored_on_load(tmp_path):
+    """The fused MLP kernels need a node count that is a multiple of 64: padding nodes (far outside the scene) are no part of a
+    checkpoint, and a loader that wants the fused path gets them back (load_deform(pad_to=64))."""
+    deform = ControlNodes(node_num=50, K=3, hyper_dim=8, local_frame=True)
+    deform.nodes.data[:, :3] = torch.randn(50, 3)
+    assert deform.pad_nodes(64) == 14 and deform.nodes.shape[0] == 64 and int(deform.live_nodes.sum()) == 50
+    live_before = deform.nodes.detach()[deform.live_nodes].clone()
+    dio.save_deform(deform, str(tmp_path), 100)
+    saved = torch.load(tmp_path / "deform" / "iteration_100" / "deform.pth", weights_only=True)
+    assert saved["nodes"].shape[0] == 50                                   # the file holds the model, not the padding
+    fresh = ControlNodes(node_num=8, K=3, hyper_dim=8, local_frame=True)
+    assert dio.load_deform(fresh, str(tmp_path)) and fresh.nodes.shape[0] == 50
+    fresh = ControlNodes(node_num=8, K=3, hyper_dim=8, local_frame=True)
+    assert dio.load_deform(fresh, str(tmp_path), pad_to=64) and fresh.nodes.shape[0] == 64 and int(fresh.live_nodes.sum()) == 50
+    assert torch.equal(fresh.nodes.detach()[fresh.live_nodes], live_before)
 
 
 def test_fit_tiny_scene_end_to_end_and_restore(tmp_path, monkeypatch):
