@@ -22,7 +22,8 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   "roofline_kernels": preprocess_fwd, binning (count + scan + scatter + per-tile sort) and surfel_bwd with the bytes SURVEY.md
                       section 8(d) defines for them (B2, B4-6, B10), same clocks;
   "twin"            : the graph-replayed steps and the eager steps of the roofline legs start from the SAME snapshot and render
-                      the same views: their per-step losses must agree (1e-5 relative over the first steps, 1e-3 over all), or the result is invalid;
+                      the same views: their per-step losses must agree (1e-5 relative over the first 3 steps; over all steps 1e-3 or 4x the
+                      difference of two eager runs, whichever is larger), or the result is invalid;
   "drift"           : the scene trains on noise targets while it is timed and its splats grow: ms/step of a second window 100
                       steps after the headline window, and the mean screen radius at both (the headline is the FIRST window);
   "cpu_baseline"    : the CPU port (C oracle rasterizer with OpenMP + PyTorch-CPU deformation/loss/Adam) timed on
@@ -63,8 +64,9 @@ WORKLOADS = {
     "c2": (50_000, 800, 800),          # BASELINE.json configs[1]: static canonical render, FORWARD ONLY, no deformation
     "tiny": (5_000, 128, 128),
     # a scene WITH structure: dgs_amd.synthetic.DynamicTruth rendered at 800x800, fitted from 100k random points with densification
-    # and the reference's stages (compressed: see trained_trainer) before the timed region -- surfels crowd onto two surfaces, so
-    # the tile lists have the statistics of a trained scene (long lists in few tiles) instead of the uniform cloud of "metric"
+    # and the reference's stages (see trained_trainer) before the timed region -- ~100k surfels crowd onto two surfaces that cover a
+    # third of the image, so the tile lists have the statistics of a trained scene (lists of 1000-2100 entries in the covered
+    # tiles, none elsewhere) instead of the uniform cloud of "metric"
     "trained": (100_000, 800, 800),
 }
 
@@ -150,18 +152,21 @@ def cpu_baseline(P, H, W, budget_s=25.0):
 
 
 def trained_trainer(P, H, W, device, pre_iterations):
-    """--workload trained: fit() on the synthetic D-NeRF-format dataset for `pre_iterations` (warm-up 1/3, regularisers from 2/3 of
-    them: the reference's three stages compressed; densification every 100 iterations from 500, opacity reset at 3000), then the
-    caller times the full late-regime step on what that produced."""
+    """--workload trained: fit() on the synthetic D-NeRF-format dataset (dgs_amd.synthetic.DynamicTruth with 40k finely textured
+    surfels, which the fit needs ~100k surfels to reproduce) for `pre_iterations` with the reference's stages: deformation
+    detached for the first 3000 iterations, regularisers from 8000, densification every 100 iterations from 500, opacity resets
+    every 3000 (train_gui.py:272-313, 410-423; shorter runs compress the stages to 0.3 / 0.8 of the run).  The caller then times the
+    full late-regime step on what that produced -- against the dataset's real target views."""
     import shutil
     import tempfile
     from dgs_amd.fit import fit
-    from dgs_amd.synthetic import write_dynamic_dnerf
+    from dgs_amd.synthetic import DynamicTruth, write_dynamic_dnerf
     tmp = tempfile.mkdtemp(prefix="dgs_trained_")
     try:
-        write_dynamic_dnerf(os.path.join(tmp, "scene"), n_train=48, n_test=2, H=H, W=W, device=device)
+        write_dynamic_dnerf(os.path.join(tmp, "scene"), n_train=48, n_test=2, H=H, W=W, device=device, truth=DynamicTruth(24000, 16000, detail=0.3))
+        warm_up, reg_from = (3000, 8000) if pre_iterations >= 10000 else (3 * pre_iterations // 10, 8 * pre_iterations // 10)
         tr, losses = fit(os.path.join(tmp, "scene"), os.path.join(tmp, "model"), iterations=pre_iterations, device=device, num_pts=P, node_num=512,
-                         seed=0, warm_up=pre_iterations // 3, regularize_from=2 * pre_iterations // 3, node_densify_at=10 ** 9)
+                         seed=0, warm_up=warm_up, regularize_from=reg_from, node_densify_at=10 ** 9)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return tr, losses
@@ -277,7 +282,7 @@ def main():
     ap.add_argument("--densify-every", type=int, default=0,
                     help="also run the in-place densification every N timed steps (off by default: the metric is the plain step)")
     ap.add_argument("--slots-factor", type=float, default=1.5, help="surfel slots per initial surfel when --densify-every is on")
-    ap.add_argument("--pre-iterations", type=int, default=3000, help="--workload trained: fit() iterations before the timed region")
+    ap.add_argument("--pre-iterations", type=int, default=10000, help="--workload trained: fit() iterations before the timed region")
     ap.add_argument("--drift-gap", type=int, default=100, help="steps between the headline window and the second (drift) window; 0: skip")
     args = ap.parse_args()
     assert args.steps <= 128, "the per-step losses of the timed steps come from a 256-entry ring"
@@ -384,7 +389,8 @@ def main():
             dt2 = float(t2.item())
         drift = {"steps_between_windows": args.drift_gap, "ms_per_step_second_window": round(dt2 / args.steps * 1e3, 4),
                  "mean_screen_radius_px": [radius_headline, mean_radius(tr)], "recaptured_in_between": tr.overflow_recoveries != recoveries,
-                 "note": "noise targets: Adam grows every splat by ~lr per step; the headline is the first window of the run"}
+                 "note": ("real target views: the scene keeps training; the headline is the first window of the run" if args.workload == "trained" else
+                          "noise targets: Adam grows every splat by ~lr per step; the headline is the first window of the run")}
 
     # ---- roofline legs = the twin check.  From the snapshot: K graph-replayed steps with the library's device-timestamp hook on
     # (one-thread kernels before and after each timed launch append the 100 MHz device counter to a ring -- legal inside a captured
@@ -422,17 +428,25 @@ def main():
         prof = _C.profile_read()
         _C.profile_enable(0)
         if replay_losses is not None:
-            rels = [abs(a - b) / max(abs(b), 1e-12) for a, b in zip(replay_losses, eager_losses)]
+            # yardstick: the same eager steps a second time.  Two eager runs differ in the order of the float atomics of the backward
+            # only, and so do a replay and an eager run -- a correct replay is as close to eager as eager is to itself
+            rewind()
+            eager2_losses = [float(tr.step()) for _ in range(args.steps)]
+            torch.cuda.synchronize()
+            relf = lambda xs, ys: [abs(a - b) / max(abs(b), 1e-12) for a, b in zip(xs, ys)]
+            rels, noise = relf(replay_losses, eager_losses), max(relf(eager2_losses, eager_losses))
             rel, rel_first = max(rels), max(rels[:3])
-            # the two runs differ in the order of the float atomics of the backward only: identical to ~1e-6 at first, then the two
-            # trajectories drift apart (Adam turns the sign of a gradient that is zero to rounding into a full step) -- 2e-6 after 20
-            # steps on the metric workload, 2e-4 on the fast-moving "trained" one.  A replay that mis-orders a node is off by O(1)
+            # identical to ~1e-6 at first, then the trajectories drift apart (Adam turns the sign of a gradient that is zero to
+            # rounding into a full step): 2e-6 after 20 steps on the metric workload, 1e-4 .. 2e-3 on the fast-moving "trained" one,
+            # eager against eager just the same.  A replay that mis-orders a node is off by O(1) from the first step
+            tol_all = max(1e-3, 4.0 * noise)
             twin = {"steps": args.steps, "max_rel_loss_difference": float("%.3g" % rel), "max_rel_loss_difference_first_3_steps": float("%.3g" % rel_first),
-                    "tolerance": {"first_3_steps": 1e-5, "all_steps": 1e-3},
+                    "eager_vs_eager_max_rel_loss_difference": float("%.3g" % noise),
+                    "tolerance": {"first_3_steps": 1e-5, "all_steps": float("%.3g" % tol_all), "rule": "max(1e-3, 4 x eager-vs-eager)"},
                     "what": "graph-replayed vs eager steps from the same snapshot (parameters, Adam state, views); float atomics in the backward are the only difference"}
-            if not (rel <= 1e-3 and rel_first <= 1e-5) or any(l != l for l in replay_losses + timed_losses):
-                raise SystemExit("graph-replayed steps disagree with their eager twin (max relative loss difference %.3g; replay %s, eager %s): result invalid"
-                                 % (rel, ["%.6f" % l for l in replay_losses], ["%.6f" % l for l in eager_losses]))
+            if not (rel <= tol_all and rel_first <= 1e-5) or any(l != l for l in replay_losses + timed_losses):
+                raise SystemExit("graph-replayed steps disagree with their eager twin (max relative loss difference %.3g, eager vs eager %.3g; replay %s, eager %s): result invalid"
+                                 % (rel, noise, ["%.6f" % l for l in replay_losses], ["%.6f" % l for l in eager_losses]))
 
     if rank == 0:
         ntiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -525,9 +539,10 @@ def main():
             "config": {"workload": ("%s: synthetic scene S(%d surfels, %dx%d, seed 0), full train step (node deform + surfel "
                                     "raster fwd/bwd + L1/D-SSIM/normal/distortion loss + Adam), 1 view per GPU per step" % (args.workload, P, W, H))
                        if args.workload != "trained" else
-                       ("trained: DynamicTruth (bobbing sphere + swinging plate) rendered to a D-NeRF-format dataset at %dx%d and fitted for %d "
-                        "iterations from 100k random points with densification (%d surfels in %d slots now); the timed step is the "
-                        "same full late-regime train step as 'metric'" % (W, H, args.pre_iterations, tr.surfels.num_surfels, tr.P)),
+                       ("trained: DynamicTruth (bobbing sphere + swinging plate, 40k textured surfels) rendered to a D-NeRF-format dataset at %dx%d "
+                        "and fitted for %d iterations from 100k random points with the reference's stages, densification and opacity resets "
+                        "(%d live surfels in %d slots now); the timed step is the same full late-regime train step as 'metric', "
+                        "on the dataset's target views" % (W, H, args.pre_iterations, tr.surfels.num_surfels, tr.P)),
                        "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "control_nodes": int(tr.deform.node_num),
                        "views_per_step": world, "parallelism": "dp%d (views sharded, one flat all-reduce)" % world,
                        "launch": "whole-step HIP graph replay" if use_graph else "eager"},

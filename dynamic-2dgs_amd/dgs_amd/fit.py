@@ -30,7 +30,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
-    scene = dio.scene_from_point_cloud(pc.points, pc.colors)
+    scene = dio.scene_from_point_cloud(pc.points, pc.colors, device=device if device.type == "cuda" else None)
     P = scene.xyz.shape[0]
     slots = int(slots or 1.25 * P)
     on_gpu = device.type == "cuda" and rasterizer_cls is None

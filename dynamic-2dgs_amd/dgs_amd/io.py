@@ -332,15 +332,17 @@ def mean_nn_dist2(points, k=3, chunk=1024):
     return out
 
 
-def scene_from_point_cloud(points, colors, sh_degree=3, fea_dim=8) -> SurfelScene:
+def scene_from_point_cloud(points, colors, sh_degree=3, fea_dim=8, device=None) -> SurfelScene:
     """GaussianModel.create_from_pcd (scene/gaussian_model.py:143-179, with_motion_mask=False): DC colour from RGB, isotropic
-    log-scales from the 3-NN spacing, identity rotations, opacity 0.1, hyper coordinates -1e-2."""
+    log-scales from the 3-NN spacing, identity rotations, opacity 0.1, hyper coordinates -1e-2.  device: where the neighbour search
+    runs (the reference's distCUDA2 runs on the GPU as well; 100k points take ~40 s on the host, well under 1 s on the device); the
+    scene comes back on the CPU either way."""
     pts = torch.as_tensor(np.asarray(points), dtype=torch.float32)
     rgb = torch.as_tensor(np.asarray(colors), dtype=torch.float32)
     P = pts.shape[0]
     f_dc = ((rgb - 0.5) / 0.28209479177387814)[:, None, :]             # RGB2SH
     f_rest = torch.zeros(P, (sh_degree + 1) ** 2 - 1, 3)
-    dist2 = torch.clamp_min(mean_nn_dist2(pts), 0.0000001)
+    dist2 = torch.clamp_min(mean_nn_dist2(pts.to(device) if device is not None else pts).cpu(), 0.0000001)
     scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 2)
     rots = torch.zeros(P, 4)
     rots[:, 0] = 1

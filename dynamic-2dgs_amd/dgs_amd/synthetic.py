@@ -78,9 +78,11 @@ def _quat_from_normal(n: torch.Tensor) -> torch.Tensor:
 
 class DynamicTruth:
     """Ground truth of the learnable test scene: a bobbing sphere and a swinging plate, a few thousand opaque surfels with smooth
-    colours.  state(t) gives the rasterizer's inputs at time t in [0, 1]."""
+    colours.  state(t) gives the rasterizer's inputs at time t in [0, 1].  detail > 0 adds a fine texture of that amplitude (period
+    ~ 4 surfel spacings), which a fit can only reproduce with about as many surfels as the truth has: the size knob of
+    bench.py's `trained` workload."""
 
-    def __init__(self, n_sphere=2400, n_plate=1600):
+    def __init__(self, n_sphere=2400, n_plate=1600, detail=0.0):
         i = torch.arange(n_sphere, dtype=torch.float32) + 0.5
         phi = torch.acos(1 - 2 * i / n_sphere)
         th = math.pi * (1 + 5 ** 0.5) * i
@@ -94,6 +96,11 @@ class DynamicTruth:
         self.sph_rgb = 0.5 + 0.45 * torch.sin(4.0 * self.sph_n + torch.tensor([0.0, 2.0, 4.0]))
         self.plate_rgb = torch.stack([0.5 + 0.45 * torch.sin(9.0 * self.plate_uv[:, 0]), 0.5 + 0.45 * torch.cos(7.0 * self.plate_uv[:, 1]),
                                       0.55 + 0.4 * torch.sin(5.0 * (self.plate_uv[:, 0] + self.plate_uv[:, 1]))], -1)
+        if detail > 0:
+            ks, kp = 0.5 * math.pi / (self.sph_scale / 0.62 / self.sph_r), 0.5 * math.pi * g
+            ph = torch.tensor([0.0, 1.3, 2.9])
+            self.sph_rgb = (self.sph_rgb + detail * torch.sin(ks * self.sph_n + ph) * torch.sin(ks * self.sph_n.roll(1, -1) + ph.flip(0))).clamp(0.02, 0.98)
+            self.plate_rgb = (self.plate_rgb + detail * torch.sin(kp * self.plate_uv[:, :1] + ph) * torch.sin(kp * self.plate_uv[:, 1:] + ph.flip(0))).clamp(0.02, 0.98)
         self.sph_q = _quat_from_normal(self.sph_n)
         self.P = n_sphere + self.plate_uv.shape[0]
 
@@ -116,7 +123,7 @@ class DynamicTruth:
         return xyz.contiguous(), scales.contiguous(), rot.contiguous(), opac, shs
 
 
-def write_dynamic_dnerf(path, n_train=60, n_test=12, H=200, W=200, device="cuda:0", fov=0.6911, radius=4.0):
+def write_dynamic_dnerf(path, n_train=60, n_test=12, H=200, W=200, device="cuda:0", fov=0.6911, radius=4.0, truth=None):
     """Render DynamicTruth with THIS package's rasterizer into a D-NeRF / Blender-format dataset (transforms_{train,test}.json with
     camera_angle_x, per-frame time and transform_matrix; RGBA PNGs, straight alpha) that dgs_amd.io.load_dnerf -- and the
     reference's readNerfSyntheticInfo -- read.  Every frame has its own camera and its own time, like D-NeRF.  GPU only."""
@@ -128,7 +135,7 @@ def write_dynamic_dnerf(path, n_train=60, n_test=12, H=200, W=200, device="cuda:
 
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from .cameras import make_camera, pose_spherical
-    truth = DynamicTruth()
+    truth = truth or DynamicTruth()
     bg = torch.zeros(3, device=device)
     for split, n, off in (("train", n_train, 0.0), ("test", n_test, 0.37)):
         os.makedirs(os.path.join(path, split), exist_ok=True)
