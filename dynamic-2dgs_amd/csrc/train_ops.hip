@@ -21,9 +21,13 @@ namespace {
 thread_local std::string g_err;
 int fail(int code, const std::string& m) { g_err = m; return code; }
 
-constexpr int kT = 32;          // output tile edge
-constexpr int kR = 5;           // window radius (11 taps)
-constexpr int kIn = kT + 2 * kR;  // 42
+constexpr int kR = 5;             // window radius (11 taps)
+constexpr int kTW = 54, kTH = 28; // output tile of a 256-thread workgroup
+constexpr int kCols = kTW + 2 * kR;   // 64 input columns: one per lane
+constexpr int kPV = 7;            // output rows per thread of the vertical pass (4 waves x 7 rows)
+constexpr int kPH = 6;            // output columns per thread of the horizontal pass (28 rows x 9 groups = 252 threads)
+constexpr int kLds = kCols + 1;
+static_assert(kCols == 64 && kTH == 4 * kPV && kTW % kPH == 0 && kTH * (kTW / kPH) <= 256, "thread maps below");
 
 struct Gauss { float w[11]; };
 
@@ -39,12 +43,64 @@ Gauss make_gauss()
 
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
-// Both SSIM kernels: one 32 x 32 output tile per 256-thread workgroup (42 x 42 inputs: 1.7x halo; the 16 x 16 tiles of round 1
-// re-read 2.6x), separable 11-tap window through LDS, and every thread computes FOUR adjacent outputs of a pass from one run of 14
-// inputs held in registers (11 taps x 4 outputs = 44 LDS reads become 14; the passes were LDS-read bound: 91 reads per pixel).
-// Same sums in the same order as before (and as the reference's conv2d would give up to fp32 summation order).
-constexpr int kPer = 4;           // outputs per thread along the filtered direction
-static_assert(kT == 32 && kT % kPer == 0, "thread maps below assume a 32 x 32 tile");
+typedef const float __attribute__((address_space(1)))* GlobalF;   // global_load instead of flat_load for pointers that come out
+                                                                  // of memory (the per-replay image slots)
+
+// loss = (1 - lambda) * sum(l1 partials) / n + lambda * (1 - sum(ssim partials) / n) + sum(regulariser partials)
+// photo = [ssim partial per workgroup (nphoto) | l1 partial per workgroup (nphoto)], reg = [nreg]; one 256-thread workgroup
+struct CombineArgs { const float* photo; int nphoto; const float* reg; int nreg; float inv_n; float lambda_dssim; float* out; };
+
+__device__ __forceinline__ void combine_partials(const CombineArgs& c, float (&s_red)[3][4])
+{
+    float a = 0.f, b = 0.f, r = 0.f;
+    {
+        float a4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0}, c4[4] = {0, 0, 0, 0};
+        for (int i = threadIdx.x; i < c.nphoto; i += 1024)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = i + 256 * u;
+                a4[u] += k < c.nphoto ? c.photo[k] : 0.f;
+                b4[u] += k < c.nphoto ? c.photo[c.nphoto + k] : 0.f;
+            }
+        for (int i = threadIdx.x; i < c.nreg; i += 1024)
+#pragma unroll
+            for (int u = 0; u < 4; u++) c4[u] += i + 256 * u < c.nreg ? c.reg[i + 256 * u] : 0.f;
+        a = (a4[0] + a4[1]) + (a4[2] + a4[3]); b = (b4[0] + b4[1]) + (b4[2] + b4[3]); r = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); r += __shfl_xor(r, d, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = a; s_red[1][threadIdx.x >> 6] = b; s_red[2][threadIdx.x >> 6] = r; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        b = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        r = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+        c.out[0] = (1.0f - c.lambda_dssim) * b * c.inv_n + c.lambda_dssim * (1.0f - a * c.inv_n) + r;
+    }
+}
+
+__global__ void __launch_bounds__(256) loss_combine_kernel(CombineArgs c)
+{
+    __shared__ float s_red[3][4];
+    combine_partials(c, s_red);
+}
+
+// Both SSIM kernels: separable 11-tap window over one 54 x 28 output tile per 256-thread workgroup.
+//   pass 1, vertical, straight from global memory: a wave owns 7 output rows, a lane one of the tile's 64 input columns, and loads
+//     its 17 input rows with fully coalesced 256-byte wave loads that are all in flight at once -- no staging of the inputs in LDS,
+//     no staging barrier (the round-2 kernels staged a 42 x 42 window element by element: 14 dependent memory round trips per
+//     workgroup, 39 us for the forward at 800 x 800 x 3; batching those loads gave 27 us, this layout 11);
+//   pass 2, horizontal, from LDS: thread = (row, 6 adjacent outputs), 16 reads per quantity.
+// Every thread filters several adjacent outputs from one run of inputs held in registers (7 + 10 rows, 6 + 10 columns).  The
+// window weights are copied into VGPRs: a VALU instruction with an SGPR source issues at 4.4 instead of 2.5 cycles on gfx950
+// (profiles/r03_valu_issue_gfx950.txt).  LDS 36 KB forward / 22 KB backward.
+#ifndef DGS_SSIM_DIAG
+#define DGS_SSIM_DIAG 0   // development only: 1 no map stores, 2 no global loads, 4 no SSIM formula (tools/diag/loss_timing.py)
+#endif
+__device__ __forceinline__ void gauss_to_vgprs(const Gauss& g, float (&w)[11])
+{
+#pragma unroll
+    for (int k = 0; k < 11; k++) { w[k] = g.w[k]; asm volatile("" : "+v"(w[k])); }
+}
 
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                        Gauss g, float* __restrict__ ssim_sum, float* __restrict__ dm_dmu1,
@@ -53,73 +109,123 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float
                                                        const float* const* __restrict__ img2_slot)
 {
     if (img2_slot) img2 = *img2_slot;   // indirection: the comparison image is chosen per graph replay by rewriting one pointer
-    __shared__ float s_a[kIn][kIn + 1], s_b[kIn][kIn + 1];
-    __shared__ float s_h[5][kIn][kT + 1];
+    __shared__ float s_v[5][kTH][kLds];
     __shared__ float s_red[8];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < kIn * kIn; i += 256) {
-        const int r = i / kIn, c = i - r * kIn;
-        const int y = y0 + r - kR, x = x0 + c - kR;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        s_a[r][c] = in ? img1[plane + (size_t)y * W + x] : 0.f;
-        s_b[r][c] = in ? img2[plane + (size_t)y * W + x] : 0.f;
-    }
-    __syncthreads();
-    for (int it = tid; it < kIn * (kT / kPer); it += 256) {  // horizontal pass: 42 rows x 8 groups of 4 columns
-        const int r = it / (kT / kPer), c0 = (it - r * (kT / kPer)) * kPer;
-        float a[kPer + 10], b[kPer + 10];
+    float w[11];
+    gauss_to_vgprs(g, w);
+    float l1 = 0.f;
+    {
+        const GlobalF p1 = (GlobalF)(img1 + plane), p2 = (GlobalF)(img2 + plane);
+        const int x = x0 + col - kR;
+        const bool xin = x >= 0 && x < W;
+        const unsigned xc = (unsigned)min(max(x, 0), W - 1);
+        float a[kPV + 10], b[kPV + 10];
 #pragma unroll
-        for (int j = 0; j < kPer + 10; j++) { a[j] = s_a[r][c0 + j]; b[j] = s_b[r][c0 + j]; }
+        for (int j = 0; j < kPV + 10; j++) {   // clamped addresses, zeros (the conv2d padding) selected afterwards
+            const int y = y0 + rg * kPV + j - kR;
+            const unsigned o = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + xc;
+            const bool in = xin && y >= 0 && y < H;
+#if DGS_SSIM_DIAG & 2
+            const float av = (float)(o & 255) * 0.003f, bv = (float)(o & 127) * 0.005f;
+#else
+            const float av = p1[o], bv = p2[o];
+#endif
+            a[j] = in ? av : 0.f;
+            b[j] = in ? bv : 0.f;
+        }
+        const bool mine = col >= kR && col < kR + kTW && xin;   // the tile's own pixels: the mean-|.| term
 #pragma unroll
-        for (int o = 0; o < kPer; o++) {
-            float m1 = 0.f, m2 = 0.f, q11 = 0.f, q22 = 0.f, q12 = 0.f;
+        for (int o = 0; o < kPV; o++)
+            if (mine && y0 + rg * kPV + o < H) l1 += fabsf(a[o + kR] - b[o + kR]);
+        // two sweeps keep the live set near 100 registers (4 workgroups per CU): means and the cross term from a, b, a b; then the
+        // squares in place of a, b
+        {
+            float ab[kPV + 10];
 #pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const float av = a[o + k], bv = b[o + k], w = g.w[k];
-                m1 += w * av; m2 += w * bv; q11 += w * av * av; q22 += w * bv * bv; q12 += w * av * bv;
+            for (int j = 0; j < kPV + 10; j++) ab[j] = a[j] * b[j];
+#pragma unroll
+            for (int o = 0; o < kPV; o++) {
+                float m1 = 0.f, m2 = 0.f, q12 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) { m1 += w[k] * a[o + k]; m2 += w[k] * b[o + k]; q12 += w[k] * ab[o + k]; }
+                const int r = rg * kPV + o;
+                s_v[0][r][col] = m1; s_v[1][r][col] = m2; s_v[4][r][col] = q12;
             }
-            s_h[0][r][c0 + o] = m1; s_h[1][r][c0 + o] = m2; s_h[2][r][c0 + o] = q11; s_h[3][r][c0 + o] = q22; s_h[4][r][c0 + o] = q12;
+        }
+#pragma unroll
+        for (int j = 0; j < kPV + 10; j++) { a[j] *= a[j]; b[j] *= b[j]; asm volatile("" : "+v"(a[j]), "+v"(b[j])); }
+#pragma unroll
+        for (int o = 0; o < kPV; o++) {
+            float q11 = 0.f, q22 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) { q11 += w[k] * a[o + k]; q22 += w[k] * b[o + k]; }
+            const int r = rg * kPV + o;
+            s_v[2][r][col] = q11; s_v[3][r][col] = q22;
         }
     }
     __syncthreads();
-    // vertical pass: thread -> column lx, rows ry .. ry + 3
-    const int lx = tid & 31, ry = (tid >> 5) * kPer;
-    float res[5][kPer];
+    float val = 0.f;
+    float res[5][kPH];
+    if (tid < kTH * (kTW / kPH)) {
+        const int r = tid / (kTW / kPH), c0 = (tid - r * (kTW / kPH)) * kPH;
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
-        float v[kPer + 10];
+        for (int q = 0; q < 5; q++) {
+            float v[kPH + 10];
 #pragma unroll
-        for (int j = 0; j < kPer + 10; j++) v[j] = s_h[q][ry + j][lx];
+            for (int j = 0; j < kPH + 10; j++) v[j] = s_v[q][r][c0 + j];
 #pragma unroll
-        for (int o = 0; o < kPer; o++) {
-            float t = 0.f;
+            for (int o = 0; o < kPH; o++) {
+                float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < 11; k++) t += g.w[k] * v[o + k];
-            res[q][o] = t;
+                for (int k = 0; k < 11; k++) t += w[k] * v[o + k];
+                res[q][o] = t;
+            }
+            // one quantity's 16 reads and 66 FMAs at a time (the compiler hoists all 80 reads otherwise, and spills)
+            asm volatile("" : "+v"(res[q][0]), "+v"(res[q][1]), "+v"(res[q][2]), "+v"(res[q][3]), "+v"(res[q][4]), "+v"(res[q][5]) :: "memory");
         }
-    }
-    const int x = x0 + lx;
-    float val = 0.f, l1 = 0.f;
+        const int y = y0 + r;
 #pragma unroll
-    for (int o = 0; o < kPer; o++) {
-        const int y = y0 + ry + o;
-        if (x < W && y < H) {
+        for (int o = 0; o < kPH; o++) {
+            const int x = x0 + c0 + o;
             const float mu1 = res[0][o], mu2 = res[1][o], s11 = res[2][o], s22 = res[3][o], s12 = res[4][o];
-            l1 += fabsf(s_a[ry + o + kR][lx + kR] - s_b[ry + o + kR][lx + kR]);
+#if DGS_SSIM_DIAG & 4
+            val += mu1 + mu2 + s11 + s22 + s12;
+            continue;
+#endif
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
             const float sg1 = s11 - mu1_sq, sg2 = s22 - mu2_sq, sg12 = s12 - mu12;
             const float A = 2.f * mu12 + kC1, B = 2.f * sg12 + kC2, Cc = mu1_sq + mu2_sq + kC1, D = sg1 + sg2 + kC2;
             const float inv_cd = 1.0f / (Cc * D);
             const float m = A * B * inv_cd;
-            val += m;
-            if (dm_dmu1) {
-                // map = A B / (Cc D) with sigma1^2 = s11 - mu1^2, sigma12 = s12 - mu1 mu2 (loss_utils.py:59-71)
-                const size_t oo = plane + (size_t)y * W + x;
-                dm_dmu1[oo] = (2.f * mu2 * B - 2.f * mu2 * A) * inv_cd - m * (2.f * mu1 / Cc - 2.f * mu1 / D);
-                dm_ds11[oo] = -m / D;
-                dm_ds12[oo] = 2.f * A * inv_cd;
+            if (x < W && y < H) val += m;
+            // map = A B / (Cc D) with sigma1^2 = s11 - mu1^2, sigma12 = s12 - mu1 mu2 (loss_utils.py:59-71)
+            res[0][o] = (2.f * mu2 * B - 2.f * mu2 * A) * inv_cd - m * (2.f * mu1 / Cc - 2.f * mu1 / D);
+            res[1][o] = -m / D;
+            res[2][o] = 2.f * A * inv_cd;
+        }
+    }
+    if (dm_dmu1 && !(DGS_SSIM_DIAG & 1)) {
+        // The derivative maps leave through LDS: a thread's 6 adjacent outputs would be 4-byte stores 24 bytes apart (18 partial
+        // cache lines per wave store; the three maps cost 12 of the kernel's 25 us that way), rows of 54 floats are 2-3 lines.
+        __syncthreads();                       // every thread is done reading s_v
+        if (tid < kTH * (kTW / kPH)) {
+            const int r = tid / (kTW / kPH), c0 = (tid - r * (kTW / kPH)) * kPH;
+#pragma unroll
+            for (int o = 0; o < kPH; o++) { s_v[0][r][c0 + o] = res[0][o]; s_v[1][r][c0 + o] = res[1][o]; s_v[2][r][c0 + o] = res[2][o]; }
+        }
+        __syncthreads();
+        typedef float __attribute__((address_space(1)))* GlobalW;
+        const GlobalW d0 = (GlobalW)(dm_dmu1 + plane), d1 = (GlobalW)(dm_ds11 + plane), d2 = (GlobalW)(dm_ds12 + plane);
+#pragma unroll
+        for (int t = 0; t < (kTH * kTW + 255) / 256; t++) {
+            const int i = tid + 256 * t, r = i / kTW, c = i - r * kTW;
+            const int y = y0 + r, x = x0 + c;
+            if (i < kTH * kTW && x < W && y < H) {
+                const unsigned oo = (unsigned)y * (unsigned)W + (unsigned)x;
+                d0[oo] = s_v[0][r][c]; d1[oo] = s_v[1][r][c]; d2[oo] = s_v[2][r][c];
             }
         }
     }
@@ -146,70 +252,97 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n
                                                        const float* __restrict__ img2, Gauss g, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_ds11, const float* __restrict__ dm_ds12,
                                                        const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1,
-                                                       const float* const* __restrict__ img2_slot)
+                                                       const float* const* __restrict__ img2_slot, CombineArgs comb)
 {
     if (img2_slot) img2 = *img2_slot;
-    __shared__ float s_in[3][kIn][kIn + 1];
-    __shared__ float s_h[3][kIn][kT + 1];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    __shared__ float s_v[3][kTH][kLds];
+    const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < kIn * kIn; i += 256) {
-        const int r = i / kIn, c = i - r * kIn;
-        const int y = y0 + r - kR, x = x0 + c - kR;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const size_t o = plane + (size_t)y * W + x;
-        s_in[0][r][c] = in ? dm_dmu1[o] : 0.f;
-        s_in[1][r][c] = in ? dm_ds11[o] : 0.f;
-        s_in[2][r][c] = in ? dm_ds12[o] : 0.f;
+    float w[11];
+    gauss_to_vgprs(g, w);
+    {
+        const GlobalF p0 = (GlobalF)(dm_dmu1 + plane), p1 = (GlobalF)(dm_ds11 + plane), p2 = (GlobalF)(dm_ds12 + plane);
+        const int x = x0 + col - kR;
+        const bool xin = x >= 0 && x < W;
+        const unsigned xc = (unsigned)min(max(x, 0), W - 1);
+        float v0[kPV + 10], v1[kPV + 10], v2[kPV + 10];
+#pragma unroll
+        for (int j = 0; j < kPV + 10; j++) {
+            const int y = y0 + rg * kPV + j - kR;
+            const unsigned o = (unsigned)min(max(y, 0), H - 1) * (unsigned)W + xc;
+            const bool in = xin && y >= 0 && y < H;
+            const float a = p0[o], b = p1[o], c = p2[o];
+            v0[j] = in ? a : 0.f;
+            v1[j] = in ? b : 0.f;
+            v2[j] = in ? c : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < kPV; o++) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) { t0 += w[k] * v0[o + k]; t1 += w[k] * v1[o + k]; t2 += w[k] * v2[o + k]; }
+            const int r = rg * kPV + o;
+            s_v[0][r][col] = t0; s_v[1][r][col] = t1; s_v[2][r][col] = t2;
+        }
     }
     __syncthreads();
-    for (int it = tid; it < kIn * (kT / kPer); it += 256) {
-        const int r = it / (kT / kPer), c0 = (it - r * (kT / kPer)) * kPer;
+    // the epilogue works on row-contiguous elements (coalesced image reads and gradient stores: see ssim_fwd_kernel); its image
+    // reads go out before the LDS pass
+    constexpr int kEp = (kTH * kTW + 255) / 256;
+    const GlobalF q1 = (GlobalF)(img1 + plane), q2 = (GlobalF)(img2 + plane);
+    float i1[kEp], i2[kEp];
+#pragma unroll
+    for (int t = 0; t < kEp; t++) {
+        const int i = min(tid + 256 * t, kTH * kTW - 1), r = i / kTW, c = i - r * kTW;
+        const unsigned oo = (unsigned)min(y0 + r, H - 1) * (unsigned)W + (unsigned)min(x0 + c, W - 1);
+        i1[t] = q1[oo]; i2[t] = q2[oo];
+    }
+    float res[3][kPH];
+    if (tid < kTH * (kTW / kPH)) {
+        const int r = tid / (kTW / kPH), c0 = (tid - r * (kTW / kPH)) * kPH;
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            float v[kPer + 10];
+            float v[kPH + 10];
 #pragma unroll
-            for (int j = 0; j < kPer + 10; j++) v[j] = s_in[q][r][c0 + j];
+            for (int j = 0; j < kPH + 10; j++) v[j] = s_v[q][r][c0 + j];
 #pragma unroll
-            for (int o = 0; o < kPer; o++) {
+            for (int o = 0; o < kPH; o++) {
                 float t = 0.f;
 #pragma unroll
-                for (int k = 0; k < 11; k++) t += g.w[k] * v[o + k];
-                s_h[q][r][c0 + o] = t;
+                for (int k = 0; k < 11; k++) t += w[k] * v[o + k];
+                res[q][o] = t;
             }
+            asm volatile("" : "+v"(res[q][0]), "+v"(res[q][1]), "+v"(res[q][2]), "+v"(res[q][3]), "+v"(res[q][4]), "+v"(res[q][5]) :: "memory");
         }
+    }
+    __syncthreads();                           // every thread is done reading s_v
+    if (tid < kTH * (kTW / kPH)) {
+        const int r = tid / (kTW / kPH), c0 = (tid - r * (kTW / kPH)) * kPH;
+#pragma unroll
+        for (int o = 0; o < kPH; o++) { s_v[0][r][c0 + o] = res[0][o]; s_v[1][r][c0 + o] = res[1][o]; s_v[2][r][c0 + o] = res[2][o]; }
     }
     __syncthreads();
-    const int lx = tid & 31, ry = (tid >> 5) * kPer;
-    float res[3][kPer];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        float v[kPer + 10];
-#pragma unroll
-        for (int j = 0; j < kPer + 10; j++) v[j] = s_h[q][ry + j][lx];
-#pragma unroll
-        for (int o = 0; o < kPer; o++) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) t += g.w[k] * v[o + k];
-            res[q][o] = t;
-        }
-    }
-    const int x = x0 + lx;
     const float gm = dL_dmean[0];
+    typedef float __attribute__((address_space(1)))* GlobalW;
+    const GlobalW dst = (GlobalW)(dL_dimg1 + plane);
 #pragma unroll
-    for (int o = 0; o < kPer; o++) {
-        const int y = y0 + ry + o;
-        if (x < W && y < H) {
-            const size_t oo = plane + (size_t)y * W + x;
+    for (int t = 0; t < kEp; t++) {
+        const int i = tid + 256 * t, r = i / kTW, c = i - r * kTW;
+        const int y = y0 + r, x = x0 + c;
+        if (i < kTH * kTW && x < W && y < H) {
             // the zero-padded symmetric window is its own adjoint
             // inv_n scales the SSIM-map adjoint, l1_coef the sign(img1 - img2) of an optional mean-|.| term
-            const float i1 = img1[oo], i2 = img2[oo];
-            const float df = i1 - i2;
+            const float df = i1[t] - i2[t];
             const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-            dL_dimg1[oo] = ((res[0][o] + 2.f * i1 * res[1][o] + i2 * res[2][o]) * inv_n + l1_coef * sg) * gm;
+            dst[(unsigned)y * (unsigned)W + (unsigned)x] = ((s_v[0][r][c] + 2.f * i1[t] * s_v[1][r][c] + i2[t] * s_v[2][r][c]) * inv_n + l1_coef * sg) * gm;
         }
+    }
+    // optional rider: the LAST workgroup of the grid also sums the forward kernels' partials into the loss value (the train step
+    // launches this kernel after both of them; a one-workgroup kernel of its own cost 5-8 us of the replayed step)
+    if (comb.out && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) {
+        __shared__ float s_red[3][4];
+        combine_partials(comb, s_red);
     }
 }
 
@@ -1113,38 +1246,6 @@ __global__ void __launch_bounds__(256) densify_accum_kernel(int P, const float* 
     max_radii[i] = max(max_radii[i], radii_vis[i]);
 }
 
-// loss = (1 - lambda) * sum(l1 partials) / n + lambda * (1 - sum(ssim partials) / n) + sum(regulariser partials)
-// photo = [ssim partial per workgroup (nphoto) | l1 partial per workgroup (nphoto)], reg = [nreg]; one workgroup
-__global__ void __launch_bounds__(256) loss_combine_kernel(const float* photo, int nphoto, const float* reg, int nreg, float inv_n,
-                                                           float lambda_dssim, float* out)
-{
-    __shared__ float s_red[3][4];
-    float a = 0.f, b = 0.f, c = 0.f;
-    {
-        float a4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0}, c4[4] = {0, 0, 0, 0};
-        for (int i = threadIdx.x; i < nphoto; i += 1024)
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int k = i + 256 * u;
-                a4[u] += k < nphoto ? photo[k] : 0.f;
-                b4[u] += k < nphoto ? photo[nphoto + k] : 0.f;
-            }
-        for (int i = threadIdx.x; i < nreg; i += 1024)
-#pragma unroll
-            for (int u = 0; u < 4; u++) c4[u] += i + 256 * u < nreg ? reg[i + 256 * u] : 0.f;
-        a = (a4[0] + a4[1]) + (a4[2] + a4[3]); b = (b4[0] + b4[1]) + (b4[2] + b4[3]); c = (c4[0] + c4[1]) + (c4[2] + c4[3]);
-    }
-    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); c += __shfl_xor(c, d, 64); }
-    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = a; s_red[1][threadIdx.x >> 6] = b; s_red[2][threadIdx.x >> 6] = c; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-        b = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-        c = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
-        out[0] = (1.0f - lambda_dssim) * b * inv_n + lambda_dssim * (1.0f - a * inv_n) + c;
-    }
-}
-
 // ---- fused regulariser loss -----------------------------------------------------------------------------------------
 __device__ __forceinline__ float clean_depth(float d)  // torch.nan_to_num(x, 0, 0): nan -> 0, +inf -> 0, -inf -> lowest
 {
@@ -1268,6 +1369,154 @@ __global__ void __launch_bounds__(256) regloss_bwd_kernel(RegArgs a, const float
         const float* gd = i < 2 ? ddx : ddy;
         atomicAdd(dd + qq, sg[i] * (gd[0] * a.rays_d[3 * qq] + gd[1] * a.rays_d[3 * qq + 1] + gd[2] * a.rays_d[3 * qq + 2]));
     }
+}
+
+// ---- regularisers, value AND gradient in one kernel (unit upstream gradient) -----------------------------------------
+// The train step differentiates loss = photometric + regularisers with dL/dloss = 1, so the regularisers' gradient image depends on
+// the rasterizer outputs only and can be produced next to the value: one pass over the allmap instead of two (regloss_fwd_kernel +
+// regloss_bwd_kernel read the same planes twice), and the depth gradient is GATHERED -- every pixel sums the four neighbouring
+// normals' contributions from LDS -- instead of 4 float atomics per pixel into a pre-cleared plane (2.6 M atomics at 800 x 800).
+//   workgroup = 30 x 14 pixels; normals ("centres") are needed on 32 x 16, back-projected points on 34 x 18
+//   phase 1: points of the 34 x 18 region -> LDS (every global load of the 3 trips in flight before the first LDS store)
+//   phase 2: thread = centre (2 trips of 32 x 8): cross product, normalisation, loss term, d/d rend_normal, and the two
+//            vectors ddx = dy x dv, ddy = dv x dx its four neighbours' points receive -> LDS
+//   phase 3: the centre's own thread gathers  +ddx(y-1) - ddx(y+1) + ddy(x-1) - ddy(x+1),  dots with its ray, stores all 8 planes
+// 33 + 20 -> 14 us at 800 x 800 (forward + backward kernels -> this one).
+constexpr int kRW = 30, kRH = 14;                 // own pixels of a workgroup
+constexpr int kCW = kRW + 2, kCH = kRH + 2;       // centres: 32 x 16
+constexpr int kQW = kRW + 4, kQH = kRH + 4;       // points: 34 x 18
+static_assert(kCW == 32 && kCH == 16, "thread maps below");
+
+__global__ void __launch_bounds__(256) regloss_fused_kernel(RegArgs a, float* __restrict__ partial, float* __restrict__ d_allmap)
+{
+    if (a.rays_slot) a.rays_d = *a.rays_slot;
+    __shared__ float s_p[3][kQH][kQW + 1];
+    __shared__ float s_g[6][kCH][kCW + 1];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kRW, y0 = blockIdx.y * kRH;      // first own pixel
+    const unsigned HW = (unsigned)a.H * (unsigned)a.W;
+    const GlobalF am = (GlobalF)a.allmap, rd = (GlobalF)a.rays_d;
+    const float ox = a.rays_o[0], oy = a.rays_o[1], oz = a.rays_o[2];
+    {
+        constexpr int kTrips = (kQW * kQH + 255) / 256;          // 3
+        float d[kTrips], r0[kTrips], r1[kTrips], r2[kTrips];
+#pragma unroll
+        for (int t = 0; t < kTrips; t++) {
+            const int i = min(tid + 256 * t, kQW * kQH - 1), r = i / kQW, c = i - r * kQW;
+            const unsigned q = (unsigned)min(max(y0 + r - 2, 0), a.H - 1) * (unsigned)a.W + (unsigned)min(max(x0 + c - 2, 0), a.W - 1);
+            d[t] = am[5 * HW + q]; r0[t] = rd[3 * q]; r1[t] = rd[3 * q + 1]; r2[t] = rd[3 * q + 2];
+        }
+#pragma unroll
+        for (int t = 0; t < kTrips; t++) {
+            const int i = tid + 256 * t, r = i / kQW, c = i - r * kQW;
+            if (i < kQW * kQH) {       // points outside the image are only read by centres that are not interior (their vectors are 0)
+                const float dc = clean_depth(d[t]);
+                s_p[0][r][c] = dc * r0[t] + ox; s_p[1][r][c] = dc * r1[t] + oy; s_p[2][r][c] = dc * r2[t] + oz;
+            }
+        }
+    }
+    const int cx = tid & 31;
+    float wv[9];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) wv[3 * c + k] = a.wvt[4 * c + k];
+    const float inv_hw = 1.0f / (float)HW;
+    const float kn = -inv_hw * a.ln;
+    // the centres' own planes and (for phase 3) the own pixels' ray and raw depth: issued before the barrier
+    float al[2], n0[2], n1[2], n2[2], ds[2], q0[2], q1[2], q2[2], raw[2];
+    bool own[2], interior[2];
+    unsigned qq[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int cy = (tid >> 5) + 8 * t;
+        const int x = x0 + cx - 1, y = y0 + cy - 1;
+        own[t] = cx >= 1 && cx <= kRW && cy >= 1 && cy <= kRH && x < a.W && y < a.H;
+        interior[t] = x >= 1 && y >= 1 && x < a.W - 1 && y < a.H - 1;
+        qq[t] = (unsigned)min(max(y, 0), a.H - 1) * (unsigned)a.W + (unsigned)min(max(x, 0), a.W - 1);
+        al[t] = am[HW + qq[t]]; n0[t] = am[2 * HW + qq[t]]; n1[t] = am[3 * HW + qq[t]]; n2[t] = am[4 * HW + qq[t]];
+        ds[t] = am[6 * HW + qq[t]]; raw[t] = am[5 * HW + qq[t]];
+        q0[t] = rd[3 * qq[t]]; q1[t] = rd[3 * qq[t] + 1]; q2[t] = rd[3 * qq[t] + 2];
+    }
+    __syncthreads();
+    float val = 0.f;
+    float gn[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int cy = (tid >> 5) + 8 * t;
+        float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f};
+        float dot = 0.f;
+        gn[t][0] = gn[t][1] = gn[t][2] = 0.f;
+        if (interior[t]) {
+            // centre (cy, cx) is point (cy + 1, cx + 1) of the region
+            float dx[3], dy[3], v[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dx[c] = s_p[c][cy + 2][cx + 1] - s_p[c][cy][cx + 1];
+                dy[c] = s_p[c][cy + 1][cx + 2] - s_p[c][cy + 1][cx];
+            }
+            v[0] = dx[1] * dy[2] - dx[2] * dy[1];
+            v[1] = dx[2] * dy[0] - dx[0] * dy[2];
+            v[2] = dx[0] * dy[1] - dx[1] * dy[0];
+            const float L = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            const float denom = fmaxf(L, 1e-12f);
+            const float n[3] = {v[0] / denom, v[1] / denom, v[2] / denom};
+            float nw[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) nw[c] = n0[t] * wv[3 * c] + n1[t] * wv[3 * c + 1] + n2[t] * wv[3 * c + 2];   // n_view @ wvt[:3,:3].T
+            const float inv = al[t] / denom;                                     // normalize(), then * alpha
+#pragma unroll
+            for (int c = 0; c < 3; c++) dot += nw[c] * v[c] * inv;
+            // d / d rend_normal (view space): -lambda/HW * wvt[:3,:3]^T-rotated surf_normal
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc += wv[3 * c + kk] * (n[c] * al[t]);
+                gn[t][kk] = kn * acc;
+            }
+            // d / d n (alpha is detached), then through F.normalize and the cross product
+            const float dn[3] = {kn * nw[0] * al[t], kn * nw[1] * al[t], kn * nw[2] * al[t]};
+            float dv[3];
+            if (L >= 1e-12f) {
+                const float nd = n[0] * dn[0] + n[1] * dn[1] + n[2] * dn[2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) dv[c] = (dn[c] - n[c] * nd) / L;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) dv[c] = dn[c] / 1e-12f;
+            }
+            ddx[0] = dy[1] * dv[2] - dy[2] * dv[1]; ddx[1] = dy[2] * dv[0] - dy[0] * dv[2]; ddx[2] = dy[0] * dv[1] - dy[1] * dv[0];   // dy x dv
+            ddy[0] = dv[1] * dx[2] - dv[2] * dx[1]; ddy[1] = dv[2] * dx[0] - dv[0] * dx[2]; ddy[2] = dv[0] * dx[1] - dv[1] * dx[0];   // dv x dx
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { s_g[c][cy][cx] = ddx[c]; s_g[3 + c][cy][cx] = ddy[c]; }
+        if (own[t]) val += (a.ln * (1.f - dot) + a.ld * ds[t]) * inv_hw;
+    }
+    __syncthreads();
+    typedef float __attribute__((address_space(1)))* GlobalW;
+    const GlobalW out = (GlobalW)d_allmap;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!own[t]) continue;
+        const int cy = (tid >> 5) + 8 * t;
+        float g3[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) g3[c] = s_g[c][cy - 1][cx] - s_g[c][cy + 1][cx] + s_g[3 + c][cy][cx - 1] - s_g[3 + c][cy][cx + 1];
+        const float r = raw[t];
+        const bool finite = !(r != r || r == INFINITY || r == -INFINITY);        // nan_to_num has zero gradient there
+        const unsigned q = qq[t];
+        out[q] = 0.f; out[HW + q] = 0.f;
+        out[2 * HW + q] = gn[t][0]; out[3 * HW + q] = gn[t][1]; out[4 * HW + q] = gn[t][2];
+        out[5 * HW + q] = finite ? g3[0] * q0[t] + g3[1] * q1[t] + g3[2] * q2[t] : 0.f;
+        out[6 * HW + q] = inv_hw * a.ld;
+        out[7 * HW + q] = 0.f;
+    }
+    for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = val;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
 // ---- flat Adam --------------------------------------------------------------------------------------------------
@@ -1404,7 +1653,7 @@ int dgs_ssim_forward(int C, int H, int W, const float* img1, const float* img2, 
     if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr))
         return fail(-1, "dgs_ssim_forward: pass all three derivative maps or none");
     static const Gauss g = make_gauss();
-    dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
+    dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C);
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img1, img2, g, ssim_sum, dm_dmu1,
                        dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr, (const float* const*)nullptr);
     hipError_t e = hipGetLastError();
@@ -1419,10 +1668,10 @@ int dgs_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dmean || !dL_dimg1)
         return fail(-1, "dgs_ssim_backward: bad argument");
     static const Gauss g = make_gauss();
-    dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
+    dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, inv_n, 0.f, img1, img2, g, dm_dmu1, dm_dsigma1_sq,
-                       dm_dsigma12, dL_dmean, dL_dimg1, (const float* const*)nullptr);
+                       dm_dsigma12, dL_dmean, dL_dimg1, (const float* const*)nullptr, CombineArgs{});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -1782,7 +2031,7 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
 }
 
 // ---- photometric loss: (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM) (train_gui.py:292-296) ---------------------
-size_t dgs_photo_blocks(int C, int H, int W) { return (size_t)((W + kT - 1) / kT) * ((H + kT - 1) / kT) * (size_t)C; }
+size_t dgs_photo_blocks(int C, int H, int W) { return (size_t)((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) * (size_t)C; }
 size_t dgs_regloss_blocks(int H, int W) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
 
 int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, float* partials, float* dm_dmu1, float* dm_dsigma1_sq,
@@ -1791,7 +2040,7 @@ int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, fl
     if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !partials || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)
         return fail(-1, "dgs_photo_forward: bad argument");
     static const Gauss g = make_gauss();
-    dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
+    dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C);
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img, gt, g, (float*)nullptr, dm_dmu1,
                        dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials, gt_slot);
     hipError_t e = hipGetLastError();
@@ -1823,28 +2072,55 @@ int dgs_regloss_forward_partials_z(int H, int W, const float* allmap, const floa
     return 0;
 }
 
+size_t dgs_regloss_fused_blocks(int H, int W) { return (size_t)((W + kRW - 1) / kRW) * ((H + kRH - 1) / kRH); }
+
+int dgs_regloss_fused(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt, float lambda_normal,
+                      float lambda_dist, float* partials, float* d_allmap, const float* const* rays_slot, void* stream)
+{
+    if (H <= 0 || W <= 0 || !allmap || (!rays_d && !rays_slot) || !rays_o || !wvt || !partials || !d_allmap)
+        return fail(-1, "dgs_regloss_fused: bad argument");
+    if ((long long)H * W * 8 >= (1ll << 32)) return fail(-2, "dgs_regloss_fused: image too large for 32-bit offsets");
+    RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, 1, nullptr};
+    hipLaunchKernelGGL(regloss_fused_kernel, dim3((W + kRW - 1) / kRW, (H + kRH - 1) / kRH), dim3(256), 0, (hipStream_t)stream, a, partials,
+                       d_allmap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("regloss_fused_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_photo_backward_combine(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                               const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
+                               const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, float* loss_out,
+                               void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !g_loss || !dL_dimg)
+        return fail(-1, "dgs_photo_backward: bad argument");
+    if (loss_out && (!photo_partials || !reg_partials || nphoto < 0 || nreg < 0)) return fail(-1, "dgs_photo_backward_combine: bad argument");
+    static const Gauss g = make_gauss();
+    dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C);
+    const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
+    CombineArgs c{photo_partials, (int)nphoto, reg_partials, (int)nreg, inv_n, lambda_dssim, loss_out};
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, -lambda_dssim * inv_n,
+                       (1.0f - lambda_dssim) * inv_n, img, gt, g, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, g_loss, dL_dimg, gt_slot, c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
                        const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
                        void* stream)
 {
-    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !g_loss || !dL_dimg)
-        return fail(-1, "dgs_photo_backward: bad argument");
-    static const Gauss g = make_gauss();
-    dim3 grid((W + kT - 1) / kT, (H + kT - 1) / kT, C);
-    const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, -lambda_dssim * inv_n,
-                       (1.0f - lambda_dssim) * inv_n, img, gt, g, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, g_loss, dL_dimg, gt_slot);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
-    return 0;
+    return dgs_photo_backward_combine(C, H, W, img, gt, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, lambda_dssim, g_loss, dL_dimg, gt_slot, nullptr, 0,
+                                      nullptr, 0, nullptr, stream);
 }
 
 int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
                      float lambda_dssim, float* out, void* stream)
 {
     if (!photo_partials || !reg_partials || !out || n <= 0 || nphoto < 0 || nreg < 0) return fail(-1, "dgs_loss_combine: bad argument");
-    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, photo_partials, (int)nphoto, reg_partials,
-                       (int)nreg, 1.0f / (float)n, lambda_dssim, out);
+    CombineArgs c{photo_partials, (int)nphoto, reg_partials, (int)nreg, 1.0f / (float)n, lambda_dssim, out};
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c);
     return hipGetLastError() == hipSuccess ? 0 : fail(-4, "loss_combine_kernel: launch failed");
 }
 

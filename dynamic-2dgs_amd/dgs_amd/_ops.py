@@ -8,7 +8,7 @@ import subprocess
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libdgs_train_ops.so")
+LIB_PATH = os.environ.get("DGS_TRAIN_OPS_LIB", os.path.join(_CSRC, "libdgs_train_ops.so"))  # override: development A/B builds only
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-munsafe-fp-atomics"]
 _lib = None
 _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_forward", "dgs_ssim_backward", "dgs_knn_points",
@@ -16,7 +16,8 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_regloss_forward", "dgs_regloss_backward", "dgs_mlp_packed_floats", "dgs_mlp_saved_floats", "dgs_mlp_scratch_floats",
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
-            "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z")
+            "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
+            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine")
 
 
 def _deps():
@@ -116,6 +117,12 @@ def load():
         lib.dgs_densify_accumulate.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp]
         lib.dgs_step_guard.restype = ci
         lib.dgs_step_guard.argtypes = [vp, vp, vp, vp, ci, vp, vp]
+        lib.dgs_photo_backward_combine.restype = ci
+        lib.dgs_photo_backward_combine.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_longlong, vp, ctypes.c_longlong, vp, vp]
+        lib.dgs_regloss_fused_blocks.restype = ctypes.c_size_t
+        lib.dgs_regloss_fused_blocks.argtypes = [ci, ci]
+        lib.dgs_regloss_fused.restype = ci
+        lib.dgs_regloss_fused.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         lib.dgs_regloss_forward_partials_z.restype = ci
         lib.dgs_regloss_forward_partials_z.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         lib.dgs_adam_step_guarded.restype = ci
@@ -634,12 +641,23 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
                               g_attrs_out, coherent)
 
 
+_ONES = {}
+
+
+def _one(dev):
+    t = _ONES.get(dev)
+    if t is None:
+        t = _ONES[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+    return t
+
+
 class _FusedTrainLoss(torch.autograd.Function):
     """(1 - l) * L1(image, gt) + l * (1 - SSIM(image, gt)) + lambda_normal * normal consistency + lambda_dist * distortion
-    from the rasterizer outputs: 4 launches forward, 3 backward."""
+    from the rasterizer outputs: 3 launches forward, 2 backward -- or, with unit_grad, 3 launches in the forward and none in the
+    backward (see fused_train_loss)."""
 
     @staticmethod
-    def forward(ctx, image, allmap, gt, rays_d, rays_o, wvt, lam_dssim, lam_n, lam_d, slots=None):
+    def forward(ctx, image, allmap, gt, rays_d, rays_o, wvt, lam_dssim, lam_n, lam_d, slots=None, unit_grad=False):
         """slots: None, or an int64 device tensor [2] holding the pointers of the target image and the ray table to use
         (read by the kernels at run time: a captured graph switches views by rewriting them)."""
         lib = load()
@@ -648,22 +666,39 @@ class _FusedTrainLoss(torch.autograd.Function):
         dev = image.device
         image, allmap, gt = image.contiguous(), allmap.contiguous(), gt.contiguous()
         C, H, W = image.shape
-        nb, nr = int(lib.dgs_photo_blocks(C, H, W)), int(lib.dgs_regloss_blocks(H, W))
+        want_grad = torch.is_grad_enabled() or allmap.requires_grad
+        unit = bool(unit_grad) and want_grad
+        nb = int(lib.dgs_photo_blocks(C, H, W))
+        nr = int(lib.dgs_regloss_fused_blocks(H, W) if unit else lib.dgs_regloss_blocks(H, W))
         part = torch.empty(2 * nb + nr, dtype=torch.float32, device=dev)  # per-workgroup partial sums, no zero fill needed
         maps = torch.empty((3, C, H, W), dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        # the backward's gradient image of the allmap: its kernel stores every plane but 5, which collects atomics and is
-        # cleared HERE by the regulariser's forward kernel (one fill launch less per step)
-        g_allmap = torch.empty_like(allmap) if torch.is_grad_enabled() or allmap.requires_grad else None
+        # the backward's gradient image of the allmap.  Two-kernel path: its kernel stores every plane but 5, which collects atomics
+        # and is cleared HERE by the regulariser's forward kernel (one fill launch less per step); unit path: stored in full here
+        g_allmap = torch.empty_like(allmap) if want_grad else None
+        g_image = torch.empty_like(image) if unit else None
         with torch.cuda.device(dev):
             st = _stream(dev)
             _check(lib, lib.dgs_photo_forward(C, H, W, image.data_ptr(), gt.data_ptr(), part.data_ptr(), maps[0].data_ptr(),
                                               maps[1].data_ptr(), maps[2].data_ptr(), gslot, st), "dgs_photo_forward")
-            _check(lib, lib.dgs_regloss_forward_partials_z(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
-                                                           lam_n, lam_d, part.data_ptr() + 8 * nb, rslot,
-                                                           None if g_allmap is None else g_allmap[5].data_ptr(), st), "dgs_regloss_forward_partials")
-            _check(lib, lib.dgs_loss_combine(part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, C * H * W, lam_dssim, loss.data_ptr(), st),
-                   "dgs_loss_combine")
+            if unit:
+                _check(lib, lib.dgs_regloss_fused(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), lam_n, lam_d,
+                                                  part.data_ptr() + 8 * nb, g_allmap.data_ptr(), rslot, st), "dgs_regloss_fused")
+                _check(lib, lib.dgs_photo_backward_combine(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
+                                                           maps[2].data_ptr(), lam_dssim, _one(dev).data_ptr(), g_image.data_ptr(), gslot,
+                                                           part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, loss.data_ptr(), st),
+                       "dgs_photo_backward_combine")     # its last workgroup sums the partials into the loss
+            else:
+                _check(lib, lib.dgs_regloss_forward_partials_z(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
+                                                               lam_n, lam_d, part.data_ptr() + 8 * nb, rslot,
+                                                               None if g_allmap is None else g_allmap[5].data_ptr(), st), "dgs_regloss_forward_partials")
+            if not unit:
+                _check(lib, lib.dgs_loss_combine(part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, C * H * W, lam_dssim, loss.data_ptr(), st),
+                       "dgs_loss_combine")
+        if unit:
+            ctx.grads = (g_image, g_allmap)
+            return loss.reshape(())
+        ctx.grads = None
         ctx.save_for_backward(image, allmap, gt, rays_d, rays_o, wvt, maps)
         ctx.lam = (lam_dssim, lam_n, lam_d)
         ctx.slots = slots
@@ -672,6 +707,10 @@ class _FusedTrainLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.grads is not None:             # unit_grad: the caller promised g == 1; both gradient images exist already
+            g_image, g_allmap = ctx.grads
+            ctx.grads = None
+            return g_image, g_allmap, None, None, None, None, None, None, None, None, None
         lib = load()
         image, allmap, gt, rays_d, rays_o, wvt, maps = ctx.saved_tensors
         gslot = None if ctx.slots is None else ctypes.c_void_p(ctx.slots.data_ptr())
@@ -692,12 +731,15 @@ class _FusedTrainLoss(torch.autograd.Function):
             _check(lib, lib.dgs_regloss_backward_slot(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
                                                       ctx.lam[1], ctx.lam[2], gd.data_ptr(), g_allmap.data_ptr(), rslot, 1, st),
                    "dgs_regloss_backward")
-        return g_image, g_allmap, None, None, None, None, None, None, None, None
+        return g_image, g_allmap, None, None, None, None, None, None, None, None, None
 
 
-def fused_train_loss(image, allmap, gt, rays_d, rays_o, wvt, lambda_dssim, lambda_normal, lambda_dist, slots=None):
+def fused_train_loss(image, allmap, gt, rays_d, rays_o, wvt, lambda_dssim, lambda_normal, lambda_dist, slots=None, unit_grad=False):
+    """unit_grad=True is the caller's PROMISE that backward() will be called with dL/dloss == 1 (Trainer: loss.backward(unit)): the
+    gradient images then depend on the forward's inputs only and are produced in the forward -- the regularisers' value and
+    gradient in one kernel (dgs_regloss_fused), nothing launched in the backward.  Any other upstream gradient would be ignored."""
     return _FusedTrainLoss.apply(image, allmap, gt.detach(), rays_d.contiguous(), rays_o.contiguous(), wvt.contiguous(),
-                                 float(lambda_dssim), float(lambda_normal), float(lambda_dist), slots)
+                                 float(lambda_dssim), float(lambda_normal), float(lambda_dist), slots, bool(unit_grad))
 
 
 def densify_view(radii, g_means2D, grad_norm, visible, radii_vis):

@@ -485,7 +485,9 @@ class Trainer:
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
                          postprocess=not fused)
         lam = dict(lambda_normal=self.lambda_normal, lambda_dist=self.lambda_dist)
-        loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, **lam) if fused else training_loss(pkg, gt, **lam)
+        # unit_grad: every backward of this trainer starts from dL/dloss = 1 (self._unit; the ARAP term is added, not multiplied), so
+        # the loss node produces its gradient images in the forward (regularisers: value and gradient in one kernel)
+        loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, unit_grad=True, **lam) if fused else training_loss(pkg, gt, **lam)
         if self.arap:
             from . import arap
             lam = arap.lambda_arap(self.iteration)       # train_gui.py:315-316, utils/time_utils.py:1228-1232

@@ -204,11 +204,24 @@ int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* ra
 int dgs_regloss_forward_partials_z(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt,
                                    float lambda_normal, float lambda_dist, float* partials, const float* const* rays_slot,
                                    float* zero_plane, void* stream);
+/* Value AND gradient of the regularisers in one kernel, for an upstream gradient dL/dloss == 1 (what the train step uses):
+ * partials[0 .. dgs_regloss_fused_blocks()) as dgs_regloss_forward_partials, and EVERY element of d_allmap[8,H,W] is stored -- the
+ * depth gradient (plane 5) is gathered from the four neighbouring normals instead of added atomically, so nothing needs clearing.
+ * Same values as dgs_regloss_forward_partials + dgs_regloss_backward_slot(g = 1) up to the summation order of plane 5. */
+size_t dgs_regloss_fused_blocks(int H, int W);
+int dgs_regloss_fused(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt, float lambda_normal,
+                      float lambda_dist, float* partials, float* d_allmap, const float* const* rays_slot, void* stream);
 int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
                      float lambda_dssim, float* out, void* stream);
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
                        const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
                        void* stream);
+/* dgs_photo_backward whose last workgroup also performs dgs_loss_combine (loss_out may be NULL: then exactly dgs_photo_backward).
+ * For callers that launch it AFTER the forward kernels that fill the partials (the unit-gradient train step). */
+int dgs_photo_backward_combine(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                               const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
+                               const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, float* loss_out,
+                               void* stream);
 
 /* Densification statistics (train_gui.py:411, scene/gaussian_model.py:484-486).  dgs_densify_view, per rendered view:
  * visible = radii > 0, grad_norm = |dL/dmeans2D[:, :2]| where visible (else 0), radii_vis = radii where visible.

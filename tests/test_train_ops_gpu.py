@@ -424,6 +424,47 @@ def test_fused_train_loss_matches_separate_terms():
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
 
 
+@pytest.mark.parametrize("H,W", [(96, 144), (61, 47), (800, 800)])
+def test_unit_gradient_loss_node_matches_two_pass_path(H, W):
+    """unit_grad=True (what the Trainer uses): regularisers' value and gradient from ONE kernel with the depth gradient gathered
+    instead of added atomically (dgs_regloss_fused), SSIM backward launched in the forward -- against the forward/backward kernel
+    pairs, and (small sizes) against the PyTorch ops.  Depth plane with NaN / +-inf pixels and a background region of zeros."""
+    from dgs_amd import losses
+    from dgs_amd.cameras import orbit_cameras
+    torch.manual_seed(2)
+    cam = orbit_cameras(1, W, H)[0].to("cuda")
+    gt = torch.rand(3, H, W, device="cuda")
+    vals = {}
+    modes = ("unit", "pair") + (("ops",) if H * W < 100_000 else ())
+    for mode in modes:
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        image = (0.6 * torch.rand(3, H, W, device="cuda", generator=gen) + 0.4 * gt).requires_grad_(True)
+        allmap = torch.rand(8, H, W, device="cuda", generator=gen)
+        allmap[5] += 2.0
+        allmap[5, H // 3: H // 3 + 7, : W // 2] = 0.0                 # background: depth 0, degenerate normals (|v| = 0)
+        allmap[5, 5, 7], allmap[5, 9, 3], allmap[5, 11, 11] = float("nan"), float("inf"), float("-inf")
+        allmap[5, 0, 0], allmap[5, H - 1, W - 1] = float("nan"), float("inf")
+        allmap.requires_grad_(True)
+        losses.FUSE_PHOTOMETRIC = mode != "ops"
+        try:
+            loss = losses.training_loss_from_allmap(image, allmap, cam, gt, unit_grad=(mode == "unit"))
+        finally:
+            losses.FUSE_PHOTOMETRIC = True
+        loss.backward(torch.ones((), device="cuda"))
+        vals[mode] = (float(loss), image.grad.clone(), allmap.grad.clone())
+    for other in modes[1:]:
+        la, lb = vals["unit"][0], vals[other][0]
+        if la == la or lb == lb:          # (-inf depth makes the reference's own loss non-finite on some layouts)
+            assert abs(la - lb) <= 1e-5 * abs(lb), (other, la, lb)
+        for a, b in ((vals["unit"][1], vals[other][1]), (vals["unit"][2], vals[other][2])):
+            fin = torch.isfinite(b)
+            assert torch.equal(torch.isfinite(a), fin), other
+            # the depth gradient is a sum of four neighbour terms that cancel at the rim of the degenerate region (values up to
+            # ~170 there): gather order vs atomic order differ by a few ulp of the largest TERM
+            assert float((a[fin] - b[fin]).abs().max()) <= 5e-5 * float(b[fin].abs().max()) + 1e-12, other
+    assert torch.equal(vals["unit"][1], vals["pair"][1])       # the SSIM backward is the same kernel on the same inputs
+
+
 def test_fused_step_matches_unfused_step():
     """Trainer with every fused stage (assembled deformation, MFMA node MLP with gradient sinks, fused loss, fused
     statistics) against the same Trainer on the PyTorch formulations: loss trajectory and statistics."""
