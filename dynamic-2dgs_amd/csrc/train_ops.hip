@@ -755,11 +755,236 @@ int launch_knn_refine_q(int N, int M, int D, const float* x, const float* nodes,
     return 0;
 }
 
+// ---- seeded refine on the matrix cores ---------------------------------------------------------------------------------
+// The 3-D block / box culling of knn_refine_kernel needs the K-th seed distance to be a SPATIAL radius.  In a trained scene it is
+// not: the 8 hyper coordinates of surfels and nodes drift apart, the 11-D distance of the third neighbour exceeds the node spacing
+// several times, every block is touched, candidate lists overflow, and the kernel is slower than the plain scan (172 us at 125 k
+// surfels x 512 nodes against 36 us on the untrained scene).  This kernel filters with the FULL distance instead, dense and
+// data-independent:   score[j][i] = |n_j|^2 - 2 x_i . n_j   as  A[32 nodes x 12] x B[12 x 32 points]  on v_mfma_f32_32x32x2f32
+// (A row = [n_0 .. n_10, |n|^2] from LDS, B column = [-2 x_0 .. -2 x_10, 1] in registers; the k pairs are {kk, kk + 6} so that a
+// lane's six A values are contiguous).  A node is a candidate of point i when  score <= T_i - |x_i|^2 + eps,  T_i the exact
+// distance of the K-th seed neighbour, eps 4e-6 (|x|^2 + max |n|^2) -- six times the rounding of the 12-term fp32 dot product, so
+// no node with exact distance <= T_i is missed.  Candidates (K plus near ties, whatever the seed's age) are then evaluated exactly
+// and ranked like the plain scan (distance, then index).  Two lanes (l, l + 32) share a point and own alternating groups of 4
+// rows of every 32-node tile (the D layout of the instruction); their top-K lists are merged at the end.  Hits are sign bits:
+// the accumulator starts at -threshold, and each result's sign is shifted into a per-lane hit word (one VALU instruction per
+// node-point pair, no branch, no list in LDS).  A garbage seed (T = inf) sets every bit: that lane scans its rows itself.
+#ifndef DGS_KNN_DIAG
+#define DGS_KNN_DIAG 0   // development only: 1 no candidate evaluation, 2 no MFMA loop
+#endif
+constexpr int kRmThreads = 512;   // 8 waves x 32 points
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// TP: pairs of 32-node tiles (one 32-bit hit word per pair and lane), Mp <= 64 TP
+template <int K, int TP>
+__global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
+                                                                     long long* __restrict__ idx, const float* __restrict__ x2, int D1, int stride2)
+{
+    extern __shared__ float s_n[];                                      // [Mp][12]: n_0 .. n_10 (zero padded), |n|^2
+    const int Mp = (M + 31) & ~31, ntiles = Mp >> 5;
+    __shared__ float s_max[kRmThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    for (int e = tid; e < Mp * 12; e += kRmThreads) s_n[e] = 0.f;
+    __syncthreads();
+    {
+        const int F = M * D;
+        for (int base = 0; base < F; base += 8 * kRmThreads) {           // 8 loads in flight per thread
+            float q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int e = base + i * kRmThreads + tid; q[i] = e < F ? nodes[e] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int e = base + i * kRmThreads + tid;
+                if (e < F) { const int r = e / D; s_n[r * 12 + (e - r * D)] = q[i]; }
+            }
+        }
+    }
+    // a wave takes groups of 32 points; the host sizes the grid so that every wave gets the same number of groups and all
+    // workgroups are resident at once (782 workgroups on 768 slots ran as two rounds: twice the time)
+    const int ngroups = (N + 31) >> 5, nwaves = gridDim.x * (kRmThreads / 64);
+    for (int grp = blockIdx.x * (kRmThreads / 64) + (tid >> 6); grp < ngroups; grp += nwaves) {
+    const int p = grp * 32 + (lane & 31);
+    const bool in = p < N;
+    float xv[11];
+#pragma unroll
+    for (int d = 0; d < 11; d++) {
+        float v = 0.f;
+        if (in && d < D) v = d < D1 ? x[(size_t)p * D1 + d] : x2[(size_t)p * stride2 + d - D1];
+        xv[d] = v;
+    }
+    int sj[K];
+    bool ok = in;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const long long j = in ? idx[(size_t)p * K + k] : 0;
+        ok = ok && j >= 0 && j < M;
+        sj[k] = (int)(j < 0 ? 0 : (j >= M ? M - 1 : j));
+    }
+#pragma unroll
+    for (int k = 1; k < K; k++)
+#pragma unroll
+        for (int k2 = 0; k2 < k; k2++) ok = ok && sj[k] != sj[k2];
+    __syncthreads();
+    float n2max = 0.f;
+    for (int j = tid; j < Mp; j += kRmThreads) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 11; c++) a += s_n[j * 12 + c] * s_n[j * 12 + c];
+        s_n[j * 12 + 11] = j < M ? a : 3.0e38f;                          // padded rows never qualify
+        if (j < M) n2max = fmaxf(n2max, a);
+    }
+    for (int d = 32; d >= 1; d >>= 1) n2max = fmaxf(n2max, __shfl_xor(n2max, d, 64));
+    if (lane == 0) s_max[tid >> 6] = n2max;
+    __syncthreads();
+    n2max = s_max[0];
+#pragma unroll
+    for (int w = 1; w < kRmThreads / 64; w++) n2max = fmaxf(n2max, s_max[w]);
+
+    auto full_dist = [&](int j) {
+        const float4 n0 = *reinterpret_cast<const float4*>(s_n + j * 12), n1 = *reinterpret_cast<const float4*>(s_n + j * 12 + 4),
+                     n2 = *reinterpret_cast<const float4*>(s_n + j * 12 + 8);
+        float a = 0.f, t;
+        // same order of operations as knn_kernel / knn_refine_kernel (groups of four coordinates): identical distances, identical ties
+        t = xv[0] - n0.x; a += t * t; t = xv[1] - n0.y; a += t * t; t = xv[2] - n0.z; a += t * t; t = xv[3] - n0.w; a += t * t;
+        t = xv[4] - n1.x; a += t * t; t = xv[5] - n1.y; a += t * t; t = xv[6] - n1.z; a += t * t; t = xv[7] - n1.w; a += t * t;
+        t = xv[8] - n2.x; a += t * t; t = xv[9] - n2.y; a += t * t; t = xv[10] - n2.z; a += t * t;
+        return a;
+    };
+    // bound from the seed (K distinct valid nodes): exact distance of its farthest member
+    float T = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) T = fmaxf(T, full_dist(sj[k]));
+    if (!ok) T = INFINITY;
+    float xx = 0.f;
+#pragma unroll
+    for (int d = 0; d < 11; d++) xx += xv[d] * xv[d];
+    // hit <=> score - thr < 0.  The subtraction rides in the accumulator: the first MFMA of a tile starts from C = -thr
+    const float nthr = in ? -(T * (1.0f + 1e-6f) - xx + (4e-6f * (xx + n2max) + 1e-30f)) : INFINITY;
+    f32x16 cthr;
+#pragma unroll
+    for (int v = 0; v < 16; v++) cthr[v] = nthr;
+    float b[6];
+#pragma unroll
+    for (int kk = 0; kk < 6; kk++) b[kk] = half ? (kk == 5 ? 1.0f : -2.0f * xv[6 + kk]) : -2.0f * xv[kk];   // (no dynamic register index)
+    unsigned hits[TP];
+    const float* arow = s_n + (lane & 31) * 12 + 6 * half;
+#pragma unroll
+    for (int w = 0; w < TP; w++) {
+        unsigned word = 0u;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int t = 2 * w + u;
+            if (t < ntiles && !(DGS_KNN_DIAG & 2)) {                     // wave-uniform
+                const float* ar = arow + t * (32 * 12);
+                const float2 a01 = *reinterpret_cast<const float2*>(ar), a23 = *reinterpret_cast<const float2*>(ar + 2),
+                             a45 = *reinterpret_cast<const float2*>(ar + 4);
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.x, b[0], cthr, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.y, b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.x, b[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.y, b[3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.x, b[4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.y, b[5], acc, 0, 0, 0);
+                // the sign bits of the 16 results are shifted into the hit word, first result ends highest (v_alignbit_b32)
+#pragma unroll
+                for (int v = 0; v < 16; v++) word = __builtin_amdgcn_alignbit(word, __float_as_uint(acc[v]), 31);
+            } else {
+                word <<= 16;
+            }
+        }
+        hits[w] = word;
+    }
+    // ---- exact evaluation of the candidates in ascending index (ties keep the lower index like the plain scan)
+    // D[i][j] of the instruction: lane = j + 32 ((i / 4) % 2), register v = 4 (i / 8) + i % 4  =>  row i = 8 (v / 4) + 4 half + v % 4;
+    // bit 31 - (16 u + v) of word w is row i of tile 2 w + u
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { bd[k] = INFINITY; bi[k] = 0x7fffffff; }
+    auto offer = [&](float dj, int j) {
+        if (dj < bd[K - 1] || (dj == bd[K - 1] && j < bi[K - 1])) {
+            bd[K - 1] = dj; bi[K - 1] = j;
+#pragma unroll
+            for (int k = K - 1; k > 0; k--) {
+                if (bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1])) {
+                    const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+                    const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int w = 0; w < TP; w++) {
+        unsigned word = hits[w];
+#if DGS_KNN_DIAG & 1
+        bi[w % K] ^= (int)word; word = 0u;      // (keeps the hit words alive)
+#endif
+        while (word) {
+            const int q = __builtin_clz(word);          // 16 u + v
+            word &= ~(0x80000000u >> q);
+            const int v = q & 15;
+            const int j = ((2 * w + (q >> 4)) << 5) + 8 * (v >> 2) + 4 * half + (v & 3);
+#if DGS_KNN_DIAG & 16
+            if (j < M) offer((float)j * xv[0], j);
+#elif DGS_KNN_DIAG & 32
+            if (j < M) bd[0] = fminf(bd[0], full_dist(j));
+#else
+            if (j < M) offer(full_dist(j), j);
+#endif
+        }
+    }
+    // merge with the partner lane's list
+    float od[K];
+    int oi[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { od[k] = __shfl_xor(bd[k], 32, 64); oi[k] = __shfl_xor(bi[k], 32, 64); }
+    if (in && half == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) offer(od[k], oi[k]);
+#pragma unroll
+        for (int k = 0; k < K; k++) idx[(size_t)p * K + k] = bi[k];
+    }
+#if DGS_KNN_DIAG & 8
+    {
+        int pc = 0;
+#pragma unroll
+        for (int w = 0; w < TP; w++) pc += __builtin_popcount(hits[w]);
+        pc += __shfl_xor(pc, 32, 64);
+        if (in && half == 0) idx[(size_t)p * K] = pc;
+    }
+#endif
+    }   // groups
+}
+
+template <int K, int TP>
+int launch_knn_refine_mfma_tp(int N, int M, int D, const float* x, const float* nodes, long long* idx, hipStream_t s, const float* x2, int D1, int stride2)
+{
+    const int Mp = (M + 31) & ~31;
+    const size_t lds = (size_t)Mp * 12 * sizeof(float);
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                                return n > 0 ? n : 256; }();
+    const int wpb = kRmThreads / 64, ngroups = (N + 31) / 32, slots = cus * 2 * wpb;     // 2 workgroups per CU are resident (91 VGPRs: 5 waves per SIMD)
+    const int iters = (ngroups + slots - 1) / slots, waves = (ngroups + iters - 1) / iters;
+    hipLaunchKernelGGL((knn_refine_mfma_kernel<K, TP>), dim3((waves + wpb - 1) / wpb), dim3(kRmThreads), lds, s, N, M, D, x, nodes, idx, x2, D1,
+                       stride2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("knn_refine_mfma_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+template <int K>
+int launch_knn_refine_mfma(int N, int M, int D, const float* x, const float* nodes, long long* idx, hipStream_t s, const float* x2, int D1, int stride2)
+{
+    if (M <= 256) return launch_knn_refine_mfma_tp<K, 4>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
+    if (M <= 512) return launch_knn_refine_mfma_tp<K, 8>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
+    return launch_knn_refine_mfma_tp<K, 16>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
+}
+
 template <int K>
 int launch_knn_refine(int N, int M, int D, const float* x, const float* nodes, long long* idx, hipStream_t s, const float* x2, int D1,
-                      int stride2)
+                      int stride2, bool mfma)
 {
     if (!x2) D1 = D;
+    if (mfma && D <= 11 && M <= 1024) return launch_knn_refine_mfma<K>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
     switch ((D + 3) / 4) {
     case 1: return launch_knn_refine_q<K, 1>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
     case 2: return launch_knn_refine_q<K, 2>(N, M, D, x, nodes, idx, s, x2, D1, stride2);
@@ -2167,10 +2392,11 @@ int dgs_knn_points2(int N, int M, int D1, int D2, int K, const float* x1, const 
     }
 }
 
-int dgs_knn_refine(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
-                   long long* idx, void* stream)
+int dgs_knn_refine_mode(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
+                        long long* idx, int mode, void* stream)
 {
     const int D = D1 + D2;
+    if (mode != 0 && mode != 1) return fail(-1, "dgs_knn_refine: mode must be 0 (3-D culling) or 1 (matrix cores)");
     if (N < 0 || M <= 0 || D1 < 3 || D2 < 0 || D > kKnnDpad || K < 1 || K > 4 || K > M) return fail(-1, "dgs_knn_refine: bad argument");
     if (M > 2048) return fail(-2, "dgs_knn_refine: more than 2048 nodes (use dgs_knn_points)");
     if (N == 0) return 0;
@@ -2178,11 +2404,17 @@ int dgs_knn_refine(int N, int M, int D1, int D2, int K, const float* x1, const f
     hipStream_t s = (hipStream_t)stream;
     const float* xb = D2 > 0 ? x2 : nullptr;
     switch (K) {
-    case 1: return launch_knn_refine<1>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
-    case 2: return launch_knn_refine<2>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
-    case 3: return launch_knn_refine<3>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
-    default: return launch_knn_refine<4>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride);
+    case 1: return launch_knn_refine<1>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride, mode == 1);
+    case 2: return launch_knn_refine<2>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride, mode == 1);
+    case 3: return launch_knn_refine<3>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride, mode == 1);
+    default: return launch_knn_refine<4>(N, M, D, x1, nodes, idx, s, xb, D1, x2_stride, mode == 1);
     }
+}
+
+int dgs_knn_refine(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
+                   long long* idx, void* stream)
+{
+    return dgs_knn_refine_mode(N, M, D1, D2, K, x1, x2, x2_stride, nodes, idx, 0, stream);
 }
 
 }  // extern "C"

@@ -17,7 +17,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
-            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine")
+            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode")
 
 
 def _deps():
@@ -93,6 +93,8 @@ def load():
         lib.dgs_knn_points2.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
         lib.dgs_knn_refine.restype = ci
         lib.dgs_knn_refine.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]
+        lib.dgs_knn_refine_mode.restype = ci
+        lib.dgs_knn_refine_mode.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp]
         lib.dgs_deform_forward.restype = ci
         lib.dgs_deform_forward.argtypes = [ci, ci, ci, vp, vp, ci] + [vp] * 14
         lib.dgs_deform_backward.restype = ci
@@ -492,10 +494,11 @@ def fused_node_mlp(net, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0), grad_sink=False):
     return _FusedNodeMLP.apply(x.detach(), t.detach(), tuple(float(v) for v in rot_bias), sink, *params)
 
 
-def knn_indices2(x1, x2, nodes, K, seed=None):
+def knn_indices2(x1, x2, nodes, K, seed=None, mode="box"):
     """knn_indices(cat([x1, x2], 1), nodes, K) without materialising the concatenation (x2 may be a column slice).
     seed: an int64 [N,K] tensor holding an earlier answer (e.g. last step's); it is refined IN PLACE to the exact
-    current answer and returned (dgs_knn_refine: ~3x cheaper than the plain scan, exact for any seed content)."""
+    current answer and returned (dgs_knn_refine: ~3x cheaper than the plain scan, exact for any seed content).  mode: "box" = 3-D
+    culling, "mfma" = dense scores on the matrix cores (dgs_knn_refine_mode; ControlNodes.pick_knn_refine chooses)."""
     lib = load()
     if seed is not None:
         N = x1.shape[0]
@@ -504,8 +507,11 @@ def knn_indices2(x1, x2, nodes, K, seed=None):
             raise RuntimeError("knn_indices2: seed must be a contiguous int64 [N,K] tensor (and <= 2048 nodes)")
         x1d, x2d, nd = x1.detach(), x2.detach(), nodes.detach()
         with torch.cuda.device(x1.device):
-            rc = lib.dgs_knn_refine(N, nd.shape[0], x1d.shape[1], x2d.shape[1], K, x1d.data_ptr(), x2d.data_ptr(), x2d.stride(0),
-                                    nd.data_ptr(), seed.data_ptr(), _stream(x1.device))
+            m = {"box": 0, "mfma": 1}[os.environ.get("DGS_KNN_REFINE", mode)]      # (env: development override)
+            if m == 1 and (x1d.shape[1] + x2d.shape[1] > 11 or nd.shape[0] > 1024):
+                m = 0
+            rc = lib.dgs_knn_refine_mode(N, nd.shape[0], x1d.shape[1], x2d.shape[1], K, x1d.data_ptr(), x2d.data_ptr(), x2d.stride(0),
+                                         nd.data_ptr(), seed.data_ptr(), m, _stream(x1.device))
         _check(lib, rc, "dgs_knn_refine")
         return seed
     x1, nodes = x1.detach(), nodes.detach()

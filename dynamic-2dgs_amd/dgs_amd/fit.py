@@ -86,6 +86,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
                 counts = tr.densify_and_prune(densify_grad_threshold, 0.01, extent, size_threshold, seed=seed)
                 if on_gpu:
                     tr.sort_surfels()   # children landed in free slots anywhere: restore the node order (in place, no re-capture)
+                    if tr.refresh_knn_mode() and log:   # the hyper coordinates train: the neighbour search may need its other kernel
+                        log("[%d] neighbour search: %s (spatial share of the K-th distance %.2f)" % (it, deform.knn_refine_mode, deform.knn_spatial_share))
                 if log:
                     log("[%d] cloned %d, split %d, pruned %d -> %d surfels (%d slots)" % ((it,) + tuple(counts) + (surfels.num_surfels, tr.P)))
             if it % opacity_reset_interval == 0 or (white_background and it == densify_from):

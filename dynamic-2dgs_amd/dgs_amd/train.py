@@ -334,6 +334,8 @@ class Trainer:
         if self._graph:            # a live capture is being replaced: settle what its last steps reported first
             if self._flush_guard():
                 return             # the recovery re-captured already (with a larger capacity / without the promise)
+        if hasattr(self.deform, "pick_knn_refine"):
+            self.deform.pick_knn_refine(self.surfels)   # the neighbour-search kernel that fits the scene now is baked into the capture
         self._capacity = int(capacity)
         _C.set_capacity(int(capacity), device=dev)   # (the context of THIS trainer's device, whatever the caller's current device is)
         # promise of the longest tile list (dgs_set_option key 6): one sort launch instead of three.  A frame that breaks it
@@ -374,7 +376,9 @@ class Trainer:
         # thread-local capture mode: with a process group alive, the collective library's watchdog thread polls events while
         # this thread captures; under the default ("global") mode such a call from ANOTHER thread invalidates the capture
         # and the watchdog dies with the error (seen once in three runs on ROCm 7 / RCCL 2.26)
-        mode = {"capture_error_mode": "thread_local"}
+        # capture ON the warm-up stream: per-stream persistent buffers created by the warm-up steps (the coherent skinning table of
+        # _ops._FusedDeform.backward) are found again instead of being allocated -- and zero-filled on every replay -- inside the graph
+        mode = {"capture_error_mode": "thread_local", "stream": s}
         self._split = self._split_ok()
         if self._split:
             # data parallel: graph 1a = forward + backward down to the rasterizer inputs (SH gradients final), eager async
@@ -428,6 +432,18 @@ class Trainer:
                 return self.enable_graph(capacity, validate=validate)
             if validate:
                 raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
+
+    def refresh_knn_mode(self):
+        """Re-evaluate which seeded neighbour search fits the scene (ControlNodes.pick_knn_refine: one host read) and, if the
+        answer changed under a captured step, capture again.  fit() calls it at densification steps."""
+        d = self.deform
+        if not hasattr(d, "pick_knn_refine") or not self.surfels.get_xyz.is_cuda:
+            return False
+        if d.pick_knn_refine(self.surfels):
+            if self._graph:
+                self.enable_graph(self._capacity)
+            return True
+        return False
 
     def _snapshot(self):
         sf = self.surfels

@@ -37,13 +37,15 @@ def test_knn_kernel_matches_bruteforce(N, M, D, K):
     assert bool((dsel[:, 1:] >= dsel[:, :-1] - 1e-6).all())
 
 
-def test_knn_refine_is_exact_for_any_seed():
-    """dgs_knn_refine == plain scan whatever the seed holds: last step's answer, random indices, duplicates, garbage."""
+@pytest.mark.parametrize("mode,fscale", [("box", 0.05), ("mfma", 0.05), ("mfma", 0.7)])
+def test_knn_refine_is_exact_for_any_seed(mode, fscale):
+    """dgs_knn_refine_mode == plain scan whatever the seed holds: last step's answer, random indices, duplicates, garbage -- for the
+    3-D culling kernel and for the matrix-core filter, the latter also with hyper coordinates that dominate the distance."""
     from dgs_amd import _ops
     g = torch.Generator().manual_seed(9)
     N, M = 30001, 1000
     x = (torch.rand(N, 3, generator=g) * 2 - 1).cuda()
-    f = (0.05 * torch.randn(N, 8, generator=g)).cuda()
+    f = (fscale * torch.randn(N, 8, generator=g)).cuda()
     nodes = torch.cat([torch.rand(M, 3, generator=g) * 2 - 1, 0.05 * torch.randn(M, 8, generator=g)], 1).cuda()
     want = _ops.knn_indices2(x, f, nodes, 3)
     assert torch.equal(want, _ops.knn_indices(torch.cat([x, f], 1), nodes, 3))
@@ -53,9 +55,49 @@ def test_knn_refine_is_exact_for_any_seed():
              "duplicates": want[:, :1].repeat(1, 3).contiguous(),
              "garbage": torch.randint(-5, 3 * M, (N, 3), generator=g).cuda()}
     for name, seed in seeds.items():
-        got = _ops.knn_indices2(x, f, nodes, 3, seed=seed)
+        got = _ops.knn_indices2(x, f, nodes, 3, seed=seed, mode=mode)
         assert got.data_ptr() == seed.data_ptr()
         assert torch.equal(got, want), name
+
+
+def test_knn_refine_matrix_core_filter_sizes_and_ties():
+    """Node counts that are not multiples of 32 / 64, fewer coordinates than 11, points that coincide with nodes (distance 0,
+    exact ties between duplicated nodes: the lower index wins like in the plain scan), a point count that leaves a partial group."""
+    from dgs_amd import _ops
+    g = torch.Generator().manual_seed(4)
+    for N, M, H in ((4099, 77, 8), (20000, 512, 8), (3000, 200, 2), (999, 33, 5)):
+        nodes = torch.cat([torch.rand(M, 3, generator=g) * 2 - 1, 0.3 * torch.randn(M, H, generator=g)], 1)
+        nodes[M // 2] = nodes[3]                       # duplicated node: ties for every point
+        nodes = nodes.cuda()
+        x = (torch.rand(N, 3, generator=g) * 2 - 1).cuda()
+        f = (0.3 * torch.randn(N, H, generator=g)).cuda()
+        x[:M], f[:M] = nodes[:, :3], nodes[:, 3:]      # points ON nodes
+        want = _ops.knn_indices2(x, f, nodes, 3)
+        for name, seed in (("exact", want.clone()), ("shifted", torch.roll(want, 1, 0).contiguous())):
+            got = _ops.knn_indices2(x, f, nodes, 3, seed=seed, mode="mfma")
+            assert torch.equal(got, want), (N, M, H, name)
+
+
+def test_pick_knn_refine_follows_the_hyper_coordinates():
+    """ControlNodes.pick_knn_refine: 3-D culling while the K-th neighbour distance is spatial, the matrix-core filter once the
+    (trained) hyper coordinates dominate it; fused deformation gives the same result under either."""
+    from dgs_amd.deform import ControlNodes
+    from dgs_amd.model import SurfelModel
+    from dgs_amd.synthetic import make_scene
+    dev = torch.device("cuda:0")
+    surfels = SurfelModel(make_scene(20000, seed=3)).to(dev)
+    d = ControlNodes(node_num=256, K=3, hyper_dim=8, local_frame=True).to(dev)
+    d.init_from_points(surfels.get_xyz.detach(), fps=True)
+    t = torch.tensor([0.3], device=dev)
+    with torch.no_grad():
+        a = [v.clone() for v in d.forward_assembled(surfels, t)]      # plain scan (no seed yet)
+        assert not d.pick_knn_refine(surfels) and d.knn_refine_mode == "box" and d.knn_spatial_share > 0.9
+        surfels.feature.add_(0.8 * torch.randn_like(surfels.feature))
+        ref = [v.clone() for v in d.forward_assembled(surfels, t)]    # refine with the 3-D culling kernel
+        assert d.pick_knn_refine(surfels) and d.knn_refine_mode == "mfma" and d.knn_spatial_share < 0.5
+        got = d.forward_assembled(surfels, t)                         # ... with the matrix-core filter
+    assert all(torch.equal(u, v) for u, v in zip(ref, got))
+    assert not torch.equal(a[0], ref[0])
 
 
 def test_knn_refine_block_culling_is_exact_on_sorted_inputs():
@@ -82,6 +124,7 @@ def test_knn_refine_block_culling_is_exact_on_sorted_inputs():
         for name, seed in (("exact", want.clone()), ("stale", stale), ("far", torch.flip(want, (0,)).contiguous())):
             got = _ops.knn_indices2(x, f, nodes, 3, seed=seed)
             assert torch.equal(got, want), (N, M, name)
+            assert torch.equal(_ops.knn_indices2(x, f, nodes, 3, seed=seed.clone(), mode="mfma"), want), (N, M, name, "mfma")
 
 
 def test_graph_captured_step_matches_eager():
