@@ -1980,6 +1980,18 @@ int dgs_regloss_backward_slot(int H, int W, const float* allmap, const float* ra
     return 0;
 }
 
+int dgs_deform_reduce(int M, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes, float* g_radius_raw,
+                      float* g_weight_raw, float* g_attrs, int accumulate, void* scratch, void* stream)
+{
+    if (M <= 0 || H < 0 || H > kLbsHmax || !scratch || !node_radius_raw || !node_weight_raw || !g_nodes || !g_radius_raw || !g_weight_raw || !g_attrs)
+        return fail(-1, "dgs_deform_reduce: bad argument");
+    const int G = kLbsAttr + H + 2;
+    hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
+                       node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1,
+                       (accumulate & 4) ? (float*)scratch : (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-4, "lbs_reduce_raw_kernel: launch failed");
+}
+
 size_t dgs_adam_plan_bytes(long long total) { return (size_t)(total / kAdamChunk + kAdamSeg + 1) * sizeof(int2); }
 
 int dgs_adam_plan(int nseg, const long long* offsets, void* plan, void* stream)
@@ -2238,10 +2250,12 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
         hipLaunchKernelGGL(kern, dim3((N + kCohThreads - 1) / kCohThreads), dim3(kCohThreads), 0, (hipStream_t)stream, a,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1,
                            (float*)scratch, kCohThreads, s);
-        hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
-                           node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1,
-                           persistent ? (float*)scratch : (float*)nullptr);
+        if (!(accumulate & 8))      // bit 3: the caller reduces the table later (dgs_deform_reduce), e.g. on another stream
+            hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
+                               node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1,
+                               persistent ? (float*)scratch : (float*)nullptr);
     } else {
+        if (accumulate & 8) return fail(-1, "dgs_deform_backward: the deferred reduce (bit 3) needs the coherent variant (bit 1)");
         const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
         hipLaunchKernelGGL((lbs_bwd_kernel<true, false>), dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1, (float*)scratch,

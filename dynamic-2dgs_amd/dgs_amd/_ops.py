@@ -17,7 +17,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
-            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode")
+            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce")
 
 
 def _deps():
@@ -93,6 +93,8 @@ def load():
         lib.dgs_knn_points2.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
         lib.dgs_knn_refine.restype = ci
         lib.dgs_knn_refine.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]
+        lib.dgs_deform_reduce.restype = ci
+        lib.dgs_deform_reduce.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp]
         lib.dgs_knn_refine_mode.restype = ci
         lib.dgs_knn_refine_mode.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp]
         lib.dgs_deform_forward.restype = ci
@@ -564,7 +566,7 @@ class _FusedDeform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                g_attrs_out=None, coherent=False):
+                g_attrs_out=None, coherent=False, reduce_later=None):
         lib = load()
         dev = xyz.device
         N, M = xyz.shape[0], nodes.shape[0]
@@ -588,6 +590,7 @@ class _FusedDeform(torch.autograd.Function):
         _check(lib, rc, "dgs_deform_forward")
         ctx.save_for_backward(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx)
         ctx.mask, ctx.H, ctx.sink, ctx.g_attrs_out, ctx.coherent = mask, H, sink, g_attrs_out, bool(coherent)
+        ctx.reduce_later = reduce_later if (g_attrs_out is not None and sink is not None) else None
         return means3D, scales, rots, opac
 
     @staticmethod
@@ -620,23 +623,34 @@ class _FusedDeform(torch.autograd.Function):
                 outs[4].zero_()
             ret, acc = outs, 0
         mask = ctx.mask
+        defer = ctx.reduce_later is not None and ctx.coherent and persistent == 4
+        flags = acc | (2 if ctx.coherent else 0) | persistent | (8 if defer else 0)
         with torch.cuda.device(dev):
             rc = lib.dgs_deform_backward(
                 N, M, H, xyz.data_ptr(), feature.data_ptr(), feature.shape[1], idx.data_ptr(), nodes.data_ptr(), node_radius.data_ptr(),
                 node_weight.data_ptr(), attrs.data_ptr(), None if mask is None else mask.data_ptr(), scaling.data_ptr(),
                 rotation.data_ptr(), opacity.data_ptr(), g_means.data_ptr(), g_scales.data_ptr(), g_rots.data_ptr(), g_opac.data_ptr(),
                 outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), outs[5].data_ptr(),
-                outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), acc | (2 if ctx.coherent else 0) | persistent, scratch.data_ptr(), _stream(dev))
+                outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), flags, scratch.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_deform_backward")
-        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None)
+        if defer:
+            def reduce(M=M, H=H, nr=node_radius, nw=node_weight, outs=outs, g_attrs=g_attrs, flags=flags, scratch=scratch, dev=dev):
+                with torch.cuda.device(dev):
+                    _check(lib, lib.dgs_deform_reduce(M, H, nr.data_ptr(), nw.data_ptr(), outs[5].data_ptr(), outs[6].data_ptr(), outs[7].data_ptr(),
+                                                      g_attrs.data_ptr(), flags & 5, scratch.data_ptr(), _stream(dev)), "dgs_deform_reduce")
+            ctx.reduce_later.append(reduce)
+        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None, None)
 
 
 def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False,
-                 g_attrs_out=None, coherent=False):
+                 g_attrs_out=None, coherent=False, reduce_later=None):
     """Raw surfel parameters + node tables + node attributes -> (means3D, scales, rotations, opacity) for the rasterizer.
     grad_sink=True: gradients of the eight parameters are ADDED to their existing .grad tensors by the kernels.
     coherent=True: the surfels are stored in the order of their nearest node (Trainer.sort_surfels) -- the backward sums per
-    wave and issues global atomics instead of building 256 per-workgroup LDS tables (dgs_deform_backward, accumulate bit 1)."""
+    wave and issues global atomics instead of building 256 per-workgroup LDS tables (dgs_deform_backward, accumulate bit 1).
+    reduce_later: a list (coherent + grad_sink + g_attrs_out only).  The backward then leaves its node table unreduced and appends
+    ONE callable to the list; the caller must run it (on any stream ordered behind the backward) before the node gradients or
+    g_attrs_out are read -- ControlNodes.finish_backward does, on the node-MLP backward's side stream."""
     params = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
     sink = None
     if grad_sink and torch.is_grad_enabled():
@@ -644,7 +658,7 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
         if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
             raise RuntimeError("fused_deform(grad_sink=True): every parameter needs a contiguous fp32 .grad")
     return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                              g_attrs_out, coherent)
+                              g_attrs_out, coherent, reduce_later)
 
 
 _ONES = {}

@@ -560,10 +560,18 @@ class Trainer:
         d = self.deform
         loss, pkg, asm, fused = self._forward(cam, gt)
         self._note_loss(loss.detach())
+        if fused and self.world == 1 and self.opt_deform is None and getattr(self, "_oflag", None) is not None:
+            # single GPU: everything the step guard reads (overflow flag, loss) exists now.  Launched here, it is out of the way
+            # when the backward ends and the surfels' Adam update starts right behind the skinning backward (_finish: advance=False)
+            with torch.no_grad():
+                self.opt_surfels.guard()
+            self._guard_early = True
         # explicit unit gradient: loss.backward() alone launches a fill for it every step
         self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
         if hasattr(d, "finish_backward") and not self.warmup:   # (warm-up: nothing behind the deformation's outputs trains)
             d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
+        elif hasattr(d, "run_pending_reduce"):
+            d.run_pending_reduce()
         if getattr(d, "_join_pending", False) and fused:
             # single GPU: the node-MLP backward now runs on the side stream and is the longer branch; the statistics kernels
             # (three launches, ~25 us of a mostly idle device) go behind the surfel update instead of in front of it (_finish)
@@ -615,6 +623,8 @@ class Trainer:
         _, _, pkg = self._half
         if not self.warmup:
             self.deform.finish_backward(join=True)
+        elif hasattr(self.deform, "run_pending_reduce"):
+            self.deform.run_pending_reduce()
         self._statistics(pkg, True, early_radii=True)
         self._half = None
 
@@ -693,6 +703,8 @@ class Trainer:
                     torch.maximum(s.max_radii2D, self._radii[:self.P], out=s.max_radii2D)
             late = getattr(self, "_late_stats", None)
             self._late_stats = None
+            adv = not getattr(self, "_guard_early", False)   # the guard kernel of this step was launched by _fwd_bwd already
+            self._guard_early = False
             if late is None:
                 accumulate()
             n_train = self.n_surfel_params - 1 if self.warmup else None   # warm-up: everything up to (not including) `feature`
@@ -716,11 +728,11 @@ class Trainer:
                 if n_train is None or first < n_train:
                     self.opt_surfels.step(first, n_train, advance=False)
             elif self.warmup:
-                self.opt_surfels.step(0, n_train)
+                self.opt_surfels.step(0, n_train, advance=adv)
             elif getattr(self.deform, "_join_pending", False):
                 # the node-MLP backward is still running on the side stream: update the surfels, which do
                 # not depend on it, meanwhile; then join and update the deformation parameters
-                self.opt_surfels.step(0, self.n_surfel_params)
+                self.opt_surfels.step(0, self.n_surfel_params, advance=adv)
                 if late is not None:
                     self._statistics(*late)
                     accumulate()
@@ -728,7 +740,7 @@ class Trainer:
                 self.deform.join_backward()
                 self.opt_surfels.step(self.n_surfel_params, None, advance=False)
             else:
-                self.opt_surfels.step()
+                self.opt_surfels.step(advance=adv)
             if late is not None:   # (not reached with the current branches: statistics are never dropped)
                 self._statistics(*late)
                 accumulate()

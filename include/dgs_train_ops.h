@@ -178,6 +178,12 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
                         float* g_xyz, float* g_scaling_raw, float* g_rotation_raw, float* g_opacity_raw, float* g_feature,
                         float* g_nodes, float* g_radius_raw, float* g_weight_raw, float* g_attrs, int accumulate, void* scratch,
                         void* stream);
+/* accumulate bit 3 (value 8, coherent variant only) makes dgs_deform_backward leave its [M][13+H+2] table unreduced: g_nodes,
+ * g_radius_raw, g_weight_raw and g_attrs are then produced by this call (same accumulate bits 0 and 2), which the caller may
+ * launch on another stream -- the train step runs it in front of the node-MLP backward on that backward's side stream, so that
+ * the surfels' Adam update starts right behind the skinning backward. */
+int dgs_deform_reduce(int M, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes, float* g_radius_raw,
+                      float* g_weight_raw, float* g_attrs, int accumulate, void* scratch, void* stream);
 
 /* Photometric loss of the train step, (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM(img, gt)) (train_gui.py:292-296),
  * on the SSIM kernels, with the regularisers of dgs_regloss_*.  Reductions go through per-workgroup partial sums (no
