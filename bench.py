@@ -545,7 +545,9 @@ def main():
                         "on the dataset's target views" % (W, H, args.pre_iterations, tr.surfels.num_surfels, tr.P)),
                        "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "control_nodes": int(tr.deform.node_num),
                        "views_per_step": world, "parallelism": "dp%d (views sharded, one flat all-reduce)" % world,
-                       "launch": "whole-step HIP graph replay" if use_graph else "eager"},
+                       "launch": "whole-step HIP graph replay" if use_graph else "eager",
+                       "neighbour_search": "%s (spatial share of the K-th neighbour distance %.2f)"
+                                           % (tr.deform.knn_refine_mode, getattr(tr.deform, "knn_spatial_share", float("nan")))},
             "roofline": roof("bwd"), "roofline_fwd": roof("fwd"),
             "roofline_valu": {"bwd": roof_valu("bwd"), "fwd": roof_valu("fwd")},
             "roofline_kernels": {"preprocess_fwd": roof_kernel("preprocess_fwd", "pre"), "binning": roof_kernel("binning", "bin"),
