@@ -674,6 +674,7 @@ struct SurfelBwdArgs {
     float* dL_dmean3D;           // [P,3]
     float* dL_dtransMat;         // [P,9]
     float* dL_dsh;               // [P,M,3]
+    int sh_all_rows;             // 1: dL_dsh is written for EVERY row and coefficient (zeros where the reference leaves the caller's values)
     float* dL_dscale;            // [P,2]
     float* dL_drot;              // [P,4]
 };
@@ -776,7 +777,9 @@ __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs 
         for (int e = threadIdx.x; e < rows_here * row; e += kSurfelBlock) {
             const int r = (int)__umulhi((unsigned)e, a.row_inv);
             const int c = e - r * row;
-            if (c < touched && a.radii[base + r] > 0) dst[e] = s_sh[r * stride + c];
+            const bool live = c < touched && a.radii[base + r] > 0;
+            if (live) dst[e] = s_sh[r * stride + c];
+            else if (a.sh_all_rows) dst[e] = 0.f;   // option 8: the caller's buffer needs no fill (a gradient bucket that is stored, not added to)
         }
     }
 }

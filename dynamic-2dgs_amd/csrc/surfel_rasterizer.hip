@@ -199,6 +199,7 @@ struct dgs_context {
     std::atomic<int> sort_regs{2};    // per-tile sort: 2 LSD radix in LDS (default), 1 bitonic network in registers, 0 bitonic in LDS
     std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
     std::atomic<int> deterministic{0};   // key 7: backward blend without atomics, fixed summation order (tests)
+    std::atomic<int> sh_all_rows{0};     // key 8: dL_dsh written for every row (zeros for culled surfels / unused bands)
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
     std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
@@ -332,6 +333,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (key == 0) { c->tight_rects.store(value != 0); return DGS_OK; }
     if (key == 1 && value >= 0 && value <= 4) { c->tile_order.store(value); return DGS_OK; }
     if (key == 7) { c->deterministic.store(value != 0); return DGS_OK; }
+    if (key == 8) { c->sh_all_rows.store(value != 0); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
@@ -789,7 +791,7 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
     sa.rec = (const float4*)(geom_buffer + gl.rec);
     sa.acc = acc;
     sa.dL_dmean2D = dL_dmean2D; sa.dL_dnormal = dL_dnormal; sa.dL_dopacity = dL_dopacity; sa.dL_dcolor = dL_dcolor;
-    sa.dL_dmean3D = dL_dmean3D; sa.dL_dtransMat = dL_dtransMat; sa.dL_dsh = dL_dsh; sa.dL_dscale = dL_dscale; sa.dL_drot = dL_drot;
+    sa.dL_dmean3D = dL_dmean3D; sa.dL_dtransMat = dL_dtransMat; sa.dL_dsh = dL_dsh; sa.sh_all_rows = ctx->sh_all_rows.load(); sa.dL_dscale = dL_dscale; sa.dL_drot = dL_drot;
     size_t sh_lds = 0;
     if (sa.shs) {
         if (M * 3 > 48) return fail(DGS_ERR_INVALID_ARGUMENT, "backward: more than 16 SH coefficients per channel");

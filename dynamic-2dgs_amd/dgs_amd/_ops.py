@@ -547,12 +547,13 @@ class DeferredNodeMLP:
         return attrs
 
     @torch.no_grad()
-    def backward(self, g_attrs):
+    def backward(self, g_attrs, store=False):
+        """store=True: the parameter gradients are overwritten instead of added to (a buffer that is never cleared)."""
         packed, saved = self.state
         sink = [p.grad for p in self.params]
         if any(g is None or not g.is_contiguous() for g in sink):
             raise RuntimeError("DeferredNodeMLP.backward: every parameter needs a contiguous .grad")
-        _mlp_backward_raw(g_attrs, packed, saved, sink, True)
+        _mlp_backward_raw(g_attrs, packed, saved, sink, not store)
         self.state = None
 
 
@@ -566,7 +567,7 @@ class _FusedDeform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                g_attrs_out=None, coherent=False, reduce_later=None):
+                g_attrs_out=None, coherent=False, reduce_later=None, sink_store=False):
         lib = load()
         dev = xyz.device
         N, M = xyz.shape[0], nodes.shape[0]
@@ -591,6 +592,7 @@ class _FusedDeform(torch.autograd.Function):
         ctx.save_for_backward(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx)
         ctx.mask, ctx.H, ctx.sink, ctx.g_attrs_out, ctx.coherent = mask, H, sink, g_attrs_out, bool(coherent)
         ctx.reduce_later = reduce_later if (g_attrs_out is not None and sink is not None) else None
+        ctx.sink_store = bool(sink_store) and sink is not None and feature.shape[1] == H
         return means3D, scales, rots, opac
 
     @staticmethod
@@ -616,7 +618,7 @@ class _FusedDeform(torch.autograd.Function):
             scratch = torch.empty(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
         tens = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
         if ctx.sink is not None:
-            outs, ret, acc = ctx.sink, [None] * 8, 1
+            outs, ret, acc = ctx.sink, [None] * 8, (0 if ctx.sink_store else 1)
         else:
             outs = [torch.empty_like(t) for t in tens]
             if feature.shape[1] > H:
@@ -639,11 +641,13 @@ class _FusedDeform(torch.autograd.Function):
                     _check(lib, lib.dgs_deform_reduce(M, H, nr.data_ptr(), nw.data_ptr(), outs[5].data_ptr(), outs[6].data_ptr(), outs[7].data_ptr(),
                                                       g_attrs.data_ptr(), flags & 5, scratch.data_ptr(), _stream(dev)), "dgs_deform_reduce")
             ctx.reduce_later.append(reduce)
-        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None, None)
+        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None, None, None)
 
 
 def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False,
                  g_attrs_out=None, coherent=False, reduce_later=None):
+    # grad_sink: False, True (ADD into the .grad tensors) or "store" (OVERWRITE them: every element of the eight tensors is written by
+    # every backward, so a gradient buffer that only ever receives stores needs no clearing; needs feature.shape[1] == H)
     """Raw surfel parameters + node tables + node attributes -> (means3D, scales, rotations, opacity) for the rasterizer.
     grad_sink=True: gradients of the eight parameters are ADDED to their existing .grad tensors by the kernels.
     coherent=True: the surfels are stored in the order of their nearest node (Trainer.sort_surfels) -- the backward sums per
@@ -658,7 +662,7 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
         if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
             raise RuntimeError("fused_deform(grad_sink=True): every parameter needs a contiguous fp32 .grad")
     return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                              g_attrs_out, coherent, reduce_later)
+                              g_attrs_out, coherent, reduce_later, grad_sink == "store")
 
 
 _ONES = {}

@@ -10,6 +10,8 @@ step over RCCL/xGMI (backend "nccl"; "gloo" in the CPU tests) -- on the HIP path
 rest of the backward and the SH update.  The bucket tail carries the densification
 statistics (train_gui.py:411, gaussian_model.py:484-486) so replicas stay identical without a second sum.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -144,6 +146,7 @@ class Trainer:
         # the end of the backward.  Costs two more graph replays per step.
         self.split3 = False
         self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
+        self.store_grads = os.environ.get("DGS_STORE_GRADS", "1") != "0"   # fused path: gradients are stored, the bucket is never cleared (_store_ok)
         self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
         # Regime of the reference step (train_gui.py:282-285,292-293).  Defaults = its late regime (iteration > 8000), which is what
         # the benchmark times; fit() walks through the schedule with set_regime():
@@ -485,13 +488,20 @@ class Trainer:
         # BUILT) -- but the 57 MB of extra writes land in the SH update, the longer branch of the step's tail (84 -> 101 us);
         # (b) the fill on its own stream next to the neighbour search, joined before the backward -- a cross-stream dependency
         # inside a replayed graph costs 5-10 us of idle device at the fork AND at the join, more than the fill.
-        if not (getattr(self, "_bucket_clean", False) and self.opt_deform is None and self.opt_surfels.zero_grads):
-            self.bucket.zero()
-        self._bucket_clean = False
+        # (c, round 3, what runs now) NO fill: on the fully fused path every element of the bucket is STORED by the kernel that
+        # produces it in every step (dL/dSH with zeros for culled rows: rasterizer option 8; the skinning backward, its node-table
+        # reduction and the node MLP's weight gradients in overwrite mode; the statistics), so nothing needs clearing (_store_ok).
         t = d.expand_time(cam.fid)
         fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
+        assemble = fused and self.fuse_deform and d.can_assemble(s)
+        self._store_now = bool(assemble and torch.is_grad_enabled() and self._store_ok())
+        if hasattr(d, "grad_sink") and d.grad_sink:
+            d.grad_sink = "store" if self._store_now else True
+        if not self._store_now and not (getattr(self, "_bucket_clean", False) and self.opt_deform is None and self.opt_surfels.zero_grads):
+            self.bucket.zero()
+        self._bucket_clean = False
         asm = None
-        if fused and self.fuse_deform and d.can_assemble(s):
+        if assemble:
             asm = d.forward_assembled(s, t)
             pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
         else:
@@ -515,13 +525,34 @@ class Trainer:
             self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
         return loss, pkg, asm, fused
 
+    def _store_ok(self):
+        """May this step run without clearing the gradient bucket?  Only if EVERY parameter in it has a producer that overwrites
+        (see _forward): packed SH through the sink, the five per-surfel parameters and the three node tensors through the fused
+        skinning backward, the node MLP's weights through its deferred backward -- and nothing adds to a .grad through autograd
+        (the ARAP term does)."""
+        if not self.store_grads or self.opt_deform is not None or self._arap_active():
+            return False
+        key = (id(self.bucket), self.surfels.feature.shape[1])
+        if getattr(self, "_store_key", None) != key:
+            s, d = self.surfels, self.deform
+            ok = (getattr(s, "packed_sh", False) and self.sh_grad_sink and self.n_sh > 0 and getattr(d, "defer_mlp_backward", False)
+                  and bool(getattr(d, "grad_sink", False)) and s.feature.shape[1] == d.hyper_dim)
+            if ok:
+                from . import _ops
+                mlp = _ops.node_mlp_params(d.network) or []
+                covered = {id(p) for p in (s._features, s._xyz, s._scaling, s._rotation, s._opacity, s.feature, d.nodes, d._node_radius,
+                                           d._node_weight)} | {id(p) for p in mlp}
+                ok = bool(mlp) and all(id(p) in covered for p in self.bucket.params)
+            self._store_key, self._store_val = key, bool(ok)
+        return self._store_val
+
     def _run_backward(self, fn, fused):
         """fn() under the SH gradient sink when it applies (the rasterizer's backward then writes dL/dSH straight into the
         bucket view of the packed parameter)."""
         s = self.surfels
         if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink:
             import diff_surfel_rasterization as dsr
-            dsr.set_sh_grad_sink(s._features.grad)
+            dsr.set_sh_grad_sink(s._features.grad, all_rows=getattr(self, "_store_now", False))
             try:
                 return fn()
             finally:

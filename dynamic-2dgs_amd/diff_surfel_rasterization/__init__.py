@@ -66,7 +66,7 @@ _SINKS = {}                   # device index -> sink tensor
 _SINKS_LOCK = threading.Lock()
 
 
-def set_sh_grad_sink(tensor, device=None):
+def set_sh_grad_sink(tensor, device=None, all_rows=False):
     """Extension (not in the reference): while set to a contiguous fp32 [P,M,3] tensor, backward passes ON THE TENSOR'S DEVICE write
     dL/dSH of the visible surfels directly into it (the kernel stores, it does not accumulate; rows of culled surfels are left as
     they are) and return no gradient for `shs`.  For trainers that keep gradients in one pre-zeroed flat buffer.  None restores
@@ -76,10 +76,17 @@ def set_sh_grad_sink(tensor, device=None):
     with _SINKS_LOCK:
         if tensor is not None:
             _SINKS[tensor.device.index] = tensor
+            touched = [tensor.device.index]
         elif device is None:
+            touched = list(_SINKS)
             _SINKS.clear()
         else:
-            _SINKS.pop(torch.device(device).index, None)
+            touched = [torch.device(device).index]
+            _SINKS.pop(touched[0], None)
+    # all_rows (dgs_set_option key 8): the backward also stores ZEROS in the rows of culled surfels and the unused SH bands, i.e. every
+    # element of the sink is written by every backward and the buffer never needs clearing; off again when the sink is removed
+    for d in touched:
+        _C.set_option(8, 1 if (tensor is not None and all_rows) else 0, device=d)
 
 
 def _sink_for(dev):

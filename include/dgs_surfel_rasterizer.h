@@ -150,6 +150,9 @@ void dgs_set_tight_rects(int on);
  * key 7 = deterministic backward (0 [default] / 1): the backward blend stores its per-(list entry, wave) sums instead of adding them
  *         with float atomics and a per-surfel kernel adds them in a fixed order -- bit-identical gradients from run to run.  For
  *         tests: R x 320 bytes of scratch from hipMallocAsync (not capturable), a linear search per (surfel, tile).
+ * key 8 = dL_dsh of the backward written for EVERY row and coefficient (0 [default]: visible rows and the active bands only, as the
+ *         reference does, so callers may accumulate into it; 1: zeros elsewhere, for callers whose gradient buffer is stored, not
+ *         added to, and therefore never cleared).
  * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
  *         host read the library cannot know which of its per-tile sort kernels will find work and launches all three; with the
  *         promise it launches only those for lists up to `value` (2048: one launch instead of three, ~10 us of an 800x800
