@@ -508,6 +508,32 @@ def test_unit_gradient_loss_node_matches_two_pass_path(H, W):
     assert torch.equal(vals["unit"][1], vals["pair"][1])       # the SSIM backward is the same kernel on the same inputs
 
 
+def test_stored_gradients_equal_cleared_and_added_ones():
+    """Trainer.store_grads (no gradient-bucket fill: every producer overwrites) against the cleared bucket the producers add to:
+    after three steps from the same state the bucket holds the same gradients segment by segment -- a producer that still added
+    into the never-cleared buffer would show up as a multiple -- and the parameters agree like two runs of one configuration."""
+    import bench
+    dev = torch.device("cuda:0")
+    res = {}
+    for store in (True, False, False):
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=4, n_targets=2)
+        tr.store_grads = store
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        assert tr._store_now == store
+        res.setdefault(store, []).append((tr.bucket.flat.clone(), [p.detach().clone() for p in tr.bucket.params], [p.numel() for p in tr.bucket.params]))
+    (fa, pa, sizes), (fb, pb, _), (fc, pc, _) = res[True][0], res[False][0], res[False][1]
+    off = 0
+    for i, n in enumerate(sizes + [fa.numel() - sum(sizes)]):
+        a, b, c = fa[off:off + n], fb[off:off + n], fc[off:off + n]
+        off += n
+        noise = float((b - c).norm()) + 1e-12 * float(b.norm()) + 1e-30        # two cleared runs: float atomics + three Adam steps apart
+        assert float((a - b).norm()) <= 4.0 * noise + 1e-4 * float(b.norm()), (i, n, float((a - b).norm()), noise, float(b.norm()))
+    for a, b, c in zip(pa, pb, pc):
+        assert float((a - b).abs().max()) <= 4.0 * float((b - c).abs().max()) + 1e-6
+
+
 def test_fused_step_matches_unfused_step():
     """Trainer with every fused stage (assembled deformation, MFMA node MLP with gradient sinks, fused loss, fused
     statistics) against the same Trainer on the PyTorch formulations: loss trajectory and statistics."""
