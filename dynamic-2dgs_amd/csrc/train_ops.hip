@@ -760,45 +760,76 @@ int launch_knn_refine_q(int N, int M, int D, const float* x, const float* nodes,
 // not: the 8 hyper coordinates of surfels and nodes drift apart, the 11-D distance of the third neighbour exceeds the node spacing
 // several times, every block is touched, candidate lists overflow, and the kernel is slower than the plain scan (172 us at 125 k
 // surfels x 512 nodes against 36 us on the untrained scene).  This kernel filters with the FULL distance instead, dense and
-// data-independent:   score[j][i] = |n_j|^2 - 2 x_i . n_j   as  A[32 nodes x 12] x B[12 x 32 points]  on v_mfma_f32_32x32x2f32
-// (A row = [n_0 .. n_10, |n|^2] from LDS, B column = [-2 x_0 .. -2 x_10, 1] in registers; the k pairs are {kk, kk + 6} so that a
-// lane's six A values are contiguous).  A node is a candidate of point i when  score <= T_i - |x_i|^2 + eps,  T_i the exact
-// distance of the K-th seed neighbour, eps 4e-6 (|x|^2 + max |n|^2) -- six times the rounding of the 12-term fp32 dot product, so
-// no node with exact distance <= T_i is missed.  Candidates (K plus near ties, whatever the seed's age) are then evaluated exactly
-// and ranked like the plain scan (distance, then index).  Two lanes (l, l + 32) share a point and own alternating groups of 4
-// rows of every 32-node tile (the D layout of the instruction); their top-K lists are merged at the end.  Hits are sign bits:
-// the accumulator starts at -threshold, and each result's sign is shifted into a per-lane hit word (one VALU instruction per
-// node-point pair, no branch, no list in LDS).  A garbage seed (T = inf) sets every bit: that lane scans its rows itself.
+// data-independent:   score[j][i] = |n_j|^2 - 2 x_i . n_j  (= d^2 - |x_i|^2)  for 32 nodes x 32 points per matrix instruction.
+//   * f32-input MFMA runs at the vector rate on gfx950 (64 cycles per 32x32x2), bf16 MFMA sixteen times faster, so both operands
+//     are split  v = hi + lo  (two bf16, 16 mantissa bits) and  x.n ~ xh.nh + xh.nl + xl.nh : three v_mfma_f32_32x32x16_bf16 per
+//     tile (K = 16 slots: 11 coordinates, |n|^2 as hi + lo against 1, 3 spare) instead of six f32 ones at four times the cycles
+//     each.  What is dropped (xl.nl and the rounding of the lo parts) is below 1.2e-5 (|x|^2 + |n|^2); products are exact in the
+//     f32 accumulator.  This is only the FILTER: a node is a candidate of point i when  score <= T_i - |x_i|^2 + eps,  T_i the
+//     exact distance of the K-th seed neighbour, eps = 1e-4 (|x|^2 + max |n|^2), so no node within the seed's bound is missed.
+//   * the accumulator starts at -(threshold), a hit is a SIGN BIT, and the 16 results of a tile are shifted into a per-lane hit
+//     word with one v_alignbit_b32 each: no compare, no branch, no list in LDS.
+//   * the K plus few candidates are evaluated exactly (f32 differences, the same operation order as the plain scan) and ranked
+//     (distance, then index).  Two lanes (l, l + 32) share a point and own alternating groups of 4 rows of every 32-node tile (the
+//     D layout of the instruction); their top-K lists are merged at the end.  A garbage seed (T = inf) sets every bit: that lane
+//     scans its rows itself.
 #ifndef DGS_KNN_DIAG
-#define DGS_KNN_DIAG 0   // development only: 1 no candidate evaluation, 2 no MFMA loop
+#define DGS_KNN_DIAG 0   // development only: 1 no candidate evaluation, 2 no MFMA loop, 8 report the candidate count
 #endif
 constexpr int kRmThreads = 512;   // 8 waves x 32 points
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rne(float v)          // round to nearest even; inputs are finite
+{
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// v -> (hi, lo) bf16 bit patterns with hi + lo ~ v to 16 mantissa bits
+__device__ __forceinline__ void bf16_split(float v, unsigned& hi, unsigned& lo)
+{
+    hi = bf16_rne(v);
+    lo = bf16_rne(v - __uint_as_float(hi << 16));
+}
 
 // TP: pairs of 32-node tiles (one 32-bit hit word per pair and lane), Mp <= 64 TP
 template <int K, int TP>
 __global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int M, int D, const float* __restrict__ x, const float* __restrict__ nodes,
                                                                      long long* __restrict__ idx, const float* __restrict__ x2, int D1, int stride2)
 {
-    extern __shared__ float s_n[];                                      // [Mp][12]: n_0 .. n_10 (zero padded), |n|^2
+    extern __shared__ float s_n[];                                      // [Mp][12] f32: n_0 .. n_10 (zero padded), |n|^2
     const int Mp = (M + 31) & ~31, ntiles = Mp >> 5;
+    uint4* s_hi = reinterpret_cast<uint4*>(s_n + (size_t)Mp * 12);      // [Mp][2] x 8 bf16: hi parts of n_0 .. n_10, |n|^2 hi, |n|^2 lo, 0 0 0
+    uint4* s_lo = s_hi + (size_t)Mp * 2;                                // [Mp][2] x 8 bf16: lo parts of n_0 .. n_10, 0 ...
     __shared__ float s_max[kRmThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    for (int e = tid; e < Mp * 12; e += kRmThreads) s_n[e] = 0.f;
-    __syncthreads();
-    {
-        const int F = M * D;
-        for (int base = 0; base < F; base += 8 * kRmThreads) {           // 8 loads in flight per thread
-            float q[8];
+    float n2max = 0.f;
+    for (int j = tid; j < Mp; j += kRmThreads) {                         // one node per thread: its row's loads are all in flight at once
+        float v[11];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const int e = base + i * kRmThreads + tid; q[i] = e < F ? nodes[e] : 0.f; }
+        for (int c = 0; c < 11; c++) v[c] = (j < M && c < D) ? nodes[(size_t)j * D + c] : 0.f;
+        float n2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int e = base + i * kRmThreads + tid;
-                if (e < F) { const int r = e / D; s_n[r * 12 + (e - r * D)] = q[i]; }
-            }
-        }
+        for (int c = 0; c < 11; c++) n2 += v[c] * v[c];
+        if (j < M) n2max = fmaxf(n2max, n2); else n2 = 3.0e38f;          // padded rows never qualify
+        float4* row = reinterpret_cast<float4*>(s_n + (size_t)j * 12);
+        row[0] = make_float4(v[0], v[1], v[2], v[3]); row[1] = make_float4(v[4], v[5], v[6], v[7]); row[2] = make_float4(v[8], v[9], v[10], n2);
+        unsigned h[13], l[13];
+#pragma unroll
+        for (int c = 0; c < 11; c++) bf16_split(v[c], h[c], l[c]);
+        bf16_split(n2, h[11], h[12]);
+        s_hi[2 * j] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        s_hi[2 * j + 1] = make_uint4(h[8] | (h[9] << 16), h[10] | (h[11] << 16), h[12], 0u);
+        s_lo[2 * j] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+        s_lo[2 * j + 1] = make_uint4(l[8] | (l[9] << 16), l[10], 0u, 0u);
     }
+    for (int d = 32; d >= 1; d >>= 1) n2max = fmaxf(n2max, __shfl_xor(n2max, d, 64));
+    if (lane == 0) s_max[tid >> 6] = n2max;
+    __syncthreads();
+    n2max = s_max[0];
+#pragma unroll
+    for (int w = 1; w < kRmThreads / 64; w++) n2max = fmaxf(n2max, s_max[w]);
+
     // a wave takes groups of 32 points; the host sizes the grid so that every wave gets the same number of groups and all
     // workgroups are resident at once (782 workgroups on 768 slots ran as two rounds: twice the time)
     const int ngroups = (N + 31) >> 5, nwaves = gridDim.x * (kRmThreads / 64);
@@ -824,22 +855,6 @@ __global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int 
     for (int k = 1; k < K; k++)
 #pragma unroll
         for (int k2 = 0; k2 < k; k2++) ok = ok && sj[k] != sj[k2];
-    __syncthreads();
-    float n2max = 0.f;
-    for (int j = tid; j < Mp; j += kRmThreads) {
-        float a = 0.f;
-#pragma unroll
-        for (int c = 0; c < 11; c++) a += s_n[j * 12 + c] * s_n[j * 12 + c];
-        s_n[j * 12 + 11] = j < M ? a : 3.0e38f;                          // padded rows never qualify
-        if (j < M) n2max = fmaxf(n2max, a);
-    }
-    for (int d = 32; d >= 1; d >>= 1) n2max = fmaxf(n2max, __shfl_xor(n2max, d, 64));
-    if (lane == 0) s_max[tid >> 6] = n2max;
-    __syncthreads();
-    n2max = s_max[0];
-#pragma unroll
-    for (int w = 1; w < kRmThreads / 64; w++) n2max = fmaxf(n2max, s_max[w]);
-
     auto full_dist = [&](int j) {
         const float4 n0 = *reinterpret_cast<const float4*>(s_n + j * 12), n1 = *reinterpret_cast<const float4*>(s_n + j * 12 + 4),
                      n2 = *reinterpret_cast<const float4*>(s_n + j * 12 + 8);
@@ -859,15 +874,26 @@ __global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int 
 #pragma unroll
     for (int d = 0; d < 11; d++) xx += xv[d] * xv[d];
     // hit <=> score - thr < 0.  The subtraction rides in the accumulator: the first MFMA of a tile starts from C = -thr
-    const float nthr = in ? -(T * (1.0f + 1e-6f) - xx + (4e-6f * (xx + n2max) + 1e-30f)) : INFINITY;
+    const float nthr = in ? -(T * (1.0f + 1e-6f) - xx + (1e-4f * (xx + n2max) + 1e-30f)) : INFINITY;
     f32x16 cthr;
 #pragma unroll
     for (int v = 0; v < 16; v++) cthr[v] = nthr;
-    float b[6];
+    // B operands of this lane's half of the K slots: slots 0..7 = coordinates 0..7 | slots 8..15 = coordinates 8..10, 1, 1, 0, 0, 0
+    bf16x8 bh, bl;
+    {
+        unsigned h[8], l[8];
 #pragma unroll
-    for (int kk = 0; kk < 6; kk++) b[kk] = half ? (kk == 5 ? 1.0f : -2.0f * xv[6 + kk]) : -2.0f * xv[kk];   // (no dynamic register index)
+        for (int e = 0; e < 8; e++) {
+            const float v = half ? (e < 3 ? -2.0f * xv[8 + (e < 3 ? e : 0)] : 0.f) : -2.0f * xv[e];      // (no dynamic register index)
+            bf16_split(v, h[e], l[e]);
+        }
+        if (half) { h[3] = 0x3f80u; h[4] = 0x3f80u; }                     // 1.0 against |n|^2 hi and lo
+        bh = __builtin_bit_cast(bf16x8, make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)));
+        bl = __builtin_bit_cast(bf16x8, make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
+    }
     unsigned hits[TP];
-    const float* arow = s_n + (lane & 31) * 12 + 6 * half;
+    const uint4* ahi = s_hi + 2 * (lane & 31) + half;
+    const uint4* alo = s_lo + 2 * (lane & 31) + half;
 #pragma unroll
     for (int w = 0; w < TP; w++) {
         unsigned word = 0u;
@@ -875,15 +901,10 @@ __global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int 
         for (int u = 0; u < 2; u++) {
             const int t = 2 * w + u;
             if (t < ntiles && !(DGS_KNN_DIAG & 2)) {                     // wave-uniform
-                const float* ar = arow + t * (32 * 12);
-                const float2 a01 = *reinterpret_cast<const float2*>(ar), a23 = *reinterpret_cast<const float2*>(ar + 2),
-                             a45 = *reinterpret_cast<const float2*>(ar + 4);
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.x, b[0], cthr, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01.y, b[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.x, b[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23.y, b[3], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.x, b[4], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a45.y, b[5], acc, 0, 0, 0);
+                const bf16x8 nh = __builtin_bit_cast(bf16x8, ahi[t * 64]), nl = __builtin_bit_cast(bf16x8, alo[t * 64]);
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nh, bh, cthr, 0, 0, 0);     // nh.xh + |n|^2 - thr
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nl, bh, acc, 0, 0, 0);             // nl.xh   (|n|^2 slots of nl are 0)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nh, bl, acc, 0, 0, 0);             // nh.xl   (those slots of xl are 0)
                 // the sign bits of the 16 results are shifted into the hit word, first result ends highest (v_alignbit_b32)
 #pragma unroll
                 for (int v = 0; v < 16; v++) word = __builtin_amdgcn_alignbit(word, __float_as_uint(acc[v]), 31);
@@ -893,7 +914,7 @@ __global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int 
         }
         hits[w] = word;
     }
-    // ---- exact evaluation of the candidates in ascending index (ties keep the lower index like the plain scan)
+    // ---- exact evaluation of the candidates (ties keep the lower index like the plain scan)
     // D[i][j] of the instruction: lane = j + 32 ((i / 4) % 2), register v = 4 (i / 8) + i % 4  =>  row i = 8 (v / 4) + 4 half + v % 4;
     // bit 31 - (16 u + v) of word w is row i of tile 2 w + u
     float bd[K];
@@ -912,26 +933,29 @@ __global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int 
             }
         }
     };
-#pragma unroll
-    for (int w = 0; w < TP; w++) {
-        unsigned word = hits[w];
 #if DGS_KNN_DIAG & 1
-        bi[w % K] ^= (int)word; word = 0u;      // (keeps the hit words alive)
-#endif
-        while (word) {
-            const int q = __builtin_clz(word);          // 16 u + v
-            word &= ~(0x80000000u >> q);
-            const int v = q & 15;
-            const int j = ((2 * w + (q >> 4)) << 5) + 8 * (v >> 2) + 4 * half + (v & 3);
-#if DGS_KNN_DIAG & 16
-            if (j < M) offer((float)j * xv[0], j);
-#elif DGS_KNN_DIAG & 32
-            if (j < M) bd[0] = fminf(bd[0], full_dist(j));
+#pragma unroll
+    for (int w = 0; w < TP; w++) bi[w % K] ^= (int)hits[w];      // (keeps the hit words alive)
 #else
+    // every trip each lane takes ITS next candidate, whichever word it is in: the number of trips is the largest candidate count of a
+    // lane (5-6), not the sum over the words of the largest count per word (14 with 1.6 candidates per lane spread over 8 words)
+    for (;;) {
+        unsigned w = 0u;
+        int wi = 0;
+#pragma unroll
+        for (int k = TP - 1; k >= 0; k--) { const bool nz = hits[k] != 0u; w = nz ? hits[k] : w; wi = nz ? k : wi; }
+        if (__ballot(w != 0u) == 0ull) break;
+        if (w != 0u) {
+            const int q = __builtin_clz(w);                  // 16 u + v
+            const unsigned bit = 0x80000000u >> q;
+#pragma unroll
+            for (int k = 0; k < TP; k++) hits[k] &= k == wi ? ~bit : ~0u;
+            const int v = q & 15;
+            const int j = ((2 * wi + (q >> 4)) << 5) + 8 * (v >> 2) + 4 * half + (v & 3);
             if (j < M) offer(full_dist(j), j);
-#endif
         }
     }
+#endif
     // merge with the partner lane's list
     float od[K];
     int oi[K];
@@ -943,15 +967,6 @@ __global__ void __launch_bounds__(kRmThreads) knn_refine_mfma_kernel(int N, int 
 #pragma unroll
         for (int k = 0; k < K; k++) idx[(size_t)p * K + k] = bi[k];
     }
-#if DGS_KNN_DIAG & 8
-    {
-        int pc = 0;
-#pragma unroll
-        for (int w = 0; w < TP; w++) pc += __builtin_popcount(hits[w]);
-        pc += __shfl_xor(pc, 32, 64);
-        if (in && half == 0) idx[(size_t)p * K] = pc;
-    }
-#endif
     }   // groups
 }
 
@@ -959,10 +974,10 @@ template <int K, int TP>
 int launch_knn_refine_mfma_tp(int N, int M, int D, const float* x, const float* nodes, long long* idx, hipStream_t s, const float* x2, int D1, int stride2)
 {
     const int Mp = (M + 31) & ~31;
-    const size_t lds = (size_t)Mp * 12 * sizeof(float);
+    const size_t lds = (size_t)Mp * (12 * sizeof(float) + 4 * sizeof(uint4));
     static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
                                 return n > 0 ? n : 256; }();
-    const int wpb = kRmThreads / 64, ngroups = (N + 31) / 32, slots = cus * 2 * wpb;     // 2 workgroups per CU are resident (91 VGPRs: 5 waves per SIMD)
+    const int wpb = kRmThreads / 64, ngroups = (N + 31) / 32, slots = cus * 2 * wpb;     // 2 workgroups per CU are resident
     const int iters = (ngroups + slots - 1) / slots, waves = (ngroups + iters - 1) / iters;
     hipLaunchKernelGGL((knn_refine_mfma_kernel<K, TP>), dim3((waves + wpb - 1) / wpb), dim3(kRmThreads), lds, s, N, M, D, x, nodes, idx, x2, D1,
                        stride2);

@@ -248,11 +248,12 @@ int dgs_densify_accumulate_guarded(int P, const float* grad_norm, const float* v
 int dgs_knn_refine(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
                    long long* idx, void* stream);
 /* dgs_knn_refine with the filter chosen by the caller.  mode 0: the 3-D culling above.  mode 1 (D1 + D2 <= 11, M <= 1024): every
- * (node, point) score |n|^2 - 2 x.n on v_mfma_f32_32x32x2_f32 against the seed's bound in the FULL D1 + D2 dimensions -- dense,
- * independent of the data; for scenes whose extra coordinates (x2: the hyper features) have drifted so far from the nodes' that
- * the K-th neighbour distance is no longer a spatial radius and the 3-D culling stops culling (trained scenes: 172 us -> 44 us at
- * 125 k points x 512 nodes; on an untrained, spatially sorted scene mode 0 is the faster one, 36 against 55 us at 200 k).  Same
- * exact result either way. */
+ * (node, point) score |n|^2 - 2 x.n on the matrix cores (operands split into two bf16 each, three v_mfma_f32_32x32x16_bf16 per
+ * 32 x 32 tile; a conservative filter, candidates are then evaluated exactly in f32) against the seed's bound in the FULL D1 + D2
+ * dimensions -- dense, independent of the data; for scenes whose extra coordinates (x2: the hyper features) have drifted so far
+ * from the nodes' that the K-th neighbour distance is no longer a spatial radius and the 3-D culling stops culling (trained scenes:
+ * 172 us -> 19 us at 125 k points x 512 nodes; its cost grows with M, so on an untrained, spatially sorted scene with 1024 nodes
+ * mode 0 is the faster one, 43 against 71 us at 200 k).  Same exact result either way. */
 int dgs_knn_refine_mode(int N, int M, int D1, int D2, int K, const float* x1, const float* x2, int x2_stride, const float* nodes,
                         long long* idx, int mode, void* stream);
 
