@@ -51,9 +51,14 @@ def depth_to_normal(cam, depth):
 
 
 def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=False, rasterizer_cls=None, postprocess=True,
-           assembled=None):
+           assembled=None, d_opacity=None, d_color=None, random_bg_color=False):
     """pc: dgs_amd.model.SurfelModel.  d_*: outputs of the deformation (or 0.0).  assembled: (means3D, scales, rotations,
-    opacity) already computed by ControlNodes.forward_assembled (then d_* are ignored)."""
+    opacity) already computed by ControlNodes.forward_assembled (then d_xyz / d_rotation / d_scaling / d_opacity are ignored).
+    d_opacity [P,1], d_color [P,3] (None in the reference's default configuration: pred_opacity / pred_color are off) and
+    random_bg_color follow gaussian_renderer/__init__.py:41,58,82-85,114: opacity + d_opacity, d_color added to the DC coefficient,
+    a fresh uniform background that the returned dict reports as 'bg_color' (the trainer composites its target over it)."""
+    if random_bg_color:
+        bg_color = torch.rand_like(bg_color)
     xyz = pc.get_xyz
     # leaf that only receives dL/dmeans2D (its values are never read): one persistent tensor per model instead of a
     # zero-filled [P,3] allocation per render
@@ -77,9 +82,12 @@ def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=Fa
         means3D = xyz + d_xyz
         scales = pc.get_scaling + d_scaling
         rotations = pc.get_rotation_bias(d_rotation)
-        opacity = pc.get_opacity
+        opacity = pc.get_opacity if d_opacity is None else pc.get_opacity + d_opacity
+    shs = pc.get_features
+    if d_color is not None and not isinstance(d_color, float):
+        shs = torch.cat([shs[:, :1] + d_color[:, None], shs[:, 1:]], dim=1)
     rendered_image, radii, allmap = rasterizer(
-        means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
+        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=None)
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "radii": radii, "allmap": allmap}
     if not postprocess:  # the fused loss / statistics kernels work on the rasterizer outputs directly (radii > 0 is the filter)

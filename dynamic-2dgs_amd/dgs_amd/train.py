@@ -15,6 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import trace
 from .losses import training_loss, training_loss_from_allmap
 from .render import camera_rays, render
 
@@ -502,8 +503,10 @@ class Trainer:
         self._bucket_clean = False
         asm = None
         if assemble:
-            asm = d.forward_assembled(s, t)
-            pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
+            with trace.stage("dgs.deform"):
+                asm = d.forward_assembled(s, t)
+            with trace.stage("dgs.rasterize"):
+                pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
         else:
             dv = d(s.get_xyz.detach(), t, s.feature, s.motion_mask)
             if self.warmup:
@@ -513,7 +516,8 @@ class Trainer:
         lam = dict(lambda_normal=self.lambda_normal, lambda_dist=self.lambda_dist)
         # unit_grad: every backward of this trainer starts from dL/dloss = 1 (self._unit; the ARAP term is added, not multiplied), so
         # the loss node produces its gradient images in the forward (regularisers: value and gradient in one kernel)
-        loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, unit_grad=True, **lam) if fused else training_loss(pkg, gt, **lam)
+        with trace.stage("dgs.loss"):
+            loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, unit_grad=True, **lam) if fused else training_loss(pkg, gt, **lam)
         if self.arap:
             from . import arap
             lam = arap.lambda_arap(self.iteration)       # train_gui.py:315-316, utils/time_utils.py:1228-1232
@@ -598,7 +602,8 @@ class Trainer:
                 self.opt_surfels.guard()
             self._guard_early = True
         # explicit unit gradient: loss.backward() alone launches a fill for it every step
-        self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
+        with trace.stage("dgs.backward"):
+            self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
         if hasattr(d, "finish_backward") and not self.warmup:   # (warm-up: nothing behind the deformation's outputs trains)
             d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
         elif hasattr(d, "run_pending_reduce"):
@@ -1082,9 +1087,12 @@ class Trainer:
             return self._sloss
         cam, gt = self.cameras[v], self.targets[v % len(self.targets)]
         if self._split_ok():
-            return self._split_step(cam, gt)
-        loss = self._fwd_bwd(cam, gt)
-        self._finish()
+            with trace.stage("dgs.step(split)"):
+                return self._split_step(cam, gt)
+        with trace.stage("dgs.forward+backward"):
+            loss = self._fwd_bwd(cam, gt)
+        with trace.stage("dgs.update"):
+            self._finish()
         return loss
 
     def _split_step(self, cam, gt):

@@ -39,6 +39,14 @@ def inputs():
     return pc, cam, torch.zeros(3), d_xyz, d_rot, d_scale
 
 
+def extra_inputs():
+    """d_opacity [P,1] and d_color [P,3] (the reference's pred_opacity / pred_color outputs; None in its default configuration)."""
+    i = torch.arange(CASE["P"], dtype=torch.float64)
+    d_opacity = (0.1 * torch.sin(0.37 * i))[:, None].float()
+    d_color = torch.stack([0.3 * torch.cos(0.21 * i + k) for k in range(3)], 1).float()
+    return d_opacity, d_color
+
+
 def import_reference_render():
     import diff_surfel_rasterization as product   # settings tuple of the product package (no native code needed for it)
     import oracle_raster_op
@@ -79,6 +87,13 @@ def main():
     assert (arrays["radii"] > 0).sum() > 100
     np.savez_compressed(os.path.join(HERE, "render_golden.npz"), **arrays)
     print({k: v.shape for k, v in arrays.items()}, "visible", int((arrays["radii"] > 0).sum()))
+    # second vector: the optional per-Gaussian opacity / colour offsets (gaussian_renderer/__init__.py:85,114)
+    d_opacity, d_color = extra_inputs()
+    with torch.no_grad():
+        out2 = ref.render(cam, pc, pipe, bg, d_xyz, d_rot, d_scale, d_opacity=d_opacity, d_color=d_color)
+    arrays2 = {k: out2[k].detach().numpy() for k in keys}
+    assert np.abs(arrays2["render"] - arrays["render"]).max() > 1e-2
+    np.savez_compressed(os.path.join(HERE, "render_golden_offsets.npz"), **arrays2)
 
 
 if __name__ == "__main__":

@@ -33,6 +33,25 @@ def test_render_dict_matches_reference_render():
         assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (k, float(np.abs(got - want).max()))
 
 
+def test_render_with_opacity_and_colour_offsets_matches_reference_render():
+    """d_opacity / d_color (off in the reference's default configuration) through dgs_amd.render.render against the imported
+    reference's render() with the same arguments."""
+    from make_render_golden import extra_inputs
+    G2 = np.load(os.path.join(HERE, "golden", "render_golden_offsets.npz"))
+    pc, cam, bg, d_xyz, d_rot, d_scale = inputs()
+    d_opacity, d_color = extra_inputs()
+    with torch.no_grad():
+        out = render(cam, pc, bg, d_xyz, d_rot, d_scale, rasterizer_cls=OracleRasterizer, d_opacity=d_opacity, d_color=d_color)
+    assert np.array_equal(out["radii"].numpy(), G2["radii"])
+    for k in ("render", "alpha", "rend_normal", "rend_dist", "depth"):
+        got, want = out[k].numpy(), G2[k]
+        assert np.abs(got - want).max() <= 4e-6 * max(1.0, np.abs(want).max()), (k, float(np.abs(got - want).max()))
+    torch.manual_seed(3)
+    with torch.no_grad():
+        a = render(cam, pc, bg, d_xyz, d_rot, d_scale, rasterizer_cls=OracleRasterizer, random_bg_color=True)
+    assert not torch.equal(a["bg_color"], bg) and a["bg_color"].shape == bg.shape          # a fresh background, reported to the caller
+
+
 import pytest  # noqa: E402
 
 

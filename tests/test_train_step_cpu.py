@@ -196,3 +196,21 @@ def test_trainer_lr_schedule_sets_the_reference_rates():
         assert abs(ld - expon_lr(k, 0.00016 * 5, 0.0000016, 40000)) <= 1e-12
         assert ln == 0.00016 * 5
     assert seen[0][0] == 0.00016 * 5 and seen[2][0] < seen[1][0] < seen[0][0]
+
+
+def test_trace_stages_are_noops_unless_enabled(monkeypatch):
+    """dgs_amd.trace: roctx ranges around the step's stages only with DGS_ROCTX=1; without it (and without the library) the context
+    manager does nothing and costs nothing."""
+    import importlib
+    from dgs_amd import trace
+    assert not trace.enabled()
+    with trace.stage("x"):
+        pass
+    monkeypatch.setenv("DGS_ROCTX", "1")
+    t2 = importlib.reload(trace)
+    try:
+        with t2.stage("dgs.test"):      # pushes / pops a range if libroctx64.so loads here, stays a no-op otherwise
+            pass
+    finally:
+        monkeypatch.delenv("DGS_ROCTX")
+        importlib.reload(trace)
