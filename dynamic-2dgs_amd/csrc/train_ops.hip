@@ -48,7 +48,32 @@ typedef const float __attribute__((address_space(1)))* GlobalF;   // global_load
 
 // loss = (1 - lambda) * sum(l1 partials) / n + lambda * (1 - sum(ssim partials) / n) + sum(regulariser partials)
 // photo = [ssim partial per workgroup (nphoto) | l1 partial per workgroup (nphoto)], reg = [nreg]; one 256-thread workgroup
-struct CombineArgs { const float* photo; int nphoto; const float* reg; int nreg; float inv_n; float lambda_dssim; float* out; };
+// Guard of a training step (dgs_step_guard; one thread).  status: [0] skip flag of this step, [1] number of skipped steps so far,
+// [2] guarded steps so far.  skip[0] != 0 means "this step must not change anything" (see step_guard_kernel below).
+__device__ __forceinline__ void step_guard_body(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, float loss)
+{
+    const bool sk = skip && skip[0] != 0;
+    if (!sk) step_count[0] += 1.0f;
+    const float n_skipped = status[1] + (sk ? 1.0f : 0.0f);
+    const float n_steps = status[2] + 1.0f;
+    status[0] = sk ? 1.0f : 0.0f;
+    status[1] = n_skipped;
+    status[2] = n_steps;
+    if (host_ring) {   // pinned host memory: (step index, skip flag, skipped so far, loss) of the last ring_len steps
+        float* e = host_ring + 4 * ((long long)n_steps % ring_len);
+        e[1] = sk ? 1.0f : 0.0f;
+        e[2] = n_skipped;
+        e[3] = loss;   // the step's loss: the host can read a history without a copy kernel per step
+        __threadfence_system();
+        e[0] = n_steps;   // written last: a reader that sees the index sees the payload
+    }
+}
+
+struct CombineArgs {
+    const float* photo; int nphoto; const float* reg; int nreg; float inv_n; float lambda_dssim; float* out;
+    // optional second rider: the step guard, run by the same thread right behind the loss it reports (g_step_count != nullptr)
+    const int* g_skip; float* g_step_count; float* g_status; float* g_ring; int g_ring_len;
+};
 
 __device__ __forceinline__ void combine_partials(const CombineArgs& c, float (&s_red)[3][4])
 {
@@ -74,7 +99,9 @@ __device__ __forceinline__ void combine_partials(const CombineArgs& c, float (&s
         a = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
         b = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
         r = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
-        c.out[0] = (1.0f - c.lambda_dssim) * b * c.inv_n + c.lambda_dssim * (1.0f - a * c.inv_n) + r;
+        const float loss = (1.0f - c.lambda_dssim) * b * c.inv_n + c.lambda_dssim * (1.0f - a * c.inv_n) + r;
+        c.out[0] = loss;
+        if (c.g_step_count) step_guard_body(c.g_skip, c.g_step_count, c.g_status, c.g_ring, c.g_ring_len, loss);
     }
 }
 
@@ -1789,22 +1816,7 @@ struct AdamSegs {
 __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restrict__ step_count, float* __restrict__ status,
                                   float* __restrict__ host_ring, int ring_len, const float* __restrict__ loss)
 {
-    // one thread.  status: [0] skip flag of this step, [1] number of skipped steps so far, [2] guarded steps so far
-    const bool sk = skip && skip[0] != 0;
-    if (!sk) step_count[0] += 1.0f;
-    const float n_skipped = status[1] + (sk ? 1.0f : 0.0f);
-    const float n_steps = status[2] + 1.0f;
-    status[0] = sk ? 1.0f : 0.0f;
-    status[1] = n_skipped;
-    status[2] = n_steps;
-    if (host_ring) {   // pinned host memory: (step index, skip flag, skipped so far, 0) of the last ring_len steps
-        float* e = host_ring + 4 * ((long long)n_steps % ring_len);
-        e[1] = sk ? 1.0f : 0.0f;
-        e[2] = n_skipped;
-        e[3] = loss ? loss[0] : 0.0f;   // the step's loss: the host can read a history without a copy kernel per step
-        __threadfence_system();
-        e[0] = n_steps;   // written last: a reader that sees the index sees the payload
-    }
+    step_guard_body(skip, step_count, status, host_ring, ring_len, loss ? loss[0] : 0.0f);   // one thread
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, float* __restrict__ grad,
@@ -2342,23 +2354,36 @@ int dgs_regloss_fused(int H, int W, const float* allmap, const float* rays_d, co
     return 0;
 }
 
-int dgs_photo_backward_combine(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
-                               const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
-                               const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, float* loss_out,
-                               void* stream)
+int dgs_photo_backward_combine_guard(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                                     const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg,
+                                     const float* const* gt_slot, const float* photo_partials, long long nphoto, const float* reg_partials,
+                                     long long nreg, float* loss_out, const int* guard_skip, float* guard_step_count, float* guard_status,
+                                     float* guard_ring, int guard_ring_len, void* stream)
 {
+    if (guard_step_count && (!loss_out || !guard_status || (guard_ring && guard_ring_len <= 0)))
+        return fail(-1, "dgs_photo_backward_combine_guard: the guard needs loss_out, status and a ring length");
     if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !g_loss || !dL_dimg)
         return fail(-1, "dgs_photo_backward: bad argument");
     if (loss_out && (!photo_partials || !reg_partials || nphoto < 0 || nreg < 0)) return fail(-1, "dgs_photo_backward_combine: bad argument");
     static const Gauss g = make_gauss();
     dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-    CombineArgs c{photo_partials, (int)nphoto, reg_partials, (int)nreg, inv_n, lambda_dssim, loss_out};
+    CombineArgs c{photo_partials, (int)nphoto, reg_partials, (int)nreg, inv_n, lambda_dssim, loss_out,
+                  guard_skip, guard_step_count, guard_status, guard_ring, guard_ring_len};
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, -lambda_dssim * inv_n,
                        (1.0f - lambda_dssim) * inv_n, img, gt, g, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, g_loss, dL_dimg, gt_slot, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_bwd_kernel: ") + hipGetErrorString(e));
     return 0;
+}
+
+int dgs_photo_backward_combine(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                               const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
+                               const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, float* loss_out,
+                               void* stream)
+{
+    return dgs_photo_backward_combine_guard(C, H, W, img, gt, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, lambda_dssim, g_loss, dL_dimg, gt_slot,
+                                            photo_partials, nphoto, reg_partials, nreg, loss_out, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
@@ -2373,7 +2398,7 @@ int dgs_loss_combine(const float* photo_partials, long long nphoto, const float*
                      float lambda_dssim, float* out, void* stream)
 {
     if (!photo_partials || !reg_partials || !out || n <= 0 || nphoto < 0 || nreg < 0) return fail(-1, "dgs_loss_combine: bad argument");
-    CombineArgs c{photo_partials, (int)nphoto, reg_partials, (int)nreg, 1.0f / (float)n, lambda_dssim, out};
+    CombineArgs c{photo_partials, (int)nphoto, reg_partials, (int)nreg, 1.0f / (float)n, lambda_dssim, out, nullptr, nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c);
     return hipGetLastError() == hipSuccess ? 0 : fail(-4, "loss_combine_kernel: launch failed");
 }

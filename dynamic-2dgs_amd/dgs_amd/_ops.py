@@ -17,7 +17,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
-            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce")
+            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard")
 
 
 def _deps():
@@ -123,6 +123,9 @@ def load():
         lib.dgs_step_guard.argtypes = [vp, vp, vp, vp, ci, vp, vp]
         lib.dgs_photo_backward_combine.restype = ci
         lib.dgs_photo_backward_combine.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_longlong, vp, ctypes.c_longlong, vp, vp]
+        lib.dgs_photo_backward_combine_guard.restype = ci
+        lib.dgs_photo_backward_combine_guard.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_longlong, vp,
+                                                         ctypes.c_longlong, vp, vp, vp, vp, vp, ci, vp]
         lib.dgs_regloss_fused_blocks.restype = ctypes.c_size_t
         lib.dgs_regloss_fused_blocks.argtypes = [ci, ci]
         lib.dgs_regloss_fused.restype = ci
@@ -345,6 +348,12 @@ class FlatAdam:
             _check(lib, lib.dgs_step_guard(skip, self.t.data_ptr(), self.status.data_ptr(), None if ring is None else ring.data_ptr(),
                                            0 if ring is None else ring.shape[0], None if self.loss is None else self.loss.data_ptr(),
                                            _stream(dev)), "dgs_step_guard")
+
+    def guard_pointers(self):
+        """(skip, step count, status, ring, ring length) for a kernel that runs the guard itself (dgs_photo_backward_combine_guard)."""
+        ring = self.host_ring
+        return (None if self.skip is None else self.skip.data_ptr(), self.t.data_ptr(), self.status.data_ptr(),
+                None if ring is None else ring.data_ptr(), 0 if ring is None else ring.shape[0])
 
     @torch.no_grad()
     def step(self, first=0, last=None, advance=True):
@@ -681,7 +690,7 @@ class _FusedTrainLoss(torch.autograd.Function):
     backward (see fused_train_loss)."""
 
     @staticmethod
-    def forward(ctx, image, allmap, gt, rays_d, rays_o, wvt, lam_dssim, lam_n, lam_d, slots=None, unit_grad=False):
+    def forward(ctx, image, allmap, gt, rays_d, rays_o, wvt, lam_dssim, lam_n, lam_d, slots=None, unit_grad=False, guard=None):
         """slots: None, or an int64 device tensor [2] holding the pointers of the target image and the ray table to use
         (read by the kernels at run time: a captured graph switches views by rewriting them)."""
         lib = load()
@@ -708,10 +717,12 @@ class _FusedTrainLoss(torch.autograd.Function):
             if unit:
                 _check(lib, lib.dgs_regloss_fused(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), lam_n, lam_d,
                                                   part.data_ptr() + 8 * nb, g_allmap.data_ptr(), rslot, st), "dgs_regloss_fused")
-                _check(lib, lib.dgs_photo_backward_combine(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
-                                                           maps[2].data_ptr(), lam_dssim, _one(dev).data_ptr(), g_image.data_ptr(), gslot,
-                                                           part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, loss.data_ptr(), st),
-                       "dgs_photo_backward_combine")     # its last workgroup sums the partials into the loss
+                gp = (None, None, None, None, 0) if guard is None else guard.guard_pointers()
+                _check(lib, lib.dgs_photo_backward_combine_guard(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
+                                                                 maps[2].data_ptr(), lam_dssim, _one(dev).data_ptr(), g_image.data_ptr(), gslot,
+                                                                 part.data_ptr(), nb, part.data_ptr() + 8 * nb, nr, loss.data_ptr(),
+                                                                 gp[0], gp[1], gp[2], gp[3], gp[4], st),
+                       "dgs_photo_backward_combine")     # its last workgroup sums the partials into the loss (and runs the step guard)
             else:
                 _check(lib, lib.dgs_regloss_forward_partials_z(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
                                                                lam_n, lam_d, part.data_ptr() + 8 * nb, rslot,
@@ -734,7 +745,7 @@ class _FusedTrainLoss(torch.autograd.Function):
         if ctx.grads is not None:             # unit_grad: the caller promised g == 1; both gradient images exist already
             g_image, g_allmap = ctx.grads
             ctx.grads = None
-            return g_image, g_allmap, None, None, None, None, None, None, None, None, None
+            return g_image, g_allmap, None, None, None, None, None, None, None, None, None, None
         lib = load()
         image, allmap, gt, rays_d, rays_o, wvt, maps = ctx.saved_tensors
         gslot = None if ctx.slots is None else ctypes.c_void_p(ctx.slots.data_ptr())
@@ -755,15 +766,19 @@ class _FusedTrainLoss(torch.autograd.Function):
             _check(lib, lib.dgs_regloss_backward_slot(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(),
                                                       ctx.lam[1], ctx.lam[2], gd.data_ptr(), g_allmap.data_ptr(), rslot, 1, st),
                    "dgs_regloss_backward")
-        return g_image, g_allmap, None, None, None, None, None, None, None, None, None
+        return g_image, g_allmap, None, None, None, None, None, None, None, None, None, None
 
 
-def fused_train_loss(image, allmap, gt, rays_d, rays_o, wvt, lambda_dssim, lambda_normal, lambda_dist, slots=None, unit_grad=False):
+def fused_train_loss(image, allmap, gt, rays_d, rays_o, wvt, lambda_dssim, lambda_normal, lambda_dist, slots=None, unit_grad=False, guard=None):
     """unit_grad=True is the caller's PROMISE that backward() will be called with dL/dloss == 1 (Trainer: loss.backward(unit)): the
     gradient images then depend on the forward's inputs only and are produced in the forward -- the regularisers' value and
-    gradient in one kernel (dgs_regloss_fused), nothing launched in the backward.  Any other upstream gradient would be ignored."""
+    gradient in one kernel (dgs_regloss_fused), nothing launched in the backward.  Any other upstream gradient would be ignored.
+    guard (unit_grad only): a FlatAdam whose step guard (dgs_step_guard) is run by the thread that writes the loss, with that loss --
+    the caller then updates with advance=False."""
+    if guard is not None and not (unit_grad and torch.is_grad_enabled()):
+        raise RuntimeError("fused_train_loss: the guard rides in the unit-gradient path only")
     return _FusedTrainLoss.apply(image, allmap, gt.detach(), rays_d.contiguous(), rays_o.contiguous(), wvt.contiguous(),
-                                 float(lambda_dssim), float(lambda_normal), float(lambda_dist), slots, bool(unit_grad))
+                                 float(lambda_dssim), float(lambda_normal), float(lambda_dist), slots, bool(unit_grad), guard)
 
 
 def densify_view(radii, g_means2D, grad_norm, visible, radii_vis):

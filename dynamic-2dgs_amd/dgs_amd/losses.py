@@ -77,7 +77,7 @@ def training_loss(pkg, gt_image, lambda_dssim=0.2, lambda_normal=0.02, lambda_di
 FUSE_PHOTOMETRIC = True  # L1 + D-SSIM + regularisers as one autograd node (csrc/train_ops.hip); False: separate ops
 
 
-def training_loss_from_allmap(image, allmap, cam, gt_image, lambda_dssim=0.2, lambda_normal=0.02, lambda_dist=1000.0, unit_grad=False):
+def training_loss_from_allmap(image, allmap, cam, gt_image, lambda_dssim=0.2, lambda_normal=0.02, lambda_dist=1000.0, unit_grad=False, guard=None):
     """Same value and gradients as training_loss(render(...), gt) but computed from the rasterizer outputs directly:
     on a HIP device the allmap post-processing (normal rotation, depth -> points -> normals) and the two regularisers
     are one fused kernel per direction (csrc/train_ops.hip) instead of ~100 elementwise launches."""
@@ -86,7 +86,7 @@ def training_loss_from_allmap(image, allmap, cam, gt_image, lambda_dssim=0.2, la
     rays_d, rays_o = camera_rays(cam, image.device)
     if FUSE_PHOTOMETRIC:
         return _ops.fused_train_loss(image, allmap, gt_image, rays_d, rays_o, cam.world_view_transform, lambda_dssim, lambda_normal,
-                                     lambda_dist, slots=getattr(cam, "slots", None), unit_grad=unit_grad)
+                                     lambda_dist, slots=getattr(cam, "slots", None), unit_grad=unit_grad, guard=guard)
     reg = _ops.fused_reg_loss(allmap, rays_d, rays_o, cam.world_view_transform, lambda_normal, lambda_dist)
     ll1 = l1_loss(image, gt_image)
     return (1.0 - lambda_dssim) * ll1 + lambda_dssim * (1.0 - ssim(image, gt_image)) + reg

@@ -15,6 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import losses as _losses
 from . import trace
 from .losses import training_loss, training_loss_from_allmap
 from .render import camera_rays, render
@@ -516,8 +517,14 @@ class Trainer:
         lam = dict(lambda_normal=self.lambda_normal, lambda_dist=self.lambda_dist)
         # unit_grad: every backward of this trainer starts from dL/dloss = 1 (self._unit; the ARAP term is added, not multiplied), so
         # the loss node produces its gradient images in the forward (regularisers: value and gradient in one kernel)
+        # single GPU: the step guard rides in the loss node (the thread that writes the loss runs it): everything it reads exists
+        # then, and the surfels' Adam update later starts right behind the skinning backward (_finish: advance=False)
+        ride = (fused and torch.is_grad_enabled() and self.world == 1 and self.opt_deform is None and getattr(self, "_oflag", None) is not None
+                and not self._arap_active() and _losses.FUSE_PHOTOMETRIC)
         with trace.stage("dgs.loss"):
-            loss = training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, unit_grad=True, **lam) if fused else training_loss(pkg, gt, **lam)
+            loss = (training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, unit_grad=True, guard=self.opt_surfels if ride else None, **lam)
+                    if fused else training_loss(pkg, gt, **lam))
+        self._guard_early = bool(ride)
         if self.arap:
             from . import arap
             lam = arap.lambda_arap(self.iteration)       # train_gui.py:315-316, utils/time_utils.py:1228-1232
@@ -595,12 +602,6 @@ class Trainer:
         d = self.deform
         loss, pkg, asm, fused = self._forward(cam, gt)
         self._note_loss(loss.detach())
-        if fused and self.world == 1 and self.opt_deform is None and getattr(self, "_oflag", None) is not None:
-            # single GPU: everything the step guard reads (overflow flag, loss) exists now.  Launched here, it is out of the way
-            # when the backward ends and the surfels' Adam update starts right behind the skinning backward (_finish: advance=False)
-            with torch.no_grad():
-                self.opt_surfels.guard()
-            self._guard_early = True
         # explicit unit gradient: loss.backward() alone launches a fill for it every step
         with trace.stage("dgs.backward"):
             self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)

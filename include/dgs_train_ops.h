@@ -228,6 +228,13 @@ int dgs_photo_backward_combine(int C, int H, int W, const float* img, const floa
                                const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg, const float* const* gt_slot,
                                const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, float* loss_out,
                                void* stream);
+/* ... whose same thread also performs dgs_step_guard (guard_step_count != NULL) with the loss it has just written: the train
+ * step's guard kernel (one thread, ~5 us of a replayed step) needs nothing that does not exist at that point. */
+int dgs_photo_backward_combine_guard(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                                     const float* dm_dsigma12, float lambda_dssim, const float* g_loss, float* dL_dimg,
+                                     const float* const* gt_slot, const float* photo_partials, long long nphoto, const float* reg_partials,
+                                     long long nreg, float* loss_out, const int* guard_skip, float* guard_step_count, float* guard_status,
+                                     float* guard_ring, int guard_ring_len, void* stream);
 
 /* Densification statistics (train_gui.py:411, scene/gaussian_model.py:484-486).  dgs_densify_view, per rendered view:
  * visible = radii > 0, grad_norm = |dL/dmeans2D[:, :2]| where visible (else 0), radii_vis = radii where visible.
