@@ -1004,7 +1004,8 @@ int launch_knn_refine_mfma_tp(int N, int M, int D, const float* x, const float* 
     const size_t lds = (size_t)Mp * (12 * sizeof(float) + 4 * sizeof(uint4));
     static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
                                 return n > 0 ? n : 256; }();
-    const int wpb = kRmThreads / 64, ngroups = (N + 31) / 32, slots = cus * 2 * wpb;     // 2 workgroups per CU are resident
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;                                         // resident workgroups per CU (LDS: 112 B per node; VGPRs: 2)
+    const int wpb = kRmThreads / 64, ngroups = (N + 31) / 32, slots = cus * per_cu * wpb;
     const int iters = (ngroups + slots - 1) / slots, waves = (ngroups + iters - 1) / iters;
     hipLaunchKernelGGL((knn_refine_mfma_kernel<K, TP>), dim3((waves + wpb - 1) / wpb), dim3(kRmThreads), lds, s, N, M, D, x, nodes, idx, x2, D1,
                        stride2);

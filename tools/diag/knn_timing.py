@@ -11,11 +11,21 @@ from dgs_amd import _ops
 
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
-for name, N, fscale in (("uniform, features ~0", 200_000, 0.01), ("features drifted", 125_000, 0.6)):
-    M = 512
+for name, N, fscale, M, coherent in (("uniform, features ~0", 200_000, 0.01, 512, False), ("features drifted", 125_000, 0.6, 512, False),
+                                  ("sorted, 1024 nodes", 200_000, 0.01, 1024, True)):
     x = torch.rand(N, 3, device=dev, generator=g) * 2 - 1
     f = torch.randn(N, 8, device=dev, generator=g) * fscale
     nodes = torch.cat([x[torch.randperm(N, device=dev, generator=g)[:M]], torch.randn(M, 8, device=dev, generator=g) * 0.01], 1).contiguous()
+    if coherent:      # nodes along a Morton curve, points in the order of their nearest node (the trainer's storage order)
+        q = ((nodes[:, :3] + 1) * 511.5).long().clamp(0, 1023)
+        code = torch.zeros(M, dtype=torch.long, device=dev)
+        for b in range(10):
+            for c in range(3):
+                code |= ((q[:, c] >> b) & 1) << (3 * b + c)
+        nodes = nodes[torch.argsort(code)].contiguous()
+        near = _ops.knn_indices2(x, f, nodes, 3)[:, 0]
+        order = torch.argsort(near, stable=True)
+        x, f = x[order].contiguous(), f[order].contiguous()
     want = _ops.knn_indices2(x, f, nodes, 3)
     stale = _ops.knn_indices2(x + 0.01 * torch.randn(N, 3, device=dev, generator=g), f, nodes, 3)
     seed = stale.clone()
