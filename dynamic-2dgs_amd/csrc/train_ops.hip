@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(256) loss_combine_kernel(CombineArgs c)
 //   pass 1, vertical, straight from global memory: a wave owns 7 output rows, a lane one of the tile's 64 input columns, and loads
 //     its 17 input rows with fully coalesced 256-byte wave loads that are all in flight at once -- no staging of the inputs in LDS,
 //     no staging barrier (the round-2 kernels staged a 42 x 42 window element by element: 14 dependent memory round trips per
-//     workgroup, 39 us for the forward at 800 x 800 x 3; batching those loads gave 27 us, this layout 11);
+//     workgroup, 39 us for the forward at 800 x 800 x 3; batching those loads gave 27 us, this layout 21: the two passes alone
+//     are 11 us, writing the 23 MB of derivative maps the rest);
 //   pass 2, horizontal, from LDS: thread = (row, 6 adjacent outputs), 16 reads per quantity.
 // Every thread filters several adjacent outputs from one run of inputs held in registers (7 + 10 rows, 6 + 10 columns).  The
 // window weights are copied into VGPRs: a VALU instruction with an SGPR source issues at 4.4 instead of 2.5 cycles on gfx950
@@ -1649,7 +1650,7 @@ __global__ void __launch_bounds__(256) regloss_bwd_kernel(RegArgs a, const float
 //   phase 2: thread = centre (2 trips of 32 x 8): cross product, normalisation, loss term, d/d rend_normal, and the two
 //            vectors ddx = dy x dv, ddy = dv x dx its four neighbours' points receive -> LDS
 //   phase 3: the centre's own thread gathers  +ddx(y-1) - ddx(y+1) + ddy(x-1) - ddy(x+1),  dots with its ray, stores all 8 planes
-// 33 + 20 -> 14 us at 800 x 800 (forward + backward kernels -> this one).
+// 11 + 23 -> 17 us at 800 x 800 (forward + backward kernels -> this one).
 constexpr int kRW = 30, kRH = 14;                 // own pixels of a workgroup
 constexpr int kCW = kRW + 2, kCH = kRH + 2;       // centres: 32 x 16
 constexpr int kQW = kRW + 4, kQH = kRH + 4;       // points: 34 x 18
