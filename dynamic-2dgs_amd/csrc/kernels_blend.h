@@ -265,6 +265,25 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, c
     else tile_order_body(ranges, weights, tiles_x * tiles_y, order, s_hist, s_wsum);
 }
 
+// The backward's two preparations as ONE launch: workgroups 0 .. n-2 clear the surfels' accumulator rows (what hipMemsetAsync did),
+// the last one orders the tiles by the length the forward traversed (tile_order_kernel) -- the two were 7 + 6 us back to back in
+// front of the backward blend of every step.
+__global__ void __launch_bounds__(1024) prep_bwd_kernel(float4* __restrict__ acc, size_t n4, const uint32_t* weights, int tiles_x, int tiles_y, int mode,
+                                                        uint32_t* order, uint32_t* group_xcd)
+{
+    __shared__ uint32_t s_hist[8 * kOrderBins];
+    __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
+    __shared__ uint32_t s_wsum[16];
+    if (blockIdx.x == gridDim.x - 1) {
+        if (mode == 4) tile_order_xcd_body(nullptr, weights, tiles_x, tiles_y, order, group_xcd, false, s_hist, s_gw, s_gx, s_wsum);
+        else tile_order_body(nullptr, weights, tiles_x * tiles_y, order, s_hist, s_wsum);
+        return;
+    }
+    const size_t stride = (size_t)(gridDim.x - 1) * 1024;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) acc[i] = z;
+}
+
 // grid size that covers every tile under `mode`
 inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
 {

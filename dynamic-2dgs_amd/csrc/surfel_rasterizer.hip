@@ -733,7 +733,21 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
     const dgs::Camera cam = make_camera(viewmatrix, campos, width, height, tan_fovx, tan_fovy);
 
     float* acc = (float*)(geom_buffer + gl.acc);
-    DGS_HIP(hipMemsetAsync(acc, 0, (size_t)P * dgs::kAccFloats * 4, stream));
+    const size_t acc_bytes = (size_t)P * dgs::kAccFloats * 4;
+    int bwd_mode = ctx->tile_order.load();
+    if (bwd_mode == 4 && dgs::order_groups(il.tiles_x, il.tiles_y) > dgs::kOrderMaxGroups) bwd_mode = 3;
+    // accumulator rows cleared and (modes 3, 4) the tiles ordered by the traversed length the forward measured: one launch
+    const bool prep_fused = R > 0 && bwd_mode >= 3 && acc_bytes % 16 == 0 && (reinterpret_cast<size_t>(acc) & 15) == 0;
+    if (prep_fused) {
+        const size_t n4 = acc_bytes / 16;
+        const int fill_blocks = (int)std::min<size_t>(1024, (n4 + 4 * 1024 - 1) / (4 * 1024));   // ~4 stores of 16 B per thread
+        hipLaunchKernelGGL(dgs::prep_bwd_kernel, dim3(fill_blocks + 1), dim3(1024), 0, stream, (float4*)acc, n4,
+                           (const uint32_t*)(img_buffer + il.tile_last), il.tiles_x, il.tiles_y, bwd_mode,
+                           (uint32_t*)(img_buffer + il.order_bwd), (uint32_t*)(img_buffer + il.group_xcd));
+        DGS_STAGE("prep_bwd", debug, stream);
+    } else {
+        DGS_HIP(hipMemsetAsync(acc, 0, acc_bytes, stream));
+    }
 
     // ---- K8 backward blend
     if (R > 0) {
@@ -744,7 +758,7 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         ba.W = width; ba.H = height; ba.tiles_x = il.tiles_x; ba.tiles_y = il.tiles_y; ba.mode = ctx->tile_order.load();
         ba.order = (const uint32_t*)(img_buffer + il.order_bwd);
         if (ba.mode == 4 && dgs::order_groups(il.tiles_x, il.tiles_y) > dgs::kOrderMaxGroups) ba.mode = 3;
-        if (ba.mode >= 3) {  // by the traversed length the forward measured
+        if (ba.mode >= 3 && !prep_fused) {  // by the traversed length the forward measured
             hipLaunchKernelGGL(dgs::tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint2*)nullptr,
                                (const uint32_t*)(img_buffer + il.tile_last), il.tiles_x, il.tiles_y, ba.mode,
                                (uint32_t*)(img_buffer + il.order_bwd), (uint32_t*)(img_buffer + il.group_xcd));
