@@ -488,11 +488,13 @@ struct BlendBwdArgs {
 //      column n of ONE 16x16 accumulator, so after the 16 instructions lane (q, n) holds four row sums of value n; three
 //      adds and two cross-row exchanges finish.  The blend kernels issue no other MFMA, the pipe is otherwise idle,
 //   2  hybrid: v_permlane32_swap folds the two wave halves first (values n and n + 8 share a register), then 8 MFMAs,
-//   3  (default) VALU only: permlane swaps across rows, bank-masked DPP adds inside a row (wave_reduce.h).
+//   3  VALU only: permlane swaps across rows, bank-masked DPP adds inside a row (wave_reduce.h),
+//   4  transposition through the wave's own LDS (wave_reduce.h: 16 ds_write_addtid_b32 + 4 ds_read_b128 + 17 VALU); DGS_RED_PHASES = 2
+//      does it in two rounds of 8 values through half the LDS.
 // Measured at 200k / 800x800 (blend bwd, ms): 0: 0.338, 1: 0.548 (the matrix pipe -- 16 x 32 cycles per visit -- becomes the
 // bottleneck), 2: 0.455, 3: 0.315.  On return lane l holds the wave total of v[l & 15] (variants 1, 2) / v[l >> 2] (variant 0); reduce16_slot() tells which.
 #ifndef DGS_BWD_REDUCE
-#define DGS_BWD_REDUCE 3
+#define DGS_BWD_REDUCE 4
 #endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -568,9 +570,25 @@ __device__ __forceinline__ float wave_reduce16_hybrid(float (&v)[16], int lane)
     return mfma_rows_finish(d0, d1);
 }
 
-__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane)
+#ifndef DGS_RED_PHASES
+#define DGS_RED_PHASES 2
+#endif
+#if DGS_BWD_REDUCE == 4
+struct BwdRed { float v[16 / DGS_RED_PHASES][64]; };   // one wave's transposition buffer
+typedef RedLds<DGS_RED_PHASES> BwdRedCtx;
+#else
+struct BwdRedCtx {};
+#endif
+
+__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane, const BwdRedCtx& rc)
 {
-#if DGS_BWD_REDUCE == 3
+#if DGS_BWD_REDUCE == 4
+#if DGS_RED_PHASES == 1
+    return wave_reduce16_lds(v, rc);
+#else
+    return wave_reduce16_lds(v, rc, lane);
+#endif
+#elif DGS_BWD_REDUCE == 3
     return wave_reduce16_dpp(v);   // wave_reduce.h: permlane swaps + bank-masked DPP adds, no LDS
 #elif DGS_BWD_REDUCE == 0
     return wave_reduce16_butterfly(v, lane);
@@ -584,7 +602,9 @@ __device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane)
 // which of the 16 values lane `lane` holds after wave_reduce16, or -1 if the lane holds a duplicate
 __device__ __forceinline__ int reduce16_slot(int lane)
 {
-#if DGS_BWD_REDUCE == 0 || DGS_BWD_REDUCE == 3
+#if DGS_BWD_REDUCE == 4 && DGS_RED_PHASES == 2
+    return (lane & 3) == 0 ? (lane >> 3) + 2 * (lane & 4) : -1;
+#elif DGS_BWD_REDUCE == 0 || DGS_BWD_REDUCE == 3 || DGS_BWD_REDUCE == 4
     return (lane & 3) == 0 ? (lane >> 2) : -1;
 #else
     return lane < 16 ? lane : -1;
@@ -599,23 +619,30 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 #ifndef DGS_BWD_MINWAVES
-#define DGS_BWD_MINWAVES 4
+#define DGS_BWD_MINWAVES 5
 #endif
 // DET = false: the per-(wave, entry) sums go into the surfel's accumulator row with hardware float atomics (order of arrival:
 // results differ at the rounding level from run to run, like the reference's).  DET = true (dgs_set_option(7, 1), tests): every
 // (list entry, wave) owns a row of det_part and stores its sums there; det_reduce_kernel adds the rows of a surfel in a fixed order.
+#ifndef DGS_BWD_CHUNK
+#define DGS_BWD_CHUNK 48
+#endif
+constexpr int kChunkB = DGS_BWD_CHUNK;   // list entries the backward stages per wave and step (lanes >= kChunkB stage nothing): sizes the slice
 struct BwdStage {            // one wave's staging slice: the chunk's visited entries, compacted (+1: the visit loop reads one slot ahead)
-    f32x4 a[3][kChunk + 1];  // alpha part of the entry's affine image (tile_affine)
-    f32x4 tw[kChunk + 1];    // (Tw.x Tw.y Tw.z opacity)
-    f32x4 tuv[kChunk + 1];   // (Tu.x Tu.y Tv.x Tv.y): k.xy, l.xy of a pixel are rebuilt from them
-    f32x4 q3[kChunk + 1];    // (n.x n.y n.z r)
-    f32x4 q4[kChunk + 1];    // (g b, 0-based list index as bits, surfel id as bits)
+    f32x4 a[3][kChunkB + 1];  // alpha part of the entry's affine image (tile_affine)
+    f32x4 tw[kChunkB + 1];    // (Tw.x Tw.y Tw.z opacity)
+    f32x4 tuv[kChunkB + 1];   // (Tu.x Tu.y Tv.x Tv.y): k.xy, l.xy of a pixel are rebuilt from them
+    f32x4 q3[kChunkB + 1];    // (n.x n.y n.z r)
+    f32x4 q4[kChunkB + 1];    // (g b, 0-based list index as bits, surfel id as bits)
 };
 
 template <bool DET>
 __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
 {
     __shared__ BwdStage s_stage[4];
+#if DGS_BWD_REDUCE == 4
+    __shared__ BwdRed s_red[4];
+#endif
 
     const int ntiles = a.tiles_x * a.tiles_y;
     int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
@@ -666,18 +693,23 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
     }
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);  // uniform by construction
     const int rslot = reduce16_slot(lane);
+    BwdRedCtx rc;
+#if DGS_BWD_REDUCE == 4
+    rc.init(&s_red[wave].v[0][0], lane);
+#endif
 
     // chunk lane l holds list entry e = top - l; the entries that can touch the quadrant are compacted in that (back to front) order
-    uint32_t id_next = wave_last - 1 - lane >= 0 ? a.point_list[range.x + (uint32_t)(wave_last - 1 - lane)] : 0u;
-    for (int top = wave_last - 1; top >= 0; top -= kChunk) {
+    const bool stager = kChunkB == 64 || lane < kChunkB;
+    uint32_t id_next = stager && wave_last - 1 - lane >= 0 ? a.point_list[range.x + (uint32_t)(wave_last - 1 - lane)] : 0u;
+    for (int top = wave_last - 1; top >= 0; top -= kChunkB) {
         const int e_mine = top - lane;
         const uint32_t id = id_next;   // (lanes beyond the front of the list hold id 0: a valid record, masked out below)
         // straight-line staging, see blend_fwd_kernel
         const float4* src = a.rec + (size_t)id * kRecQuads;
         const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3s = src[3], q4s = src[4], bx = src[5];
-        id_next = e_mine - kChunk >= 0 ? a.point_list[range.x + (uint32_t)(e_mine - kChunk)] : 0u;
+        id_next = stager && e_mine - kChunkB >= 0 ? a.point_list[range.x + (uint32_t)(e_mine - kChunkB)] : 0u;
         const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
-        const bool hit = (e_mine >= 0) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
+        const bool hit = stager & (e_mine >= 0) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
         const unsigned long long m = __ballot(hit);
         if (m == 0ull) continue;
         if (hit) {
@@ -726,7 +758,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
                 for (int k = 0; k < 16; k++) asm volatile("" : : "v"(out[k]));
                 asm volatile("" : : "s"(dst));
 #else
-                const float tot = wave_reduce16(out, lane);
+                const float tot = wave_reduce16(out, lane, rc);
 #endif
 #if DGS_DIAG_BWD == 0
                 if (rslot >= 0) {
@@ -755,9 +787,197 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
     }
 }
 
+// ---- backward blend, one list per 16-lane row (round 4) -------------------------------------------------------------------
+// In blend_bwd_kernel above all 64 lanes of a wave visit the same entry, and 30 of them blend it on the 200k / 800x800 scene
+// (tools/blend_stats.py).  Here every DPP row of the wave -- one 4x4 pixel block of the quadrant (surfel_math.h lane_pixel) --
+// walks the list of the entries that can reach ITS block: while staging, a lane tests its entry against the four blocks
+// (blocks_hit_linear: the record's pixel box, then a tangent-plane bound of the footprint's conic; also what decides whether the
+// entry is staged at all), the entry's planes are stored once per wave, compacted as before, and each block it reaches gets the
+// slot number appended to its row's byte list (rank among the ballot of that block).  One wave-instruction of the visit loop then
+// serves four (entry, block) pairs: lane l reads the planes of the slot its row is at (four addresses per ds_read_b128), rows that
+// have run out of entries read the null slot (opacity 0: fails the alpha test, contributes exact zeros).  A row's list also stops
+// at ITS pixels' last contributor instead of the wave's.  The 16 partials are summed per row (wave_reduce.h rows_reduce16) and all
+// 64 lanes issue one atomic each: row r' = (l >> 1) & 3 of value (l >> 3) + 8 (l & 1), to the surfel of row r's entry.
+// Per-pixel arithmetic and entry order are those of blend_bwd_kernel; the sums reach the accumulator rows in 16 instead of 4
+// pieces per (tile, entry).  Iterations per wave: 0.87 of the visits of the kernel above on the 200k / 800x800 scene (hm_row_stats).
+#ifndef DGS_BWD_ROWS
+#define DGS_BWD_ROWS 0
+#endif
+static_assert(kChunkB <= 60, "a row's byte list holds 64 slots and is read two ahead");
+constexpr int kNullSlot = kChunkB;   // the slot behind the staged ones: the entry that contributes nothing
+template <bool DET>
+struct BwdRowStage {
+    f32x4 a[3][kChunkB + 1];
+    f32x4 tw[kChunkB + 1];     // (Tw.x Tw.y Tw.z opacity)
+    f32x4 tuv[kChunkB + 1];    // (Tu.x Tu.y Tv.x Tv.y)
+    f32x4 q3[kChunkB + 1];     // (n.x n.y n.z r)
+    f32x4 q4[kChunkB + 1];     // (g b, 0-based list index as bits, byte offset of the surfel's accumulator row; null slot: index INT_MAX, offset ~0)
+    uint32_t idx[4][16];       // row r: the slots of its block's entries in visit order, one byte each
+    float red[DET ? 10 : 9][64];   // rows_reduce16: 8 values per round + one row of per-lane words (two in the deterministic variant)
+};
+
+template <bool DET>
+__global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_rows_kernel(BlendBwdArgs a)
+{
+    __shared__ BwdRowStage<DET> s_stage[4];
+
+    const int ntiles = a.tiles_x * a.tiles_y;
+    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
+    if (a.mode < 3 && tile >= ntiles) return;
+    if (a.mode >= 3) tile = (int)a.order[tile];
+    if (tile >= ntiles) return;   // mode 4: empty slot
+    if (a.tile_last[tile] == 0u) return;   // no pixel of the tile blended anything
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int lx_, ly_;
+    lane_pixel(tid, lx_, ly_);
+    const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
+    const bool inside = px < a.W && py < a.H;
+    const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+    const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
+    const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
+    const float qx = tpx + (float)(8 * (wave & 1)), qy = tpy + (float)(8 * (wave >> 1));
+    const float qus0 = kSqrt2 * ((wave & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((wave & 2) ? 0.5f : -7.5f);
+    const float us = kSqrt2 * ((float)lx_ - 7.5f), vs = kSqrt2 * ((float)ly_ - 7.5f);
+    const uint2 range = a.ranges[tile];
+    BwdRowStage<DET>& S = s_stage[wave];
+
+    const size_t plane = (size_t)ntiles * kTilePix;
+    const size_t slot_px = (size_t)tile * kTilePix + tid;
+    PixBwdA st;
+    {
+        float gpix[3] = {0.f, 0.f, 0.f}, goth[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (inside) {
+            const size_t HW = (size_t)a.H * a.W;
+            const size_t pix = (size_t)py * a.W + px;
+#pragma unroll
+            for (int c = 0; c < 3; c++) gpix[c] = a.dL_dpix[c * HW + pix];
+#pragma unroll
+            for (int c = 0; c < 8; c++) goth[c] = a.dL_dothers[c * HW + pix];
+        }
+        const int last = inside ? (int)a.n_contrib[slot_px] : 0;
+        const int medc = inside ? (int)a.n_contrib[plane + slot_px] : 0;
+        pixbwd_init_affine(st, inside ? a.final_T[slot_px] : 0.f, a.final_T[plane + slot_px], a.final_T[2 * plane + slot_px], last, medc, gpix,
+                           goth, a.bg);
+    }
+    // a row's list ends at its own pixels' last contributor; the wave walks the tile's list back to front from the largest of the four
+    const int row_last = row_max16(st.last_contributor);
+    const int rl0 = __builtin_amdgcn_readlane(row_last, 0), rl1 = __builtin_amdgcn_readlane(row_last, 16);
+    const int rl2 = __builtin_amdgcn_readlane(row_last, 32), rl3 = __builtin_amdgcn_readlane(row_last, 48);
+    const int wave_last = max(max(rl0, rl1), max(rl2, rl3));
+    RedRows rc;
+    rc.init(&S.red[0][0], lane);
+    // the null slot: planes of an entry that fails the alpha test for every pixel and whose other constants are finite
+    if (lane < 7) {
+        f32x4* planes[7] = {&S.a[0][kNullSlot], &S.a[1][kNullSlot], &S.a[2][kNullSlot], &S.tw[kNullSlot], &S.tuv[kNullSlot], &S.q3[kNullSlot], &S.q4[kNullSlot]};
+        f32x4 z = mk4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 6) z = mk4(0.f, 0.f, __int_as_float(0x7fffffff), __uint_as_float(0xffffffffu));
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            if (lane == k) *planes[k] = z;
+    }
+    const uint8_t* my_list = (const uint8_t*)&S.idx[row][0];
+    const int kk = (lane >> 3) + 8 * (lane & 1);   // the value this lane finishes (rows_reduce16)
+
+    const bool stager = lane < kChunkB;
+    uint32_t id_next = stager && wave_last - 1 - lane >= 0 ? a.point_list[range.x + (uint32_t)(wave_last - 1 - lane)] : 0u;
+    for (int top = wave_last - 1; top >= 0; top -= kChunkB) {
+        const int e_mine = top - lane;
+        const uint32_t id = id_next;   // (lanes beyond the front of the list hold id 0: a valid record, masked out below)
+        const float4* src = a.rec + (size_t)id * kRecQuads;
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3s = src[3], q4s = src[4], bx = src[5];
+        id_next = stager && e_mine - kChunkB >= 0 ? a.point_list[range.x + (uint32_t)(e_mine - kChunkB)] : 0u;
+        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+        const uint32_t bm = (stager & (e_mine >= 0)) ? blocks_hit_linear(ta, qus0, qvs0, as_quad(bx), qx, qy) : 0u;
+        const bool h0 = (bm & 1u) && e_mine < rl0, h1 = (bm & 2u) && e_mine < rl1, h2 = (bm & 4u) && e_mine < rl2, h3 = (bm & 8u) && e_mine < rl3;
+        const bool hit = h0 | h1 | h2 | h3;
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        ((uint32_t*)&S.idx[0][0])[lane] = 0x01010101u * (uint32_t)kNullSlot;   // every list: null slots behind its entries
+        if (hit) {
+            const int slot = lane_rank(m);
+            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+            S.tw[slot] = mk4(q1.z, q1.w, q2.x, q2.w);
+            S.tuv[slot] = mk4(q0.x, q0.y, q0.w, q1.x);
+            S.q3[slot] = mk4(q3s);
+            S.q4[slot] = mk4(q4s.x, q4s.y, __int_as_float(e_mine), __uint_as_float(id * (uint32_t)(kAccFloats * 4)));
+            uint8_t* lists = (uint8_t*)&S.idx[0][0];
+            if (h0) lists[lane_rank(m0)] = (uint8_t)slot;
+            if (h1) lists[64 + lane_rank(m1)] = (uint8_t)slot;
+            if (h2) lists[128 + lane_rank(m2)] = (uint8_t)slot;
+            if (h3) lists[192 + lane_rank(m3)] = (uint8_t)slot;
+        }
+        __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
+        const int n01 = max(__builtin_popcountll(m0), __builtin_popcountll(m1)), n23 = max(__builtin_popcountll(m2), __builtin_popcountll(m3));
+        const int niter = __builtin_amdgcn_readfirstlane(max(n01, n23));   // (ballot popcounts: uniform, the loop counter belongs on the scalar unit)
+        int sl = my_list[0];
+        int sl_next = my_list[1];
+        f32x4 a0 = S.a[0][sl], a1 = S.a[1][sl], a2 = S.a[2][sl];
+        f32x4 tw = S.tw[sl], tuv = S.tuv[sl], q3 = S.q3[sl], q4 = S.q4[sl];
+        for (int i = 0; i < niter; i++) {
+            AlphaEval ev;
+            bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
+#if DGS_PIN_PREFETCH
+            asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
+#endif
+            sl = sl_next;
+            a0 = S.a[0][sl]; a1 = S.a[1][sl]; a2 = S.a[2][sl];
+            DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
+            const int e = __float_as_int(q4.z);   // 0-based list index of the row's entry == the reference's `contributor`
+            ok = ok & (e < st.last_contributor);
+            if (__ballot(ok) != 0ull) {
+                bool use3d;
+                const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
+                ok = ok & (depth >= kNear);
+                float out[16], out2d[2];
+                pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
+                                   Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
+                uint32_t rid, re;
+#if DGS_DIAG_BWD >= 2
+                float tot = 0.f; rid = __float_as_uint(q4.w); re = 0;
+                for (int k = 0; k < 16; k++) asm volatile("" : : "v"(out[k]));
+#else
+                const float tot = rows_reduce16<DET>(out, __float_as_uint(q4.w), __float_as_uint(q4.z), rc, lane, rid, re);
+#endif
+#if DGS_DIAG_BWD >= 1
+                asm volatile("" : : "v"(tot), "v"(rid));
+                if (false) {
+#else
+                if (rid != 0xffffffffu && tot != 0.0f) {
+#endif   // (a row without an entry, or one none of whose pixels blended it, adds nothing)
+                    if (DET) a.det_part[(((size_t)(range.x + re) * 4 + wave) * 4 + ((lane >> 1) & 3)) * kAccFloats + kk] = tot;
+                    else atomicAdd((float*)((char*)a.acc + (rid + 4u * (uint32_t)kk)), tot);   // rid = byte offset of the surfel's accumulator row
+                }
+                if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                    const float mx = row_sum16(out2d[0]);
+                    const float my = row_sum16(out2d[1]);
+                    if ((lane & 15) == 0 && (mx != 0.0f || my != 0.0f)) {
+                        float* dst = DET ? a.det_part + (((size_t)(range.x + (uint32_t)e) * 4 + wave) * 4 + row) * kAccFloats
+                                         : (float*)((char*)a.acc + __float_as_uint(q4.w));
+                        if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
+                        else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                    }
+                }
+            }
+#if DGS_PIN_PREFETCH
+            asm volatile("" : "+v"(st.T) : : "memory");
+#endif
+            tw = S.tw[sl]; tuv = S.tuv[sl]; q3 = S.q3[sl]; q4 = S.q4[sl];
+            DGS_PIN4(tw); DGS_PIN4(tuv); DGS_PIN4(q3); DGS_PIN4(q4);
+            sl_next = my_list[i + 2];
+            asm volatile("" : "+v"(sl_next));   // requested here, a visit before the address is formed from it
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Deterministic reduction of the backward blend (test option): one thread per surfel walks the tiles of its rectangle in
 // row-major order, finds its entry in the tile's sorted list and adds the four waves' rows in order 0..3.  Same sums as the
 // atomics in ONE fixed order: two runs give bit-identical gradients.  Slow by design (linear search of the lists).
+constexpr int kDetRows = DGS_BWD_ROWS ? 16 : 4;   // rows of det_part per list entry: one per (wave, 16-lane row) or per wave
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const int* radii, const uint2* rects, int tiles_x, const uint2* ranges,
                                                          const uint32_t* point_list, const float* part, float* acc)
 {
@@ -773,8 +993,8 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const int* radii
             const uint2 rg = ranges[y * tiles_x + x];
             for (uint32_t pos = rg.x; pos < rg.y; pos++) {
                 if (point_list[pos] != (uint32_t)idx) continue;
-                for (int w = 0; w < 4; w++) {
-                    const float* row = part + ((size_t)pos * 4 + w) * kAccFloats;
+                for (int w = 0; w < kDetRows; w++) {
+                    const float* row = part + ((size_t)pos * kDetRows + w) * kAccFloats;
 #pragma unroll
                     for (int k = 0; k < kAccFloats; k++) sum[k] += row[k];
                 }

@@ -201,14 +201,15 @@ DGS_HD void tight_tile_rect(const float* Tu, const float* Tv, const float* Tw, f
     if (fy1 < (double)y1) y1 = fy1 > (double)y0 ? (int)fy1 : y0;
 }
 
-// Pixel <-> lane mapping of the blend kernels: wave w of a tile's workgroup owns the 8x8 quadrant (w & 1, w >> 1), lane l
-// the pixel (l & 7, l >> 3) inside it.  Square wave footprints are visited by ~10 % fewer (wave, entry) pairs than 16x4
-// strips for the same splats (tools/blend_stats.py).
+// Pixel <-> lane mapping of the blend kernels: wave w of a tile's workgroup owns the 8x8 quadrant (w & 1, w >> 1); its 16-lane
+// DPP row r = lane >> 4 owns the 4x4 block (r & 1, r >> 1) of the quadrant, lane j = lane & 15 of the row the pixel (j & 3, j >> 2)
+// of the block.  (Square wave footprints are visited by ~10 % fewer (wave, entry) pairs than 16x4 strips for the same splats,
+// tools/blend_stats.py; rows as blocks since round 4, when every row got its own list.)
 DGS_HD void lane_pixel(int tid, int& lx, int& ly)
 {
-    const int w = tid >> 6, l = tid & 63;
-    lx = 8 * (w & 1) + (l & 7);
-    ly = 8 * (w >> 1) + (l >> 3);
+    const int w = tid >> 6, l = tid & 63, r = l >> 4, j = l & 15;
+    lx = 8 * (w & 1) + 4 * (r & 1) + (j & 3);
+    ly = 8 * (w >> 1) + 4 * (r >> 1) + (j >> 2);
 }
 
 // Bit w set: the box reaches a pixel centre of quadrant w of the tile whose first pixel is (px0, py0).  Used by the blend
@@ -505,6 +506,60 @@ DGS_HD bool block_hit_affine(const TileAffine& t, float us0, float us1, float vs
     qm = fminf(qm, Qf(clampf(-(c * y1 + d) * inv_a, x0, x1), y1));
     hit |= qm <= tol;
     return can_pass & (hit | no_ellipse);
+}
+
+// Which of the four 4x4 pixel blocks of an 8x8 quadrant can the entry reach with alpha >= 1/255?  Bit b = block (b & 1, b >> 1);
+// (us0, vs0) = scaled tile-relative coordinates of the quadrant's first pixel.  Used by the row-per-block blend kernels (round 4):
+// every 16-lane row of a wave walks the list of ITS block.  Same footprint as block_hit_affine -- the conic Q = |P.xy|^2 - tau P.z^2
+// <= 0, P = A + x B + y C, or the low-pass disc x^2 + y^2 <= tau -- but the four blocks are small (half extent h = 1.5 sqrt2 in
+// these coordinates) and a splat that reaches the quadrant is mostly much larger, so instead of minimising Q over each block
+// exactly (interior point + four clamped edges: ~75 operations per block) Q is bounded from below by its tangent plane at the
+// block's centre: Q(c + d) >= Q(c) - h (|Qx(c)| + |Qy(c)|) for |d.x|, |d.y| <= h, valid because Q is convex when the conic is a
+// proper ellipse (anything else counts as a hit).  Conservative by construction: a block is only dropped when the bound proves
+// that no pixel centre of it lies inside the (1 % + 0.01 inflated) footprint; what the bound gives away against the exact
+// minimum is ~4 % more (entry, block) pairs on the 200k / 800x800 scene (tools/blend_stats.py).
+// bx = the record's exact pixel box (x_lo, x_hi, y_lo, y_hi); (qx, qy) = absolute coordinates of the quadrant's first pixel.
+DGS_HD uint32_t blocks_hit_linear(const TileAffine& t, float us0, float vs0, const Quad& bx, float qx, float qy)
+{
+    const float tau = 2.0f * logf(255.0f * t.a2.w) * 1.01f + 0.01f;
+    const bool can_pass = tau > 0.0f;                    // false: opacity below 1/255 (or not a number)
+    const float Ax = t.a0.x, Ay = t.a0.y, Az = t.a0.z, Bx = t.a0.w, By = t.a1.x, Bz = t.a1.y, Cx = t.a1.z, Cy = t.a1.w, Cz = t.a2.x;
+    const float a = Bx * Bx + By * By - tau * Bz * Bz, b = Cx * Cx + Cy * Cy - tau * Cz * Cz;
+    const float c = Bx * Cx + By * Cy - tau * Bz * Cz;
+    const float det = a * b - c * c;
+    const bool no_ellipse = !((a > 0.0f) & (b > 0.0f) & (det > 1e-6f * a * b));   // not a bounded, well-conditioned ellipse: a hit
+    const float h = 1.5f * kSqrt2;
+    // block centres in (x, y) = cs - (us, vs): column i, row j
+    const float xm[2] = {t.a2.y - (us0 + 1.5f * kSqrt2), t.a2.y - (us0 + 5.5f * kSqrt2)};
+    const float ym[2] = {t.a2.z - (vs0 + 1.5f * kSqrt2), t.a2.z - (vs0 + 5.5f * kSqrt2)};
+    // the record's pixel box against the two columns / rows of block centres (pixel centres qx + 0.5 .. + 3.5 and + 4.5 .. + 7.5)
+    const bool bxc[2] = {bx.y >= qx + 0.5f && bx.x <= qx + 3.5f, bx.y >= qx + 4.5f && bx.x <= qx + 7.5f};
+    const bool byr[2] = {bx.w >= qy + 0.5f && bx.z <= qy + 3.5f, bx.w >= qy + 4.5f && bx.z <= qy + 7.5f};
+    // low-pass disc: squared distance from the centre (x = y = 0) to the block, per column / row
+    float gx2[2], gy2[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float gx = fmaxf(fabsf(xm[i]) - h, 0.0f), gy = fmaxf(fabsf(ym[i]) - h, 0.0f);
+        gx2[i] = gx * gx; gy2[i] = gy * gy;
+    }
+    const float tau_d = tau * 1.0001f;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float Pxi = Ax + xm[i] * Bx, Pyi = Ay + xm[i] * By, Pzi = Az + xm[i] * Bz;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float Px = Pxi + ym[j] * Cx, Py = Pyi + ym[j] * Cy, Pz = Pzi + ym[j] * Cz;
+            const float tPz = tau * Pz;
+            const float Q = Px * Px + (Py * Py - tPz * Pz);
+            const float hQx = Px * Bx + (Py * By - tPz * Bz), hQy = Px * Cx + (Py * Cy - tPz * Cz);   // half the partial derivatives
+            const float lb = Q - (2.0f * h) * (fabsf(hQx) + fabsf(hQy));
+            const float tol = 4e-6f * (Px * Px + Py * Py + tPz * Pz);
+            const bool hit = (lb <= tol) | no_ellipse | (gx2[i] + gy2[j] <= tau_d);
+            m |= (hit & bxc[i] & byr[j]) ? (1u << (2 * j + i)) : 0u;
+        }
+    }
+    return can_pass ? m : 0u;
 }
 
 // quadrant w of the tile: us in [us_lo(w), us_lo(w) + 7 sqrt2]

@@ -718,6 +718,7 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
     if (int e = check_common(P, width, height, means3D)) return e;
     if (P == 0) return DGS_OK;  // rasterize_points.cu:204
     if (transMat_precomp) return fail(DGS_ERR_UNSUPPORTED, "transMat_precomp (cov3D_precomp) is not supported");
+    if ((unsigned long long)P * dgs::kAccFloats * 4ull >= 0xffffffffull) return fail(DGS_ERR_UNSUPPORTED, "backward: more than 53 million surfels (32-bit accumulator offsets)");
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail(DGS_ERR_INVALID_ARGUMENT, "scratch buffer is NULL");
     if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dtransMat ||
         !dL_dscale || !dL_drot || !scales || !rotations || !viewmatrix || !campos || !background)
@@ -779,17 +780,25 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
             // test option: every (list entry, wave) stores its sums in a row of its own, a per-surfel kernel adds them in a fixed
             // order.  R x 320 bytes of scratch from the stream-ordered allocator (not capturable: tests run eagerly)
             float* part = nullptr;
-            const size_t bytes = (size_t)R * 4 * dgs::kAccFloats * sizeof(float);
+            const size_t bytes = (size_t)R * dgs::kDetRows * dgs::kAccFloats * sizeof(float);
             DGS_HIP(hipMallocAsync((void**)&part, bytes, stream));
             DGS_HIP(hipMemsetAsync(part, 0, bytes, stream));
             ba.det_part = part;
+#if DGS_BWD_ROWS
+            hipLaunchKernelGGL(dgs::blend_bwd_rows_kernel<true>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+#else
             hipLaunchKernelGGL(dgs::blend_bwd_kernel<true>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+#endif
             hipLaunchKernelGGL(dgs::det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, radii,
                                (const uint2*)(geom_buffer + gl.rects), il.tiles_x, ba.ranges, ba.point_list, (const float*)part, acc);
             DGS_HIP(hipFreeAsync(part, stream));
         } else {
             ba.det_part = nullptr;
+#if DGS_BWD_ROWS
+            hipLaunchKernelGGL(dgs::blend_bwd_rows_kernel<false>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+#else
             hipLaunchKernelGGL(dgs::blend_bwd_kernel<false>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+#endif
         }
         if (timed) prof_end(ctx, stream, pp, ba.tile_last, il.ntiles);
         DGS_STAGE("blend_bwd", debug, stream);

@@ -44,6 +44,201 @@ __device__ __forceinline__ float wave_reduce16_dpp(float (&v)[16])
     return e;
 }
 
+// ---- the same sum through LDS (DGS_BWD_REDUCE == 4) ------------------------------------------------------------------
+// The DPP / permlane version above is 36 VALU instructions of the expensive classes (v_permlane*_swap 8.5 cycles, DPP adds
+// 4.4-4.8) = ~170 of a backward visit's ~500 issue cycles, while the LDS pipe of the blend kernels is 22 % busy
+// (SQ_LDS_IDX_ACTIVE, profiles/r03_pmc_metric.json).  Here the wave TRANSPOSES the 64 x 16 partials through its own 4 KB of
+// LDS: every lane stores value k into row k with ds_write_addtid_b32 (address = M0 + offset + 4 * lane: no address VGPR,
+// 2 LDS cycles per row), then lane l = 4 k + p reads a quarter of row k -- four ds_read_b128 -- and adds its 16 numbers (15 plain
+// v_add_f32), and two quad DPP adds join the four quarters: 17 VALU instructions.  The quarter a lane reads in round i is
+// rotated by (lane >> 3) & 3 so that the 16 lanes the LDS serves per cycle (MI355X_MICROARCH.md: {0-3, 12-15, 20-27}, ...)
+// hit 16 different 16-byte columns of the 256-byte bank row: conflict free.  PH = 2 does it in two rounds of 8 values through
+// 2 KB (lane l = 8 k + p reads an eighth of row k: 2 reads, 7 adds, 3 DPP adds per round).
+// On return every lane of quad k holds the wave total of v[k] (PH = 1; same contract as wave_reduce16_dpp), or, for PH = 2,
+// lanes 8 k .. 8 k + 3 hold v[k] and lanes 8 k + 4 .. 8 k + 7 hold v[k + 8] (reduce16_slot in kernels_blend.h).
+typedef float red_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int PH>
+struct RedLds {
+    uint32_t m0;                  // LDS byte address of this wave's buffer (wave-uniform)
+    const red_f32x4* rd[4 / PH];  // this lane's read addresses, one per round
+    __device__ __forceinline__ void init(float* buf /* this wave's [16 / PH][64] floats */, int lane)
+    {
+        m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)buf);
+        if (PH == 1) {
+            const int k = lane >> 2, p = lane & 3, s = (lane >> 3) & 3;
+#pragma unroll
+            for (int i = 0; i < 4 / PH; i++) rd[i] = (const red_f32x4*)(buf + k * 64) + 4 * ((i + s) & 3) + p;
+        } else {
+            const int k = lane >> 3, p = lane & 7, s = (lane >> 4) & 1;
+#pragma unroll
+            for (int i = 0; i < 4 / PH; i++) rd[i] = (const red_f32x4*)(buf + k * 64) + 2 * p + ((i + s) & 1);
+        }
+    }
+};
+
+__device__ __forceinline__ float red_sum4(const red_f32x4& x) { return (x.x + x.y) + (x.z + x.w); }
+
+__device__ __forceinline__ void red_store8(uint32_t m0, float a, float b, float c, float d, float e, float f, float g, float h)
+{
+    asm volatile(
+        "s_mov_b32 m0, %8\n\t"
+        "s_nop 0\n\t"                                   // SALU write of M0 -> LDS add-TID instruction: one wait state
+        "ds_write_addtid_b32 %0 offset:0\n\t"
+        "ds_write_addtid_b32 %1 offset:256\n\t"
+        "ds_write_addtid_b32 %2 offset:512\n\t"
+        "ds_write_addtid_b32 %3 offset:768\n\t"
+        "ds_write_addtid_b32 %4 offset:1024\n\t"
+        "ds_write_addtid_b32 %5 offset:1280\n\t"
+        "ds_write_addtid_b32 %6 offset:1536\n\t"
+        "ds_write_addtid_b32 %7 offset:1792"
+        :
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h), "s"(m0)
+        : "memory");
+}
+
+__device__ __forceinline__ void red_store8_hi(uint32_t m0, float a, float b, float c, float d, float e, float f, float g, float h)   // rows 8..15
+{
+    asm volatile(
+        "s_mov_b32 m0, %8\n\t"
+        "s_nop 0\n\t"
+        "ds_write_addtid_b32 %0 offset:2048\n\t"
+        "ds_write_addtid_b32 %1 offset:2304\n\t"
+        "ds_write_addtid_b32 %2 offset:2560\n\t"
+        "ds_write_addtid_b32 %3 offset:2816\n\t"
+        "ds_write_addtid_b32 %4 offset:3072\n\t"
+        "ds_write_addtid_b32 %5 offset:3328\n\t"
+        "ds_write_addtid_b32 %6 offset:3584\n\t"
+        "ds_write_addtid_b32 %7 offset:3840"
+        :
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h), "s"(m0)
+        : "memory");
+}
+
+__device__ __forceinline__ float wave_reduce16_lds(float (&v)[16], const RedLds<1>& r)
+{
+    // (M0 is written and consumed inside each asm block; nothing else in these kernels uses it)
+    red_store8(r.m0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    red_store8_hi(r.m0, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
+    const red_f32x4 x0 = *r.rd[0], x1 = *r.rd[1], x2 = *r.rd[2], x3 = *r.rd[3];
+    float t = (red_sum4(x0) + red_sum4(x1)) + (red_sum4(x2) + red_sum4(x3));
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(t));
+    return t;
+}
+
+__device__ __forceinline__ float red_row8(float t)   // sum over the 8 lanes 8 j .. 8 j + 7
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(t));
+    return t;
+}
+
+__device__ __forceinline__ float wave_reduce16_lds(float (&v)[16], const RedLds<2>& r, int lane)
+{
+    red_store8(r.m0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    const red_f32x4 x0 = *r.rd[0], x1 = *r.rd[1];
+    red_store8(r.m0, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);   // (LDS operations of a wave execute in order: the reads above see round 1)
+    const red_f32x4 y0 = *r.rd[0], y1 = *r.rd[1];
+    const float lo = red_row8(red_sum4(x0) + red_sum4(x1));
+    const float hi = red_row8(red_sum4(y0) + red_sum4(y1));
+    return (lane & 4) ? hi : lo;
+}
+
+// ---- row-wise sums for the row-per-block backward (kernels_blend.h blend_bwd_rows_kernel) ----------------------------------
+// Every 16-lane row r of the wave holds the 16 partials of ITS OWN list entry; wanted: for every row the 16 sums over its 16
+// lanes.  Same transposition as above, in two rounds of 8 values through 2 KB: all lanes store value k into row k
+// (ds_write_addtid_b32), then lane l -- value k = l >> 3, source row r' = (l >> 1) & 3, half h = l & 1 -- reads the 8 numbers of
+// (k, r', h) with two ds_read_b128 (rotated by (l >> 4) & 1: conflict free, see above), adds them (7 v_add_f32) and joins the two
+// halves with one quad DPP add.  After the two rounds lane l keeps the total of value (l >> 3) + 8 (l & 1) of row (l >> 1) & 3:
+// 64 results, 64 lanes, one global atomic each -- no lane carries a duplicate.  Row 8 of the buffer transports one 32-bit word
+// per lane (the surfel id of the row's entry) to the lanes that finish that row; row 9 a second one (deterministic variant).
+struct RedRows {
+    uint32_t m0;                 // LDS byte address of this wave's buffer
+    const red_f32x4* rd[2];      // this lane's two read addresses
+    const uint32_t* meta;        // word of source row (lane >> 1) & 3 in row 8 (row 9: + 64)
+    __device__ __forceinline__ void init(float* buf /* [10][64] */, int lane)
+    {
+        m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)buf);
+        const int k = lane >> 3, r = (lane >> 1) & 3, h = lane & 1, s = (lane >> 4) & 1;
+#pragma unroll
+        for (int i = 0; i < 2; i++) rd[i] = (const red_f32x4*)(buf + k * 64) + 4 * r + 2 * h + ((i + s) & 1);
+        meta = (const uint32_t*)(buf + 8 * 64) + 16 * r;
+    }
+};
+
+__device__ __forceinline__ void red_store_word(uint32_t w, int row /* 8 or 9 */)   // M0 as left by red_store8
+{
+    if (row == 8) asm volatile("ds_write_addtid_b32 %0 offset:2048" : : "v"(w) : "memory");
+    else asm volatile("ds_write_addtid_b32 %0 offset:2304" : : "v"(w) : "memory");
+}
+
+__device__ __forceinline__ float red_pair(float t)   // t + the neighbouring lane's t (lanes 2 j, 2 j + 1)
+{
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(t));
+    return t;
+}
+
+// on return: the total of value (lane >> 3) + 8 (lane & 1) over the 16 lanes of row (lane >> 1) & 3, and in w8 (w9) the word that
+// row's lanes passed as word8 (word9; only transported when TWO)
+template <bool TWO>
+__device__ __forceinline__ float rows_reduce16(float (&v)[16], uint32_t word8, uint32_t word9, const RedRows& r, int lane, uint32_t& w8, uint32_t& w9)
+{
+    red_store8(r.m0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    red_store_word(word8, 8);
+    if (TWO) red_store_word(word9, 9);
+    const red_f32x4 x0 = *r.rd[0], x1 = *r.rd[1];
+    w8 = r.meta[0];
+    w9 = TWO ? r.meta[64] : 0u;
+    red_store8(r.m0, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);   // (LDS operations of a wave execute in order: the reads above see round 1)
+    const red_f32x4 y0 = *r.rd[0], y1 = *r.rd[1];
+    const float lo = red_pair(red_sum4(x0) + red_sum4(x1));
+    const float hi = red_pair(red_sum4(y0) + red_sum4(y1));
+    return (lane & 1) ? hi : lo;
+}
+
+// sum over the 16 lanes of a row, on every lane of the row (rare 2-D filter branch of the backward)
+__device__ __forceinline__ float row_sum16(float t)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(t));
+    return t;
+}
+
+// maximum over the 16 lanes of a row, on every lane of the row
+__device__ __forceinline__ int row_max16(int t)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(t));
+    return t;
+}
+
 // Eight values: on return the eight lanes 8k .. 8k+7 hold the wave total of v[k].
 __device__ __forceinline__ float wave_reduce8_dpp(float (&v)[8])
 {

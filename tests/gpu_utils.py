@@ -67,7 +67,8 @@ def run_hip_raw(case, dev="cuda:0"):
 
     tid = np.arange(256)
     lane, wave = tid & 63, tid >> 6
-    lx, ly = 8 * (wave & 1) + (lane & 7), 8 * (wave >> 1) + (lane >> 3)   # surfel_math.h lane_pixel
+    row, j = lane >> 4, lane & 15
+    lx, ly = 8 * (wave & 1) + 4 * (row & 1) + (j & 3), 8 * (wave >> 1) + 4 * (row >> 1) + (j >> 2)   # surfel_math.h lane_pixel
 
     def untile(a):  # [T,256] tile-major (slot = thread id) -> [H,W]
         a = a.reshape(tiles_y, tiles_x, 256)

@@ -49,10 +49,12 @@ void hm_preprocess(int P, int D, int M, const float* means3D, const float* scale
 // reference's form (pair_eval) OR in the affine form the kernels evaluate (alpha_affine + alpha_depth).
 // Bits 4..7: the quadrant mask the blend kernels use (box test refined by quad_hit_affine); bits 8..11: the box test alone.
 // -1: the branchy and branch-free reference-form evaluations disagree; -2 / -3: a quadrant is reachable although the record's
-// bounding box (q5) / the conic refinement says it is not (quadrant culling of the blend kernels would be wrong).
+// bounding box (q5) / the conic refinement says it is not (quadrant culling of the blend kernels would be wrong); -4: the same for
+// a 4x4 block under blocks_hit_linear (the row-per-block kernels' test).
 int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
 {
     int any = 0;
+    uint32_t any16 = 0;   // bit (4 (ly / 4) + lx / 4): some pixel of that 4x4 block passes
     const float X0 = (float)(tx * 16) + 8.0f, Y0 = (float)(ty * 16) + 8.0f;
     const TileAffine ta = tile_affine(Q(r, 0), Q(r, 1), Q(r, 2), X0, Y0);
     for (int ly = 0; ly < 16; ly++)
@@ -68,7 +70,17 @@ int hm_tile_reachable(int W, int H, int tx, int ty, const float* r)
             bool use3d;
             kc = kc && alpha_depth(ev, r[6], r[7], r[8], use3d) >= kNear;
             any |= (ka || kc) ? (1 << ((ly >> 3) * 2 + (lx >> 3))) : 0;
+            any16 |= (ka || kc) ? (1u << ((ly >> 2) * 4 + (lx >> 2))) : 0u;
         }
+    // the row-per-block kernels' test (blocks_hit_linear): bit b of quadrant w = block (b & 1, b >> 1) of the quadrant
+    for (int w = 0; w < 4; w++) {
+        const float qx = (float)(tx * 16 + 8 * (w & 1)), qy = (float)(ty * 16 + 8 * (w >> 1));
+        const uint32_t bm = blocks_hit_linear(ta, kSqrt2 * ((w & 1) ? 0.5f : -7.5f), kSqrt2 * ((w & 2) ? 0.5f : -7.5f), Quad{r[20], r[21], r[22], r[23]}, qx, qy);
+        for (int b = 0; b < 4; b++) {
+            const int bxi = 2 * (w & 1) + (b & 1), byi = 2 * (w >> 1) + (b >> 1);
+            if (((any16 >> (byi * 4 + bxi)) & 1u) && !((bm >> b) & 1u)) return -4;   // a 4x4 block with a passing pixel was dropped
+        }
+    }
     const uint32_t box = quad_mask(r[20], r[21], r[22], r[23], (float)(tx * 16), (float)(ty * 16));
     uint32_t mask = 0;
     for (int w = 0; w < 4; w++) mask |= (((box >> w) & 1u) && quad_hit_affine(ta, w)) ? (1u << w) : 0u;
@@ -199,6 +211,81 @@ static inline bool wave_sees(int w, const float* r, float px0, float py0)
     const float yf = py0 + 4.0f * w + 0.5f;
     return r[21] >= px0 + 0.5f && r[20] <= px0 + 15.5f && r[23] >= yf && r[22] <= yf + 3.0f;
 }
+// Iteration counts of a blend kernel whose 16-lane rows walk their own 4x4 block's list (round-4 design study).  Per (tile,
+// quadrant wave): the list is staged in chunks of `chunk` entries; an entry goes on the list of block b (the four 4x4 blocks of the
+// quadrant) when its pixel box and block_hit_affine at 4x4 granularity say it can reach the block and the block still has a live
+// pixel at the start of the chunk; the wave then runs max_b(list length) iterations.  out[0] = visits of today's kernel (one per
+// entry that hits the quadrant), out[1] = row iterations with rows synchronised per chunk, out[2] = with rows free to drift
+// (max over blocks of the whole-list totals), out[3] = sum of (entry, block) pairs / 4 (perfect balance), out[4] = blending
+// lane-visits (pixels that blend), out[5] = (entry, block) pairs, out[6] = (entry, block) pairs with a passing live pixel that the
+// test dropped (must be 0).  linear = 1: the kernels' test (blocks_hit_linear, which replaces the quadrant test as well);
+// 0: quadrant test + the exact minimum per block (block_hit_affine).
+extern "C" void hm_row_stats(int W, int H, int chunk, int linear, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*8*/)
+{
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    double visits = 0, it_sync = 0, it_free = 0, pairs = 0, blend_px = 0, missed = 0;
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const int tile = ty * tiles_x + tx;
+            const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            const float px0 = (float)(tx * 16), py0 = (float)(ty * 16);
+            for (int w = 0; w < 4; w++) {
+                PixFwd st[64]; bool done[64];
+                for (int k = 0; k < 64; k++) {
+                    pixfwd_init(st[k]);
+                    const int x = 8 * (w & 1) + (k & 7), y = 8 * (w >> 1) + (k >> 3);
+                    done[k] = !(tx * 16 + x < W && ty * 16 + y < H);
+                }
+                double tot_b[4] = {0, 0, 0, 0};
+                for (uint32_t base = r0; base < r1; base += chunk) {
+                    int alive = 0, balive[4] = {0, 0, 0, 0};
+                    for (int k = 0; k < 64; k++) if (!done[k]) { alive++; balive[((k >> 3) >> 2) * 2 + ((k & 7) >> 2)] = 1; }
+                    if (!alive) break;
+                    int nb[4] = {0, 0, 0, 0};
+                    for (uint32_t e = base; e < r1 && e < base + chunk; e++) {
+                        const float* r = rec + (size_t)point_list[e] * kRecFloats;
+                        const TileAffine ta = tile_affine(Q(r, 0), Q(r, 1), Q(r, 2), px0 + 8.0f, py0 + 8.0f);
+                        const bool qhit = ((quad_mask(r[20], r[21], r[22], r[23], px0, py0) >> w) & 1u) && quad_hit_affine(ta, w);
+                        uint32_t bm = 0;
+                        if (linear) {
+                            const float qx = px0 + 8.0f * (w & 1), qy = py0 + 8.0f * (w >> 1);
+                            bm = blocks_hit_linear(ta, kSqrt2 * ((w & 1) ? 0.5f : -7.5f), kSqrt2 * ((w & 2) ? 0.5f : -7.5f), Quad{r[20], r[21], r[22], r[23]}, qx, qy);
+                        } else if (qhit) {
+                            for (int b = 0; b < 4; b++) {
+                                const float bx = 8.0f * (w & 1) + 4.0f * (b & 1), by = 8.0f * (w >> 1) + 4.0f * (b >> 1);   // first pixel of the block in the tile
+                                const float xf = px0 + bx + 0.5f, yf = py0 + by + 0.5f;
+                                if (!(r[21] >= xf && r[20] <= xf + 3.0f && r[23] >= yf && r[22] <= yf + 3.0f)) continue;
+                                const float us0 = kSqrt2 * (bx - 7.5f), vs0 = kSqrt2 * (by - 7.5f);
+                                if (block_hit_affine(ta, us0, us0 + 3.0f * kSqrt2, vs0, vs0 + 3.0f * kSqrt2)) bm |= 1u << b;
+                            }
+                        }
+                        if (qhit) visits += 1;
+                        for (int b = 0; b < 4; b++)
+                            if (balive[b] && ((bm >> b) & 1u)) nb[b]++;
+                        for (int k = 0; k < 64; k++) {
+                            if (done[k]) continue;
+                            const int x = 8 * (w & 1) + (k & 7), y = 8 * (w >> 1) + (k >> 3);
+                            PairEval ev;
+                            if (pair_eval_bf(px0 + x + 0.5f, py0 + y + 0.5f, Q(r, 0), Q(r, 1), Q(r, 2), ev)) {
+                                if (!((bm >> (((k >> 3) >> 2) * 2 + ((k & 7) >> 2))) & 1u)) missed += 1;
+                                blend_px += 1;
+                                st[k].contributor = e - r0 + 1;
+                                if (!pixfwd_blend(st[k], ev, Q(r, 3), Q(r, 4))) done[k] = true;
+                            }
+                        }
+                    }
+                    int mx = 0;
+                    for (int b = 0; b < 4; b++) { mx = nb[b] > mx ? nb[b] : mx; tot_b[b] += nb[b]; pairs += nb[b]; }
+                    it_sync += mx;
+                }
+                double mt = 0;
+                for (int b = 0; b < 4; b++) mt = tot_b[b] > mt ? tot_b[b] : mt;
+                it_free += mt;
+            }
+        }
+    out[0] = visits; out[1] = it_sync; out[2] = it_free; out[3] = pairs / 4.0; out[4] = blend_px; out[5] = pairs; out[6] = missed;
+}
+
 extern "C" void hm_blend_stats(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* rec, double* out /*16*/)
 {
     // per (tile, entry, 16x4 strip) with the wave still alive: visited = the entry's pixel box touches the strip (what the

@@ -152,6 +152,7 @@ def test_tight_tile_rects_are_conservative(hm, cfg):
                 assert r != -1, "pair_eval / pair_eval_bf disagree"
                 assert r != -2, "bounding box culls a reachable 8x8 quadrant (surfel %d, tile %d,%d)" % (i, tx, ty)
                 assert r != -3, "conic mask culls a reachable 8x8 quadrant (surfel %d, tile %d,%d)" % (i, tx, ty)
+                assert r != -4, "blocks_hit_linear culls a reachable 4x4 block (surfel %d, tile %d,%d)" % (i, tx, ty)
                 if inside:
                     quads += [bin(r & 15).count("1"), bin((r >> 4) & 15).count("1"), bin((r >> 8) & 15).count("1")]
                 if not inside:

@@ -31,3 +31,12 @@ for shape, name in ((0, "16x4 strips, box"), (2, "8x8 quadrants, box"), (1, "8x8
   if g_shape_is_quadrant := (shape >= 1):
       print("of the 4 4x4 sub-blocks of a visited quadrant: %.2f hold a blending pixel (%.2f a passing one); of the 2 8x4 halves: %.2f"
             % (out[12] / max(vis, 1), out[14] / max(vis, 1), out[13] / max(vis, 1)))
+# ---- row-per-block kernels (round 4): iterations a wave would run if each of its four 16-lane rows walked its own 4x4 block's list
+for chunk, linear in ((64, 0), (64, 1), (48, 1)):
+    out = np.zeros(8)
+    hm.hm_row_stats(W, H, chunk, linear, p(np.ascontiguousarray(ranges)), p(np.ascontiguousarray(plist)), p(rec), p(out))
+    v, s_, f, b, px, pairs, missed = out[:7]
+    print("---- rows, %d entries per chunk, %s block test: visits of the quadrant kernel %d ; row iterations %d (%.3f of the visits), with free-running rows %.3f, "
+          "perfectly balanced %.3f ; %.2f blocks per visit ; %.1f of 16 lanes blend per (entry, block) ; dropped pairs with a passing pixel: %d"
+          % (chunk, "tangent-plane" if linear else "exact", v, s_, s_ / v, f / v, b / v, pairs / v, px / pairs, missed))
+
