@@ -492,7 +492,12 @@ struct BlendBwdArgs {
 //   4  transposition through the wave's own LDS (wave_reduce.h: 16 ds_write_addtid_b32 + 4 ds_read_b128 + 17 VALU); DGS_RED_PHASES = 2
 //      does it in two rounds of 8 values through half the LDS.
 // Measured at 200k / 800x800 (blend bwd, ms): 0: 0.338, 1: 0.548 (the matrix pipe -- 16 x 32 cycles per visit -- becomes the
-// bottleneck), 2: 0.455, 3: 0.315.  On return lane l holds the wave total of v[l & 15] (variants 1, 2) / v[l >> 2] (variant 0); reduce16_slot() tells which.
+// bottleneck), 2: 0.455, 3: 0.315 (round 2; 0.304 on the round-4 kernel), 4 (default since round 4): 0.267 with two rounds, 48 staged
+// entries per chunk and 5 workgroups per CU (30 KB of LDS); one round through 4 KB: 0.304 at 3 workgroups per CU (64 entries per chunk),
+// 0.277 at 4 (48), 0.272 at 5 (32); two rounds at 4 workgroups per CU (64): 0.281 -- the occupancy decides, the chunk size does not
+// (variant 3 with 48 entries: 0.304).  Where the 0.267 go (DGS_DIAG_BWD): atomics 0.009, reduction 0.056 (0.104 with variant 3),
+// gradient arithmetic 0.10, alpha evaluation + loop + staging 0.104.
+// On return lane l holds the wave total of v[l & 15] (variants 1, 2) / v[l >> 2] (variants 0, 3, 4 with one round); reduce16_slot() tells which.
 #ifndef DGS_BWD_REDUCE
 #define DGS_BWD_REDUCE 4
 #endif
@@ -799,7 +804,21 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
 // at ITS pixels' last contributor instead of the wave's.  The 16 partials are summed per row (wave_reduce.h rows_reduce16) and all
 // 64 lanes issue one atomic each: row r' = (l >> 1) & 3 of value (l >> 3) + 8 (l & 1), to the surfel of row r's entry.
 // Per-pixel arithmetic and entry order are those of blend_bwd_kernel; the sums reach the accumulator rows in 16 instead of 4
-// pieces per (tile, entry).  Iterations per wave: 0.87 of the visits of the kernel above on the 200k / 800x800 scene (hm_row_stats).
+// pieces per (tile, entry).  Iterations per wave: 0.87 of the visits of the kernel above on the 200k / 800x800 scene (tools/blend_stats.py:
+// a splat that reaches a quadrant reaches 2.9 of its 4 blocks, and the four rows of a wave wait for the longest list of the chunk).
+//
+// MEASURED AND NOT THE DEFAULT (round 4; parity suite green; same lease, 200k / 800x800, ms per launch):
+//     blend_bwd_kernel, DPP reduction (round 3)      0.304
+//     blend_bwd_kernel, LDS reduction (the default)  0.269
+//     this kernel                                    0.704     without its atomics 0.253, without reduction + atomics 0.189
+// The float atomics, free in the kernel above (0.271 -> 0.262 without them), are what this design cannot afford: a visit there ends
+// in 16 lanes adding to ONE 64-byte accumulator row -- the wave-wide sum has already merged the up to four blocks an entry reaches in
+// the quadrant -- while an iteration here ends in 64 lanes adding to up to four rows, and whenever the rows of the wave sit on the same
+// entry (large splats: most of the time) four lanes of one instruction hit the same address.  3.5 M (entry, block) pairs x 16 lanes
+// instead of 1.2 M visits x 16: the L2's atomic units are the bound (0.45 ms).  Merging equal targets across the four rows before
+// the atomic costs ~14 DPP-class instructions per iteration (two exchange steps of value + target) -- as much as the 13 % fewer
+// iterations save, and the upper bound without any atomic is only 6 % under the default.  Kept as the committed A/B
+// (-DDGS_BWD_ROWS=1, tools/ab_variants.sh); lane_pixel keeps the block layout, which costs the default nothing.
 #ifndef DGS_BWD_ROWS
 #define DGS_BWD_ROWS 0
 #endif
