@@ -285,7 +285,9 @@ def main():
     ap.add_argument("--pre-iterations", type=int, default=10000, help="--workload trained: fit() iterations before the timed region")
     ap.add_argument("--drift-gap", type=int, default=100, help="steps between the headline window and the second (drift) window; 0: skip")
     args = ap.parse_args()
-    assert args.steps <= 128, "the per-step losses of the timed steps come from a 256-entry ring"
+    # the per-step losses of the timed steps are read back from the step guard's pinned ring: size it for the run asked for
+    from dgs_amd.train import Trainer as _Trainer
+    _Trainer.GUARD_RING = max(_Trainer.GUARD_RING, 2 * (args.steps + args.warmup) + 64)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -456,7 +458,10 @@ def main():
         # --pmc runs of THIS command, corrected as MI355X_MICROARCH.md prescribes).  Reported only when the file was taken on this
         # workload AND on the library sources that are loaded now (hash of sources + flags).
         pmc, pmc_src = {}, None
-        pmc_path = os.path.join("profiles", "r03_pmc_%s.json" % args.workload)
+        # the newest round's file for this workload (profiles/rNN_pmc_<workload>.json); a file of other sources is named, not used
+        import glob as _glob
+        _cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % args.workload)))
+        pmc_path = os.path.join("profiles", os.path.basename(_cands[-1])) if _cands else os.path.join("profiles", "r04_pmc_%s.json" % args.workload)
         try:
             with open(os.path.join(ROOT, pmc_path)) as f:
                 pj = json.load(f)
@@ -520,14 +525,19 @@ def main():
             ms, n, src, label = d
             R, Pv = src["R"] / max(src["pre_n"], 1), src["Pv"] / max(src["pre_n"], 1)
             b = kernel_bytes(name, P, Pv, R, M, ntiles)
-            gbs = b["survey"] / (ms * 1e-3) / 1e9
+            # binning: the SURVEY figure prices the reference's 6-pass radix sort; this implementation buckets once and sorts in LDS, so
+            # the fraction is taken on the bytes it actually moves (the SURVEY figure stays next to it)
+            basis = "own" if name == "binning" else "survey"
+            gbs = b[basis] / (ms * 1e-3) / 1e9
             kernels = {"preprocess_fwd": ["preprocess_fwd_kernel"], "surfel_bwd": ["surfel_bwd_kernel"],
                        "binning": ["count_tiles_lds_kernel", "column_pass_kernel", "scan_tiles_kernel", "scatter_keys_lds_kernel", "sort_tiles_radix_kernel"]}[name]
             traffic = [pmc_of(k, "hbm_traffic_bytes_per_launch") for k in kernels]
             return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                     "traffic": None if any(t is None for t in traffic) else int(sum(t * (2 if k == "column_pass_kernel" else 1) for t, k in zip(traffic, kernels))),
-                    "avg_ms": round(ms, 4), "alg_bytes_per_launch": round(b["survey"]), "own_bytes_per_launch": round(b["own"]),
-                    "own_GBs": round(b["own"] / (ms * 1e-3) / 1e9, 2), "formula": b["formula"], "R": round(R), "P_visible": round(Pv),
+                    "avg_ms": round(ms, 4), "frac_basis": "own_bytes_per_launch" if basis == "own" else "alg_bytes_per_launch (SURVEY 8d)",
+                    "alg_bytes_per_launch": round(b["survey"]), "own_bytes_per_launch": round(b["own"]),
+                    "own_GBs": round(b["own"] / (ms * 1e-3) / 1e9, 2), "survey_GBs": round(b["survey"] / (ms * 1e-3) / 1e9, 2),
+                    "survey_frac": round(b["survey"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "formula": b["formula"], "R": round(R), "P_visible": round(Pv),
                     "timing": "%s, %d launches" % (label, n)}
 
         out = {

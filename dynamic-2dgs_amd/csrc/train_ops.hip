@@ -1807,6 +1807,10 @@ struct AdamSegs {
     float lr_final[kAdamSeg];
     float sched_steps[kAdamSeg];
     float sched_t0;
+    // step origin of a segment: its bias corrections use t - t_origin.  torch.optim.Adam counts steps PER PARAMETER and skips
+    // parameters without a gradient, so a parameter that joins the optimisation late (the reference's deformation and `feature`
+    // after the warm-up, train_gui.py:281-285) starts at step 1 while the run's counter t is in the thousands
+    float t_origin[kAdamSeg];
     float gscale;   // gradients are read as grad * gscale (data parallel: the bucket holds the SUM over ranks, gscale = 1 / world)
     int zero_grad;  // the gradient is cleared behind the read (optimizer.step() + zero_grad() in one pass; also on a skipped step)
 };
@@ -1831,7 +1835,8 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
     const int s = pl.x;
     const long long seg_len = sg.off[s + 1] - sg.off[s];
     const float t = step_count[0];
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    const float ts = fmaxf(t - sg.t_origin[s], 1.0f);
+    const float bc1 = 1.0f - powf(b1, ts), bc2 = 1.0f - powf(b2, ts);
     float lr = sg.lr[s];
     if (sg.sched_steps[s] > 0.0f) {
         // the reference sets the rate AFTER optimizer.step(): step t runs at schedule(t - 1)
@@ -2053,6 +2058,10 @@ int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets,
                        const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                        float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
                        float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream);
+int dgs_adam_step_origin(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                         const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                         const float* step_origins, float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq,
+                         const float* step_count, float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream);
 
 int dgs_adam_step(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* grad, float* exp_avg,
                   float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, void* stream)
@@ -2099,6 +2108,15 @@ int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets,
                        float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
                        float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream)
 {
+    return dgs_adam_step_origin(nseg, params, offsets, lrs, lrs2, periods, splits, lrs_final, sched_steps, sched_t0, nullptr, grad_scale, grad,
+                                zero_grad, exp_avg, exp_avg_sq, step_count, beta1, beta2, eps, plan, skip, stream);
+}
+
+int dgs_adam_step_origin(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                         const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                         const float* step_origins, float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq,
+                         const float* step_count, float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream)
+{
     if ((lrs_final != nullptr) != (sched_steps != nullptr)) return fail(-1, "dgs_adam_step_sched: pass lrs_final and sched_steps together");
     if (nseg <= 0 || nseg > kAdamSeg || !params || !offsets || !lrs || !grad || !exp_avg || !exp_avg_sq || !step_count || !plan)
         return fail(-1, "dgs_adam_step: bad argument");
@@ -2113,6 +2131,8 @@ int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets,
         if (sg.period[s] < 0 || sg.split[s] < 0) return fail(-1, "dgs_adam_step_pattern: negative period / split");
         sg.lr_final[s] = lrs_final ? lrs_final[s] : lrs[s];
         sg.sched_steps[s] = sched_steps ? sched_steps[s] : 0.0f;
+        sg.t_origin[s] = step_origins ? step_origins[s] : 0.0f;
+        if (!(sg.t_origin[s] >= 0.0f)) return fail(-1, "dgs_adam_step_origin: negative step origin");
         if (sg.sched_steps[s] > 0.0f && !(lrs[s] > 0.0f && sg.lr_final[s] > 0.0f))
             return fail(-1, "dgs_adam_step_sched: a scheduled segment needs positive initial and final rates");
     }

@@ -17,7 +17,8 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_mlp_forward", "dgs_mlp_backward", "dgs_knn_points2", "dgs_deform_forward", "dgs_deform_backward", "dgs_photo_forward",
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
-            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard")
+            "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard",
+            "dgs_adam_step_origin")
 
 
 def _deps():
@@ -138,6 +139,9 @@ def load():
         lib.dgs_adam_step_zero.restype = ci
         lib.dgs_adam_step_zero.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, ci, vp, vp, vp,
                                            ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        lib.dgs_adam_step_origin.restype = ci
+        lib.dgs_adam_step_origin.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_float, vp, ci, vp, vp, vp,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         lib.dgs_densify_accumulate_guarded.restype = ci
         lib.dgs_densify_accumulate_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]
         if lib.dgs_train_ops_abi_version() != 1:
@@ -283,6 +287,8 @@ class FlatAdam:
         self._lr_final = (ctypes.c_float * n_)(*[float(schedules[i][0]) if i in schedules else self.lrs[i] for i in range(n_)])
         self._sched_steps = (ctypes.c_float * n_)(*[float(schedules[i][1]) if i in schedules else 0.0 for i in range(n_)])
         self.sched_t0 = float(sched_t0)
+        # step origin per parameter (dgs_adam_step_origin): the bias corrections of parameter i use t - origin[i]; set_origin()
+        self._origin = (ctypes.c_float * n_)(*([0.0] * n_))
         self.grad_scale = 1.0   # gradients are read as grad * grad_scale (1 / world when the bucket holds the sum over ranks)
         # step guard (dgs_step_guard): `skip` = a device int32 that is non-zero when this step must not change anything (a
         # rank's rasterizer overflowed its list capacity); None = every step is applied
@@ -327,6 +333,13 @@ class FlatAdam:
                                 sl(self._sched_steps, ctypes.c_float), plan)
         return self._plans[key]
 
+    def set_origin(self, first, last, t0):
+        """Parameters [first, last) count their Adam steps from t0 (the run's step count when they join the optimisation): what
+        torch.optim.Adam's per-parameter step does for a parameter whose .grad was None until then.  Kernel arguments: a captured
+        step must be re-captured afterwards."""
+        for i in range(first, self._n if last is None else last):
+            self._origin[i] = float(t0)
+
     def moments(self, p):
         """(exp_avg, exp_avg_sq) of parameter p as views shaped like p (state surgery of dgs_amd/densify.py)."""
         for i, q in enumerate(self.params):
@@ -363,11 +376,12 @@ class FlatAdam:
         dev = self.grad.device
         last = self._n if last is None else last
         k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, plan = self._range(first, last)
+        origin = (ctypes.c_float * k)(*list(self._origin)[first:last])
         skip = None if self.skip is None else self.skip.data_ptr()
         with torch.cuda.device(dev):
             if advance:
                 self.guard()
-            rc = lib.dgs_adam_step_zero(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, float(self.grad_scale),
+            rc = lib.dgs_adam_step_origin(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, origin, float(self.grad_scale),
                                         self.grad.data_ptr(), 1 if self.zero_grads else 0,
                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
                                         self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
@@ -566,7 +580,32 @@ class DeferredNodeMLP:
         self.state = None
 
 
-_COHERENT_TABLES = {}
+class CoherentTables:
+    """The persistent zeroed [M][13+H+2] node tables of the coherent skinning backward, owned by whoever runs it (ControlNodes keeps
+    one per module: two trainers in one process never add into each other's table).  One table per (device, M, H, stream): two
+    backward passes on different streams must not share one; created during the warm-up steps that precede a capture, never inside
+    one.  The reduce kernel leaves a table zeroed again; a backward whose deferred reduction never ran (an exception between the
+    two) leaves sums behind -- the table is marked dirty for that span and cleared before it is used again."""
+
+    def __init__(self):
+        self._tables = {}
+        self._dirty = set()
+
+    def get(self, lib, dev, M, H):
+        key = (dev, M, H, int(torch.cuda.current_stream(dev).cuda_stream))
+        t = self._tables.get(key)
+        if t is None:
+            t = self._tables[key] = torch.zeros(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
+        elif key in self._dirty:
+            t.zero_()
+            self._dirty.discard(key)
+        return key, t
+
+    def mark(self, key, dirty):
+        (self._dirty.add if dirty else self._dirty.discard)(key)
+
+
+_DEFAULT_TABLES = CoherentTables()   # for callers of fused_deform that do not bring their own
 
 
 class _FusedDeform(torch.autograd.Function):
@@ -576,7 +615,7 @@ class _FusedDeform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                g_attrs_out=None, coherent=False, reduce_later=None, sink_store=False):
+                g_attrs_out=None, coherent=False, reduce_later=None, sink_store=False, tables=None):
         lib = load()
         dev = xyz.device
         N, M = xyz.shape[0], nodes.shape[0]
@@ -602,6 +641,7 @@ class _FusedDeform(torch.autograd.Function):
         ctx.mask, ctx.H, ctx.sink, ctx.g_attrs_out, ctx.coherent = mask, H, sink, g_attrs_out, bool(coherent)
         ctx.reduce_later = reduce_later if (g_attrs_out is not None and sink is not None) else None
         ctx.sink_store = bool(sink_store) and sink is not None and feature.shape[1] == H
+        ctx.tables = tables if tables is not None else _DEFAULT_TABLES
         return means3D, scales, rots, opac
 
     @staticmethod
@@ -615,13 +655,7 @@ class _FusedDeform(torch.autograd.Function):
         g_attrs = torch.empty_like(attrs) if ctx.g_attrs_out is None else ctx.g_attrs_out  # deferred node MLP: caller's buffer
         persistent = 0
         if ctx.coherent:
-            # one persistent zeroed [M][13+H+2] table per (device, M, H, stream): the reduce kernel leaves it zeroed again.  Keyed
-            # by the stream as well: two backward passes on different streams must not add into one table (created during the
-            # warm-up steps that precede a capture, never inside one)
-            key = (dev, M, H, int(torch.cuda.current_stream(dev).cuda_stream))
-            scratch = _COHERENT_TABLES.get(key)
-            if scratch is None:
-                scratch = _COHERENT_TABLES[key] = torch.zeros(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
+            tkey, scratch = ctx.tables.get(lib, dev, M, H)   # the caller's persistent zeroed table (CoherentTables)
             persistent = 4
         else:
             scratch = torch.empty(int(lib.dgs_lbs_scratch_bytes(M, H)), dtype=torch.uint8, device=dev)
@@ -645,16 +679,20 @@ class _FusedDeform(torch.autograd.Function):
                 outs[6].data_ptr(), outs[7].data_ptr(), g_attrs.data_ptr(), flags, scratch.data_ptr(), _stream(dev))
         _check(lib, rc, "dgs_deform_backward")
         if defer:
+            tables = ctx.tables
+            tables.mark(tkey, True)   # sums stay in the table until the deferred reduction has run
+
             def reduce(M=M, H=H, nr=node_radius, nw=node_weight, outs=outs, g_attrs=g_attrs, flags=flags, scratch=scratch, dev=dev):
                 with torch.cuda.device(dev):
                     _check(lib, lib.dgs_deform_reduce(M, H, nr.data_ptr(), nw.data_ptr(), outs[5].data_ptr(), outs[6].data_ptr(), outs[7].data_ptr(),
                                                       g_attrs.data_ptr(), flags & 5, scratch.data_ptr(), _stream(dev)), "dgs_deform_reduce")
+                tables.mark(tkey, False)
             ctx.reduce_later.append(reduce)
-        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None, None, None)
+        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None, None, None, None)
 
 
 def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False,
-                 g_attrs_out=None, coherent=False, reduce_later=None):
+                 g_attrs_out=None, coherent=False, reduce_later=None, tables=None):
     # grad_sink: False, True (ADD into the .grad tensors) or "store" (OVERWRITE them: every element of the eight tensors is written by
     # every backward, so a gradient buffer that only ever receives stores needs no clearing; needs feature.shape[1] == H)
     """Raw surfel parameters + node tables + node attributes -> (means3D, scales, rotations, opacity) for the rasterizer.
@@ -663,7 +701,8 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
     wave and issues global atomics instead of building 256 per-workgroup LDS tables (dgs_deform_backward, accumulate bit 1).
     reduce_later: a list (coherent + grad_sink + g_attrs_out only).  The backward then leaves its node table unreduced and appends
     ONE callable to the list; the caller must run it (on any stream ordered behind the backward) before the node gradients or
-    g_attrs_out are read -- ControlNodes.finish_backward does, on the node-MLP backward's side stream."""
+    g_attrs_out are read -- ControlNodes.finish_backward does, on the node-MLP backward's side stream.
+    tables: the CoherentTables that own the persistent node table of the coherent backward (default: a process-wide one)."""
     params = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
     sink = None
     if grad_sink and torch.is_grad_enabled():
@@ -671,7 +710,7 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
         if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
             raise RuntimeError("fused_deform(grad_sink=True): every parameter needs a contiguous fp32 .grad")
     return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                              g_attrs_out, coherent, reduce_later, grad_sink == "store")
+                              g_attrs_out, coherent, reduce_later, grad_sink == "store", tables)
 
 
 _ONES = {}

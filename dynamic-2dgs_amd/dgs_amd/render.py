@@ -89,7 +89,8 @@ def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=Fa
     rendered_image, radii, allmap = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=None)
-    rets = {"render": rendered_image, "viewspace_points": screenspace_points, "radii": radii, "allmap": allmap}
+    # 'bg_color' on both paths: with random_bg_color the caller composites its target over the SAME background (gaussian_renderer/__init__.py:41,114)
+    rets = {"render": rendered_image, "viewspace_points": screenspace_points, "radii": radii, "allmap": allmap, "bg_color": bg_color}
     if not postprocess:  # the fused loss / statistics kernels work on the rasterizer outputs directly (radii > 0 is the filter)
         return rets
     rets["visibility_filter"] = radii > 0

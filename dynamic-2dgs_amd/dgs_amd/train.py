@@ -208,6 +208,9 @@ class Trainer:
             self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat, patterns=patterns,
                                              schedules=schedules, sched_t0=float(self._steps_done))
             self.opt_deform = None
+            if old is not None and hasattr(old, "_origin") and len(old._origin) == len(plist):
+                for i in range(len(plist)):   # rebuilt state (grow / node densification): the parameters keep their step origins
+                    self.opt_surfels._origin[i] = old._origin[i]
             self.opt_surfels.zero_grads = False  # True: step + zero_grad in one pass, see _forward for why it is off
             self._bucket_clean = False
             self._init_guard(old)
@@ -543,9 +546,13 @@ class Trainer:
         (the ARAP term does)."""
         if not self.store_grads or self.opt_deform is not None or self._arap_active():
             return False
-        key = (id(self.bucket), self.surfels.feature.shape[1])
-        if getattr(self, "_store_key", None) != key:
-            s, d = self.surfels, self.deform
+        s, d = self.surfels, self.deform
+        # everything the verdict depends on is in the key: the bucket and optimiser objects themselves (kept alive by the key, so an
+        # id cannot be reused), and the public switches a caller may flip between steps
+        key = (self.bucket, self.opt_surfels, s.feature.shape[1], bool(self.sh_grad_sink), bool(getattr(d, "defer_mlp_backward", False)),
+               bool(getattr(d, "grad_sink", False)), bool(getattr(d, "overlap_streams", False)))
+        old = getattr(self, "_store_key", None)
+        if old is None or len(old) != len(key) or any(a is not b and a != b for a, b in zip(old, key)):
             ok = (getattr(s, "packed_sh", False) and self.sh_grad_sink and self.n_sh > 0 and getattr(d, "defer_mlp_backward", False)
                   and bool(getattr(d, "grad_sink", False)) and s.feature.shape[1] == d.hyper_dim)
             if ok:
@@ -563,11 +570,13 @@ class Trainer:
         s = self.surfels
         if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink:
             import diff_surfel_rasterization as dsr
-            dsr.set_sh_grad_sink(s._features.grad, all_rows=getattr(self, "_store_now", False))
+            # the sink belongs to THIS trainer's SH parameter (keyed by the tensor the forward was given): other trainers on the
+            # device keep theirs, and removing it afterwards removes nothing else
+            dsr.set_sh_grad_sink(s._features.grad, all_rows=getattr(self, "_store_now", False), shs=s._features)
             try:
                 return fn()
             finally:
-                dsr.set_sh_grad_sink(None)
+                dsr.set_sh_grad_sink(None, shs=s._features)
         return fn()
 
     def _statistics(self, pkg, fused, early_radii=False):
@@ -900,6 +909,11 @@ class Trainer:
         if new == (self.warmup, self.lambda_normal, self.lambda_dist):
             return False
         self._flush_guard()
+        if self.warmup and not new[0] and self.opt_deform is None:
+            # `feature` and the deformation parameters join the optimisation now: torch.optim.Adam (the reference, train_gui.py:281-285,
+            # 427-432) has skipped them so far, so their own step count starts at 1 -- not at the run's count, which would switch
+            # the bias corrections off for moments that start from zero (3-6 x the learning rate for the first few hundred steps)
+            self.opt_surfels.set_origin(self.n_surfel_params - 1, None, float(self.opt_surfels.t.item()))
         self.warmup, self.lambda_normal, self.lambda_dist = new
         if self._graph:
             self._graph = None

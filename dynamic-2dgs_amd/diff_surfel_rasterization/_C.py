@@ -424,7 +424,7 @@ def profile_reset(device=None):
 
 def profile_read(device=None):
     """Accumulated over the timed launches: blend kernels {'fwd_ms', 'fwd_n', 'bwd_ms', 'bwd_n', 'fwd_S', 'bwd_S'}, and
-    {'pre_ms', 'pre_n'} preprocess_fwd, {'bin_ms', 'bin_n'} binning (count + scan + scatter + per-tile sort), {'sbw_ms', 'sbw_n'}
+    {'pre_ms', 'pre_n'} preprocess_fwd, {'bin_ms', 'bin_n'} binning (count + scan + scatter + per-tile sort; kernel time only in capacity mode: the exact-size path has a host read inside the span), {'sbw_ms', 'sbw_n'}
     surfel_bwd, 'R' = sum of num_rendered, 'Pv' = sum of visible surfels over the timed forwards."""
     out = (ctypes.c_double * 14)()
     with _on(device):

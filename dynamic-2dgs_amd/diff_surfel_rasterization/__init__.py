@@ -62,36 +62,49 @@ def _guarded(fn, args, debug, dump_name, what):
 
 import threading
 
-_SINKS = {}                   # device index -> sink tensor
+_SINKS = {}                   # (device index, data_ptr of the shs tensor or None) -> (sink tensor, all_rows)
 _SINKS_LOCK = threading.Lock()
+_BWD_LOCKS = {}               # device index -> lock around (option 8, backward launch): the option lives in the device's default context
 
 
-def set_sh_grad_sink(tensor, device=None, all_rows=False):
-    """Extension (not in the reference): while set to a contiguous fp32 [P,M,3] tensor, backward passes ON THE TENSOR'S DEVICE write
-    dL/dSH of the visible surfels directly into it (the kernel stores, it does not accumulate; rows of culled surfels are left as
-    they are) and return no gradient for `shs`.  For trainers that keep gradients in one pre-zeroed flat buffer.  None restores
-    the reference behaviour (for `device`, or for every device when no device is given).  The state is per DEVICE, like the
-    library's default contexts: two trainers on two devices do not see each other's sink.  It cannot be per thread: autograd runs
-    the backward of a HIP device on that device's own worker thread, not on the thread that called backward()."""
+def set_sh_grad_sink(tensor, device=None, all_rows=False, shs=None):
+    """Extension (not in the reference): while set to a contiguous fp32 [P,M,3] tensor, backward passes write dL/dSH of the visible
+    surfels directly into it (the kernel stores, it does not accumulate; rows of culled surfels are left as they are) and return no
+    gradient for `shs`.  For trainers that keep gradients in one flat buffer.
+
+    shs=<tensor>: the sink belongs to THAT `shs` input -- only backward passes of forwards that were given this tensor use it.  This is
+    the form an owner of parameters uses (dgs_amd.train.Trainer does): any number of trainers can share a device, each with its own
+    sink, in any interleaving.  Without `shs` the sink applies to every backward on the tensor's device that has no sink of its own
+    (one per device; the round-2 form).  None removes: the sink of `shs`, or the device-wide one of `device`, or -- neither given --
+    every sink.  The state cannot be per thread: autograd runs the backward of a HIP device on that device's own worker thread, not
+    on the thread that called backward().
+
+    all_rows (dgs_set_option key 8, set around each backward that uses this sink): the backward also stores ZEROS in the rows of
+    culled surfels and the unused SH bands, i.e. every element of the sink is written by every backward and the buffer never needs
+    clearing."""
     with _SINKS_LOCK:
         if tensor is not None:
-            _SINKS[tensor.device.index] = tensor
-            touched = [tensor.device.index]
-        elif device is None:
-            touched = list(_SINKS)
-            _SINKS.clear()
+            _SINKS[(tensor.device.index, None if shs is None else shs.data_ptr())] = (tensor, bool(all_rows))
+        elif shs is not None:
+            _SINKS.pop((shs.device.index, shs.data_ptr()), None)
+        elif device is not None:
+            _SINKS.pop((torch.device(device).index, None), None)
         else:
-            touched = [torch.device(device).index]
-            _SINKS.pop(touched[0], None)
-    # all_rows (dgs_set_option key 8): the backward also stores ZEROS in the rows of culled surfels and the unused SH bands, i.e. every
-    # element of the sink is written by every backward and the buffer never needs clearing; off again when the sink is removed
-    for d in touched:
-        _C.set_option(8, 1 if (tensor is not None and all_rows) else 0, device=d)
+            _SINKS.clear()
 
 
-def _sink_for(dev):
+def _sink_for(dev, sh):
     with _SINKS_LOCK:
-        return _SINKS.get(dev.index)
+        hit = _SINKS.get((dev.index, sh.data_ptr())) if sh is not None and sh.numel() else None
+        return hit if hit is not None else _SINKS.get((dev.index, None), (None, False))
+
+
+def _bwd_lock(dev):
+    with _SINKS_LOCK:
+        lk = _BWD_LOCKS.get(dev.index)
+        if lk is None:
+            lk = _BWD_LOCKS[dev.index] = threading.Lock()
+        return lk
 
 
 class _SurfelRasterFn(torch.autograd.Function):
@@ -120,17 +133,21 @@ class _SurfelRasterFn(torch.autograd.Function):
         call = (cfg.bg, means3D, radii, colors_precomp, scales, rotations, cfg.scale_modifier, cov3Ds_precomp,
                 cfg.viewmatrix, cfg.projmatrix, cfg.tanfovx, cfg.tanfovy, g_color, g_allmap, sh, cfg.sh_degree, cfg.campos,
                 geom, ctx.n_rendered, binning, img, cfg.debug)
-        sink = _sink_for(means3D.device)
+        sink, all_rows = _sink_for(means3D.device, sh)
         if sink is not None and not (sink.shape == sh.shape and sink.dtype == torch.float32 and sink.is_contiguous()
                                      and sink.device == sh.device):
             raise RuntimeError("set_sh_grad_sink: the sink must be a contiguous fp32 tensor of the shape of shs")
-        if sink is not None:
-            (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
-                lambda *a: _C.rasterize_gaussians_backward(*a, dL_dsh_out=sink), call, cfg.debug, "snapshot_bw.dump", "backward")
-            g_sh = None
-        else:
-            (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
-                _C.rasterize_gaussians_backward, call, cfg.debug, "snapshot_bw.dump", "backward")
+        # option 8 (zeros for culled rows) belongs to the sink of THIS call; it is a switch of the device's default context, so it is
+        # set and the launches are issued under one lock per device (the kernels read it at launch time, on the host)
+        with _bwd_lock(means3D.device):
+            _C.set_option(8, 1 if (sink is not None and all_rows) else 0, device=means3D.device.index)
+            if sink is not None:
+                (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
+                    lambda *a: _C.rasterize_gaussians_backward(*a, dL_dsh_out=sink), call, cfg.debug, "snapshot_bw.dump", "backward")
+                g_sh = None
+            else:
+                (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
+                    _C.rasterize_gaussians_backward, call, cfg.debug, "snapshot_bw.dump", "backward")
         return (g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_transMat, None)
 
 

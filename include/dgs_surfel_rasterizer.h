@@ -176,7 +176,8 @@ int dgs_read_overflow(int reset);
  * dgs_profile_read returns accumulated milliseconds and launch counts since the last reset (up to 14 values):
  * out[0..1] fwd blend (ms, n), out[2..3] bwd blend (ms, n), out[4], out[5] = sum over the timed fwd / bwd launches of
  * S = sum_tiles(entries traversed), the unit of the blend kernels' algorithmic-bytes formula;
- * out[6..7] preprocess_fwd (ms, n), out[8..9] binning = count + scan + scatter + per-tile sort (ms, n), out[10..11] surfel_bwd
+ * out[6..7] preprocess_fwd (ms, n), out[8..9] binning = count + scan + scatter + per-tile sort (ms, n; kernel time only in
+ * capacity mode -- in exact-size mode the span also holds the host's read of num_rendered and the binning allocator), out[10..11] surfel_bwd
  * (ms, n), out[12] = sum of num_rendered, out[13] = sum of visible surfels (radii > 0) over the timed forwards. */
 void dgs_profile_enable(int mode);
 void dgs_profile_reset(void);

@@ -127,6 +127,15 @@ int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets,
                        const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                        float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
                        float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream);
+/* The same with a step ORIGIN per segment (host array, may be NULL = all 0): the bias corrections of segment s use
+ * max(step_count - step_origins[s], 1).  torch.optim.Adam keeps a step count per parameter and skips parameters whose .grad is
+ * None, so a parameter that joins the optimisation late -- the reference's deformation network, control nodes and `feature`
+ * after the warm-up (train_gui.py:281-285, 427-432) -- starts at step 1; pass the run's step count at that moment as its origin.
+ * Learning-rate schedules keep using the run's counter. */
+int dgs_adam_step_origin(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                         const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                         const float* step_origins, float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq,
+                         const float* step_count, float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream);
 
 /* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:
  * posenc(xyz,10) | timenet(posenc(t,6)): 13->256->30, 8 x 256 ReLU layers, skip concat after layer 4, heads

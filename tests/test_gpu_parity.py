@@ -120,6 +120,75 @@ def test_forward_backward_match_oracle(cfg):
         assert rel_l2(hip[k], og[k]) <= 2e-4, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
 
 
+def _degenerate_case():
+    """A small scene in which a third of the surfels is made extreme: edge-on to within 1e-3 .. 1e-5 rad of the viewing ray (p.z of the
+    ray-splat intersection ~ 0 on every pixel: 1 / p.z overflows towards the horizon line and the reference falls back to the
+    low-pass disc), needle-shaped (1 : 1e4 axes), sub-pixel, larger than the image, and a few just behind / in front of the 0.2
+    near plane."""
+    import math
+    case = small_case(P=600, H=80, W=96, seed=21, view=2, scale_mul=1.5, sh_degree=1)
+    g = np.random.default_rng(7)
+    xyz, sc, rot = case["means3D"].numpy().copy(), case["scales"].numpy().copy(), case["rotations"].numpy().copy()
+    cam = case["campos"].numpy().astype(np.float64)
+
+    def quat_from_columns(c0, c1, c2):   # rotation matrix with these columns -> (w, x, y, z)
+        R = np.stack([c0, c1, c2], axis=1)
+        w = math.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+        if w > 1e-6:
+            return np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+        x = math.sqrt(max(0.0, 1.0 + R[0, 0] - R[1, 1] - R[2, 2])) / 2.0
+        return np.array([0.0, x, (R[0, 1] + R[1, 0]) / (4 * x), (R[0, 2] + R[2, 0]) / (4 * x)]) if x > 1e-6 else np.array([0.0, 0.0, 1.0, 0.0])
+
+    for i in range(0, 200):
+        kind = i % 5
+        if kind == 0:      # edge-on: the normal is perpendicular to the viewing ray up to a tiny tilt
+            v = xyz[i].astype(np.float64) - cam
+            v /= np.linalg.norm(v)
+            u = np.cross(v, g.standard_normal(3)); u /= np.linalg.norm(u)
+            tilt = 10.0 ** g.uniform(-5, -3)
+            n = u * math.cos(tilt) + v * math.sin(tilt)
+            t1 = np.cross(n, np.cross(v, n)); t1 /= np.linalg.norm(t1)
+            t2 = np.cross(n, t1)
+            rot[i] = quat_from_columns(t1, t2, n).astype(np.float32)
+            sc[i] = (0.3, 0.3)
+        elif kind == 1:    # needle
+            sc[i] = (0.5, 5e-5)
+        elif kind == 2:    # far below a pixel
+            sc[i] = (1e-4, 2e-4)
+        elif kind == 3:    # covers the whole image
+            sc[i] = (6.0, 4.0)
+        else:              # around the near plane: 0.15 .. 0.3 in front of the camera along its axis
+            fwd = case["viewmatrix"].numpy()[:3, 2].astype(np.float64)   # third column of W2C^T's rotation block = camera z in the world
+            xyz[i] = (cam + fwd * g.uniform(0.15, 0.3) + 0.02 * g.standard_normal(3)).astype(np.float32)
+            sc[i] = (0.01, 0.02)
+    case["means3D"], case["scales"], case["rotations"] = torch.from_numpy(xyz), torch.from_numpy(sc), torch.from_numpy(rot)
+    return case
+
+
+def test_degenerate_splats_match_oracle():
+    """Edge-on, needle, sub-pixel, image-filling and near-plane surfels: bounds the documented departure of alpha_affine
+    (a pair whose rho3d overflows is skipped where the reference would fall back to the low-pass disc) and exercises the conservative
+    footprint tests (block_hit_affine: not-an-ellipse branches) on real degenerate conics.  Same tolerances as the regular scenes."""
+    from gpu_utils import frac_close, hip_median_contrib, median_flips, rel_l2, run_hip
+    case = _degenerate_case()
+    gc, go = _cot(case)
+    orc = oracle_from_case(case)
+    assert int((orc.radii > 0).sum()) > 300
+    flips = median_flips(hip_median_contrib(case), orc)
+    go[5][flips] = 0.0
+    go[7][flips] = 0.0
+    og = orc.backward(gc, go)
+    hip = run_hip(case, gc, go)
+    assert np.array_equal(hip["radii"], orc.radii)
+    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 2e-4, 2e-2, "color")
+    am, om = hip["allmap"].copy(), orc.allmap.copy()
+    for ch in (5, 7):
+        am[ch][flips] = om[ch][flips]
+    frac_close(am, om, 5e-5, 2e-5, 2e-4, 2e-1, "allmap")
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
+        assert rel_l2(hip[k], og[k]) <= 1e-3, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
+
+
 def test_precomputed_colors_and_no_grad_path():
     from gpu_utils import frac_close, rel_l2, run_hip
     case = small_case(P=500, H=64, W=64, seed=12, view=3, scale_mul=2.0)

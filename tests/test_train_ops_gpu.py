@@ -581,6 +581,71 @@ def test_flat_adam_matches_torch_adam():
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), float((p - q).abs().max())
 
 
+def test_flat_adam_late_parameters_start_their_own_step_count():
+    """The reference un-detaches the deformation after the warm-up (train_gui.py:281-285): until then `feature` and the deformation
+    parameters have no gradient and torch.optim.Adam skips them, so their per-parameter step count starts at 1 when they join.
+    FlatAdam keeps ONE device counter; set_origin gives the late segments t - t0 in the bias corrections (dgs_adam_step_origin).
+    Without it the first updates of moments that start from zero run at 1 / (1 - beta1^t) ~ 1 instead of 10 x the raw moment."""
+    from dgs_amd import _ops
+    from dgs_amd.train import FlatGradBucket
+    torch.manual_seed(1)
+    shapes = [(500, 3), (500, 8), (64, 30)]
+    lrs = [1e-3, 2e-3, 5e-4]
+    a = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    bucket = FlatGradBucket(a)
+    flat = _ops.FlatAdam(a, lrs, bucket.flat)
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=0.0, eps=1e-15)
+    warm = 30
+    for it in range(warm + 6):
+        late = it >= warm
+        if it == warm:
+            flat.set_origin(1, None, float(flat.t.item()))
+        g = [torch.randn(*s, generator=torch.Generator().manual_seed(100 * it + i)).cuda() for i, s in enumerate(shapes)]
+        for i, (p, q, gi) in enumerate(zip(a, b, g)):
+            p.grad.copy_(gi)
+            q.grad = gi.clone() if (i == 0 or late) else None   # torch skips parameters without a gradient
+        flat.step(0, None if late else 1)
+        ref.step()
+        for p, q in zip(a, b):
+            assert torch.allclose(p, q, rtol=2e-5, atol=2e-7), (it, float((p - q).abs().max()))
+
+
+def test_two_trainers_interleaved_on_one_device_do_not_share_state():
+    """Per-trainer state (round 4): the SH gradient sink is keyed by the trainer's own SH parameter and the persistent node table of
+    the coherent skinning backward belongs to the trainer's deformation module.  Two trainers on ONE device, stepped alternately,
+    must train exactly as each does alone -- with the per-device state of round 3 the second trainer's backward removed or
+    replaced the first one's sink (dL/dSH then came back through autograd into a bucket that store mode never clears)."""
+    import bench
+    import diff_surfel_rasterization as dsr
+    dev = torch.device("cuda:0")
+
+    def make(P):
+        tr = bench.build_trainer(P, 96, 128, dev, n_views=8, n_targets=2)
+        tr.set_regime(warmup=False, lambda_normal=0.05, lambda_dist=100.0)
+        return tr
+
+    def run_alone(P, n):
+        tr = make(P)
+        losses = [float(tr.step()) for _ in range(n)]
+        return losses, tr.surfels._features.detach().clone(), tr.deform.nodes.detach().clone()
+
+    la, fa, na = run_alone(3000, 4)
+    lb, fb, nb = run_alone(5000, 4)
+    A, B = make(3000), make(5000)
+    ia, ib = [], []
+    for _ in range(4):
+        ia.append(float(A.step()))
+        ib.append(float(B.step()))
+    assert not dsr._SINKS, "a trainer left its sink behind"
+    # float atomics in the backward: steps agree to rounding, not bit for bit
+    for x, y in zip(la + lb, ia + ib):
+        assert abs(x - y) <= 2e-4 * abs(x), (la, ia, lb, ib)
+    for alone, both in ((fa, A.surfels._features), (fb, B.surfels._features), (na, A.deform.nodes), (nb, B.deform.nodes)):
+        d = float((alone - both).abs().max())
+        assert d <= 1e-4 * max(float(alone.abs().max()), 1e-6), d
+
+
 def test_fused_reg_loss_matches_render_postprocess():
     """dgs_regloss_forward/backward against the PyTorch post-processing of dgs_amd.render.render + the two
     regulariser terms of training_loss, on the rasterizer's real allmap."""

@@ -1,11 +1,11 @@
 # Round artefacts of the final code, two phases on the GPU box (the bench lines read the PMC files of phase 1 from profiles/):
-#   phase 1:  tools/final_artifacts.sh pmc      -> gpurun_out/pmc_r03_metric.json, pmc_r03_c5.json  (copy to profiles/r03_pmc_<workload>.json)
-#   phase 2:  tools/final_artifacts.sh lines    -> gpurun_out/r03_bench_line*.json, kernel stats, per-step summary, timeline
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=r03
+#   phase 1:  tools/final_artifacts.sh pmc      -> gpurun_out/pmc_r04_metric.json, pmc_r04_c5.json  (copy to profiles/r04_pmc_<workload>.json)
+#   phase 2:  tools/final_artifacts.sh lines    -> gpurun_out/r04_bench_line*.json, kernel stats, per-step summary, timeline
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=r04
 cd $R
 if [ "$1" = "pmc" ]; then
-  bash tools/pmc_kernels.sh r03_metric "dgs::" metric 2>&1 | tail -12
-  bash tools/pmc_kernels.sh r03_c5 "dgs::" c5 2>&1 | tail -12
+  bash tools/pmc_kernels.sh r04_metric "dgs::" metric 2>&1 | tail -12
+  bash tools/pmc_kernels.sh r04_c5 "dgs::" c5 2>&1 | tail -12
   exit 0
 fi
 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; tail -c 200 $O/${TAG}_bench_line.json; echo
@@ -15,6 +15,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o k -- python $R/bench.py --no-cpu-baseline --no-roofline-legs --steps 10 > $O/${TAG}_prof.log 2>&1
 F=$(ls $O/${TAG}_prof/*kernel_stats.csv 2>/dev/null | head -1); T=$(ls $O/${TAG}_prof/*kernel_trace.csv 2>/dev/null | head -1)
 cp $F $O/${TAG}_bench_graph_200k_800_kernel_stats.csv
-python $R/tools/graph_step_profile.py $T 10 0 0 > $O/${TAG}_graph_step_summary.txt 2>&1; head -8 $O/${TAG}_graph_step_summary.txt
+python $R/tools/graph_step_profile.py $T 10 40 0 > $O/${TAG}_graph_step_summary.txt 2>&1; head -8 $O/${TAG}_graph_step_summary.txt
 python $R/tools/graph_step_timeline.py $T 10 0 5 > $O/${TAG}_graph_step_timeline.txt 2>&1; tail -3 $O/${TAG}_graph_step_timeline.txt
 rm -rf $O/${TAG}_prof

@@ -2,7 +2,7 @@
 """Generator of tools/micro/valu_issue_bench.hip: what does a wave64 instruction of the classes the blend kernels are built
 from cost on gfx950, measured in SHADER CYCLES (s_memtime inside the kernel; s_memrealtime next to it gives the clock)?
 
-Round 2's table (profiles/r02_valu_rate_gfx950.txt) divided wall time by an assumed 2.4 GHz and let the compiler pick the
+Round 2's table (removed in round 4) divided wall time by an assumed 2.4 GHz and let the compiler pick the
 registers; VERDICT r02 asked for a reconciliation with the guide's 2 cycles per v_fma_f32.  Here every loop body is ONE asm
 block with fixed registers (so operand banks, encodings and dependencies are exactly what the variant's name says), every wave
 stamps s_memtime / s_memrealtime around its loop and reports the SIMD it ran on, and the host prints, per variant and per
