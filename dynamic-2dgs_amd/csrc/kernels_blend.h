@@ -464,6 +464,179 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(B
     }
 }
 
+// ---- forward blend, one list per 16-lane row (round 4) ----------------------------------------------------------------------
+// Same idea as blend_bwd_rows_kernel below, where it is described; in the forward nothing is summed across lanes and nothing is
+// added to global memory, so the design pays here: every DPP row of the wave -- one 4x4 pixel block of the quadrant -- walks the
+// list of the entries that can reach ITS block (blocks_hit_linear while staging; a block whose 16 pixels are all finished takes no
+// more entries), the planes of an entry are stored once per wave, and the visit loop runs max-over-rows(list length) times with
+// four slot addresses per LDS read instead of one.  Per-pixel arithmetic and entry order are those of blend_fwd_kernel: the results
+// are bit-identical.  0.87 of that kernel's visits on the 200k / 800x800 scene (tools/blend_stats.py).
+#ifndef DGS_FWD_ROWS
+#define DGS_FWD_ROWS 1
+#endif
+constexpr int kChunkF = 64;          // entries staged per wave and step by the row kernel: one per lane
+constexpr int kNullSlotF = kChunkF;  // the slot behind the staged ones: planes of an entry that fails the alpha test for every pixel
+struct FwdRowStage {
+    f32x4 a[3][kChunkF + 1];
+    f32x4 tw[kChunkF + 1];     // (Tw.x Tw.y Tw.z, 1-based list position as bits)
+    f32x4 q3[kChunkF + 1];     // (n.x n.y n.z r)
+    f32x4 q4[kChunkF + 1];     // (g b - -)
+    uint32_t idx[4][17];       // row r: the slots of its block's entries in list order, one byte each (68: the loop reads two ahead of a full list)
+};
+
+__global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_kernel(BlendFwdArgs a)
+{
+    __shared__ FwdRowStage s_stage[4];
+    __shared__ uint32_t s_max[4];
+
+    const int ntiles = a.tiles_x * a.tiles_y;
+    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
+    if (a.mode < 3 && tile >= ntiles) return;
+    if (a.mode >= 3) tile = (int)a.order[tile];
+    if (tile >= ntiles) return;   // mode 4: empty slot
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int lx_, ly_;
+    lane_pixel(tid, lx_, ly_);
+    const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
+    const bool inside = px < a.W && py < a.H;
+    const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
+    const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
+    const float qx = tpx + (float)(8 * (wave & 1)), qy = tpy + (float)(8 * (wave >> 1));
+    const float qus0 = kSqrt2 * ((wave & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((wave & 2) ? 0.5f : -7.5f);
+    float us = inside ? kSqrt2 * ((float)lx_ - 7.5f) : __builtin_nanf("");   // NaN = this pixel takes no further entry
+    const float vs = kSqrt2 * ((float)ly_ - 7.5f);
+
+    const uint2 range = a.ranges[tile];
+    const uint32_t len = range.y - range.x;
+    FwdRowStage& S = s_stage[wave];
+    if (lane < 6) {   // the null slot: opacity 0 (alpha = 0 * G fails the test, also for G = NaN), everything else finite
+        f32x4* planes[6] = {&S.a[0][kNullSlotF], &S.a[1][kNullSlotF], &S.a[2][kNullSlotF], &S.tw[kNullSlotF], &S.q3[kNullSlotF], &S.q4[kNullSlotF]};
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (lane == k) *planes[k] = mk4(0.f, 0.f, 0.f, 0.f);
+    }
+    const uint8_t* my_list = (const uint8_t*)&S.idx[row][0];
+
+    PixFwd st;
+    pixfwd_init(st);
+
+    auto visit = [&](auto track_median, int niter) {
+        int sl = my_list[0];
+        int sl_next = my_list[1];
+        f32x4 a0 = S.a[0][sl], a1 = S.a[1][sl], a2 = S.a[2][sl];
+        f32x4 tw = S.tw[sl], q3 = S.q3[sl], q4 = S.q4[sl];
+        for (int i = 0; i < niter; i++) {
+            AlphaEval e;
+            const bool pass = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
+#if DGS_PIN_PREFETCH
+            asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
+#endif
+            sl = sl_next;
+            a0 = S.a[0][sl]; a1 = S.a[1][sl]; a2 = S.a[2][sl];
+            bool use3d;
+            const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
+            float w, test_T;
+            pixfwd_weight(st, e.alpha, w, test_T);
+            const bool ok = pass & (depth >= kNear);      // forward.cu:388
+            const bool blend = ok & !(test_T < kTmin);
+            if (blend) {
+                st.contributor = __float_as_uint(tw.w);   // 1-based list position (forward.cu:356)
+                pixfwd_accumulate<decltype(track_median)::value>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
+            }
+            us = (ok ^ blend) ? __builtin_nanf("") : us;   // passed but saturated: the pixel is finished
+#if DGS_PIN_PREFETCH
+            asm volatile("" : "+v"(st.T), "+v"(us) : : "memory");
+#endif
+            tw = S.tw[sl]; q3 = S.q3[sl]; q4 = S.q4[sl];
+            sl_next = my_list[i + 2];
+            asm volatile("" : "+v"(sl_next));   // requested here, a visit before the address is formed from it
+        }
+    };
+
+    uint32_t id_next = (uint32_t)lane < len ? a.point_list[range.x + lane] : 0u;
+    unsigned long long alive = __ballot(inside);   // lanes that still take entries
+    for (uint32_t base = 0; base < len && alive != 0ull; base += kChunkF) {
+        const uint32_t e_mine = base + (uint32_t)lane;
+        const uint32_t id = id_next;   // (lanes beyond the end of the list hold id 0: a valid record, masked out below)
+        const float4* src = a.rec + (size_t)id * kRecQuads;
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
+        id_next = e_mine + kChunkF < len ? a.point_list[range.x + e_mine + kChunkF] : 0u;
+        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+        uint32_t bm = e_mine < len ? blocks_hit_linear(ta, qus0, qvs0, as_quad(bx), qx, qy) : 0u;
+        // a block whose pixels are all finished takes no more entries
+        bm &= (((uint32_t)alive & 0xffffu) ? 1u : 0u) | (((uint32_t)(alive >> 16) & 0xffffu) ? 2u : 0u) |
+              (((uint32_t)(alive >> 32) & 0xffffu) ? 4u : 0u) | (((uint32_t)(alive >> 48) & 0xffffu) ? 8u : 0u);
+        const bool hit = bm != 0u;
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;
+        const unsigned long long m0 = __ballot((bm & 1u) != 0u), m1 = __ballot((bm & 2u) != 0u), m2 = __ballot((bm & 4u) != 0u), m3 = __ballot((bm & 8u) != 0u);
+        ((uint32_t*)&S.idx[0][0])[lane] = 0x01010101u * (uint32_t)kNullSlotF;   // every list: null slots behind its entries
+        if (lane < 4) ((uint32_t*)&S.idx[0][0])[64 + lane] = 0x01010101u * (uint32_t)kNullSlotF;
+        if (hit) {
+            const int slot = lane_rank(m);
+            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+            S.tw[slot] = mk4(q1.z, q1.w, q2.x, __uint_as_float(e_mine + 1u));
+            S.q3[slot] = mk4(q3);
+            S.q4[slot] = mk4(q4);
+            uint8_t* lists = (uint8_t*)&S.idx[0][0];
+            if (bm & 1u) lists[lane_rank(m0)] = (uint8_t)slot;
+            if (bm & 2u) lists[68 + lane_rank(m1)] = (uint8_t)slot;
+            if (bm & 4u) lists[136 + lane_rank(m2)] = (uint8_t)slot;
+            if (bm & 8u) lists[204 + lane_rank(m3)] = (uint8_t)slot;
+        }
+        __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
+        const int n01 = max(__builtin_popcountll(m0), __builtin_popcountll(m1)), n23 = max(__builtin_popcountll(m2), __builtin_popcountll(m3));
+        const int niter = __builtin_amdgcn_readfirstlane(max(n01, n23));
+        // median bookkeeping (forward.cu:421-425) only while some pixel of the wave still has T > 0.5
+        if (__ballot(st.T > 0.5f && us == us) != 0ull) visit(std::true_type{}, niter);
+        else visit(std::false_type{}, niter);
+        __builtin_amdgcn_wave_barrier();
+        alive = __ballot(us == us);   // wave-level early out (forward.cu:334-336 votes per block)
+    }
+
+    uint32_t mx = inside ? st.last : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = __shfl_xor(mx, d, 64);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t mm = s_max[0];
+        mm = s_max[1] > mm ? s_max[1] : mm;
+        mm = s_max[2] > mm ? s_max[2] : mm;
+        mm = s_max[3] > mm ? s_max[3] : mm;
+        a.tile_last[tile] = mm;
+    }
+
+    const size_t plane = (size_t)ntiles * kTilePix;
+    const size_t slot = (size_t)tile * kTilePix + tid;
+    a.final_T[slot] = st.T;
+    a.final_T[plane + slot] = st.dist1;
+    a.final_T[2 * plane + slot] = st.dist2;
+    a.n_contrib[slot] = st.last;
+    a.n_contrib[plane + slot] = st.med_c;
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = (size_t)py * a.W + px;
+        a.out_color[pix] = st.C[0] + st.T * a.bg[0];
+        a.out_color[HW + pix] = st.C[1] + st.T * a.bg[1];
+        a.out_color[2 * HW + pix] = st.C[2] + st.T * a.bg[2];
+        a.out_others[pix] = st.D;                 // DEPTH_OFFSET 0   (auxiliary.h:25-30)
+        a.out_others[HW + pix] = 1.f - st.T;      // ALPHA_OFFSET 1
+        a.out_others[2 * HW + pix] = st.N[0];     // NORMAL_OFFSET 2..4
+        a.out_others[3 * HW + pix] = st.N[1];
+        a.out_others[4 * HW + pix] = st.N[2];
+        a.out_others[5 * HW + pix] = st.med_d;    // MIDDEPTH_OFFSET 5
+        a.out_others[6 * HW + pix] = st.distortion;  // DISTORTION_OFFSET 6
+        a.out_others[7 * HW + pix] = st.med_w;    // MEDIAN_WEIGHT_OFFSET 7
+    }
+}
+
 struct BlendBwdArgs {
     const uint2* ranges;
     const uint32_t* order;

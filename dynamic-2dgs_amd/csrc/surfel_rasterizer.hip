@@ -700,7 +700,11 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     }
     Prof::Pair pp;
     const bool timed = prof_begin(ctx, 0, stream, pp);
+#if DGS_FWD_ROWS
+    hipLaunchKernelGGL(dgs::blend_fwd_rows_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, fa);
+#else
     hipLaunchKernelGGL(dgs::blend_fwd_kernel, dim3(grid), dim3(dgs::kTilePix), 0, stream, fa);
+#endif
     if (timed) prof_end(ctx, stream, pp, fa.tile_last, il.ntiles);
     DGS_STAGE("blend_fwd", debug, stream);
     return R;

@@ -11,7 +11,7 @@ done
 for rep in 1 2; do
 for so in $D/ab_*.so; do
   printf "%-14s " $(basename $so .so)
-  DGS_SURFEL_LIB=$so timeout 300 python $R/tools/quick_timing.py "$@" 2>&1 | tail -2 | tr '\n' ' '
+  DGS_SURFEL_LIB=$so timeout 300 python $R/tools/quick_timing.py "$@" 2>&1 | tail -3 | tr '\n' ' '
   echo
 done
 done
