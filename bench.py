@@ -268,6 +268,83 @@ def timed_steps(tr, k, world, densify_every=0, densify_log=None):
     return time.perf_counter() - t0
 
 
+def _max_over_ranks(x, device):
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def choose_split3(tr, args, world, device, use_graph):
+    """N > 1: two or three pieces of the data-parallel step?  (Trainer.split3: the per-surfel gradients leave as a slice of their own
+    under the node-MLP backward.)  Which one wins depends on what the links deliver on this box, so both are timed here, before the
+    headline -- W warm-up + K steps each on the step as it will be run -- and every rank takes the faster one (the MAX over ranks of
+    each timing decides, so all ranks agree)."""
+    if world == 1 or not use_graph or not tr._split_ok():
+        return None
+    res = {}
+    for flag in (False, True):
+        tr.split3 = flag
+        tr._graph = None
+        tr.enable_graph(tr._capacity, validate=False)
+        for _ in range(args.warmup):
+            tr.step()
+        res[flag] = _max_over_ranks(timed_steps(tr, args.steps, world), device) / args.steps * 1e3
+    pick = res[True] < res[False]
+    if tr.split3 != pick:
+        tr.split3 = pick
+        tr._graph = None
+        tr.enable_graph(tr._capacity, validate=False)
+    return {"ms_per_step_two_pieces": round(res[False], 4), "ms_per_step_three_pieces": round(res[True], 4), "chosen": "three" if pick else "two"}
+
+
+def comm_report(tr, args, world, device, ms_headline, split_choice):
+    """N > 1: what the step's collectives cost on THIS box, so that the first multi-GPU number explains itself.
+      slices: every all-reduce of the step timed alone, back to back (same sizes, same dtype / op, scratch buffers): ms and bus
+        bandwidth 2 (N-1)/N x bytes / time -- what a ring moves per link direction, comparable to the 153 GB/s of one xGMI link and to
+        the ~230 GB/s the plan in DESIGN.md section 8 needs for >= 6x at N = 8;
+      ms_per_step_no_collectives: W + K steps of the same captured step with every collective skipped (Trainer.no_collectives), from a
+        snapshot that is restored afterwards (the replicas diverge without their all-reduce);
+      exposed_ms_per_step: headline - that = communication the step does not hide."""
+    wire = tr.wire_bytes_per_step()
+    out = {"world": world, "backend": dist.get_backend(), "wire_bytes_per_step": wire, "wire_bf16": bool(tr.wire_bf16), "split3": split_choice, "slices": {}}
+    reps = 10
+    for name, nbytes in wire.items():
+        if name == "total" or not nbytes:
+            continue
+        is_radii = name == "radii"
+        half = tr.wire_bf16 and name in ("sh", "mid")   # these slices cross as bfloat16 (Trainer.wire_bf16)
+        buf = torch.zeros(nbytes // (2 if half else 4), dtype=torch.int32 if is_radii else (torch.bfloat16 if half else torch.float32), device=device)
+        op = dist.ReduceOp.MAX if is_radii else dist.ReduceOp.SUM
+        for _ in range(3):
+            dist.all_reduce(buf, op=op)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf, op=op)
+        torch.cuda.synchronize()
+        ms = _max_over_ranks(time.perf_counter() - t0, device) / reps * 1e3
+        out["slices"][name] = {"bytes": int(nbytes), "ms": round(ms, 4), "bus_GBs": round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 2)}
+        del buf
+    snap, it0 = tr._snapshot(), tr.iteration
+    tr.no_collectives = True
+    try:
+        for _ in range(args.warmup):
+            tr.step()
+        ms_free = _max_over_ranks(timed_steps(tr, args.steps, world), device) / args.steps * 1e3
+    finally:
+        tr.no_collectives = False
+        tr._restore(snap)
+        tr.iteration = it0
+        if getattr(tr, "_oflag", None) is not None:
+            tr._oflag.zero_()
+    out["ms_per_step_no_collectives"] = round(ms_free, 4)
+    out["exposed_ms_per_step"] = round(ms_headline - ms_free, 4)
+    out["sum_of_slices_ms"] = round(sum(v["ms"] for v in out["slices"].values()), 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +423,7 @@ def main():
     # capture promised the rasterizer (longest tile list, list capacity): the trainer's step guard then skips that step,
     # re-captures and renders the view again (Trainer._recover_overflow).  A timed region in which that happened contains a
     # re-capture and is not reported: warm-up + timed region are run again on the re-captured step (at most twice).
+    split_choice = choose_split3(tr, args, world, device, use_graph)
     attempts = 0
     while True:
         attempts += 1
@@ -374,6 +452,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     radius_headline = mean_radius(tr)
+    comm = comm_report(tr, args, world, device, dt / args.steps * 1e3, split_choice) if world > 1 else None
 
     # ---- everything below is measured AFTER the headline and does not change it --------------------------------------------
     # The scene state the headline window ended with is kept: the drift leg trains on, the roofline legs and the twin check
@@ -446,7 +525,10 @@ def main():
                     "eager_vs_eager_max_rel_loss_difference": float("%.3g" % noise),
                     "tolerance": {"first_3_steps": 1e-5, "all_steps": float("%.3g" % tol_all), "rule": "max(1e-3, 4 x eager-vs-eager)"},
                     "what": "graph-replayed vs eager steps from the same snapshot (parameters, Adam state, views); float atomics in the backward are the only difference"}
-            if not (rel <= tol_all and rel_first <= 1e-5) or any(l != l for l in replay_losses + timed_losses):
+            twin_bad = not (rel <= tol_all and rel_first <= 1e-5) or any(l != l for l in replay_losses + timed_losses)
+            if world > 1:   # one verdict for all ranks: a rank that left alone would leave the others inside a collective
+                twin_bad = _max_over_ranks(1.0 if twin_bad else 0.0, device) > 0.0
+            if twin_bad:
                 raise SystemExit("graph-replayed steps disagree with their eager twin (max relative loss difference %.3g, eager vs eager %.3g; replay %s, eager %s): result invalid"
                                  % (rel, noise, ["%.6f" % l for l in replay_losses], ["%.6f" % l for l in eager_losses]))
 
@@ -564,6 +646,8 @@ def main():
                                  "surfel_bwd": roof_kernel("surfel_bwd", "sbw")},
             "twin": twin, "drift": drift,
         }
+        if comm is not None:
+            out["comm"] = comm
         if pre_losses is not None:
             k = max(len(pre_losses) // 10, 1)
             out["config"]["pre_training_loss"] = {"first_tenth_mean": round(sum(pre_losses[:k]) / k, 5), "last_tenth_mean": round(sum(pre_losses[-k:]) / k, 5)}

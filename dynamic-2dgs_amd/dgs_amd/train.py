@@ -147,6 +147,16 @@ class Trainer:
         # there, under the node-MLP backward + weight gradients; only the deformation parameters and the statistics wait for
         # the end of the backward.  Costs two more graph replays per step.
         self.split3 = False
+        # diagnostic (bench.py's `comm` object): True makes every collective of the step a no-op, so that a window of steps timed
+        # with it shows what the step costs WITHOUT communication (the replicas diverge: callers restore a snapshot afterwards)
+        self.no_collectives = False
+        # Lever for links that deliver less than the plan needs: the two big slices of the split step -- the SH
+        # gradients and, with split3, the per-surfel gradients -- cross the wire as bfloat16 (half the bytes: 57.7 -> 38.5 MB per step
+        # at 200k surfels) and come back into the fp32 bucket.  A DELIBERATE change of the training numerics (8 mantissa bits on the
+        # summed gradient of these slices; Adam normalises the scale away), off by default; every rank receives the same reduced
+        # values, so the replicas stay bit-identical.  The deformation parameters, the densification statistics and the radii stay
+        # fp32 / int32.  DGS_WIRE_BF16=1 switches it on in bench.py.
+        self.wire_bf16 = os.environ.get("DGS_WIRE_BF16", "0") == "1"
         self.sh_grad_sink = True  # packed SH on HIP: no separate dL/dSH buffer, no accumulate pass
         self.store_grads = os.environ.get("DGS_STORE_GRADS", "1") != "0"   # fused path: gradients are stored, the bucket is never cleared (_store_ok)
         self.fuse_deform = True  # HIP: KNN + node MLP + skinning + surfel activations as fused kernels (ControlNodes.forward_assembled)
@@ -310,7 +320,7 @@ class Trainer:
         self._guard_events.clear()
         self.overflow_recoveries += 1
         if getattr(self, "_list_hint", 0):
-            self._list_hint = 0             # first suspect: a tile list longer than promised (enable_graph re-captures without it)
+            self._list_hint = self._next_list_hint()   # first suspect: a tile list longer than promised (enable_graph re-captures with the next tier)
         else:
             self._capacity = 2 * self._capacity
         self._graph = None
@@ -434,12 +444,22 @@ class Trainer:
             self._scam.load(self._vtab[0])
             torch.cuda.synchronize()
         if _C.read_overflow(device=dev):
-            if self._list_hint:            # perhaps only the promised list length was exceeded: withdraw it and capture again
-                self._list_hint = 0
+            if self._list_hint:            # perhaps only the promised list length was exceeded: next tier and capture again
+                self._list_hint = self._next_list_hint()
                 self._graph = None
                 return self.enable_graph(capacity, validate=validate)
             if validate:
                 raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
+
+    # Promise of the longest tile list (dgs_set_option key 6) in the tiers of the library's sort kernels: up to 2048 entries one
+    # launch, up to 3584 two, up to 57 344 (16 segments of 3584 + merge) four, no promise (0) five.  A view that breaks the promise
+    # moves the trainer one tier up -- a densified scene with lists of a few thousand entries keeps the cheap tiers it fits.
+    LIST_HINT_TIERS = (2048, 3584, 57344, 0)
+
+    def _next_list_hint(self):
+        t = self.LIST_HINT_TIERS
+        cur = getattr(self, "_list_hint", 0)
+        return t[t.index(cur) + 1] if cur in t and cur != 0 else 0
 
     def refresh_knn_mode(self):
         """Re-evaluate which seeded neighbour search fits the scene (ControlNodes.pick_knn_refine: one host read) and, if the
@@ -678,10 +698,42 @@ class Trainer:
         """Elements of the second bucket segment: the surfel parameters behind the SH coefficients."""
         return sum(p.numel() for p in self.bucket.params[1:self.n_surfel_params])
 
+    class _NoWork:
+        """stand-in for the work handle of a collective that was not issued (Trainer.no_collectives)"""
+        @staticmethod
+        def wait():
+            return True
+
+    class _Bf16Work:
+        """work handle of a slice that crossed the wire as bfloat16: wait() = the collective, then the copy back into the fp32 bucket"""
+        def __init__(self, work, dst, src):
+            self.work, self.dst, self.src = work, dst, src
+
+        def wait(self):
+            self.work.wait()
+            self.dst.copy_(self.src)
+            return True
+
+    def _sum_slice_start(self, lo, hi):
+        """async all-reduce (SUM) of bucket.flat[lo:hi]; with wire_bf16 through a persistent bfloat16 copy of the slice"""
+        sl = self.bucket.flat[lo:hi]
+        if not self.wire_bf16:
+            return dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True)
+        wire = getattr(self, "_wire", None)
+        if wire is None or wire.numel() != self.bucket.flat.numel() or wire.device != sl.device:
+            wire = self._wire = torch.empty(self.bucket.flat.numel(), dtype=torch.bfloat16, device=sl.device)
+        w = wire[lo:hi]
+        w.copy_(sl)
+        return self._Bf16Work(dist.all_reduce(w, op=dist.ReduceOp.SUM, async_op=True), sl, w)
+
     def _reduce_mid_start(self):
-        return dist.all_reduce(self.bucket.flat[self.n_sh:self.n_sh + self._n_mid()], op=dist.ReduceOp.SUM, async_op=True)
+        if self.no_collectives:
+            return self._NoWork
+        return self._sum_slice_start(self.n_sh, self.n_sh + self._n_mid())
 
     def _reduce_tail_start(self):
+        if self.no_collectives:
+            return []
         return [dist.all_reduce(self.bucket.flat[self.n_sh + self._n_mid():], op=dist.ReduceOp.SUM, async_op=True)]
 
     def _finish_mid(self):
@@ -691,12 +743,18 @@ class Trainer:
             self.opt_surfels.step(1, self.n_surfel_params - 1 if self.warmup else self.n_surfel_params, advance=False)
 
     def _reduce_sh_start(self):
-        return dist.all_reduce(self.bucket.flat[:self.n_sh], op=dist.ReduceOp.SUM, async_op=True)
+        if self.no_collectives:
+            return self._NoWork
+        return self._sum_slice_start(0, self.n_sh)
 
     def _reduce_radii_start(self):
+        if self.no_collectives:
+            return self._NoWork
         return dist.all_reduce(self._radii, op=dist.ReduceOp.MAX, async_op=True)
 
     def _reduce_rest_start(self):
+        if self.no_collectives:
+            return []
         return [dist.all_reduce(self.bucket.flat[self.n_sh:], op=dist.ReduceOp.SUM, async_op=True)]
 
     def wire_bytes_per_step(self):
@@ -706,10 +764,12 @@ class Trainer:
         n_flat = self.bucket.flat.numel()
         n_radii = self.P + 4
         sh = self.n_sh if self._split_ok() else 0
-        out = {"sh": 4 * sh, "rest": 4 * (n_flat - sh), "radii": 4 * n_radii, "total": 4 * (n_flat + n_radii)}
+        big = 2 if (self.wire_bf16 and sh) else 4   # bytes per element of the slices that can cross as bfloat16
+        out = {"sh": big * sh, "rest": 4 * (n_flat - sh), "radii": 4 * n_radii}
         if sh and self.split3:   # 'mid' leaves when the skinning backward is done, 'rest' (deformation parameters + statistics) last
-            out["mid"] = 4 * self._n_mid()
-            out["rest"] -= out["mid"]
+            out["mid"] = big * self._n_mid()
+            out["rest"] -= 4 * self._n_mid()
+        out["total"] = sum(out.values())
         return out
 
     @property
@@ -718,6 +778,8 @@ class Trainer:
         return self.opt_deform is None and self.world > 1
 
     def _reduce(self):
+        if self.no_collectives:
+            return
         self.bucket.all_reduce_mean(average=not self._fold_mean)
         if self.world > 1:
             dist.all_reduce(self._radii, op=dist.ReduceOp.MAX)

@@ -41,3 +41,9 @@ def test_bench_two_ranks_prints_one_valid_line():
     assert r["value"] > 0 and abs(r["value"] - 2 * 1e3 / r["ms_per_step"]) <= 1e-2 * r["value"]   # whole-job rate = world views per step
     assert r["roofline"] and r["roofline"]["kernel"] == "blend_bwd_kernel" and 0 < r["roofline"]["frac"] < 1
     assert "cpu_baseline" not in r   # rank 0 at N = 1 only
+    # the communication object (N > 1): every slice timed alone, the step without collectives, what stays exposed, the 2 / 3 piece choice
+    c = r["comm"]
+    assert c["world"] == 2 and c["backend"] == "gloo" and c["wire_bytes_per_step"]["total"] > 50e6
+    assert set(c["slices"]) >= {"sh", "rest", "radii"} and all(v["ms"] > 0 and v["bus_GBs"] > 0 for v in c["slices"].values())
+    assert 0 < c["ms_per_step_no_collectives"] < r["ms_per_step"] and abs(c["exposed_ms_per_step"] - (r["ms_per_step"] - c["ms_per_step_no_collectives"])) < 1e-3
+    assert c["split3"]["chosen"] in ("two", "three") and c["split3"]["ms_per_step_two_pieces"] > 0 and c["split3"]["ms_per_step_three_pieces"] > 0

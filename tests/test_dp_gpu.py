@@ -67,6 +67,65 @@ def test_data_parallel_graph_replay_keeps_replicas_identical():
     assert same and finite and all(0.0 < l < 10.0 for l in losses), losses
 
 
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        out = {}
+        for bf16 in (False, True):
+            for split3 in (False, True):
+                tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
+                tr.wire_bf16, tr.split3 = bf16, split3
+                tr.enable_graph(capacity=40 * 20000)
+                assert tr._split, "the split step is the one with separate slices"
+                losses = [float(tr.step()) for _ in range(3)]
+                torch.cuda.synchronize()
+                params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
+                gp = [torch.zeros_like(params) for _ in range(world)]
+                dist.all_gather(gp, params)
+                out[(bf16, split3)] = (all(torch.equal(gp[0], g) for g in gp), bool(torch.isfinite(params).all()), losses, tr.wire_bytes_per_step(), tr.n_sh, tr._n_mid())
+                del tr
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bfloat16_wire_keeps_replicas_identical_and_halves_the_big_slices():
+    """Trainer.wire_bf16 (the lever for slow links, off by default): the SH slice -- and with split3 the per-surfel slice -- cross the
+    wire as bfloat16.  Every rank receives the same reduced values: replicas stay BIT-identical; the bytes handed to the collectives
+    move as wire_bytes_per_step states; the loss trajectory stays next to the fp32 one (it is a change of the numerics, bounded here)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for key, (same, finite, losses, wire, n_sh, n_mid) in out.items():
+        bf16, split3 = key
+        assert same and finite, key
+        assert wire["sh"] == (2 if bf16 else 4) * n_sh, (key, wire)
+        assert ("mid" in wire) == split3 and (not split3 or wire["mid"] == (2 if bf16 else 4) * n_mid), (key, wire)
+        assert wire["total"] == sum(v for k, v in wire.items() if k != "total")
+    n_sh, n_mid = out[(True, False)][4], out[(True, False)][5]
+    assert out[(True, False)][3]["total"] == out[(False, False)][3]["total"] - 2 * n_sh
+    assert out[(True, True)][3]["total"] == out[(False, True)][3]["total"] - 2 * (n_sh + n_mid)
+    for split3 in (False, True):
+        for a, b in zip(out[(False, split3)][2], out[(True, split3)][2]):
+            assert abs(a - b) <= 2e-3 * abs(a), (out[(False, split3)][2], out[(True, split3)][2])
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
