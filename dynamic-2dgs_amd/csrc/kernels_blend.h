@@ -52,6 +52,8 @@ __device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long lon
     return ((unsigned long long)hi << 32) | lo;
 }
 
+struct LongThr { uint32_t fwd, bwd; };   // long-tile path: thresholds of this launch (list length / traversed length), in the image buffer
+
 struct BlendFwdArgs {
     const uint2* ranges;         // [T]
     const uint32_t* order;       // [T] dispatch order (mode 3) or null
@@ -61,7 +63,8 @@ struct BlendFwdArgs {
     const float* bg;             // [3] device
     float* final_T;              // [3][T*256] tile-major: T, dist1, dist2
     uint32_t* n_contrib;         // [2][T*256] tile-major: last contributor, median contributor
-    uint32_t* tile_last;         // [T] max over the tile of `last contributor`
+    uint32_t* tile_last;         // [T] max over the tile of `last contributor` (zeroed by scan_tiles_kernel, written with atomicMax)
+    const LongThr* long_thr;     // thresholds of the long-tile path, or null (path off: grid = blend_grid_size)
     float* out_color;            // [3,H,W]
     float* out_others;           // [8,H,W]
 };
@@ -269,12 +272,27 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, c
 // the last one orders the tiles by the length the forward traversed (tile_order_kernel) -- the two were 7 + 6 us back to back in
 // front of the backward blend of every step.
 __global__ void __launch_bounds__(1024) prep_bwd_kernel(float4* __restrict__ acc, size_t n4, const uint32_t* weights, int tiles_x, int tiles_y, int mode,
-                                                        uint32_t* order, uint32_t* group_xcd)
+                                                        uint32_t* order, uint32_t* group_xcd, uint32_t* long_thr /*[2]: [1] written here*/, uint32_t long_div)
 {
     __shared__ uint32_t s_hist[8 * kOrderBins];
     __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
     __shared__ uint32_t s_wsum[16];
     if (blockIdx.x == gridDim.x - 1) {
+        {   // long-tile path of the backward blend: a tile is long from 512 traversed entries and (sum of the traversed lengths) / long_div on
+            const int ntiles = tiles_x * tiles_y;
+            uint32_t sum = 0;
+            for (int t = threadIdx.x; t < ntiles; t += 1024) sum += weights[t];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+            if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = 0;
+                for (int w = 0; w < 16; w++) tot += s_wsum[w];
+                long_thr[1] = max(512u, tot / max(long_div, 1u));
+            }
+            __syncthreads();
+        }
         if (mode == 4) tile_order_xcd_body(nullptr, weights, tiles_x, tiles_y, order, group_xcd, false, s_hist, s_gw, s_gx, s_wsum);
         else tile_order_body(nullptr, weights, tiles_x * tiles_y, order, s_hist, s_wsum);
         return;
@@ -474,6 +492,48 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(B
 #ifndef DGS_FWD_ROWS
 #define DGS_FWD_ROWS 1
 #endif
+
+// ---- long tiles (round 4) ---------------------------------------------------------------------------------------------------
+// A tile is one workgroup and a quadrant one wave that walks the tile's list serially, so a launch is never shorter than its longest
+// list -- and a lone wave issues one instruction per ~8 cycles however much of the device is idle: on a densified scene, whose few
+// covered tiles hold lists of 1-2 k entries, the heaviest tile alone was the launch.  The `kLongSlots` tiles at
+// the head of the longest-first dispatch order whose length exceeds a per-launch threshold (long_thr: written next to the order by the
+// kernel that sorts it) therefore get FOUR workgroups, one per quadrant, and the four waves of such a workgroup take the four quarters
+// of the list.  The transmittance recurrence T <- T - alpha T is a product, so a quarter needs only the product of the quarters in
+// front of it: pass 1 evaluates alpha over the own quarter and leaves that product per pixel in LDS, pass 2 starts from the
+// product of the earlier quarters and blends the quarter exactly like the short path (same thresholds, same per-entry arithmetic),
+// and the four partial states are combined in list order (sums; the distortion term's running sums enter linearly and are added in
+// afterwards).  1.5 x the arithmetic on a quarter of the critical path.  What differs from the serial walk is the rounding of T at the
+// quarter boundaries (a product of products) and the order of the sums -- a few ulp; the results are deterministic.
+// Grid (tile order 3 only): blocks [0, 4 kLongSlots) = (slot, quadrant) pairs, quadrant-major -- a short tile in one of these slots is
+// rendered by its quadrant-0 block, the other three exit --, blocks behind them the remaining slots of the order.
+constexpr int kLongSlots = 256;
+
+// blockIdx -> (tile, quadrant of a long tile or -1).  Returns false when the block has nothing to do.
+__device__ __forceinline__ bool long_decode(int bid, const uint32_t* order, int ntiles, uint32_t thr, const uint32_t* lengths /*[T] or null*/,
+                                            const uint2* ranges, int& tile, int& lq)
+{
+    lq = -1;
+    if (bid >= 4 * kLongSlots) {
+        const int slot = bid - 3 * kLongSlots;
+        if (slot >= ntiles) return false;
+        tile = (int)order[slot];
+        return tile < ntiles;
+    }
+    // (slot, quadrant) = (bid % kLongSlots, bid / kLongSlots): the quadrant-0 blocks -- all a short tile needs -- are the first kLongSlots
+    // blocks of the launch, in order, spread over the 8 XCDs like any other run of blocks (bid >> 2 / bid & 3 put every one of them
+    // on XCD 0 or 4: +28 % on the uniform scene)
+    const int slot = bid % kLongSlots, sub = bid / kLongSlots;
+    if (slot >= ntiles) return false;
+    tile = (int)order[slot];
+    if (tile >= ntiles) return false;
+    const uint32_t len = lengths ? lengths[tile] : ranges[tile].y - ranges[tile].x;
+    if (len > thr) { lq = sub; return true; }
+    return sub == 0;
+}
+
+inline int long_grid_size(int ntiles) { return ntiles + 3 * kLongSlots; }
+
 constexpr int kChunkF = 64;          // entries staged per wave and step by the row kernel: one per lane
 constexpr int kNullSlotF = kChunkF;  // the slot behind the staged ones: planes of an entry that fails the alpha test for every pixel
 struct FwdRowStage {
@@ -484,16 +544,186 @@ struct FwdRowStage {
     uint32_t idx[4][17];       // row r: the slots of its block's entries in list order, one byte each (68: the loop reads two ahead of a full list)
 };
 
+// one quarter's state per pixel, handed to the combine through LDS (aliases the staging slices once every wave is done with them)
+enum FwdLongSlot { kLPC0, kLPC1, kLPC2, kLPD, kLPN0, kLPN1, kLPN2, kLPd1, kLPd2, kLPdist, kLPTin, kLPTout, kLPmedd, kLPmedw, kLPlast, kLPmedc, kLPCount };
+struct FwdLongPart { float v[kLPCount][64]; };
+static_assert(sizeof(FwdLongPart) <= sizeof(FwdRowStage), "the partial states alias the staging slices");
+
+// quadrant q of long tile `tile`: this workgroup's wave w takes the w-th quarter of the list (see "long tiles" above)
+__device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, int q, FwdRowStage* s_stage /*[4]*/, float (*s_P)[64])
+{
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int lx_, ly_;
+    lane_pixel(64 * q + lane, lx_, ly_);
+    const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
+    const bool inside = px < a.W && py < a.H;
+    const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
+    const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
+    const float qx = tpx + (float)(8 * (q & 1)), qy = tpy + (float)(8 * (q >> 1));
+    const float qus0 = kSqrt2 * ((q & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((q & 2) ? 0.5f : -7.5f);
+    const float us_px = inside ? kSqrt2 * ((float)lx_ - 7.5f) : __builtin_nanf("");
+    const float vs = kSqrt2 * ((float)ly_ - 7.5f);
+    const uint2 range = a.ranges[tile];
+    const uint32_t len = range.y - range.x;
+    const uint32_t b0 = (uint32_t)(((unsigned long long)len * (unsigned)seg) >> 2), b1 = (uint32_t)(((unsigned long long)len * (unsigned)(seg + 1)) >> 2);
+    FwdRowStage& S = s_stage[seg];
+
+    float us = us_px;
+    PixFwd st;
+    pixfwd_init(st);
+    float P = 1.0f;   // pass 1: product of (1 - alpha) over the quarter's entries that pass the alpha and near tests
+
+    // one chunk of 64 list entries: records -> affine images -> the entries that can touch the quadrant, compacted (as blend_fwd_kernel)
+    auto stage = [&](uint32_t base, uint32_t id, unsigned long long& m) {
+        const uint32_t e_mine = base + (uint32_t)lane;
+        const float4* src = a.rec + (size_t)id * kRecQuads;
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
+        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+        const bool hit = (e_mine < b1) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
+        m = __ballot(hit);
+        if (hit) {
+            const int slot = lane_rank(m);
+            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+            S.tw[slot] = mk4(q1.z, q1.w, q2.x, __uint_as_float(e_mine + 1u));
+            S.q3[slot] = mk4(q3);
+            S.q4[slot] = mk4(q4);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto walk = [&](auto pass2) {
+        constexpr bool kBlend = decltype(pass2)::value;
+        uint32_t id_next = b0 + (uint32_t)lane < b1 ? a.point_list[range.x + b0 + lane] : 0u;
+        unsigned long long alive = __ballot(us == us);
+        for (uint32_t base = b0; base < b1 && alive != 0ull; base += kChunk) {
+            const uint32_t id = id_next;
+            id_next = base + kChunk + (uint32_t)lane < b1 ? a.point_list[range.x + base + kChunk + lane] : 0u;
+            unsigned long long m;
+            stage(base, id, m);
+            const int nhit = __builtin_popcountll(m);
+            f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
+            f32x4 tw = S.tw[0], q3 = S.q3[0], q4 = S.q4[0];
+            for (int i = 0; i < nhit; i++) {
+                AlphaEval e;
+                const bool pass = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
+                asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");
+                a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
+                bool use3d;
+                const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
+                const bool ok = pass & (depth >= kNear);
+                if (!kBlend) {
+                    const float ae = ok ? e.alpha : 0.0f;
+                    P = P - ae * P;
+                } else {
+                    float w, test_T;
+                    pixfwd_weight(st, e.alpha, w, test_T);
+                    const bool blend = ok & !(test_T < kTmin);
+                    if (blend) {
+                        st.contributor = __float_as_uint(tw.w);
+                        pixfwd_accumulate<true>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
+                    }
+                    us = (ok ^ blend) ? __builtin_nanf("") : us;
+                    asm volatile("" : "+v"(st.T), "+v"(us) : : "memory");
+                }
+                tw = S.tw[i + 1]; q3 = S.q3[i + 1]; q4 = S.q4[i + 1];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (kBlend) alive = __ballot(us == us);
+        }
+    };
+
+    walk(std::false_type{});
+    s_P[seg][lane] = P;
+    __syncthreads();
+    float T_in = 1.0f;
+    for (int j = 0; j < seg; j++) T_in *= s_P[j][lane];
+    st.T = T_in;
+    us = (T_in >= kTmin) ? us_px : __builtin_nanf("");   // (a pixel below 1e-4 blends nothing: test_T <= T)
+    walk(std::true_type{});
+    __syncthreads();   // every wave is done with its staging slice: the partial states go there
+    FwdLongPart* part = reinterpret_cast<FwdLongPart*>(s_stage);
+    {
+        float (*v)[64] = part[seg].v;
+        v[kLPC0][lane] = st.C[0]; v[kLPC1][lane] = st.C[1]; v[kLPC2][lane] = st.C[2]; v[kLPD][lane] = st.D;
+        v[kLPN0][lane] = st.N[0]; v[kLPN1][lane] = st.N[1]; v[kLPN2][lane] = st.N[2];
+        v[kLPd1][lane] = st.dist1; v[kLPd2][lane] = st.dist2; v[kLPdist][lane] = st.distortion;
+        v[kLPTin][lane] = T_in; v[kLPTout][lane] = st.T; v[kLPmedd][lane] = st.med_d; v[kLPmedw][lane] = st.med_w;
+        v[kLPlast][lane] = __uint_as_float(st.last); v[kLPmedc][lane] = __uint_as_float(st.med_c);
+    }
+    __syncthreads();
+    if (seg != 0) return;
+    // ---- the four quarters in list order
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, d1 = 0.f, d2 = 0.f, dist = 0.f, T = 1.0f, medd = 0.f, medw = 0.f;
+    uint32_t last = 0u, medc = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float (*v)[64] = part[k].v;
+        const float W = v[kLPTin][lane] - v[kLPTout][lane];   // sum of the quarter's blending weights (T only moves by them)
+        // distortion (forward.cu:413-417): err_i = m_i^2 A_i + dist2_i - 2 m_i dist1_i with the running sums of ALL earlier entries; the
+        // quarter used its own sums, the earlier quarters' totals enter linearly
+        dist += v[kLPdist][lane] + (d2 * W - 2.0f * d1 * v[kLPd1][lane]);
+        C0 += v[kLPC0][lane]; C1 += v[kLPC1][lane]; C2 += v[kLPC2][lane]; D += v[kLPD][lane];
+        N0 += v[kLPN0][lane]; N1 += v[kLPN1][lane]; N2 += v[kLPN2][lane];
+        d1 += v[kLPd1][lane]; d2 += v[kLPd2][lane];
+        const uint32_t lk = __float_as_uint(v[kLPlast][lane]), mk = __float_as_uint(v[kLPmedc][lane]);
+        if (lk != 0u) { last = lk; T = v[kLPTout][lane]; }
+        if (mk != 0u) { medc = mk; medd = v[kLPmedd][lane]; medw = v[kLPmedw][lane]; }
+    }
+    uint32_t mx = inside ? last : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(mx, d, 64);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0) atomicMax(&a.tile_last[tile], mx);
+    const size_t plane = (size_t)ntiles * kTilePix;
+    const size_t slot = (size_t)tile * kTilePix + 64 * q + lane;
+    a.final_T[slot] = T;
+    a.final_T[plane + slot] = d1;
+    a.final_T[2 * plane + slot] = d2;
+    a.n_contrib[slot] = last;
+    a.n_contrib[plane + slot] = medc;
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = (size_t)py * a.W + px;
+        a.out_color[pix] = C0 + T * a.bg[0];
+        a.out_color[HW + pix] = C1 + T * a.bg[1];
+        a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
+        a.out_others[pix] = D;
+        a.out_others[HW + pix] = 1.f - T;
+        a.out_others[2 * HW + pix] = N0;
+        a.out_others[3 * HW + pix] = N1;
+        a.out_others[4 * HW + pix] = N2;
+        a.out_others[5 * HW + pix] = medd;
+        a.out_others[6 * HW + pix] = dist;
+        a.out_others[7 * HW + pix] = medw;
+    }
+}
+
 __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_kernel(BlendFwdArgs a)
 {
     __shared__ FwdRowStage s_stage[4];
     __shared__ uint32_t s_max[4];
+    __shared__ float s_P[4][64];
 
     const int ntiles = a.tiles_x * a.tiles_y;
-    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
-    if (a.mode < 3 && tile >= ntiles) return;
-    if (a.mode >= 3) tile = (int)a.order[tile];
-    if (tile >= ntiles) return;   // mode 4: empty slot
+    int tile;
+    if (a.long_thr) {   // tile order 3 with the long-tile path: see long_decode
+        int lq;
+        if (!long_decode(blockIdx.x, a.order, ntiles, a.long_thr->fwd, nullptr, a.ranges, tile, lq)) return;
+        if (lq >= 0) {
+            blend_fwd_long(a, tile, lq, s_stage, s_P);
+            return;
+        }
+    } else {
+        tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
+        if (a.mode < 3 && tile >= ntiles) return;
+        if (a.mode >= 3) tile = (int)a.order[tile];
+        if (tile >= ntiles) return;   // mode 4: empty slot
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     int lx_, ly_;
@@ -651,6 +881,7 @@ struct BlendBwdArgs {
     const float* dL_dothers;  // [8,H,W]
     float* acc;               // [P, kAccFloats], zeroed
     float* det_part;          // deterministic variant only: [num_rendered][4 waves][kAccFloats], zeroed (see det_reduce_kernel)
+    const LongThr* long_thr;  // thresholds of the long-tile path, or null (path off: grid = blend_grid_size)
 };
 
 // ---- wave reduction of the 16 per-surfel partials of one (wave, entry) visit --------------------------------------------
@@ -796,6 +1027,11 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+#ifndef DGS_BWD_ROWS
+#define DGS_BWD_ROWS 0   // 1: the row-per-block backward kernel (measured, not the default: see blend_bwd_rows_kernel)
+#endif
+constexpr int kDetRows = DGS_BWD_ROWS ? 16 : 4;   // rows of det_part per list entry: one per (wave, 16-lane row) or per wave
+
 #ifndef DGS_BWD_MINWAVES
 #define DGS_BWD_MINWAVES 5
 #endif
@@ -814,37 +1050,34 @@ struct BwdStage {            // one wave's staging slice: the chunk's visited en
     f32x4 q4[kChunkB + 1];    // (g b, 0-based list index as bits, surfel id as bits)
 };
 
-template <bool DET>
-__global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
+// One quadrant of a tile, back to front.  LONG = false: the whole list behind the quadrant's last contributor, one wave (the kernel's
+// normal path, q = wave).  LONG = true ("long tiles" above blend_fwd_rows_kernel): the workgroup is ONE quadrant of a long tile and its
+// wave `seg` takes the seg-th quarter of that range.  Both recurrences of the backward are linear in the state that enters a quarter --
+// T <- T / (1 - alpha) and acc <- (1 - alpha) acc + alpha u, with alpha and u functions of the entry and the pixel only -- so pass 1
+// walks the quarter once without the gradient arithmetic and leaves (F, A, B) per pixel: T_out = F T_in, acc_out = A acc_in + B; every
+// wave then composes the quarters behind its own (they were walked by the other waves at the same time) and runs the real pass from
+// the state that reaches it.  1.4 x the arithmetic on a quarter of the critical path; the gradients differ from the serial walk in
+// rounding only (products and sums taken quarter-wise), like two runs of the atomic backward do.
+template <bool DET, bool LONG>
+__device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, int q, int seg, BwdStage& S, const BwdRedCtx& rc, float* xfer /*LONG: [4][3][64]*/)
 {
-    __shared__ BwdStage s_stage[4];
-#if DGS_BWD_REDUCE == 4
-    __shared__ BwdRed s_red[4];
-#endif
-
     const int ntiles = a.tiles_x * a.tiles_y;
-    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
-    if (a.mode < 3 && tile >= ntiles) return;
-    if (a.mode >= 3) tile = (int)a.order[tile];
-    if (tile >= ntiles) return;   // mode 4: empty slot
-    if (a.tile_last[tile] == 0u) return;   // no pixel of the tile blended anything
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     int lx_, ly_;
-    lane_pixel(tid, lx_, ly_);
+    lane_pixel(64 * q + lane, lx_, ly_);
     const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
     const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
     const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
-    const float qx = tpx + (float)(8 * (wave & 1)), qy = tpy + (float)(8 * (wave >> 1));
-    const float qus0 = kSqrt2 * ((wave & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((wave & 2) ? 0.5f : -7.5f);
+    const float qx = tpx + (float)(8 * (q & 1)), qy = tpy + (float)(8 * (q >> 1));
+    const float qus0 = kSqrt2 * ((q & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((q & 2) ? 0.5f : -7.5f);
     const float us = kSqrt2 * ((float)lx_ - 7.5f), vs = kSqrt2 * ((float)ly_ - 7.5f);
     const uint2 range = a.ranges[tile];
-    BwdStage& S = s_stage[wave];
 
     const size_t plane = (size_t)ntiles * kTilePix;
-    const size_t slot_px = (size_t)tile * kTilePix + tid;
+    const size_t slot_px = (size_t)tile * kTilePix + 64 * q + lane;
     PixBwdA st;
     {
         float gpix[3] = {0.f, 0.f, 0.f}, goth[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -871,98 +1104,162 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
     }
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);  // uniform by construction
     const int rslot = reduce16_slot(lane);
-    BwdRedCtx rc;
-#if DGS_BWD_REDUCE == 4
-    rc.init(&s_red[wave].v[0][0], lane);
-#endif
+    // the range of list entries this wave walks: [lo, hi), back to front
+    const int lo = LONG ? (int)(((long long)wave_last * seg) >> 2) : 0, hi = LONG ? (int)(((long long)wave_last * (seg + 1)) >> 2) : wave_last;
+    float xF = 1.0f, xA = 1.0f, xB = 0.0f;   // pass 1 (LONG): the quarter's transfer of (T, acc)
 
     // chunk lane l holds list entry e = top - l; the entries that can touch the quadrant are compacted in that (back to front) order
     const bool stager = kChunkB == 64 || lane < kChunkB;
-    uint32_t id_next = stager && wave_last - 1 - lane >= 0 ? a.point_list[range.x + (uint32_t)(wave_last - 1 - lane)] : 0u;
-    for (int top = wave_last - 1; top >= 0; top -= kChunkB) {
-        const int e_mine = top - lane;
-        const uint32_t id = id_next;   // (lanes beyond the front of the list hold id 0: a valid record, masked out below)
-        // straight-line staging, see blend_fwd_kernel
-        const float4* src = a.rec + (size_t)id * kRecQuads;
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3s = src[3], q4s = src[4], bx = src[5];
-        id_next = stager && e_mine - kChunkB >= 0 ? a.point_list[range.x + (uint32_t)(e_mine - kChunkB)] : 0u;
-        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
-        const bool hit = stager & (e_mine >= 0) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
-        const unsigned long long m = __ballot(hit);
-        if (m == 0ull) continue;
-        if (hit) {
-            const int slot = lane_rank(m);
-            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
-            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
-            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
-            S.tw[slot] = mk4(q1.z, q1.w, q2.x, q2.w);
-            S.tuv[slot] = mk4(q0.x, q0.y, q0.w, q1.x);
-            S.q3[slot] = mk4(q3s);
-            S.q4[slot] = mk4(q4s.x, q4s.y, __int_as_float(e_mine), __uint_as_float(id));
-        }
-        __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
-        const int nhit = __builtin_popcountll(m);
-        f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
-        f32x4 tw = S.tw[0], tuv = S.tuv[0], q3 = S.q3[0], q4 = S.q4[0];
-        for (int i = 0; i < nhit; i++) {
-            AlphaEval ev;
-            bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
+    auto walk = [&](auto light_tag) {
+        constexpr bool kLight = decltype(light_tag)::value;
+        uint32_t id_next = stager && hi - 1 - lane >= lo ? a.point_list[range.x + (uint32_t)(hi - 1 - lane)] : 0u;
+        for (int top = hi - 1; top >= lo; top -= kChunkB) {
+            const int e_mine = top - lane;
+            const uint32_t id = id_next;   // (lanes beyond the front of the range hold id 0: a valid record, masked out below)
+            // straight-line staging, see blend_fwd_kernel
+            const float4* src = a.rec + (size_t)id * kRecQuads;
+            const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3s = src[3], q4s = src[4], bx = src[5];
+            id_next = stager && e_mine - kChunkB >= lo ? a.point_list[range.x + (uint32_t)(e_mine - kChunkB)] : 0u;
+            const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
+            const bool hit = stager & (e_mine >= lo) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) continue;
+            if (hit) {
+                const int slot = lane_rank(m);
+                S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
+                S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
+                S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
+                S.tw[slot] = mk4(q1.z, q1.w, q2.x, q2.w);
+                S.tuv[slot] = mk4(q0.x, q0.y, q0.w, q1.x);
+                S.q3[slot] = mk4(q3s);
+                S.q4[slot] = mk4(q4s.x, q4s.y, __int_as_float(e_mine), __uint_as_float(id));
+            }
+            __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
+            const int nhit = __builtin_popcountll(m);
+            f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
+            f32x4 tw = S.tw[0], tuv = S.tuv[0], q3 = S.q3[0], q4 = S.q4[0];
+            for (int i = 0; i < nhit; i++) {
+                AlphaEval ev;
+                bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
 #if DGS_PIN_PREFETCH
-            asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
+                asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
 #endif
-            a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
-            DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
-            const int e = __builtin_amdgcn_readfirstlane(__float_as_int(q4.z));  // 0-based list index == the reference's `contributor`
-            ok = ok & (e < st.last_contributor);
-            if (__ballot(ok) != 0ull) {
-                bool use3d;
-                const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
-                ok = ok & (depth >= kNear);
-                // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step_affine)
-                float out[16], out2d[2];
+                a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
+                DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
+                const int e = __builtin_amdgcn_readfirstlane(__float_as_int(q4.z));  // 0-based list index == the reference's `contributor`
+                ok = ok & (e < st.last_contributor);
+                if (__ballot(ok) != 0ull) {
+                    bool use3d;
+                    const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
+                    ok = ok & (depth >= kNear);
+                    if (kLight) {
+                        // pass 1 of a long tile: only what the two recurrences need (pixbwd_step_affine's alpha, 1 / (1 - alpha) and u)
+                        const float alpha = ok ? ev.alpha : 0.f;
+                        const float u = pixbwd_u_affine(st, ok, depth, e, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
+                        xF = xF * fast_rcp(1.f - alpha);
+                        xA = xA - alpha * xA;
+                        xB = xB + alpha * (u - xB);
+                    } else {
+                    // every lane runs the step; a lane that does not blend the entry contributes exact zeros (pixbwd_step_affine)
+                    float out[16], out2d[2];
 #if DGS_DIAG_BWD == 3
-                for (int k = 0; k < 16; k++) out[k] = depth;
-                out2d[0] = out2d[1] = 0.f;
-                asm volatile("" : : "v"(depth), "v"(tuv.x), "v"(q3.x), "v"(q4.x));
+                    for (int k = 0; k < 16; k++) out[k] = depth;
+                    out2d[0] = out2d[1] = 0.f;
+                    asm volatile("" : : "v"(depth), "v"(tuv.x), "v"(q3.x), "v"(q4.x));
 #else
-                pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
-                                   Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
+                    pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
+                                       Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
 #endif
-                // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
-                float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * 4 + wave) * kAccFloats
-                                 : a.acc + (size_t)__builtin_amdgcn_readfirstlane(__float_as_uint(q4.w)) * kAccFloats;
+                    // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
+                    float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * kDetRows + q) * kAccFloats
+                                     : a.acc + (size_t)__builtin_amdgcn_readfirstlane(__float_as_uint(q4.w)) * kAccFloats;
 #if DGS_DIAG_BWD >= 2
-                float tot = 0.f;
-                for (int k = 0; k < 16; k++) asm volatile("" : : "v"(out[k]));
-                asm volatile("" : : "s"(dst));
+                    float tot = 0.f;
+                    for (int k = 0; k < 16; k++) asm volatile("" : : "v"(out[k]));
+                    asm volatile("" : : "s"(dst));
 #else
-                const float tot = wave_reduce16(out, lane, rc);
+                    const float tot = wave_reduce16(out, lane, rc);
 #endif
 #if DGS_DIAG_BWD == 0
-                if (rslot >= 0) {
-                    if (DET) dst[rslot] = tot;
-                    else atomicAdd(dst + rslot, tot);
-                }
+                    if (rslot >= 0) {
+                        if (DET) dst[rslot] = tot;
+                        else atomicAdd(dst + rslot, tot);
+                    }
 #else
-                asm volatile("" : : "v"(tot));
+                    asm volatile("" : : "v"(tot));
 #endif
-                if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
-                    const float mx = wave_sum(out2d[0]);
-                    const float my = wave_sum(out2d[1]);
-                    if (lane == 0) {
-                        if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
-                        else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                    if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                        const float mx = wave_sum(out2d[0]);
+                        const float my = wave_sum(out2d[1]);
+                        if (lane == 0) {
+                            if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
+                            else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
+                        }
+                    }
                     }
                 }
-            }
 #if DGS_PIN_PREFETCH
-            asm volatile("" : "+v"(st.T) : : "memory");
+                asm volatile("" : "+v"(st.T) : : "memory");
 #endif
-            tw = S.tw[i + 1]; tuv = S.tuv[i + 1]; q3 = S.q3[i + 1]; q4 = S.q4[i + 1];
-            DGS_PIN4(tw); DGS_PIN4(tuv); DGS_PIN4(q3); DGS_PIN4(q4);
+                tw = S.tw[i + 1]; tuv = S.tuv[i + 1]; q3 = S.q3[i + 1]; q4 = S.q4[i + 1];
+                DGS_PIN4(tw); DGS_PIN4(tuv); DGS_PIN4(q3); DGS_PIN4(q4);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+    };
+
+    if (LONG) {
+        walk(std::true_type{});
+        xfer[(seg * 3 + 0) * 64 + lane] = xF;
+        xfer[(seg * 3 + 1) * 64 + lane] = xA;
+        xfer[(seg * 3 + 2) * 64 + lane] = xB;
+        __syncthreads();
+        // the state that reaches this quarter: (T_final, 0) through the quarters behind it, back to front
+        float T = st.T, acc = 0.0f;
+        for (int j = 3; j > seg; j--) {
+            T = T * xfer[(j * 3 + 0) * 64 + lane];
+            acc = xfer[(j * 3 + 1) * 64 + lane] * acc + xfer[(j * 3 + 2) * 64 + lane];
+        }
+        st.T = T;
+        st.acc = acc;
+        __syncthreads();   // xfer lives in the reduction buffers, which the real pass writes
     }
+    walk(std::false_type{});
+}
+
+template <bool DET>
+__global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
+{
+    __shared__ BwdStage s_stage[4];
+#if DGS_BWD_REDUCE == 4
+    __shared__ BwdRed s_red[4];
+    static_assert(sizeof(BwdRed) * 4 >= 4 * 3 * 64 * sizeof(float), "the long path's transfer table lives in the reduction buffers");
+#endif
+
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tile, lq = -1;
+#if DGS_BWD_REDUCE == 4
+    if (a.long_thr) {   // tile order 3 with the long-tile path (long_decode)
+        if (!long_decode(blockIdx.x, a.order, ntiles, a.long_thr->bwd, a.tile_last, a.ranges, tile, lq)) return;
+    } else
+#endif
+    {
+        tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
+        if (a.mode < 3 && tile >= ntiles) return;
+        if (a.mode >= 3) tile = (int)a.order[tile];
+        if (tile >= ntiles) return;   // mode 4: empty slot
+    }
+    if (a.tile_last[tile] == 0u) return;   // no pixel of the tile blended anything
+    BwdRedCtx rc;
+#if DGS_BWD_REDUCE == 4
+    rc.init(&s_red[wave].v[0][0], lane);
+    if (lq >= 0) {
+        bwd_quadrant<DET, true>(a, tile, lq, wave, s_stage[wave], rc, &s_red[0].v[0][0]);
+        return;
+    }
+#endif
+    bwd_quadrant<DET, false>(a, tile, wave, 0, s_stage[wave], rc, nullptr);
 }
 
 // ---- backward blend, one list per 16-lane row (round 4) -------------------------------------------------------------------
@@ -1169,7 +1466,6 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_rows_ker
 // Deterministic reduction of the backward blend (test option): one thread per surfel walks the tiles of its rectangle in
 // row-major order, finds its entry in the tile's sorted list and adds the four waves' rows in order 0..3.  Same sums as the
 // atomics in ONE fixed order: two runs give bit-identical gradients.  Slow by design (linear search of the lists).
-constexpr int kDetRows = DGS_BWD_ROWS ? 16 : 4;   // rows of det_part per list entry: one per (wave, 16-lane row) or per wave
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const int* radii, const uint2* rects, int tiles_x, const uint2* ranges,
                                                          const uint32_t* point_list, const float* part, float* acc)
 {

@@ -201,9 +201,12 @@ __global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P,
 __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts, int ntiles, uint2* ranges, uint32_t* cursor,
                                                           uint32_t* total_out /*[3]: num_rendered, longest list, overflow*/,
                                                           uint32_t cap, int* overflow, uint32_t* order /*or null*/, uint32_t list_hint,
-                                                          int tiles_x, int tiles_y, int order_mode, uint32_t* group_xcd)
+                                                          int tiles_x, int tiles_y, int order_mode, uint32_t* group_xcd,
+                                                          uint32_t* tile_last /*[T]: zeroed here*/, uint32_t* long_thr /*[2]: [0] written here*/, uint32_t long_div)
 {
     __shared__ uint32_t s_wsum[4], s_wmax[4];
+    // the forward blend writes the per-tile maximum of the last contributor with atomicMax (a long tile is four workgroups)
+    for (int t = threadIdx.x; t < ntiles; t += 1024) tile_last[t] = 0u;
     __shared__ uint32_t s_hist[8 * kOrderBins];
     __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
     __shared__ uint32_t s_osum[16];
@@ -248,6 +251,9 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts
             total_out[1] = longest;
             total_out[2] = over ? 1u : 0u;
             if (over && overflow) atomicOr(overflow, 1);
+            // long-tile path of the forward blend (kernels_blend.h): worth its extra arithmetic only where ONE tile's serial walk is as
+            // long as the whole launch's throughput-bound time -- a list is long from 768 entries and num_rendered / long_div on
+            long_thr[0] = max(768u, total / max(long_div, 1u));
         }
     }
     if (order) {

@@ -799,6 +799,21 @@ DGS_HD void pixbwd_init_affine(PixBwdA& s, float T_final, float dist1, float dis
     s.last_contributor = last; s.med_c = med_c;
 }
 
+// The `u` of pixbwd_step_affine alone (same expressions): what the entry contributes to the "behind" recurrence acc <- acc + alpha (u - acc).
+// Pass 1 of the long-tile backward needs it without the gradient arithmetic.
+DGS_HD float pixbwd_u_affine(const PixBwdA& s, bool ok, float depth, int contributor, const Quad& q3, const Quad& q4)
+{
+    const float c_d = ok ? depth : 1.f;
+    const float r_d = fast_rcp(c_d);
+    const float m_d = kDepthC1 - kDepthC2 * r_d;
+    const bool is_med = ok & (contributor == s.med_c - 1);
+    const float tz = m_d * s.gA - s.gD;
+    float u = s.gD2 + m_d * (tz - s.gD) + s.g_alpha;
+    u += is_med ? s.g_medw : 0.f;
+    u = q3.w * s.g_pix[0] + (q4.x * s.g_pix[1] + (q4.y * s.g_pix[2] + (q3.x * s.g_normal[0] + (q3.y * s.g_normal[1] + (q3.z * s.g_normal[2] + (c_d * s.g_depth + u))))));
+    return u;
+}
+
 // tuv = (Tu.x, Tu.y, Tv.x, Tv.y); (pfx, pfy) absolute pixel centre.  out[16] in AccSlot order, out2d = dL_dmean2D (rare branch).
 DGS_HD void pixbwd_step_affine(PixBwdA& s, const AlphaEval& e, bool ok, bool use3d, float depth, int contributor, float pfx, float pfy,
                                float Twx, float Twy, const Quad& tuv, float opacity, const Quad& q3, const Quad& q4, float* out /*[16]*/,

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -73,7 +74,7 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-    size_t final_T, n_contrib, ranges, tile_last, order_fwd, order_bwd, group_xcd, tile_counts, cursor, bytes;
+    size_t final_T, n_contrib, ranges, tile_last, order_fwd, order_bwd, group_xcd, tile_counts, cursor, long_thr, bytes;
     bool lds_bins;  // per-workgroup LDS histograms fit (T * 4 bytes <= 144 KB)
     int tiles_x, tiles_y, ntiles;
     ImageLayout(int W, int H)
@@ -95,6 +96,7 @@ struct ImageLayout {
         lds_bins = (size_t)ntiles * 4 <= 144 * 1024;
         // LDS path: G x T matrix of per-workgroup counts / cursors; fallback: T global cursors
         cursor = c.take(lds_bins ? (size_t)dgs::kBinGroups * ntiles * 4 : (size_t)ntiles * 4);
+        long_thr = c.take(sizeof(dgs::LongThr));   // thresholds of the long-tile path (forward: scan_tiles_kernel, backward: prep_bwd_kernel)
         bytes = align_up(c.off, 128);
     }
 };
@@ -194,12 +196,25 @@ struct HostStage {
 }  // namespace
 
 struct dgs_context {
+    dgs_context()
+    {
+        if (const char* e = getenv("DGS_LONG_TILES")) long_tiles.store(atoi(e) != 0);   // A/B runs of whole programs (bench.py, the test suite)
+    }
     int device = 0;
     std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
     std::atomic<int> sort_regs{2};    // per-tile sort: 2 LSD radix in LDS (default), 1 bitonic network in registers, 0 bitonic in LDS
     std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
     std::atomic<int> deterministic{0};   // key 7: backward blend without atomics, fixed summation order (tests)
     std::atomic<int> sh_all_rows{0};     // key 8: dL_dsh written for every row (zeros for culled surfels / unused bands)
+    std::atomic<int> long_tiles{1};      // key 9: four workgroups (one per quadrant, four list quarters each) for the longest tiles
+    // Measured (tools/diag/long_tune.py, blend fwd / bwd in ms; uniform 200k scene | densified `trained` scene, 90 k surfels):
+    //   path off 0.126 / 0.259 | 0.146 / 0.443;  divisors 800 / 512: 0.121 / 0.248 | 0.171 / 0.349;  400 / 256: .. | 0.167 / 0.405;
+    //   1600 / 1024: 0.145 / 0.249 | 0.170 / 0.356;  200 / 128: 0.122 / 0.248 | 0.145 / 0.439.
+    // The backward of a densified scene is as long as its longest tile and gains 21 %; the forward there is mostly throughput-bound --
+    // any tile it treats as long costs more (1.5 x the arithmetic, the walk of the list behind the saturation point) than the shorter
+    // tail returns -- so its divisor only lets through a tile that holds more than 1 / 150 of all list entries.
+    std::atomic<int> long_div_fwd{150};  // key 10: a list is long from num_rendered / this (and 768 entries) on
+    std::atomic<int> long_div_bwd{512};  // key 11: a tile is long from (sum of traversed lengths) / this (and 512 entries) on
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
     std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
@@ -334,6 +349,9 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (key == 1 && value >= 0 && value <= 4) { c->tile_order.store(value); return DGS_OK; }
     if (key == 7) { c->deterministic.store(value != 0); return DGS_OK; }
     if (key == 8) { c->sh_all_rows.store(value != 0); return DGS_OK; }
+    if (key == 9) { c->long_tiles.store(value != 0); return DGS_OK; }
+    if (key == 10 && value > 0) { c->long_div_fwd.store(value); return DGS_OK; }
+    if (key == 11 && value > 0) { c->long_div_bwd.store(value); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
@@ -582,7 +600,7 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
                        il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)capacity, overflow,
                        tile_order >= 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr,   // + the forward's dispatch order
                        (uint32_t)(capacity > 0 ? ctx->list_hint.load() : 0), il.tiles_x, il.tiles_y, tile_order,
-                       (uint32_t*)(img + il.group_xcd));
+                       (uint32_t*)(img + il.group_xcd), (uint32_t*)(img + il.tile_last), (uint32_t*)(img + il.long_thr), (uint32_t)ctx->long_div_fwd.load());
     DGS_STAGE("scan_tiles", debug, stream);
 
     // ---- num_rendered to the host: the binning buffer is sized from it (rasterizer_impl.cu:281-285).
@@ -693,6 +711,13 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     fa.out_color = out_color;
     fa.out_others = out_others;
     int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, fa.mode);
+    fa.long_thr = nullptr;
+#if DGS_FWD_ROWS
+    if (fa.mode == 3 && ctx->long_tiles.load() && !ctx->grid_limit_fwd.load()) {   // long-tile path (kernels_blend.h): four workgroups for the longest lists
+        fa.long_thr = (const dgs::LongThr*)(img + il.long_thr);
+        grid = dgs::long_grid_size(il.ntiles);
+    }
+#endif
     if (const int lim = ctx->grid_limit_fwd.load()) {
         grid = lim < grid ? lim : grid;
         DGS_HIP(hipMemsetAsync(img + il.final_T, 0, il.ranges - il.final_T, stream));   // final_T, n_contrib of the skipped tiles
@@ -751,7 +776,7 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         const int fill_blocks = (int)std::min<size_t>(1024, (n4 + 4 * 1024 - 1) / (4 * 1024));   // ~4 stores of 16 B per thread
         hipLaunchKernelGGL(dgs::prep_bwd_kernel, dim3(fill_blocks + 1), dim3(1024), 0, stream, (float4*)acc, n4,
                            (const uint32_t*)(img_buffer + il.tile_last), il.tiles_x, il.tiles_y, bwd_mode,
-                           (uint32_t*)(img_buffer + il.order_bwd), (uint32_t*)(img_buffer + il.group_xcd));
+                           (uint32_t*)(img_buffer + il.order_bwd), (uint32_t*)(img_buffer + il.group_xcd), (uint32_t*)(img_buffer + il.long_thr), (uint32_t)ctx->long_div_bwd.load());
         DGS_STAGE("prep_bwd", debug, stream);
     } else {
         DGS_HIP(hipMemsetAsync(acc, 0, acc_bytes, stream));
@@ -780,6 +805,13 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         ba.dL_dothers = dL_depths;
         ba.acc = acc;
         int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, ba.mode);
+        ba.long_thr = nullptr;
+#if !DGS_BWD_ROWS && DGS_BWD_REDUCE == 4
+        if (ba.mode == 3 && prep_fused && ctx->long_tiles.load() && !ctx->grid_limit_bwd.load()) {   // long-tile path (kernels_blend.h)
+            ba.long_thr = (const dgs::LongThr*)(img_buffer + il.long_thr);
+            grid = dgs::long_grid_size(il.ntiles);
+        }
+#endif
         if (const int lim = ctx->grid_limit_bwd.load()) grid = lim < grid ? lim : grid;
         Prof::Pair pp;
         const bool timed = prof_begin(ctx, 1, stream, pp);

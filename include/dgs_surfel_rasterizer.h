@@ -149,10 +149,15 @@ void dgs_set_tight_rects(int on);
  * key 3 = per-tile sort: 2 LSD radix sort in LDS [default], 1 bitonic network with the keys in registers, 0 bitonic network in LDS,
  * key 7 = deterministic backward (0 [default] / 1): the backward blend stores its per-(list entry, wave) sums instead of adding them
  *         with float atomics and a per-surfel kernel adds them in a fixed order -- bit-identical gradients from run to run.  For
- *         tests: R x 320 bytes of scratch from hipMallocAsync (not capturable), a linear search per (surfel, tile).
+ *         tests: R x 320 bytes of scratch (R x 1280 with the row-per-block A/B kernel) from hipMallocAsync (not capturable), a linear search per (surfel, tile).
  * key 8 = dL_dsh of the backward written for EVERY row and coefficient (0 [default]: visible rows and the active bands only, as the
  *         reference does, so callers may accumulate into it; 1: zeros elsewhere, for callers whose gradient buffer is stored, not
  *         added to, and therefore never cleared).
+ * key 9 = long-tile path of the blend kernels (1 [default] / 0; tile order 3 only): the tiles at the head of the longest-first dispatch
+ *         order whose list (forward) / traversed length (backward) exceeds a per-launch threshold get four workgroups -- one per 8x8
+ *         quadrant, four list quarters each -- instead of one; deterministic, results differ from the serial walk in rounding only.
+ * key 10 / key 11 = thresholds of that path: a forward list is long from num_rendered / value entries on (default 150; never below
+ *         768), a backward tile from (sum of the traversed lengths) / value on (default 512; never below 512).
  * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
  *         host read the library cannot know which of its per-tile sort kernels will find work and launches all three; with the
  *         promise it launches only those for lists up to `value` (2048: one launch instead of three, ~10 us of an 800x800

@@ -214,11 +214,13 @@ def test_every_tile_order_renders_the_same(shape):
     gc, go = _cot(case)
     outs = {}
     try:
+        _C.set_option(9, 0)   # the long-tile path exists under tile order 3 only and rounds differently: an orthogonal switch, off here
         for mode in (3, 0, 1, 2, 4):
             _C.set_option(1, mode)
             outs[mode] = run_hip(case, gc, go, debug=False)
     finally:
         _C.set_option(1, 3)
+        _C.set_option(9, 1)
     ref = outs[3]
     for mode in (0, 1, 2, 4):
         o = outs[mode]
@@ -405,6 +407,81 @@ def test_long_tile_lists_use_all_sort_paths(sort_mode, P):
     assert hip["R"] == orc.num_rendered
     assert np.array_equal(hip["point_list"], orc.field("point_list"))
     frac_close(hip["color"], orc.color, 2e-5, 1e-5, 5e-4, 2e-2, "color")  # 96x96 image: one flipped pixel is 1.1e-4
+
+
+def _clustered_case(P=7000, n_cluster=3000, H=128, W=160, seed=51):
+    """A cloud with a dense knot: n_cluster surfels packed into a ball that projects onto a few tiles, so those tiles' lists are an
+    order of magnitude longer than the mean list -- the situation densification produces and the long-tile path exists for."""
+    case = small_case(P=P, H=H, W=W, seed=seed, view=3, scale_mul=1.0, sh_degree=1)
+    g = np.random.default_rng(seed)
+    xyz = case["means3D"].numpy().copy()
+    centre = np.array([0.15, -0.1, 0.2], np.float32)
+    xyz[:n_cluster] = centre + 0.05 * g.standard_normal((n_cluster, 3)).astype(np.float32)
+    case["means3D"] = torch.from_numpy(xyz)
+    op = case["opacities"].numpy().copy()
+    op[:n_cluster] *= 0.15          # thin enough that the lists are traversed deep
+    case["opacities"] = torch.from_numpy(op)
+    return case
+
+
+def test_long_tile_path_matches_the_serial_walk_and_the_oracle():
+    """dgs_set_option(9, .): the longest tiles are rendered by four workgroups (one per quadrant, four list quarters per workgroup,
+    kernels_blend.h "long tiles") instead of one.  Against the serial walk of the same lists the result may differ in rounding only
+    (T at the quarter boundaries is a product of products, the sums are added quarter by quarter); against the oracle it meets the
+    same bounds; two runs are bit-identical."""
+    from diff_surfel_rasterization import _C
+    from gpu_utils import frac_close, hip_median_contrib, median_flips, rel_l2, run_hip, run_hip_raw
+    case = _clustered_case()
+    gc, go = _cot(case)
+    orc = oracle_from_case(case)
+    lens = orc.field("ranges")[:, 1] - orc.field("ranges")[:, 0]
+    assert lens.max() > 1500 and lens.max() > 4 * lens.mean(), (lens.max(), lens.mean())
+    outs = {}
+    try:
+        _C.set_option(10, 32)   # forward: lists longer than R / 32 = 1124 entries (the default, R / 150, is for scenes with ONE dominant tile)
+        _C.set_option(11, 32)
+        for on in (1, 0, 1):
+            _C.set_option(9, on)
+            outs.setdefault(on, []).append((run_hip(case, gc, go, debug=False), run_hip_raw(case)))
+    finally:
+        _C.set_option(9, 1)
+        _C.set_option(10, 150)
+        _C.set_option(11, 512)
+    (l1, r1), (l2, r2) = outs[1]
+    (s0, rs) = outs[0][0]
+    assert int((r1["tile_last"] > 0).sum()) > 0
+    assert np.array_equal(l1["color"], l2["color"]) and np.array_equal(l1["allmap"], l2["allmap"]), "the long path is not deterministic"
+    # long vs serial: same lists, same thresholds up to the rounding of T
+    assert np.array_equal(r1["point_list"], rs["point_list"])
+    differ = (r1["n_contrib"] != rs["n_contrib"]).any(axis=0)
+    assert differ.mean() <= 2e-4, "last / median contributor differs on %d pixels" % differ.sum()
+    assert not np.array_equal(l1["color"], s0["color"]), "the scene has no long tile: the path was not exercised"
+    for k, tol in (("color", 2e-6), ("allmap", 2e-5)):
+        d = np.abs(l1[k] - s0[k])[:, ~differ]
+        assert d.max() <= tol * max(1.0, float(np.abs(s0[k]).max())), (k, float(d.max()))
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
+        assert rel_l2(l1[k], s0[k]) <= 1e-4, "%s rel-L2 %.3e" % (k, rel_l2(l1[k], s0[k]))
+        assert not np.array_equal(l1[k], s0[k])
+    # the backward's long path alone (serial forward feeding it is the same forward: option 9 switches both, so compare the gradients
+    # of two long runs with the deterministic reduction: the quarter-wise recurrences must reproduce themselves bit for bit)
+    try:
+        _C.set_option(10, 32); _C.set_option(11, 32); _C.set_option(7, 1)
+        d1, d2 = run_hip(case, gc, go, debug=False), run_hip(case, gc, go, debug=False)
+    finally:
+        _C.set_option(7, 0); _C.set_option(10, 150); _C.set_option(11, 512)
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
+        assert np.array_equal(d1[k], d2[k]), k
+        assert rel_l2(d1[k], l1[k]) <= 1e-4, k
+    og = orc.backward(gc, go)
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
+        assert rel_l2(l1[k], og[k]) <= 1e-3, "%s vs oracle rel-L2 %.3e" % (k, rel_l2(l1[k], og[k]))
+    # long path vs oracle
+    flips = median_flips(hip_median_contrib(case), orc)
+    am, om = l1["allmap"].copy(), orc.allmap.copy()
+    for ch in (5, 7):
+        am[ch][flips] = om[ch][flips]
+    frac_close(l1["color"], orc.color, 2e-5, 1e-5, 2e-4, 2e-2, "color")
+    frac_close(am, om, 5e-5, 2e-5, 2e-4, 1e-1, "allmap")
 
 
 def test_config_c2_static_forward_only_50k_800():

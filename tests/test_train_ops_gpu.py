@@ -530,8 +530,14 @@ def test_stored_gradients_equal_cleared_and_added_ones():
         off += n
         noise = float((b - c).norm()) + 1e-12 * float(b.norm()) + 1e-30        # two cleared runs: float atomics + three Adam steps apart
         assert float((a - b).norm()) <= 4.0 * noise + 1e-4 * float(b.norm()), (i, n, float((a - b).norm()), noise, float(b.norm()))
+    # Parameters after three Adam steps: Adam turns a gradient that is zero to rounding into a full step of either sign, so a few
+    # elements per run land 2 lr apart between ANY two runs (float atomics); the maximum difference of one pair of runs is a draw
+    # from that tail, not a yardstick for another pair (tools/diag/store_probe.py: pairwise maxima of one configuration spread over
+    # a factor of ten).  The 99.9th percentile is stable; a producer that added into the uncleared bucket would move every element.
+    q = lambda x: float(torch.quantile(x.abs().reshape(-1)[:4_000_000].float(), 0.999))
     for a, b, c in zip(pa, pb, pc):
-        assert float((a - b).abs().max()) <= 4.0 * float((b - c).abs().max()) + 1e-6
+        assert q(a - b) <= 4.0 * q(b - c) + 1e-6, (tuple(a.shape), q(a - b), q(b - c))
+        assert float((a - b).abs().max()) <= 50.0 * float((b - c).abs().max()) + 1e-4
 
 
 def test_fused_step_matches_unfused_step():

@@ -1,0 +1,52 @@
+"""Dev tool (GPU box): the long-tile path (dgs_set_option 9 / 10 / 11) on the `trained` bench scene and on the uniform metric scene:
+blend kernel times per setting.  usage: python tools/diag/long_tune.py [pre_iterations]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "dynamic-2dgs_amd"))
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch
+
+import bench
+from diff_surfel_rasterization import _C
+
+dev = torch.device("cuda:0")
+SETTINGS = [("off", 0, 800, 512), ("800/512", 1, 800, 512), ("400/256", 1, 400, 256), ("1600/1024", 1, 1600, 1024), ("800/2048", 1, 800, 2048), ("200/128", 1, 200, 128)]
+
+
+def run(tr, views, tag):
+    tr._graph = None
+    _C.set_capacity(0)
+    _C.set_option(6, 0)
+    snap, it0 = tr._snapshot(), tr.iteration
+    for name, on, df, db in SETTINGS:
+        _C.set_option(9, on); _C.set_option(10, df); _C.set_option(11, db)
+        tr._restore(snap); tr.iteration = it0
+        for v in views:
+            tr.iteration = v
+            tr.step()
+        torch.cuda.synchronize()
+        tr._restore(snap)
+        _C.profile_enable(1)
+        _C.profile_reset()
+        for _ in range(3):
+            for v in views:
+                tr.iteration = v
+                tr.step()
+        torch.cuda.synchronize()
+        p = _C.profile_read()
+        _C.profile_enable(0)
+        print("%-8s %-10s fwd blend %.3f ms, bwd blend %.3f ms" % (tag, name, p["fwd_ms"] / max(p["fwd_n"], 1), p["bwd_ms"] / max(p["bwd_n"], 1)), flush=True)
+    _C.set_option(9, 1); _C.set_option(10, 800); _C.set_option(11, 512)
+    tr._restore(snap)
+
+
+tr = bench.build_trainer(200_000, 800, 800, dev)
+run(tr, [0, 8, 16, 24], "metric")
+del tr
+tr, _ = bench.trained_trainer(100_000, 800, 800, dev, int(sys.argv[1]) if len(sys.argv) > 1 else 10000)
+tr.set_regime(warmup=False, lambda_normal=0.02, lambda_dist=1000.0)
+print("trained: live surfels", tr.surfels.num_surfels)
+run(tr, [5, 17, 33, 41], "trained")
