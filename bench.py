@@ -232,7 +232,7 @@ def forward_only(args, P, H, W, device):
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "c2: static canonical render of S(%d surfels, %dx%d, seed 0), forward only, no deformation" % (P, W, H),
                       "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "launch": "eager, through GaussianRasterizer.forward"},
-           "roofline": {"bound": "hbm", "kernel": "blend_fwd_kernel", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "blend_fwd_rows_kernel", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "timing": "HIP events on the launch stream, the timed steps themselves",
                         "avg_kernel_ms": round(ms / max(n, 1), 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S / max(n, 1))}}
     print(json.dumps(out), flush=True)
@@ -557,6 +557,9 @@ def main():
         except Exception as ex:
             pmc_src = "no PMC profile for this workload (%s)" % type(ex).__name__
 
+        # the blend kernels as the library launches them (the forward walks one list per 16-lane row since round 4)
+        KNAME = {"fwd": "blend_fwd_rows_kernel", "bwd": "blend_bwd_kernel"}
+
         def pmc_of(kernel, counter):
             return pmc.get("dgs::" + kernel, {}).get(counter)
 
@@ -576,8 +579,8 @@ def main():
             S = src[kind + "_S"] / n
             bytes_per = blend_bytes(S, ntiles, H * W, backward=(kind == "bwd"))
             gbs = bytes_per / (ms * 1e-3) / 1e9
-            r = {"bound": "hbm", "kernel": "blend_%s_kernel" % kind, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": pmc_of("blend_%s_kernel" % kind, "hbm_traffic_bytes_per_launch"),
+            r = {"bound": "hbm", "kernel": KNAME[kind], "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": pmc_of(KNAME[kind], "hbm_traffic_bytes_per_launch"),
                  "traffic_source": pmc_src, "timing": "%s, %d launches" % (label, n),
                  "avg_kernel_ms": round(ms, 4), "alg_bytes_per_launch": round(bytes_per), "S_per_launch": round(S)}
             if src is prof_graph and prof and prof[kind + "_n"]:
@@ -586,15 +589,15 @@ def main():
 
         def roof_valu(kind):
             d = duration(kind)
-            insts = pmc_of("blend_%s_kernel" % kind, "SQ_INSTS_VALU")
+            insts = pmc_of(KNAME[kind], "SQ_INSTS_VALU")
             if not d or not insts:
                 return None
             ms = d[0]
             peak = 0.5 * 1024 * 2.4e9   # MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles on a SIMD-32; 1024 SIMDs; 2.4 GHz
             ach = insts / (ms * 1e-3)
-            return {"bound": "valu_issue", "kernel": "blend_%s_kernel" % kind, "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
+            return {"bound": "valu_issue", "kernel": KNAME[kind], "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
                     "unit": "G wave64 VALU instructions/s", "frac": round(ach / peak, 4), "valu_instructions_per_launch": insts,
-                    "salu_instructions_per_launch": pmc_of("blend_%s_kernel" % kind, "SQ_INSTS_SALU"), "avg_kernel_ms": round(ms, 4),
+                    "salu_instructions_per_launch": pmc_of(KNAME[kind], "SQ_INSTS_SALU"), "avg_kernel_ms": round(ms, 4),
                     "cycles_per_instruction_per_simd": round(1024 * 2.4e9 * ms * 1e-3 / insts, 2),
                     "measured_issue_ceiling": "2.5 cycles per plain FMA / mul / add, 4.4-4.8 with an SGPR operand, for comparisons, min/max, "
                                               "selects, DPP; 8.5-12.7 for v_rcp / v_exp (profiles/r03_valu_issue_gfx950.txt)",
