@@ -26,7 +26,7 @@
 namespace dgs {
 
 #ifndef DGS_FWD_MINWAVES
-#define DGS_FWD_MINWAVES 1
+#define DGS_FWD_MINWAVES 5   // (the long-tile path's extra state must not cost the short path its fifth wave per SIMD)
 #endif
 #ifndef DGS_PIN_PREFETCH
 #define DGS_PIN_PREFETCH 1
@@ -498,13 +498,12 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(B
 // list -- and a lone wave issues one instruction per ~8 cycles however much of the device is idle: on a densified scene, whose few
 // covered tiles hold lists of 1-2 k entries, the heaviest tile alone was the launch.  The `kLongSlots` tiles at
 // the head of the longest-first dispatch order whose length exceeds a per-launch threshold (long_thr: written next to the order by the
-// kernel that sorts it) therefore get FOUR workgroups, one per quadrant, and the four waves of such a workgroup take the four quarters
-// of the list.  The transmittance recurrence T <- T - alpha T is a product, so a quarter needs only the product of the quarters in
-// front of it: pass 1 evaluates alpha over the own quarter and leaves that product per pixel in LDS, pass 2 starts from the
-// product of the earlier quarters and blends the quarter exactly like the short path (same thresholds, same per-entry arithmetic),
-// and the four partial states are combined in list order (sums; the distortion term's running sums enter linearly and are added in
-// afterwards).  1.5 x the arithmetic on a quarter of the critical path.  What differs from the serial walk is the rounding of T at the
-// quarter boundaries (a product of products) and the order of the sums -- a few ulp; the results are deterministic.
+// kernel that sorts it) therefore get FOUR workgroups, one per quadrant, whose four waves share the list: both recurrences of the
+// backward and the forward's T <- T - alpha T are linear in the state that enters a stretch of the list, so a stretch can be walked
+// before that state is known (a light pass leaves the stretch's transfer per pixel), the transfers are composed, and the real pass
+// starts from the state that reaches the stretch.  Backward: quarters of the traversed range (bwd_quadrant<.., LONG = true>); forward:
+// rounds of four chunks, which end where the serial walk ends (blend_fwd_long).  1.4-1.5 x the arithmetic on a quarter of the critical
+// path.  What differs from the serial walk is rounding (products and sums taken stretch-wise); the results are deterministic.
 // Grid (tile order 3 only): blocks [0, 4 kLongSlots) = (slot, quadrant) pairs, quadrant-major -- a short tile in one of these slots is
 // rendered by its quadrant-0 block, the other three exit --, blocks behind them the remaining slots of the order.
 constexpr int kLongSlots = 256;
@@ -544,13 +543,21 @@ struct FwdRowStage {
     uint32_t idx[4][17];       // row r: the slots of its block's entries in list order, one byte each (68: the loop reads two ahead of a full list)
 };
 
-// one quarter's state per pixel, handed to the combine through LDS (aliases the staging slices once every wave is done with them)
-enum FwdLongSlot { kLPC0, kLPC1, kLPC2, kLPD, kLPN0, kLPN1, kLPN2, kLPd1, kLPd2, kLPdist, kLPTin, kLPTout, kLPmedd, kLPmedw, kLPlast, kLPmedc, kLPCount };
-struct FwdLongPart { float v[kLPCount][64]; };
+// ---- forward, long tile: one quadrant per workgroup, the list in ROUNDS of four chunks ---------------------------------------
+// Wave w of the workgroup takes chunk 4 r + w of round r (64 list entries).  Per round: stage the chunk once; pass 1 over the staged
+// entries = alpha only, product of (1 - alpha) per pixel -> LDS, barrier; T_in of the wave = T at the start of the round x the
+// products of the waves in front of it; pass 2 over the SAME staged entries = the short path's blend from T_in; the round's weights
+// and distortion sums -> LDS, barrier; every wave adds the cross terms of the distortion (its entries against the running sums of
+// everything in front of them, which enter linearly) and takes T behind the round from the last wave.  The walk ends like the serial
+// one, when no pixel of the quadrant takes entries any more -- a quarter-per-wave split of the WHOLE list (the first version) walked
+// the list behind the saturation point as well: 3.6 x slower than the serial kernel on an opaque knot (40 k surfels on a few tiles).
+enum FwdLongSlot { kLPC0, kLPC1, kLPC2, kLPD, kLPN0, kLPN1, kLPN2, kLPdist, kLPT, kLPmedd, kLPmedw, kLPlast, kLPmedc, kLPCount };
+struct FwdLongPart { float v[kLPCount][64]; };            // a wave's state per pixel for the final combine (aliases the staging slices)
 static_assert(sizeof(FwdLongPart) <= sizeof(FwdRowStage), "the partial states alias the staging slices");
+struct FwdLongX { float P[4][64], W[4][64], d1[4][64], d2[4][64]; unsigned long long done[4]; };   // one round's exchange (single copy: the
+// products are read between the round's two barriers and next written behind the second one; the other arrays the other way round)
 
-// quadrant q of long tile `tile`: this workgroup's wave w takes the w-th quarter of the list (see "long tiles" above)
-__device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, int q, FwdRowStage* s_stage /*[4]*/, float (*s_P)[64])
+__device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, int q, FwdRowStage* s_stage /*[4]*/, FwdLongX& X)
 {
     const int ntiles = a.tiles_x * a.tiles_y;
     const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
@@ -567,43 +574,69 @@ __device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, 
     const float vs = kSqrt2 * ((float)ly_ - 7.5f);
     const uint2 range = a.ranges[tile];
     const uint32_t len = range.y - range.x;
-    const uint32_t b0 = (uint32_t)(((unsigned long long)len * (unsigned)seg) >> 2), b1 = (uint32_t)(((unsigned long long)len * (unsigned)(seg + 1)) >> 2);
     FwdRowStage& S = s_stage[seg];
 
-    float us = us_px;
     PixFwd st;
     pixfwd_init(st);
-    float P = 1.0f;   // pass 1: product of (1 - alpha) over the quarter's entries that pass the alpha and near tests
+    float T_round = 1.0f;        // T in front of the current round (pixels that still take entries)
+    float T_final = 1.0f;        // T behind this wave's last blend
+    float d1_tot = 0.f, d2_tot = 0.f;   // the distortion's running sums in front of the current round (the same in all four waves)
+    bool done_pix = !inside;     // saturated (forward.cu:402-406) in some wave's chunk, or outside the image
 
-    // one chunk of 64 list entries: records -> affine images -> the entries that can touch the quadrant, compacted (as blend_fwd_kernel)
-    auto stage = [&](uint32_t base, uint32_t id, unsigned long long& m) {
-        const uint32_t e_mine = base + (uint32_t)lane;
+    uint32_t id_next = 64u * (uint32_t)seg + (uint32_t)lane < len ? a.point_list[range.x + 64u * seg + lane] : 0u;
+    for (uint32_t base = 0; base < len; base += 4 * kChunk) {
+        const uint32_t e_mine = base + 64u * (uint32_t)seg + (uint32_t)lane;
+        const uint32_t id = id_next;
+        id_next = e_mine + 4 * kChunk < len ? a.point_list[range.x + e_mine + 4 * kChunk] : 0u;
+        // stage the wave's chunk (as blend_fwd_kernel: the entries that can touch the quadrant, compacted)
         const float4* src = a.rec + (size_t)id * kRecQuads;
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3r = src[3], q4r = src[4], bx = src[5];
         const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
-        const bool hit = (e_mine < b1) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
-        m = __ballot(hit);
+        const bool hit = (e_mine < len) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
+        const unsigned long long m = __ballot(hit);
         if (hit) {
             const int slot = lane_rank(m);
             S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
             S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
             S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
             S.tw[slot] = mk4(q1.z, q1.w, q2.x, __uint_as_float(e_mine + 1u));
-            S.q3[slot] = mk4(q3);
-            S.q4[slot] = mk4(q4);
+            S.q3[slot] = mk4(q3r);
+            S.q4[slot] = mk4(q4r);
         }
         __builtin_amdgcn_wave_barrier();
-    };
-    auto walk = [&](auto pass2) {
-        constexpr bool kBlend = decltype(pass2)::value;
-        uint32_t id_next = b0 + (uint32_t)lane < b1 ? a.point_list[range.x + b0 + lane] : 0u;
-        unsigned long long alive = __ballot(us == us);
-        for (uint32_t base = b0; base < b1 && alive != 0ull; base += kChunk) {
-            const uint32_t id = id_next;
-            id_next = base + kChunk + (uint32_t)lane < b1 ? a.point_list[range.x + base + kChunk + lane] : 0u;
-            unsigned long long m;
-            stage(base, id, m);
-            const int nhit = __builtin_popcountll(m);
+        const int nhit = __builtin_popcountll(m);
+        // ---- pass 1: the chunk's product of (1 - alpha) over the entries that pass the alpha and near tests
+        float P = 1.0f;
+        {
+            f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0], tw = S.tw[0];
+            for (int i = 0; i < nhit; i++) {
+                AlphaEval e;
+                const bool pass = alpha_affine(us_px, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
+                asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");
+                a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
+                bool use3d;
+                const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
+                const float ae = (pass & (depth >= kNear)) ? e.alpha : 0.0f;
+                P = P - ae * P;
+                tw = S.tw[i + 1];
+            }
+        }
+        X.P[seg][lane] = P;
+        __syncthreads();
+        float T_in = T_round, T_in3 = T_round;    // T in front of this wave's chunk / of the last wave's
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float Pj = X.P[j][lane];
+            T_in = j < seg ? T_in * Pj : T_in;
+            T_in3 *= Pj;
+        }
+        // ---- pass 2: the short path's blend of the same staged entries, from T_in
+        float us = (!done_pix && T_in >= kTmin) ? us_px : __builtin_nanf("");   // (a pixel below 1e-4 blends nothing: test_T <= T)
+        const bool took = us == us;
+        const uint32_t last_before = st.last;
+        st.T = T_in;
+        st.dist1 = 0.f; st.dist2 = 0.f;    // the round's own sums; the sums in front of the chunk are added in below
+        if (__ballot(took) != 0ull) {
             f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
             f32x4 tw = S.tw[0], q3 = S.q3[0], q4 = S.q4[0];
             for (int i = 0; i < nhit; i++) {
@@ -613,64 +646,60 @@ __device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, 
                 a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
                 bool use3d;
                 const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
+                float w, test_T;
+                pixfwd_weight(st, e.alpha, w, test_T);
                 const bool ok = pass & (depth >= kNear);
-                if (!kBlend) {
-                    const float ae = ok ? e.alpha : 0.0f;
-                    P = P - ae * P;
-                } else {
-                    float w, test_T;
-                    pixfwd_weight(st, e.alpha, w, test_T);
-                    const bool blend = ok & !(test_T < kTmin);
-                    if (blend) {
-                        st.contributor = __float_as_uint(tw.w);
-                        pixfwd_accumulate<true>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
-                    }
-                    us = (ok ^ blend) ? __builtin_nanf("") : us;
-                    asm volatile("" : "+v"(st.T), "+v"(us) : : "memory");
+                const bool blend = ok & !(test_T < kTmin);
+                if (blend) {
+                    st.contributor = __float_as_uint(tw.w);
+                    pixfwd_accumulate<true>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
                 }
+                us = (ok ^ blend) ? __builtin_nanf("") : us;
+                asm volatile("" : "+v"(st.T), "+v"(us) : : "memory");
                 tw = S.tw[i + 1]; q3 = S.q3[i + 1]; q4 = S.q4[i + 1];
             }
-            __builtin_amdgcn_wave_barrier();
-            if (kBlend) alive = __ballot(us == us);
         }
-    };
+        __builtin_amdgcn_wave_barrier();
+        const float W_own = T_in - st.T, d1_own = st.dist1, d2_own = st.dist2;   // (T only moves by the blending weights)
+        X.W[seg][lane] = W_own; X.d1[seg][lane] = d1_own; X.d2[seg][lane] = d2_own;
+        const unsigned long long sat = __ballot(took && !(us == us));   // pixels that saturated in this chunk
+        if (lane == 0) X.done[seg] = sat;
+        if (st.last != last_before) T_final = st.T;
+        __syncthreads();
+        // distortion (forward.cu:413-417): err_i = m_i^2 A_i + dist2_i - 2 m_i dist1_i with the running sums of ALL earlier entries; the
+        // chunk used its own sums, everything in front of it enters linearly
+        float p1 = d1_tot, p2 = d2_tot;
+        for (int j = 0; j < seg; j++) { p1 += X.d1[j][lane]; p2 += X.d2[j][lane]; }
+        st.distortion += p2 * W_own - 2.0f * p1 * d1_own;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { d1_tot += X.d1[j][lane]; d2_tot += X.d2[j][lane]; }
+        const unsigned long long any_sat = X.done[0] | X.done[1] | X.done[2] | X.done[3];
+        done_pix = done_pix | (((any_sat >> lane) & 1ull) != 0ull);
+        T_round = T_in3 - X.W[3][lane];   // T behind the last wave's chunk (its T_in minus its weights: the operation it performed)
+        if (__ballot(!done_pix && T_round >= kTmin) == 0ull) break;   // (the same verdict in all four waves: same data)
+    }
 
-    walk(std::false_type{});
-    s_P[seg][lane] = P;
-    __syncthreads();
-    float T_in = 1.0f;
-    for (int j = 0; j < seg; j++) T_in *= s_P[j][lane];
-    st.T = T_in;
-    us = (T_in >= kTmin) ? us_px : __builtin_nanf("");   // (a pixel below 1e-4 blends nothing: test_T <= T)
-    walk(std::true_type{});
-    __syncthreads();   // every wave is done with its staging slice: the partial states go there
+    __syncthreads();   // every wave is done with its staging slice: the waves' states go there
     FwdLongPart* part = reinterpret_cast<FwdLongPart*>(s_stage);
     {
         float (*v)[64] = part[seg].v;
         v[kLPC0][lane] = st.C[0]; v[kLPC1][lane] = st.C[1]; v[kLPC2][lane] = st.C[2]; v[kLPD][lane] = st.D;
         v[kLPN0][lane] = st.N[0]; v[kLPN1][lane] = st.N[1]; v[kLPN2][lane] = st.N[2];
-        v[kLPd1][lane] = st.dist1; v[kLPd2][lane] = st.dist2; v[kLPdist][lane] = st.distortion;
-        v[kLPTin][lane] = T_in; v[kLPTout][lane] = st.T; v[kLPmedd][lane] = st.med_d; v[kLPmedw][lane] = st.med_w;
+        v[kLPdist][lane] = st.distortion; v[kLPT][lane] = T_final; v[kLPmedd][lane] = st.med_d; v[kLPmedw][lane] = st.med_w;
         v[kLPlast][lane] = __uint_as_float(st.last); v[kLPmedc][lane] = __uint_as_float(st.med_c);
     }
     __syncthreads();
     if (seg != 0) return;
-    // ---- the four quarters in list order
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, d1 = 0.f, d2 = 0.f, dist = 0.f, T = 1.0f, medd = 0.f, medw = 0.f;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, dist = 0.f, T = 1.0f, medd = 0.f, medw = 0.f;
     uint32_t last = 0u, medc = 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float (*v)[64] = part[k].v;
-        const float W = v[kLPTin][lane] - v[kLPTout][lane];   // sum of the quarter's blending weights (T only moves by them)
-        // distortion (forward.cu:413-417): err_i = m_i^2 A_i + dist2_i - 2 m_i dist1_i with the running sums of ALL earlier entries; the
-        // quarter used its own sums, the earlier quarters' totals enter linearly
-        dist += v[kLPdist][lane] + (d2 * W - 2.0f * d1 * v[kLPd1][lane]);
         C0 += v[kLPC0][lane]; C1 += v[kLPC1][lane]; C2 += v[kLPC2][lane]; D += v[kLPD][lane];
-        N0 += v[kLPN0][lane]; N1 += v[kLPN1][lane]; N2 += v[kLPN2][lane];
-        d1 += v[kLPd1][lane]; d2 += v[kLPd2][lane];
+        N0 += v[kLPN0][lane]; N1 += v[kLPN1][lane]; N2 += v[kLPN2][lane]; dist += v[kLPdist][lane];
         const uint32_t lk = __float_as_uint(v[kLPlast][lane]), mk = __float_as_uint(v[kLPmedc][lane]);
-        if (lk != 0u) { last = lk; T = v[kLPTout][lane]; }
-        if (mk != 0u) { medc = mk; medd = v[kLPmedd][lane]; medw = v[kLPmedw][lane]; }
+        if (lk > last) { last = lk; T = v[kLPT][lane]; }                  // the wave that blended the pixel's last contributor holds its final T
+        if (mk > medc) { medc = mk; medd = v[kLPmedd][lane]; medw = v[kLPmedw][lane]; }
     }
     uint32_t mx = inside ? last : 0u;
 #pragma unroll
@@ -682,8 +711,8 @@ __device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, 
     const size_t plane = (size_t)ntiles * kTilePix;
     const size_t slot = (size_t)tile * kTilePix + 64 * q + lane;
     a.final_T[slot] = T;
-    a.final_T[plane + slot] = d1;
-    a.final_T[2 * plane + slot] = d2;
+    a.final_T[plane + slot] = d1_tot;
+    a.final_T[2 * plane + slot] = d2_tot;
     a.n_contrib[slot] = last;
     a.n_contrib[plane + slot] = medc;
     if (inside) {
@@ -707,7 +736,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_ker
 {
     __shared__ FwdRowStage s_stage[4];
     __shared__ uint32_t s_max[4];
-    __shared__ float s_P[4][64];
+    __shared__ FwdLongX s_x;      // long tiles: the rounds' exchange
 
     const int ntiles = a.tiles_x * a.tiles_y;
     int tile;
@@ -715,7 +744,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_ker
         int lq;
         if (!long_decode(blockIdx.x, a.order, ntiles, a.long_thr->fwd, nullptr, a.ranges, tile, lq)) return;
         if (lq >= 0) {
-            blend_fwd_long(a, tile, lq, s_stage, s_P);
+            blend_fwd_long(a, tile, lq, s_stage, s_x);
             return;
         }
     } else {

@@ -13,7 +13,7 @@ import bench
 from diff_surfel_rasterization import _C
 
 dev = torch.device("cuda:0")
-SETTINGS = [("off", 0, 800, 512), ("800/512", 1, 800, 512), ("400/256", 1, 400, 256), ("1600/1024", 1, 1600, 1024), ("800/2048", 1, 800, 2048), ("200/128", 1, 200, 128)]
+SETTINGS = [("off", 0, 800, 512), ("150/512", 1, 150, 512), ("800/512", 1, 800, 512), ("3200/512", 1, 3200, 512), ("800/1024", 1, 800, 1024)]
 
 
 def run(tr, views, tag):
