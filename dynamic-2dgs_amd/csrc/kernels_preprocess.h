@@ -91,6 +91,8 @@ constexpr int kBinGroups = 256;
 constexpr int kBinThreads = 1024;   // 16 waves per workgroup (one workgroup per CU): a chunk of ~782 surfels is ONE trip of the loop below instead of
                                     // three dependent ones (radii -> rectangle -> LDS atomics); count 12 -> 7, scatter 17 -> 14 us
 
+constexpr int kBigRect = 32;   // tiles: a larger tile rectangle is walked by the whole wave instead of its own thread
+
 struct BinArgs {
     int P, ntiles, tiles_x, chunk;   // chunk = surfels per workgroup
     const uint32_t* state;  // [3] num_rendered, longest, overflow (scatter is skipped when overflow is set)
@@ -108,12 +110,27 @@ __global__ void __launch_bounds__(kBinThreads) count_tiles_lds_kernel(BinArgs a)
     for (int t = tid; t < a.ntiles; t += kBinThreads) s_hist[t] = 0;
     __syncthreads();
     const int end = min(a.P, (g + 1) * a.chunk);
-    for (int idx = g * a.chunk + tid; idx < end; idx += kBinThreads) {
-        if (!(a.radii[idx] > 0)) continue;
-        const uint2 r = a.rects[idx];
+    const int lane = tid & 63;
+    for (int base = g * a.chunk; base < end; base += kBinThreads) {   // (all threads of a wave take the trip together: wave-wide votes below)
+        const int idx = base + tid;
+        const bool vis = idx < end && a.radii[idx] > 0;
+        const uint2 r = vis ? a.rects[idx] : make_uint2(0u, 0u);
         const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
+        const int w = max(x1 - x0, 0), area = w * max(y1 - y0, 0);
+        const bool big = area > kBigRect;
+        if (!big)
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
+        // a rectangle of hundreds of tiles in ONE thread's loop is what the other 63 lanes wait for (a densified scene keeps a few
+        // screen-filling splats: count 36 us / scatter 43 us for a third of the uniform scene's pairs): the wave walks it together
+        unsigned long long todo = __ballot(big);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int X0 = __builtin_amdgcn_readlane(x0, src), Y0 = __builtin_amdgcn_readlane(y0, src);
+            const int Wd = __builtin_amdgcn_readlane(w, src), n = __builtin_amdgcn_readlane(area, src);
+            for (int t = lane; t < n; t += 64) atomicAdd(&s_hist[(Y0 + t / Wd) * a.tiles_x + X0 + t % Wd], 1u);
+        }
     }
     __syncthreads();
     for (int t = tid; t < a.ntiles; t += kBinThreads) a.M[(size_t)g * a.ntiles + t] = s_hist[t];
@@ -170,14 +187,28 @@ __global__ void __launch_bounds__(kBinThreads) scatter_keys_lds_kernel(BinArgs a
     for (int t = tid; t < a.ntiles; t += kBinThreads) s_cur[t] = a.M[(size_t)g * a.ntiles + t];
     __syncthreads();
     const int end = min(a.P, (g + 1) * a.chunk);
-    for (int idx = g * a.chunk + tid; idx < end; idx += kBinThreads) {
-        if (!(a.radii[idx] > 0)) continue;
-        const uint2 r = a.rects[idx];
+    const int lane = tid & 63;
+    for (int base = g * a.chunk; base < end; base += kBinThreads) {
+        const int idx = base + tid;
+        const bool vis = idx < end && a.radii[idx] > 0;
+        const uint2 r = vis ? a.rects[idx] : make_uint2(0u, 0u);
         const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
-        if (x1 <= x0 || y1 <= y0) continue;
-        const uint64_t key = ((uint64_t)__float_as_uint(a.rec[(size_t)idx * kRecQuads + 4].z) << 32) | (uint32_t)idx;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) a.keys[atomicAdd(&s_cur[y * a.tiles_x + x], 1u)] = key;
+        const int w = max(x1 - x0, 0), area = w * max(y1 - y0, 0);
+        const uint32_t depth = area > 0 ? __float_as_uint(a.rec[(size_t)idx * kRecQuads + 4].z) : 0u;
+        const uint64_t key = ((uint64_t)depth << 32) | (uint32_t)idx;
+        const bool big = area > kBigRect;
+        if (!big)
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) a.keys[atomicAdd(&s_cur[y * a.tiles_x + x], 1u)] = key;
+        unsigned long long todo = __ballot(big);   // large rectangles: the wave walks them together (count_tiles_lds_kernel)
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int X0 = __builtin_amdgcn_readlane(x0, src), Y0 = __builtin_amdgcn_readlane(y0, src);
+            const int Wd = __builtin_amdgcn_readlane(w, src), n = __builtin_amdgcn_readlane(area, src);
+            const uint64_t k = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)depth, src) << 32) | (uint32_t)__builtin_amdgcn_readlane(idx, src);
+            for (int t = lane; t < n; t += 64) a.keys[atomicAdd(&s_cur[(Y0 + t / Wd) * a.tiles_x + X0 + t % Wd], 1u)] = k;
+        }
     }
 }
 
@@ -460,8 +491,11 @@ __global__ void __launch_bounds__(256) sort_tiles_reg_kernel(const uint2* ranges
 // never took less than ~73 us per launch, with or without work (36 workgroups that find nothing to sort: 73 us; this one: 2 us).
 // The cause was not isolated -- bare allocations of 16 .. 160 KB launch in 2.5 us whatever their size
 // (tools/micro/lds_launch_bench.hip) -- but the 60-KB instantiation does not show it, and its segments run side by side.
-constexpr int kSegCap = 3584;
-constexpr int kMaxSegs = 16;
+// Round 4: the segments are as long as the main kernel's lists (2048) and EVERY list beyond that is cut into them -- the 3584-entry
+// single-workgroup instantiation that used to take the lists of 2 049 .. 3 584 entries is gone: one workgroup of four waves needs
+// 25-50 us for such a list (the launch a densified scene waited for), two or more segments side by side + the rank / merge step half.
+constexpr int kSegCap = 2048;
+constexpr int kMaxSegs = 28;
 template <int CAP, bool SEG = false>
 __global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* ranges, int ntiles, const uint64_t* keys, uint32_t* point_list, int lo,
                                                                uint64_t* seg_out = nullptr)
@@ -592,7 +626,7 @@ __global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* rang
 // Lists of more than kSegCap entries, second step: every key of segment y finds its place in the whole list -- its index in
 // its own (sorted) segment plus, for every other segment, the number of keys below it.  Keys are unique inside a list (the
 // surfel index is part of the key), so "below" needs no tie rule and the result is the reference's stable (depth, index) order.
-// A thread owns 14 CONSECUTIVE keys of its segment; the other segments pass through LDS one at a time (29 KB, coalesced load):
+// A thread owns 8 CONSECUTIVE keys of its segment; the other segments pass through LDS one at a time (17 KB, coalesced load):
 // the number of its keys below each of the thread's keys is a branch-free binary search in LDS.
 // Searching the other segments where they lie, in global memory, is a chain of ~200 dependent loads per thread: 0.67 ms.
 // (LDS index i lives at i + i / 32: the threads' search positions are ~32 keys apart, which would be one bank.)
@@ -618,7 +652,7 @@ __global__ void __launch_bounds__(256) merge_segments_kernel(const uint2* ranges
             __syncthreads();
             for (int i = threadIdx.x; i < len; i += 256) s_other[i + (i >> 5)] = base[o * kSegCap + i];
             __syncthreads();
-            // branch-free lower bound of all 14 keys at once: 12 rounds of 14 independent LDS reads (a merge-style walk from key to
+            // branch-free lower bound of all 8 keys at once: 12 rounds of 8 independent LDS reads (a merge-style walk from key to
             // key is a chain of dependent reads inside a divergent loop: 25 us per segment instead of ~2)
             int pos[kPer];
 #pragma unroll
@@ -634,7 +668,7 @@ __global__ void __launch_bounds__(256) merge_segments_kernel(const uint2* ranges
                 }
             }
 #pragma unroll
-            for (int i = 0; i < kPer; i++) rank[i] += pos[i];   // (padding keys of a thread with fewer than 14 are never written)
+            for (int i = 0; i < kPer; i++) rank[i] += pos[i];   // (padding keys of a thread with fewer than 8 are never written)
         }
 #pragma unroll
         for (int i = 0; i < kPer; i++)

@@ -207,13 +207,12 @@ struct dgs_context {
     std::atomic<int> deterministic{0};   // key 7: backward blend without atomics, fixed summation order (tests)
     std::atomic<int> sh_all_rows{0};     // key 8: dL_dsh written for every row (zeros for culled surfels / unused bands)
     std::atomic<int> long_tiles{1};      // key 9: four workgroups (one per quadrant, four list quarters each) for the longest tiles
-    // Measured (tools/diag/long_tune.py, blend fwd / bwd in ms; uniform 200k scene | densified `trained` scene, 90 k surfels):
-    //   path off 0.126 / 0.259 | 0.146 / 0.443;  divisors 800 / 512: 0.121 / 0.248 | 0.171 / 0.349;  400 / 256: .. | 0.167 / 0.405;
-    //   1600 / 1024: 0.145 / 0.249 | 0.170 / 0.356;  200 / 128: 0.122 / 0.248 | 0.145 / 0.439.
-    // The backward of a densified scene is as long as its longest tile and gains 21 %; the forward there is mostly throughput-bound --
-    // any tile it treats as long costs more (1.5 x the arithmetic, the walk of the list behind the saturation point) than the shorter
-    // tail returns -- so its divisor only lets through a tile that holds more than 1 / 150 of all list entries.
-    std::atomic<int> long_div_fwd{150};  // key 10: a list is long from num_rendered / this (and 768 entries) on
+    // Measured (tools/diag/long_tune.py, blend fwd / bwd in ms; uniform 200k scene | ONE densified scene, 88 k surfels, kept as a checkpoint):
+    //   path off 0.127 / 0.264 | 0.140 / 0.358;  forward divisor 150: 0.124 | 0.139, 400: .. | 0.130, 800: 0.125 | 0.131, 1600: .. | 0.131,
+    //   3200: 0.133 | ..;  backward divisor 256: .. | 0.331, 512: 0.253 | 0.280, 1024: 0.259 | 0.281, 2048: .. | 0.283.
+    // The backward of a densified scene is as long as its longest tiles and gains 22 %; its forward is closer to throughput-bound and
+    // gains 7 %; an opaque knot (40 k of 100 k surfels on a few tiles) pays 2-4 % for the forward path (0.112 -> 0.114-0.116).
+    std::atomic<int> long_div_fwd{400};  // key 10: a list is long from num_rendered / this (and 768 entries) on
     std::atomic<int> long_div_bwd{512};  // key 11: a tile is long from (sum of traversed lengths) / this (and 512 entries) on
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
@@ -649,17 +648,13 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         uint32_t* plist = (uint32_t*)(bin + bl.point_list);
         const int sort_mode = ctx->sort_regs.load();
         if (sort_mode == 2) {
-            // per-tile LSD radix sort (default): lists up to 2048 entries in 36 KB of LDS (one workgroup per tile), up to 3584 in
-            // 60 KB (grid-stride launch: such lists are rare); longer ones as segments of 3584 sorted side by side + a rank/merge
-            // step, up to 16 segments; beyond 57 344 entries the global-memory network.  Every tile picks its kernel on the
-            // device; when the longest list is known on the host (exact-size mode, or promised) the launches that cannot have
-            // work are skipped.
+            // per-tile LSD radix sort (default): lists up to 2048 entries in 36 KB of LDS (one workgroup per tile); longer ones as
+            // segments of 2048 sorted side by side by the same kernel + a rank / merge step, up to 28 segments; beyond 57 344 entries
+            // the global-memory network.  Every tile picks its kernel on the device; when the longest list is known on the host
+            // (exact-size mode, or promised) the launches that cannot have work are skipped.
             const int big_grid = il.ntiles < 256 ? il.ntiles : 256;
             hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<2048>), dim3(il.ntiles), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
                                (const uint64_t*)keys, plist, 0);
-            if (longest > 2048u)
-                hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<dgs::kSegCap>), dim3(big_grid), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
-                                   (const uint64_t*)keys, plist, 2048);
             if (longest > (uint32_t)dgs::kSegCap) {
                 // (a 30 000-entry list on ONE workgroup's global-memory network took 0.45 ms; a crowded tile is exactly what
                 // densification produces)

@@ -452,9 +452,9 @@ class Trainer:
                 raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
 
     # Promise of the longest tile list (dgs_set_option key 6) in the tiers of the library's sort kernels: up to 2048 entries one
-    # launch, up to 3584 two, up to 57 344 (16 segments of 3584 + merge) four, no promise (0) five.  A view that breaks the promise
+    # launch, up to 57 344 (28 segments of 2048 + merge) three, no promise (0) four.  A view that breaks the promise
     # moves the trainer one tier up -- a densified scene with lists of a few thousand entries keeps the cheap tiers it fits.
-    LIST_HINT_TIERS = (2048, 3584, 57344, 0)
+    LIST_HINT_TIERS = (2048, 57344, 0)
 
     def _next_list_hint(self):
         t = self.LIST_HINT_TIERS

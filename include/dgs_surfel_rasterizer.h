@@ -156,12 +156,11 @@ void dgs_set_tight_rects(int on);
  * key 9 = long-tile path of the blend kernels (1 [default] / 0; tile order 3 only): the tiles at the head of the longest-first dispatch
  *         order whose list (forward) / traversed length (backward) exceeds a per-launch threshold get four workgroups -- one per 8x8
  *         quadrant, four list quarters each -- instead of one; deterministic, results differ from the serial walk in rounding only.
- * key 10 / key 11 = thresholds of that path: a forward list is long from num_rendered / value entries on (default 150; never below
+ * key 10 / key 11 = thresholds of that path: a forward list is long from num_rendered / value entries on (default 400; never below
  *         768), a backward tile from (sum of the traversed lengths) / value on (default 512; never below 512).
  * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
- *         host read the library cannot know which of its per-tile sort kernels will find work and launches all three; with the
- *         promise it launches only those for lists up to `value` (2048: one launch instead of three, ~10 us of an 800x800
- *         forward).  A frame that breaks the promise is treated exactly like a capacity overflow: background, flag raised,
+ *         host read the library cannot know which of its per-tile sort kernels will find work and launches all four; with the
+ *         promise it launches only those for lists up to `value` (2048: one launch; 57344 = 28 segments of 2048: three).  A frame that breaks the promise is treated exactly like a capacity overflow: background, flag raised,
  * key 4 / key 5 = diagnostic: the backward / forward blend processes only the first `value` tiles of its dispatch order
  *         (0 = all); results are then incomplete -- for measuring how long the heaviest tiles run on an otherwise idle device.
  * Returns DGS_OK or an error. */

@@ -438,14 +438,14 @@ def test_long_tile_path_matches_the_serial_walk_and_the_oracle():
     assert lens.max() > 1500 and lens.max() > 4 * lens.mean(), (lens.max(), lens.mean())
     outs = {}
     try:
-        _C.set_option(10, 32)   # forward: lists longer than R / 32 = 1124 entries (the default, R / 150, is for scenes with ONE dominant tile)
+        _C.set_option(10, 32)   # forward: lists longer than R / 32 = 1124 entries (the default is R / 400)
         _C.set_option(11, 32)
         for on in (1, 0, 1):
             _C.set_option(9, on)
             outs.setdefault(on, []).append((run_hip(case, gc, go, debug=False), run_hip_raw(case)))
     finally:
         _C.set_option(9, 1)
-        _C.set_option(10, 150)
+        _C.set_option(10, 400)
         _C.set_option(11, 512)
     (l1, r1), (l2, r2) = outs[1]
     (s0, rs) = outs[0][0]
@@ -468,7 +468,7 @@ def test_long_tile_path_matches_the_serial_walk_and_the_oracle():
         _C.set_option(10, 32); _C.set_option(11, 32); _C.set_option(7, 1)
         d1, d2 = run_hip(case, gc, go, debug=False), run_hip(case, gc, go, debug=False)
     finally:
-        _C.set_option(7, 0); _C.set_option(10, 150); _C.set_option(11, 512)
+        _C.set_option(7, 0); _C.set_option(10, 400); _C.set_option(11, 512)
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
         assert np.array_equal(d1[k], d2[k]), k
         assert rel_l2(d1[k], l1[k]) <= 1e-4, k

@@ -37,7 +37,8 @@ def run(tr, views, tag):
 tr = bench.build_trainer(200_000, 800, 800, dev)
 run(tr, None, "metric")
 del tr
-tr, _ = bench.trained_trainer(100_000, 800, 800, dev, int(sys.argv[1]) if len(sys.argv) > 1 else 10000)
-tr.set_regime(warmup=False, lambda_normal=0.02, lambda_dist=1000.0)
-print("trained: live surfels", tr.surfels.num_surfels)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from trained_cache import load
+tr = load(dev)   # the cached fit (tools/diag/trained_cache.py): the same scene in every run
+print("trained (cached): live surfels", tr.surfels.num_surfels)
 run(tr, None, "trained")

@@ -13,7 +13,7 @@ import bench
 from diff_surfel_rasterization import _C
 
 dev = torch.device("cuda:0")
-SETTINGS = [("off", 0, 800, 512), ("150/512", 1, 150, 512), ("800/512", 1, 800, 512), ("3200/512", 1, 3200, 512), ("800/1024", 1, 800, 1024)]
+SETTINGS = [("off", 0, 800, 512), ("150/512", 1, 150, 512), ("400/512", 1, 400, 512), ("800/512", 1, 800, 512), ("1600/512", 1, 1600, 512), ("150/256", 1, 150, 256), ("150/1024", 1, 150, 1024), ("150/2048", 1, 150, 2048)]
 
 
 def run(tr, views, tag):
@@ -46,7 +46,8 @@ def run(tr, views, tag):
 tr = bench.build_trainer(200_000, 800, 800, dev)
 run(tr, [0, 8, 16, 24], "metric")
 del tr
-tr, _ = bench.trained_trainer(100_000, 800, 800, dev, int(sys.argv[1]) if len(sys.argv) > 1 else 10000)
-tr.set_regime(warmup=False, lambda_normal=0.02, lambda_dist=1000.0)
-print("trained: live surfels", tr.surfels.num_surfels)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from trained_cache import load
+tr = load(dev)   # the cached fit (tools/diag/trained_cache.py): the same scene in every run
+print("trained (cached): live surfels", tr.surfels.num_surfels)
 run(tr, [5, 17, 33, 41], "trained")

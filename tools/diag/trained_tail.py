@@ -39,11 +39,22 @@ for v in (5, 17, 33):
     rng = ib[off[2]:off[2] + T * 8].view(np.uint32).reshape(T, 2)
     ln = (rng[:, 1] - rng[:, 0]).astype(np.int64)
     tl = ib[off[3]:off[3] + T * 4].view(np.uint32).astype(np.int64)
+    goff = _C.debug_layout(0, P=tr.P)
+    gb = geom.cpu().numpy()
+    rc = gb[goff[4]:goff[4] + tr.P * 8].view(np.uint32).reshape(tr.P, 2)
+    rad = radii.cpu().numpy()
+    area = ((rc[:, 0] >> 16).astype(np.int64) - (rc[:, 0] & 0xffff)) * ((rc[:, 1] >> 16).astype(np.int64) - (rc[:, 1] & 0xffff))
+    area[rad <= 0] = 0
+    chunk = (tr.P + 255) // 256
+    per_wg = np.add.reduceat(area, np.arange(0, tr.P, chunk))
+    print("  tile rectangles: visible %d, tiles per visible surfel mean %.1f p99 %d max %d ; surfels above 32 tiles: %d (%.1f %% of the pairs), above 256: %d (%.1f %%) ; pairs per binning workgroup: mean %.0f max %d"
+          % ((rad > 0).sum(), area[rad > 0].mean(), np.quantile(area[rad > 0], .99), area.max(), (area > 32).sum(), 100.0 * area[area > 32].sum() / area.sum(),
+             (area > 256).sum(), 100.0 * area[area > 256].sum() / area.sum(), per_wg.mean(), per_wg.max()))
     srt = np.sort(tl)[::-1]
     print("view %d: R %d | list length: max %d p99 %d p90 %d mean(non-empty) %.0f | traversed (tile_last): sum %d max %d top-8 %s p99 %d p90 %d p50 %d | tiles with traversed > 256: %d, > 512: %d, > 1024: %d"
           % (v, R, ln.max(), *np.quantile(ln[ln > 0], [.99, .9]).astype(int), ln[ln > 0].mean(), tl.sum(), tl.max(), srt[:8].tolist(),
              *np.quantile(tl[tl > 0], [.99, .9, .5]).astype(int), int((tl > 256).sum()), int((tl > 512).sum()), int((tl > 1024).sum())))
-for N in (0, 1, 4, 16, 64, 256):
+for N in ():
     _C.set_option(5, N)
     _C.set_option(4, N)
     for _ in range(2):
