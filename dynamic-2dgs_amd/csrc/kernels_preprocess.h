@@ -91,7 +91,10 @@ constexpr int kBinGroups = 256;
 constexpr int kBinThreads = 1024;   // 16 waves per workgroup (one workgroup per CU): a chunk of ~782 surfels is ONE trip of the loop below instead of
                                     // three dependent ones (radii -> rectangle -> LDS atomics); count 12 -> 7, scatter 17 -> 14 us
 
-constexpr int kBigRect = 32;   // tiles: a larger tile rectangle is walked by the whole wave instead of its own thread
+#ifndef DGS_BIG_RECT
+#define DGS_BIG_RECT 64
+#endif
+constexpr int kBigRect = DGS_BIG_RECT;   // tiles: a larger tile rectangle is walked by the whole wave instead of its own thread
 
 struct BinArgs {
     int P, ntiles, tiles_x, chunk;   // chunk = surfels per workgroup
@@ -121,6 +124,7 @@ __global__ void __launch_bounds__(kBinThreads) count_tiles_lds_kernel(BinArgs a)
         if (!big)
             for (int y = y0; y < y1; y++)
                 for (int x = x0; x < x1; x++) atomicAdd(&s_hist[y * a.tiles_x + x], 1u);
+        // (more than 64 tiles: below that the lanes of the wave would idle, and on the uniform scene the vote alone costs 1 us)
         // a rectangle of hundreds of tiles in ONE thread's loop is what the other 63 lanes wait for (a densified scene keeps a few
         // screen-filling splats: count 36 us / scatter 43 us for a third of the uniform scene's pairs): the wave walks it together
         unsigned long long todo = __ballot(big);
@@ -129,7 +133,11 @@ __global__ void __launch_bounds__(kBinThreads) count_tiles_lds_kernel(BinArgs a)
             todo &= todo - 1;
             const int X0 = __builtin_amdgcn_readlane(x0, src), Y0 = __builtin_amdgcn_readlane(y0, src);
             const int Wd = __builtin_amdgcn_readlane(w, src), n = __builtin_amdgcn_readlane(area, src);
-            for (int t = lane; t < n; t += 64) atomicAdd(&s_hist[(Y0 + t / Wd) * a.tiles_x + X0 + t % Wd], 1u);
+            const float inv_w = __frcp_rn((float)Wd);
+            for (int t = lane; t < n; t += 64) {
+                const int row = (int)(((float)t + 0.5f) * inv_w);   // t / Wd without the integer division (t < 2^16, Wd <= 2^8: exact)
+                atomicAdd(&s_hist[(Y0 + row) * a.tiles_x + X0 + (t - row * Wd)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -207,7 +215,11 @@ __global__ void __launch_bounds__(kBinThreads) scatter_keys_lds_kernel(BinArgs a
             const int X0 = __builtin_amdgcn_readlane(x0, src), Y0 = __builtin_amdgcn_readlane(y0, src);
             const int Wd = __builtin_amdgcn_readlane(w, src), n = __builtin_amdgcn_readlane(area, src);
             const uint64_t k = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)depth, src) << 32) | (uint32_t)__builtin_amdgcn_readlane(idx, src);
-            for (int t = lane; t < n; t += 64) a.keys[atomicAdd(&s_cur[(Y0 + t / Wd) * a.tiles_x + X0 + t % Wd], 1u)] = k;
+            const float inv_w = __frcp_rn((float)Wd);
+            for (int t = lane; t < n; t += 64) {
+                const int row = (int)(((float)t + 0.5f) * inv_w);
+                a.keys[atomicAdd(&s_cur[(Y0 + row) * a.tiles_x + X0 + (t - row * Wd)], 1u)] = k;
+            }
         }
     }
 }
@@ -498,8 +510,9 @@ constexpr int kSegCap = 2048;
 constexpr int kMaxSegs = 28;
 template <int CAP, bool SEG = false>
 __global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* ranges, int ntiles, const uint64_t* keys, uint32_t* point_list, int lo,
-                                                               uint64_t* seg_out = nullptr)
+                                                               uint64_t* seg_out = nullptr, const uint32_t* state = nullptr /*[1] = longest list*/)
 {
+    if (SEG && state && (uint32_t)blockIdx.y * (uint32_t)CAP >= state[1]) return;   // no list of this launch reaches this segment index
     __shared__ uint32_t s_key[2][CAP];
     __shared__ uint32_t s_val[2][CAP];
     __shared__ uint32_t s_hist[4][256];      // per wave: running digit counts, then exclusive global offsets
@@ -630,8 +643,10 @@ __global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* rang
 // the number of its keys below each of the thread's keys is a branch-free binary search in LDS.
 // Searching the other segments where they lie, in global memory, is a chain of ~200 dependent loads per thread: 0.67 ms.
 // (LDS index i lives at i + i / 32: the threads' search positions are ~32 keys apart, which would be one bank.)
-__global__ void __launch_bounds__(256) merge_segments_kernel(const uint2* ranges, int ntiles, const uint64_t* seg_keys /*scratch*/, uint32_t* point_list)
+__global__ void __launch_bounds__(256) merge_segments_kernel(const uint2* ranges, int ntiles, const uint64_t* seg_keys /*scratch*/, uint32_t* point_list,
+                                                             const uint32_t* state /*[1] = longest list*/)
 {
+    if ((uint32_t)blockIdx.y * (uint32_t)kSegCap >= state[1]) return;   // no list of this launch reaches this segment index
     constexpr int kPer = kSegCap / 256;
     __shared__ uint64_t s_other[kSegCap + kSegCap / 32];
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

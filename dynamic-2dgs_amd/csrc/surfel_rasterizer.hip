@@ -658,11 +658,14 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
             if (longest > (uint32_t)dgs::kSegCap) {
                 // (a 30 000-entry list on ONE workgroup's global-memory network took 0.45 ms; a crowded tile is exactly what
                 // densification produces)
-                const dim3 seg_grid(il.ntiles < 64 ? il.ntiles : 64, dgs::kMaxSegs);
+                // 256 columns of workgroups walk the tiles (64 were enough while segments were rare: at 1 M surfels / 1600 x 1600 thousands of
+                // tiles hold 2-4 k entries and a column handled 156 of them one after the other); rows that no list reaches exit at once
+                const dim3 seg_grid(il.ntiles < 256 ? il.ntiles : 256, dgs::kMaxSegs);
+                const uint32_t* state = (const uint32_t*)(geom + gl.total);
                 hipLaunchKernelGGL((dgs::sort_tiles_radix_kernel<dgs::kSegCap, true>), seg_grid, dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
-                                   (const uint64_t*)keys, plist, 0, (uint64_t*)(bin + bl.scratch));
+                                   (const uint64_t*)keys, plist, 0, (uint64_t*)(bin + bl.scratch), state);
                 hipLaunchKernelGGL(dgs::merge_segments_kernel, seg_grid, dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
-                                   (const uint64_t*)(bin + bl.scratch), plist);
+                                   (const uint64_t*)(bin + bl.scratch), plist, state);
             }
             if (longest > (uint32_t)(dgs::kSegCap * dgs::kMaxSegs))
                 hipLaunchKernelGGL(dgs::sort_tiles_global_kernel, dim3(big_grid), dim3(256), 0, stream, (const uint2*)ranges, il.ntiles,
