@@ -1819,6 +1819,19 @@ struct AdamSegs {
 // ran out of list capacity and rendered background (under data parallelism the flag rides in the MAX all-reduce of the radii,
 // so every rank sees the same value) -- and the update kernels return without touching parameters, moments, statistics or
 // the step count.
+// First node of a captured step: the view of this replay.  row_out <- table[v] with v = override[0] if it is >= 0 (then reset to -1),
+// else (counter[0] * stride + offset) mod nrows; counter[0] += 1.  A step that walks its views in the default order needs no host
+// copy in front of the replay (the 256-byte row copy + the idle device behind it were ~10 us of every 0.8 ms step).
+__global__ void __launch_bounds__(64) select_row_kernel(const float* __restrict__ table, int nrows, int row_floats, int* __restrict__ counter,
+                                                        int* __restrict__ override_, int stride, int offset, float* __restrict__ row_out)
+{
+    const int ov = override_[0], c = counter[0];
+    const int v = ov >= 0 ? (ov % nrows) : (int)(((long long)c * stride + offset) % nrows);
+    for (int i = threadIdx.x; i < row_floats; i += 64) row_out[i] = table[(size_t)v * row_floats + i];
+    __syncthreads();
+    if (threadIdx.x == 0) { counter[0] = c + 1; override_[0] = -1; }
+}
+
 __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restrict__ step_count, float* __restrict__ status,
                                   float* __restrict__ host_ring, int ring_len, const float* __restrict__ loss)
 {
@@ -2085,6 +2098,14 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
 {
     return dgs_adam_step_guarded(nseg, params, offsets, lrs, lrs2, periods, splits, lrs_final, sched_steps, sched_t0, grad_scale, grad,
                                  exp_avg, exp_avg_sq, step_count, beta1, beta2, eps, plan, nullptr, stream);
+}
+
+int dgs_select_row(const float* table, int nrows, int row_floats, int* counter, int* override_, int stride, int offset, float* row_out, void* stream)
+{
+    if (!table || !counter || !override_ || !row_out || nrows <= 0 || row_floats <= 0 || stride <= 0 || offset < 0)
+        return fail(-1, "dgs_select_row: bad argument");
+    hipLaunchKernelGGL(select_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table, nrows, row_floats, counter, override_, stride, offset, row_out);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-4, "select_row_kernel: launch failed");
 }
 
 int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, const float* loss, void* stream)

@@ -18,7 +18,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
             "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard",
-            "dgs_adam_step_origin")
+            "dgs_adam_step_origin", "dgs_select_row")
 
 
 def _deps():
@@ -139,6 +139,8 @@ def load():
         lib.dgs_adam_step_zero.restype = ci
         lib.dgs_adam_step_zero.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, ci, vp, vp, vp,
                                            ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        lib.dgs_select_row.restype = ci
+        lib.dgs_select_row.argtypes = [vp, ci, ci, vp, vp, ci, ci, vp, vp]
         lib.dgs_adam_step_origin.restype = ci
         lib.dgs_adam_step_origin.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_float, vp, ci, vp, vp, vp,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
@@ -263,6 +265,16 @@ def lbs_supported(M, H):
     lib.dgs_lbs_supported.restype = ctypes.c_int
     lib.dgs_lbs_supported.argtypes = [ctypes.c_int, ctypes.c_int]
     return bool(lib.dgs_lbs_supported(int(M), int(H)))
+
+
+def select_row(table, counter, override, stride, offset, row_out):
+    """dgs_select_row: the view row of this replay, chosen on the device (see include/dgs_train_ops.h)."""
+    lib = load()
+    dev = table.device
+    assert table.dtype == torch.float32 and table.is_contiguous() and row_out.is_contiguous() and counter.dtype == torch.int32 and override.dtype == torch.int32
+    with torch.cuda.device(dev):
+        _check(lib, lib.dgs_select_row(table.data_ptr(), table.shape[0], table.shape[1], counter.data_ptr(), override.data_ptr(), int(stride), int(offset),
+                                       row_out.data_ptr(), _stream(dev)), "dgs_select_row")
 
 
 class FlatAdam:

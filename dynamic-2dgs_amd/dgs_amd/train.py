@@ -374,6 +374,12 @@ class Trainer:
         self._vtab = torch.stack(rows).to(dev)
         self._scam = StaticCamera(self.cameras[0], dev, self._rays[0][0], self._targets_c[0])
         self._scam.load(self._vtab[0])
+        # the view of a replay is chosen ON THE DEVICE by the first node of the graph (dgs_select_row): step counter + override word.
+        # The host mirrors the counter; a step that asks for another view than the default order's writes the override first.
+        self._dev_select = os.environ.get("DGS_DEVICE_VIEW_SELECT", "1") != "0"
+        self._vctr = torch.full((1,), int(self.iteration), dtype=torch.int32, device=dev)
+        self._vovr = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        self._vctr_host = int(self.iteration)
         self._sgt = self._scam.target
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -402,6 +408,7 @@ class Trainer:
             # data parallel: graph 1a = forward + backward down to the rasterizer inputs (SH gradients final), eager async
             # all-reduce of the SH segment, graph 1b = rest of the backward, eager all-reduce of the rest, graph 2 = update
             with torch.cuda.graph(self._g1, **mode):
+                self._select_view_node()
                 self._sloss = self._fwd_bwd_a(self._scam, self._sgt)
             self._g1b = torch.cuda.CUDAGraph()
             self._g1c = None
@@ -416,6 +423,7 @@ class Trainer:
                     self._fwd_bwd_b()
         else:
             with torch.cuda.graph(self._g1, **mode):
+                self._select_view_node()
                 self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
                 if self.world == 1:
                     self._finish()
@@ -460,6 +468,12 @@ class Trainer:
         t = self.LIST_HINT_TIERS
         cur = getattr(self, "_list_hint", 0)
         return t[t.index(cur) + 1] if cur in t and cur != 0 else 0
+
+    def _select_view_node(self):
+        """First node of a captured step (see enable_graph): the view row of this replay, chosen on the device."""
+        if self._dev_select:
+            from . import _ops
+            _ops.select_row(self._vtab, self._vctr, self._vovr, self.world, self.rank, self._scam.row)
 
     def refresh_knn_mode(self):
         """Re-evaluate which seeded neighbour search fits the scene (ControlNodes.pick_knn_refine: one host read) and, if the
@@ -1136,7 +1150,17 @@ class Trainer:
 
     def _step_view(self, v):
         if self._graph:
-            self._scam.load(self._vtab[v])   # one 256-byte copy: camera matrices, time, and the pointers of target / ray table
+            if self._dev_select:
+                # default order: nothing to do on the host -- the graph's first node takes row (counter * world + rank) mod V and counts
+                it = self.iteration - 1            # the iteration this step belongs to (step() has counted it already)
+                if it != self._vctr_host:          # the host's counter was moved (a rewind after skipped steps, a tool): bring the device's along
+                    self._vctr.fill_(it)
+                    self._vctr_host = it
+                if v != (it * self.world + self.rank) % len(self.cameras):   # a view order of the caller's own
+                    self._vovr.fill_(v)
+                self._vctr_host += 1
+            else:
+                self._scam.load(self._vtab[v])   # one 256-byte copy: camera matrices, time, and the pointers of target / ray table
             self._g1.replay()
             if self._g1b is not None:
                 rwork = self._reduce_radii_start()   # radii + overflow flag (small): first, the SH update's guard reads it

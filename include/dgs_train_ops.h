@@ -116,6 +116,12 @@ int dgs_adam_step_sched(int nseg, float* const* params, const long long* offsets
  *   dgs_adam_step_guarded / dgs_densify_accumulate_guarded: return without changing anything when skip[0] != 0.
  * A frame that overflowed therefore trains nothing -- not the parameters, not the moments, not the statistics. */
 int dgs_step_guard(const int* skip, float* step_count, float* status, float* host_ring, int ring_len, const float* loss, void* stream);
+
+/* View selection on the device (first node of a captured step): row_out[0 .. row_floats) <- table[v], v = override[0] if >= 0 (then
+ * reset to -1) else (counter[0] * stride + offset) mod nrows; counter[0] += 1.  A replayed step that walks its views in the default
+ * order (rank r of `stride` ranks renders view (i * stride + r) mod nrows in step i, dgs_amd.train.Trainer.view_for) then needs no
+ * host-issued copy per step; any other order writes `override` before the replay. */
+int dgs_select_row(const float* table, int nrows, int row_floats, int* counter, int* override_, int stride, int offset, float* row_out, void* stream);
 int dgs_adam_step_guarded(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
                           const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                           float grad_scale, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count, float beta1,
