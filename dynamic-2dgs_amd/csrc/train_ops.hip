@@ -130,18 +130,27 @@ __device__ __forceinline__ void gauss_to_vgprs(const Gauss& g, float (&w)[11])
     for (int k = 0; k < 11; k++) { w[k] = g.w[k]; asm volatile("" : "+v"(w[k])); }
 }
 
-__global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
-                                                       Gauss g, float* __restrict__ ssim_sum, float* __restrict__ dm_dmu1,
-                                                       float* __restrict__ dm_ds11, float* __restrict__ dm_ds12,
-                                                       float* __restrict__ l1_sum, float* __restrict__ partial,
-                                                       const float* const* __restrict__ img2_slot)
+struct SsimFwdArgs {
+    int H, W;
+    const float* img1; const float* img2;
+    float* ssim_sum; float* dm_dmu1; float* dm_ds11; float* dm_ds12; float* l1_sum; float* partial;
+    const float* const* img2_slot;
+};
+constexpr int kSsimFwdLds = 5 * kTH * kLds + 8;   // floats
+
+// workgroup (bx, by, bz) of a (gx, gy, gz) grid; `lds` = kSsimFwdLds floats
+__device__ __forceinline__ void ssim_fwd_body(const SsimFwdArgs& A, const Gauss& g, int bx, int by, int bz, int gx, int gy, int gz,
+                                              float* __restrict__ lds)
 {
-    if (img2_slot) img2 = *img2_slot;   // indirection: the comparison image is chosen per graph replay by rewriting one pointer
-    __shared__ float s_v[5][kTH][kLds];
-    __shared__ float s_red[8];
+    const int H = A.H, W = A.W;
+    const float* __restrict__ img1 = A.img1;
+    const float* __restrict__ img2 = A.img2_slot ? *A.img2_slot : A.img2;   // indirection: the comparison image is chosen per graph replay by rewriting one pointer
+    float* __restrict__ dm_dmu1 = A.dm_dmu1; float* __restrict__ dm_ds11 = A.dm_ds11; float* __restrict__ dm_ds12 = A.dm_ds12;
+    float (*s_v)[kTH][kLds] = reinterpret_cast<float (*)[kTH][kLds]>(lds);
+    float* s_red = lds + 5 * kTH * kLds;
     const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6;
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
-    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int x0 = bx * kTW, y0 = by * kTH;
+    const size_t plane = (size_t)bz * H * W;
     float w[11];
     gauss_to_vgprs(g, w);
     float l1 = 0.f;
@@ -262,18 +271,24 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, const float
     __syncthreads();
     if (tid == 0) {
         const float vs = s_red[0] + s_red[1] + s_red[2] + s_red[3], vl = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-        if (partial) {
+        if (A.partial) {
             // one slot per workgroup, summed by loss_combine_kernel: thousands of atomics on ONE address serialise in a
             // single L2 channel (~13 ns each) and were most of this kernel's run time
-            const int nb = gridDim.x * gridDim.y * gridDim.z;
-            const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            partial[b] = vs;
-            partial[nb + b] = vl;
+            const int nb = gx * gy * gz;
+            const int b = (bz * gy + by) * gx + bx;
+            A.partial[b] = vs;
+            A.partial[nb + b] = vl;
         } else {
-            atomicAdd(ssim_sum, vs);
-            if (l1_sum) atomicAdd(l1_sum, vl);
+            atomicAdd(A.ssim_sum, vs);
+            if (A.l1_sum) atomicAdd(A.l1_sum, vl);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) ssim_fwd_kernel(SsimFwdArgs A, Gauss g)
+{
+    __shared__ float lds[kSsimFwdLds];
+    ssim_fwd_body(A, g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, lds);
 }
 
 __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, float inv_n, float l1_coef, const float* __restrict__ img1,
@@ -1656,14 +1671,18 @@ constexpr int kCW = kRW + 2, kCH = kRH + 2;       // centres: 32 x 16
 constexpr int kQW = kRW + 4, kQH = kRH + 4;       // points: 34 x 18
 static_assert(kCW == 32 && kCH == 16, "thread maps below");
 
-__global__ void __launch_bounds__(256) regloss_fused_kernel(RegArgs a, float* __restrict__ partial, float* __restrict__ d_allmap)
+constexpr int kRegLds = 3 * kQH * (kQW + 1) + 6 * kCH * (kCW + 1) + 4;   // floats
+
+// workgroup (bx, by) of a grid gx wide; `lds` = kRegLds floats
+__device__ __forceinline__ void regloss_fused_body(RegArgs a, float* __restrict__ partial, float* __restrict__ d_allmap, int bx, int by, int gx,
+                                                   float* __restrict__ lds)
 {
     if (a.rays_slot) a.rays_d = *a.rays_slot;
-    __shared__ float s_p[3][kQH][kQW + 1];
-    __shared__ float s_g[6][kCH][kCW + 1];
-    __shared__ float s_red[4];
+    float (*s_p)[kQH][kQW + 1] = reinterpret_cast<float (*)[kQH][kQW + 1]>(lds);
+    float (*s_g)[kCH][kCW + 1] = reinterpret_cast<float (*)[kCH][kCW + 1]>(lds + 3 * kQH * (kQW + 1));
+    float* s_red = lds + 3 * kQH * (kQW + 1) + 6 * kCH * (kCW + 1);
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kRW, y0 = blockIdx.y * kRH;      // first own pixel
+    const int x0 = bx * kRW, y0 = by * kRH;      // first own pixel
     const unsigned HW = (unsigned)a.H * (unsigned)a.W;
     const GlobalF am = (GlobalF)a.allmap, rd = (GlobalF)a.rays_d;
     const float ox = a.rays_o[0], oy = a.rays_o[1], oz = a.rays_o[2];
@@ -1785,7 +1804,37 @@ __global__ void __launch_bounds__(256) regloss_fused_kernel(RegArgs a, float* __
     for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
     if ((tid & 63) == 0) s_red[tid >> 6] = val;
     __syncthreads();
-    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tid == 0) partial[by * gx + bx] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ void __launch_bounds__(256) regloss_fused_kernel(RegArgs a, float* __restrict__ partial, float* __restrict__ d_allmap)
+{
+    __shared__ float lds[kRegLds];
+    regloss_fused_body(a, partial, d_allmap, blockIdx.x, blockIdx.y, gridDim.x, lds);
+}
+
+// Both forward halves of the loss in ONE launch (dgs_loss_forward_merged).  The photometric kernel (SSIM windows: FMA-bound with a
+// store-heavy epilogue) and the regulariser kernel (three short phases between barriers: latency-bound) read different
+// rasterizer outputs and write different buffers; launched one after the other each leaves the chip partly idle (1305 and 1566
+// workgroups at 800 x 800: a second partial round of workgroups each) and pays its own launch gap.  Here the two kinds of
+// workgroup alternate in one grid while both last, so that every CU holds both at once.
+__global__ void __launch_bounds__(256) loss_fwd_merged_kernel(SsimFwdArgs A, Gauss g, int sgx, int sgy, int sgz, RegArgs a,
+                                                              float* __restrict__ reg_partial, float* __restrict__ d_allmap, int rgx, int rgy)
+{
+    constexpr int kMergedLds = kSsimFwdLds > kRegLds ? kSsimFwdLds : kRegLds;
+    __shared__ float lds[kMergedLds];
+    const int ns = sgx * sgy * sgz, nr = rgx * rgy, both = 2 * min(ns, nr);
+    const int bid = blockIdx.x;
+    bool photo; int i;
+    if (bid < both) { photo = !(bid & 1); i = bid >> 1; }
+    else { photo = ns > nr; i = bid - both + min(ns, nr); }
+    if (photo) {
+        const int bz = i / (sgx * sgy), r = i - bz * (sgx * sgy), by = r / sgx, bx = r - by * sgx;
+        ssim_fwd_body(A, g, bx, by, bz, sgx, sgy, sgz, lds);
+    } else {
+        const int by = i / rgx, bx = i - by * rgx;
+        regloss_fused_body(a, reg_partial, d_allmap, bx, by, rgx, lds);
+    }
 }
 
 // ---- flat Adam --------------------------------------------------------------------------------------------------
@@ -1926,8 +1975,8 @@ int dgs_ssim_forward(int C, int H, int W, const float* img1, const float* img2, 
         return fail(-1, "dgs_ssim_forward: pass all three derivative maps or none");
     static const Gauss g = make_gauss();
     dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C);
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img1, img2, g, ssim_sum, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, (float*)nullptr, (const float* const*)nullptr);
+    const SsimFwdArgs A{H, W, img1, img2, ssim_sum, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_fwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -2350,8 +2399,8 @@ int dgs_photo_forward(int C, int H, int W, const float* img, const float* gt, fl
         return fail(-1, "dgs_photo_forward: bad argument");
     static const Gauss g = make_gauss();
     dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C);
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, img, gt, g, (float*)nullptr, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr, partials, gt_slot);
+    const SsimFwdArgs A{H, W, img, gt, nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, nullptr, partials, gt_slot};
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("ssim_fwd_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -2394,6 +2443,28 @@ int dgs_regloss_fused(int H, int W, const float* allmap, const float* rays_d, co
                        d_allmap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("regloss_fused_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int dgs_loss_forward_merged(int C, int H, int W, const float* img, const float* gt, float* photo_partials, float* dm_dmu1,
+                            float* dm_dsigma1_sq, float* dm_dsigma12, const float* const* gt_slot, const float* allmap, const float* rays_d,
+                            const float* rays_o, const float* wvt, float lambda_normal, float lambda_dist, float* reg_partials,
+                            float* d_allmap, const float* const* rays_slot, void* stream)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !photo_partials || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !allmap ||
+        (!rays_d && !rays_slot) || !rays_o || !wvt || !reg_partials || !d_allmap)
+        return fail(-1, "dgs_loss_forward_merged: bad argument");
+    if ((long long)H * W * 8 >= (1ll << 32)) return fail(-2, "dgs_loss_forward_merged: image too large for 32-bit offsets");
+    static const Gauss g = make_gauss();
+    const int sgx = (W + kTW - 1) / kTW, sgy = (H + kTH - 1) / kTH, rgx = (W + kRW - 1) / kRW, rgy = (H + kRH - 1) / kRH;
+    const long long total = (long long)sgx * sgy * C + (long long)rgx * rgy;
+    if (total >= (1ll << 31)) return fail(-2, "dgs_loss_forward_merged: grid too large");
+    const SsimFwdArgs A{H, W, img, gt, nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, nullptr, photo_partials, gt_slot};
+    const RegArgs a{H, W, allmap, rays_d, rays_o, wvt, lambda_normal, lambda_dist, rays_slot, 1, nullptr};
+    hipLaunchKernelGGL(loss_fwd_merged_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, A, g, sgx, sgy, C, a, reg_partials,
+                       d_allmap, rgx, rgy);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-4, std::string("loss_fwd_merged_kernel: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -18,7 +18,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
             "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard",
-            "dgs_adam_step_origin", "dgs_select_row")
+            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged")
 
 
 def _deps():
@@ -131,6 +131,8 @@ def load():
         lib.dgs_regloss_fused_blocks.argtypes = [ci, ci]
         lib.dgs_regloss_fused.restype = ci
         lib.dgs_regloss_fused.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+        lib.dgs_loss_forward_merged.restype = ci
+        lib.dgs_loss_forward_merged.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         lib.dgs_regloss_forward_partials_z.restype = ci
         lib.dgs_regloss_forward_partials_z.argtypes = [ci, ci, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         lib.dgs_adam_step_guarded.restype = ci
@@ -735,6 +737,9 @@ def _one(dev):
     return t
 
 
+_MERGED_LOSS_FORWARD = os.environ.get("DGS_MERGED_LOSS_FORWARD", "1") != "0"   # 0: the two forward kernels launched one after the other (A/B)
+
+
 class _FusedTrainLoss(torch.autograd.Function):
     """(1 - l) * L1(image, gt) + l * (1 - SSIM(image, gt)) + lambda_normal * normal consistency + lambda_dist * distortion
     from the rasterizer outputs: 3 launches forward, 2 backward -- or, with unit_grad, 3 launches in the forward and none in the
@@ -763,11 +768,18 @@ class _FusedTrainLoss(torch.autograd.Function):
         g_image = torch.empty_like(image) if unit else None
         with torch.cuda.device(dev):
             st = _stream(dev)
-            _check(lib, lib.dgs_photo_forward(C, H, W, image.data_ptr(), gt.data_ptr(), part.data_ptr(), maps[0].data_ptr(),
-                                              maps[1].data_ptr(), maps[2].data_ptr(), gslot, st), "dgs_photo_forward")
+            if unit and _MERGED_LOSS_FORWARD:   # both forward halves in one launch (ssim 21 + regularisers 17.5 us -> see DESIGN.md section 7)
+                _check(lib, lib.dgs_loss_forward_merged(C, H, W, image.data_ptr(), gt.data_ptr(), part.data_ptr(), maps[0].data_ptr(),
+                                                        maps[1].data_ptr(), maps[2].data_ptr(), gslot, allmap.data_ptr(), rays_d.data_ptr(),
+                                                        rays_o.data_ptr(), wvt.data_ptr(), lam_n, lam_d, part.data_ptr() + 8 * nb,
+                                                        g_allmap.data_ptr(), rslot, st), "dgs_loss_forward_merged")
+            else:
+                _check(lib, lib.dgs_photo_forward(C, H, W, image.data_ptr(), gt.data_ptr(), part.data_ptr(), maps[0].data_ptr(),
+                                                  maps[1].data_ptr(), maps[2].data_ptr(), gslot, st), "dgs_photo_forward")
             if unit:
-                _check(lib, lib.dgs_regloss_fused(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), lam_n, lam_d,
-                                                  part.data_ptr() + 8 * nb, g_allmap.data_ptr(), rslot, st), "dgs_regloss_fused")
+                if not _MERGED_LOSS_FORWARD:
+                    _check(lib, lib.dgs_regloss_fused(H, W, allmap.data_ptr(), rays_d.data_ptr(), rays_o.data_ptr(), wvt.data_ptr(), lam_n, lam_d,
+                                                      part.data_ptr() + 8 * nb, g_allmap.data_ptr(), rslot, st), "dgs_regloss_fused")
                 gp = (None, None, None, None, 0) if guard is None else guard.guard_pointers()
                 _check(lib, lib.dgs_photo_backward_combine_guard(C, H, W, image.data_ptr(), gt.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
                                                                  maps[2].data_ptr(), lam_dssim, _one(dev).data_ptr(), g_image.data_ptr(), gslot,

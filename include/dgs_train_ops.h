@@ -232,6 +232,13 @@ int dgs_regloss_forward_partials_z(int H, int W, const float* allmap, const floa
 size_t dgs_regloss_fused_blocks(int H, int W);
 int dgs_regloss_fused(int H, int W, const float* allmap, const float* rays_d, const float* rays_o, const float* wvt, float lambda_normal,
                       float lambda_dist, float* partials, float* d_allmap, const float* const* rays_slot, void* stream);
+/* dgs_photo_forward and dgs_regloss_fused in ONE launch: the two kinds of workgroup alternate in one grid (they read different
+ * rasterizer outputs and write different buffers), so neither leaves the chip half idle in its last round of workgroups and one
+ * launch gap goes away.  Same outputs, bit for bit, as the two calls. */
+int dgs_loss_forward_merged(int C, int H, int W, const float* img, const float* gt, float* photo_partials, float* dm_dmu1,
+                            float* dm_dsigma1_sq, float* dm_dsigma12, const float* const* gt_slot, const float* allmap, const float* rays_d,
+                            const float* rays_o, const float* wvt, float lambda_normal, float lambda_dist, float* reg_partials,
+                            float* d_allmap, const float* const* rays_slot, void* stream);
 int dgs_loss_combine(const float* photo_partials, long long nphoto, const float* reg_partials, long long nreg, long long n,
                      float lambda_dssim, float* out, void* stream);
 int dgs_photo_backward(int C, int H, int W, const float* img, const float* gt, const float* dm_dmu1, const float* dm_dsigma1_sq,
