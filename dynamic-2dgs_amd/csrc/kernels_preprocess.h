@@ -104,6 +104,8 @@ struct BinArgs {
     const float4* rec;
     uint32_t* M;            // [kBinGroups, T] counts, then bucket write cursors
     uint64_t* keys;         // [R] (scatter only)
+    uint32_t* sync;         // count only: nsync words cleared for bin_offsets_kernel (its workgroups' aggregates and ticket), or null
+    int nsync;
 };
 
 __global__ void __launch_bounds__(kBinThreads) count_tiles_lds_kernel(BinArgs a)
@@ -111,6 +113,8 @@ __global__ void __launch_bounds__(kBinThreads) count_tiles_lds_kernel(BinArgs a)
     extern __shared__ uint32_t s_hist[];
     const int g = blockIdx.x, tid = threadIdx.x;
     for (int t = tid; t < a.ntiles; t += kBinThreads) s_hist[t] = 0;
+    if (g == 0 && a.sync)
+        for (int i = tid; i < a.nsync; i += kBinThreads) a.sync[i] = 0u;
     __syncthreads();
     const int end = min(a.P, (g + 1) * a.chunk);
     const int lane = tid & 63;
@@ -306,6 +310,142 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts
         __syncthreads();
         if (order_mode == 4) tile_order_xcd_body(ranges, nullptr, tiles_x, tiles_y, order, group_xcd, true, s_hist, s_gw, s_gx, s_osum);
         else tile_order_body(ranges, nullptr, ntiles, order, s_hist, s_osum);
+    }
+}
+
+// Column sums, scan of the tile counts, bucket cursors and the forward's dispatch order in ONE launch (LDS-histogram path): replaces
+// column_pass(counts) + scan_tiles + column_pass(cursors), three dependent launches of 5 + 10 + 5 us, each mostly launch and memory
+// latency.  Workgroup b = 64 tiles x all kBinGroups rows of M, as in column_pass_kernel; its 64 tile counts are scanned by its
+// first wave and the offset of the block is the sum of the aggregates of the workgroups before it, which every workgroup
+// publishes (flag in the top bit) the moment it has it -- a one-level decoupled look-back: nobody waits for anything but
+// lower-numbered workgroups, which are dispatched first.  The rows of M were read once and are rewritten from registers.
+// The workgroup that finishes LAST (ticket) does what needs every range: num_rendered, the longest list, the capacity
+// check (on overflow it clears all ranges again), tile_last, long_thr[0] and the dispatch order of the forward blend.
+// sync: [2 nb + 1] words, zero on entry (count_tiles_lds_kernel clears them): aggregates, maxima, ticket.
+struct OffsetsArgs {
+    uint32_t* M; int ntiles; uint2* ranges;
+    uint32_t* state;        // [3]: num_rendered, longest list, overflow
+    uint32_t cap; int* overflow; uint32_t list_hint;
+    uint32_t* order;        // or null
+    int tiles_x, tiles_y, order_mode;
+    uint32_t* group_xcd; uint32_t* tile_last; uint32_t* long_thr; uint32_t long_div;
+    uint32_t* sync;
+};
+
+__global__ void __launch_bounds__(64 * kColGroups) bin_offsets_kernel(OffsetsArgs a)
+{
+    constexpr int kRows = kBinGroups / kColGroups;
+    constexpr uint32_t kFlag = 0x80000000u;
+    __shared__ uint32_t s_part[kColGroups][64];
+    __shared__ uint32_t s_start[64];
+    __shared__ uint32_t s_last;
+    __shared__ uint32_t s_hist[8 * kOrderBins];
+    __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
+    __shared__ uint32_t s_osum[16];
+    const int tid = threadIdx.x, tx = tid & 63, ry = tid >> 6;
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int t = b * 64 + tx;
+    uint32_t* const agg = a.sync;
+    uint32_t* const amax = a.sync + nb;
+    uint32_t* const ticket = a.sync + 2 * nb;
+    uint32_t v[kRows];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kRows; i++) v[i] = 0;
+    if (t < a.ntiles) {
+#pragma unroll
+        for (int i = 0; i < kRows; i++) v[i] = a.M[(size_t)(ry * kRows + i) * a.ntiles + t];
+#pragma unroll
+        for (int i = 0; i < kRows; i++) sum += v[i];
+    }
+    s_part[ry][tx] = sum;
+    __syncthreads();
+    if (ry == 0) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < kColGroups; r++) c += s_part[r][tx];
+        uint32_t inc = c, mx = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t n = __shfl_up(inc, d, 64);
+            if (tx >= d) inc += n;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+        if (tx == 63) {
+            __hip_atomic_store(&amax[b], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&agg[b], kFlag | inc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t before = 0;
+        for (int j = tx; j < b; j += 64) {
+            uint32_t w = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (!(w & kFlag)) {
+                __builtin_amdgcn_s_sleep(1);
+                w = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            before += w & ~kFlag;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+        const uint32_t start = before + inc - c;
+        s_start[tx] = start;
+        if (t < a.ntiles) a.ranges[t] = make_uint2(start, start + c);
+    }
+    __syncthreads();
+    if (t < a.ntiles) {
+        uint32_t run = s_start[tx];
+        for (int r = 0; r < ry; r++) run += s_part[r][tx];
+#pragma unroll
+        for (int i = 0; i < kRows; i++) {
+            a.M[(size_t)(ry * kRows + i) * a.ntiles + t] = run;
+            run += v[i];
+        }
+    }
+    // ticket: the ranges of this workgroup are released before it, the last one acquires everybody's.  ONE thread fences (behind the
+    // barrier that completes the workgroup's stores): an agent-scope fence writes back / invalidates the XCD's L2, and 1024 threads
+    // x 40 workgroups doing that made this kernel 39 us instead of 12
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const bool last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(nb - 1);
+        if (last) __threadfence();
+        s_last = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    uint32_t tot = 0, lng = 0;
+    for (int j = tid; j < nb; j += 64 * kColGroups) {
+        tot += __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~kFlag;
+        lng = max(lng, __hip_atomic_load(&amax[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        tot += (uint32_t)__shfl_xor((int)tot, d, 64);
+        lng = max(lng, (uint32_t)__shfl_xor((int)lng, d, 64));
+    }
+    if (tx == 0) { s_part[0][ry] = tot; s_part[1][ry] = lng; }
+    __syncthreads();
+    uint32_t total = 0, longest = 0;
+#pragma unroll
+    for (int r = 0; r < kColGroups; r++) { total += s_part[0][r]; longest = max(longest, s_part[1][r]); }
+    // capacity mode: the lists must fit the pre-sized buffer, and -- if the caller promised a longest list (list_hint: only the
+    // sort kernels for lists up to it were launched) -- no list may be longer than promised (scan_tiles_kernel)
+    const bool over = a.cap > 0 && (total > a.cap || (a.list_hint > 0 && longest > a.list_hint));
+    if (over)
+        for (int i = tid; i < a.ntiles; i += 64 * kColGroups) a.ranges[i] = make_uint2(0u, 0u);
+    for (int i = tid; i < a.ntiles; i += 64 * kColGroups) a.tile_last[i] = 0u;
+    if (tid == 0) {
+        a.state[0] = total;
+        a.state[1] = longest;
+        a.state[2] = over ? 1u : 0u;
+        if (over && a.overflow) atomicOr(a.overflow, 1);
+        a.long_thr[0] = max(768u, total / max(a.long_div, 1u));
+    }
+    if (a.order) {
+        __threadfence_block();
+        __syncthreads();
+        if (a.order_mode == 4) tile_order_xcd_body(a.ranges, nullptr, a.tiles_x, a.tiles_y, a.order, a.group_xcd, true, s_hist, s_gw, s_gx, s_osum);
+        else tile_order_body(a.ranges, nullptr, a.ntiles, a.order, s_hist, s_osum);
     }
 }
 

@@ -92,7 +92,8 @@ struct ImageLayout {
         order_fwd = c.take(order_len * 4);
         order_bwd = c.take(order_len * 4);
         group_xcd = c.take((size_t)dgs::kOrderMaxGroups * 4);   // tile order 4: the forward's group -> XCD map, reused by the backward
-        tile_counts = c.take((size_t)ntiles * 4);
+        // global-atomics path: the T tile counts; LDS-histogram path: the 2 ceil(T / 64) + 1 words bin_offsets_kernel's workgroups meet in
+        tile_counts = c.take((size_t)(ntiles > 2 * ((ntiles + 63) / 64) + 1 ? ntiles : 2 * ((ntiles + 63) / 64) + 1) * 4);
         lds_bins = (size_t)ntiles * 4 <= 144 * 1024;
         // LDS path: G x T matrix of per-workgroup counts / cursors; fallback: T global cursors
         cursor = c.take(lds_bins ? (size_t)dgs::kBinGroups * ntiles * 4 : (size_t)ntiles * 4);
@@ -199,6 +200,7 @@ struct dgs_context {
     dgs_context()
     {
         if (const char* e = getenv("DGS_LONG_TILES")) long_tiles.store(atoi(e) != 0);   // A/B runs of whole programs (bench.py, the test suite)
+        if (const char* e = getenv("DGS_MERGED_OFFSETS")) merged_offsets.store(atoi(e) != 0);
     }
     int device = 0;
     std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
@@ -214,6 +216,7 @@ struct dgs_context {
     // gains 7 %; an opaque knot (40 k of 100 k surfels on a few tiles) pays 2-4 % for the forward path (0.112 -> 0.114-0.116).
     std::atomic<int> long_div_fwd{400};  // key 10: a list is long from num_rendered / this (and 768 entries) on
     std::atomic<int> long_div_bwd{512};  // key 11: a tile is long from (sum of traversed lengths) / this (and 512 entries) on
+    std::atomic<int> merged_offsets{1};  // key 12: tile counts -> ranges, bucket cursors and dispatch order in one launch (bin_offsets_kernel); 0 = column pass, scan, column pass
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
     std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
@@ -351,6 +354,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (key == 9) { c->long_tiles.store(value != 0); return DGS_OK; }
     if (key == 10 && value > 0) { c->long_div_fwd.store(value); return DGS_OK; }
     if (key == 11 && value > 0) { c->long_div_bwd.store(value); return DGS_OK; }
+    if (key == 12) { c->merged_offsets.store(value != 0); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
@@ -580,10 +584,15 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     ba_.radii = radii; ba_.rects = pa.rects; ba_.rec = pa.rec; ba_.M = cursor; ba_.keys = nullptr;
     ba_.state = (const uint32_t*)(geom + gl.total);
     const size_t hist_bytes = (size_t)il.ntiles * 4;
+    const int off_blocks = (il.ntiles + 63) / 64;
+    const bool merged_offsets = il.lds_bins && ctx->merged_offsets.load();
+    ba_.sync = merged_offsets ? tile_counts : nullptr;
+    ba_.nsync = 2 * off_blocks + 1;
     if (il.lds_bins) {
         hipLaunchKernelGGL(dgs::count_tiles_lds_kernel, dim3(dgs::kBinGroups), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
-        hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(64 * dgs::kColGroups), 0, stream, cursor, il.ntiles,
-                           (const uint2*)nullptr, tile_counts);
+        if (!merged_offsets)
+            hipLaunchKernelGGL(dgs::column_pass_kernel, dim3(off_blocks), dim3(64 * dgs::kColGroups), 0, stream, cursor, il.ntiles,
+                               (const uint2*)nullptr, tile_counts);
     } else {
         DGS_HIP(hipMemsetAsync(tile_counts, 0, hist_bytes, stream));
         hipLaunchKernelGGL(dgs::count_tiles_global_kernel, dim3(gl.nblocks), dim3(dgs::kSurfelBlock), 0, stream, P, (const int*)radii,
@@ -595,6 +604,18 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
     int tile_order = ctx->tile_order.load();
     if (tile_order == 4 && dgs::order_groups(il.tiles_x, il.tiles_y) > dgs::kOrderMaxGroups) tile_order = 3;   // > 128 x 128 tiles
+    if (merged_offsets) {
+        // column sums + scan + bucket cursors + dispatch order in one launch (kernels_preprocess.h: bin_offsets_kernel)
+        dgs::OffsetsArgs oa;
+        oa.M = cursor; oa.ntiles = il.ntiles; oa.ranges = ranges; oa.state = (uint32_t*)(geom + gl.total);
+        oa.cap = (uint32_t)capacity; oa.overflow = overflow; oa.list_hint = (uint32_t)(capacity > 0 ? ctx->list_hint.load() : 0);
+        oa.order = tile_order >= 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr;
+        oa.tiles_x = il.tiles_x; oa.tiles_y = il.tiles_y; oa.order_mode = tile_order;
+        oa.group_xcd = (uint32_t*)(img + il.group_xcd); oa.tile_last = (uint32_t*)(img + il.tile_last);
+        oa.long_thr = (uint32_t*)(img + il.long_thr); oa.long_div = (uint32_t)ctx->long_div_fwd.load();
+        oa.sync = tile_counts;
+        hipLaunchKernelGGL(dgs::bin_offsets_kernel, dim3(off_blocks), dim3(64 * dgs::kColGroups), 0, stream, oa);
+    } else
     hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
                        il.lds_bins ? (uint32_t*)nullptr : cursor, (uint32_t*)(geom + gl.total), (uint32_t)capacity, overflow,
                        tile_order >= 3 ? (uint32_t*)(img + il.order_fwd) : (uint32_t*)nullptr,   // + the forward's dispatch order
@@ -631,8 +652,9 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         // ---- K4 scatter (depth, index) keys into the tile buckets
         uint64_t* keys = (uint64_t*)(bin + bl.keys);
         if (il.lds_bins) {
-            hipLaunchKernelGGL(dgs::column_pass_kernel, dim3((il.ntiles + 63) / 64), dim3(64 * dgs::kColGroups), 0, stream, cursor, il.ntiles,
-                               (const uint2*)ranges, (uint32_t*)nullptr);
+            if (!merged_offsets)
+                hipLaunchKernelGGL(dgs::column_pass_kernel, dim3(off_blocks), dim3(64 * dgs::kColGroups), 0, stream, cursor, il.ntiles,
+                                   (const uint2*)ranges, (uint32_t*)nullptr);
             ba_.keys = keys;
             hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
         } else {

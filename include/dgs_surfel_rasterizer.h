@@ -158,6 +158,9 @@ void dgs_set_tight_rects(int on);
  *         quadrant, four list quarters each -- instead of one; deterministic, results differ from the serial walk in rounding only.
  * key 10 / key 11 = thresholds of that path: a forward list is long from num_rendered / value entries on (default 400; never below
  *         768), a backward tile from (sum of the traversed lengths) / value on (default 512; never below 512).
+ * key 12 = binning offsets in one launch (1 [default] / 0): per-tile counts -> tile ranges, bucket write cursors, num_rendered, the
+ *         capacity check and the forward's dispatch order by one kernel whose workgroups exchange their aggregates (decoupled
+ *         look-back); 0 = the three launches (column pass, one-workgroup scan, column pass) it replaces.  Same results.
  * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
  *         host read the library cannot know which of its per-tile sort kernels will find work and launches all four; with the
  *         promise it launches only those for lists up to `value` (2048: one launch; 57344 = 28 segments of 2048: three).  A frame that breaks the promise is treated exactly like a capacity overflow: background, flag raised,

@@ -231,6 +231,33 @@ def test_every_tile_order_renders_the_same(shape):
             assert np.abs(o[k] - ref[k]).max() <= 2e-4 * scale + 1e-12, (mode, k)
 
 
+@pytest.mark.parametrize("shape", [(16, 16), (96, 80), (200, 136), (1040, 1030), (1600, 1600)])
+def test_binning_offsets_in_one_launch_equal_the_three_launches(shape):
+    """dgs_set_option(12, m): tile counts -> ranges, bucket cursors, num_rendered and dispatch order by ONE kernel whose workgroups
+    exchange aggregates (bin_offsets_kernel: 1 .. 157 workgroups at these sizes, the last one ragged) or by column pass + scan +
+    column pass: the same tile lists, hence a bit-identical forward, and gradients equal up to the order
+    of the atomic sums.  Repeated, because a lost aggregate or a stale range would show as a frame that differs now and then."""
+    from diff_surfel_rasterization import _C
+    from gpu_utils import run_hip
+    H, W = shape
+    case = small_case(P=40000 if H > 1000 else 6000, H=H, W=W, seed=23, view=1, scale_mul=1.5)
+    gc, go = _cot(case)
+    try:
+        _C.set_option(12, 0)
+        ref = run_hip(case, gc, go, debug=False)
+        _C.set_option(12, 1)
+        for rep in range(4):
+            o = run_hip(case, gc, go, debug=False)
+            assert (o["radii"] > 0).any()
+            assert np.array_equal(o["color"], ref["color"]) and np.array_equal(o["allmap"], ref["allmap"]), rep
+            assert np.array_equal(o["radii"], ref["radii"]), rep
+            for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh", "dL_dmeans2D"):
+                scale = np.abs(ref[k]).max()
+                assert np.abs(o[k] - ref[k]).max() <= 2e-4 * scale + 1e-12, (rep, k)
+    finally:
+        _C.set_option(12, 1)
+
+
 @pytest.mark.parametrize("cfg", [dict(P=3000, H=96, W=80, seed=9, view=4), dict(P=20000, H=200, W=200, seed=3, view=1, scale_mul=1.5)])
 def test_deterministic_backward_is_reproducible_and_equals_the_atomic_one(cfg):
     """dgs_set_option(7, 1): the backward blend stores its per-(list entry, wave) sums and a per-surfel kernel adds them in a fixed
