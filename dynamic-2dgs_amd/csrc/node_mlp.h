@@ -117,10 +117,27 @@ __device__ __forceinline__ const float* w_row(const Weights& w, int l, int n)
     return l == 10 ? w.hw[n] : w.W[l] + (size_t)n * l_in(l);
 }
 
-// one thread per float4 of the two operand arrays: forward [l][k/4][c] = W_l[c][col(4 (k/4) + s)], backward
-// [l][j/4][c] = W_l[4 (j/4) + s][col(c)]
-__global__ void __launch_bounds__(256) mlp_pack_kernel(Weights w, float4* __restrict__ packed)
+// The view of a replayed step (dgs_select_row): row_out <- table[v] with v = override[0] if it is >= 0 (then reset to -1), else
+// (counter[0] * stride + offset) mod nrows; counter[0] += 1.  One workgroup.
+struct SelectArgs {
+    const float* table; int nrows, row_floats; int* counter; int* override_; int stride, offset; float* row_out;
+};
+__device__ __forceinline__ void select_row_body(const SelectArgs& q)
 {
+    const int ov = q.override_[0], c = q.counter[0];
+    const int v = ov >= 0 ? (ov % q.nrows) : (int)(((long long)c * q.stride + q.offset) % q.nrows);
+    for (int i = threadIdx.x; i < q.row_floats; i += blockDim.x) q.row_out[i] = q.table[(size_t)v * q.row_floats + i];
+    __syncthreads();
+    if (threadIdx.x == 0) { q.counter[0] = c + 1; q.override_[0] = -1; }
+}
+
+// one thread per float4 of the two operand arrays: forward [l][k/4][c] = W_l[c][col(4 (k/4) + s)], backward
+// [l][j/4][c] = W_l[4 (j/4) + s][col(c)].  Rider (sel.table != null): one more workgroup at the end of the grid picks the view of
+// this step -- the node MLP behind this kernel is the first consumer of the view's time, and as a node of its own in front of the
+// step the selection cost its 4 us + the 5-6 us fork behind it.
+__global__ void __launch_bounds__(256) mlp_pack_kernel(Weights w, float4* __restrict__ packed, SelectArgs sel)
+{
+    if (sel.table && blockIdx.x == gridDim.x - 1) { select_row_body(sel); return; }
     int g = blockIdx.x * 256 + threadIdx.x;
     if (g < kNL * kW) {
         int l = g >> 8, c = g & 255;

@@ -1871,15 +1871,7 @@ struct AdamSegs {
 // First node of a captured step: the view of this replay.  row_out <- table[v] with v = override[0] if it is >= 0 (then reset to -1),
 // else (counter[0] * stride + offset) mod nrows; counter[0] += 1.  A step that walks its views in the default order needs no host
 // copy in front of the replay (the 256-byte row copy + the idle device behind it were ~10 us of every 0.8 ms step).
-__global__ void __launch_bounds__(64) select_row_kernel(const float* __restrict__ table, int nrows, int row_floats, int* __restrict__ counter,
-                                                        int* __restrict__ override_, int stride, int offset, float* __restrict__ row_out)
-{
-    const int ov = override_[0], c = counter[0];
-    const int v = ov >= 0 ? (ov % nrows) : (int)(((long long)c * stride + offset) % nrows);
-    for (int i = threadIdx.x; i < row_floats; i += 64) row_out[i] = table[(size_t)v * row_floats + i];
-    __syncthreads();
-    if (threadIdx.x == 0) { counter[0] = c + 1; override_[0] = -1; }
-}
+__global__ void __launch_bounds__(64) select_row_kernel(mlp::SelectArgs q) { mlp::select_row_body(q); }
 
 __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restrict__ step_count, float* __restrict__ status,
                                   float* __restrict__ host_ring, int ring_len, const float* __restrict__ loss)
@@ -2153,7 +2145,8 @@ int dgs_select_row(const float* table, int nrows, int row_floats, int* counter, 
 {
     if (!table || !counter || !override_ || !row_out || nrows <= 0 || row_floats <= 0 || stride <= 0 || offset < 0)
         return fail(-1, "dgs_select_row: bad argument");
-    hipLaunchKernelGGL(select_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table, nrows, row_floats, counter, override_, stride, offset, row_out);
+    const mlp::SelectArgs q{table, nrows, row_floats, counter, override_, stride, offset, row_out};
+    hipLaunchKernelGGL(select_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, q);
     return hipGetLastError() == hipSuccess ? 0 : fail(-4, "select_row_kernel: launch failed");
 }
 
@@ -2230,7 +2223,17 @@ static const int kHeadRows[4] = {4, 3, 4, 2};
 int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
                     const float* rot_bias, float* packed, float* saved, float* attrs, void* stream)
 {
+    return dgs_mlp_forward_select(M, x, x_stride, t, t_stride, params, rot_bias, packed, saved, attrs, nullptr, 0, 0, nullptr, nullptr, 1, 0,
+                                  nullptr, stream);
+}
+
+int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
+                           const float* rot_bias, float* packed, float* saved, float* attrs, const float* table, int nrows, int row_floats,
+                           int* counter, int* override_, int stride, int offset, float* row_out, void* stream)
+{
     if (M <= 0 || M % 64) return fail(-1, "dgs_mlp_forward: M must be a positive multiple of 64");
+    if (table && (!counter || !override_ || !row_out || nrows <= 0 || row_floats <= 0 || stride <= 0 || offset < 0))
+        return fail(-1, "dgs_mlp_forward_select: bad view table arguments");
     if (!x || !t || !params || !packed || !saved || !attrs) return fail(-1, "dgs_mlp_forward: null pointer");
     mlp::Weights w{};
     for (int l = 0; l < 10; l++) { w.W[l] = params[2 * l]; w.b[l] = params[2 * l + 1]; }
@@ -2240,7 +2243,8 @@ int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_s
     for (; r < 16; r++) { w.hw[r] = w.hw[0]; w.hb[r] = w.hb[0]; }
     hipStream_t s = (hipStream_t)stream;
     int nthreads = mlp::kFwdVecs + mlp::kBwdVecs;   // one thread per float4 of the two operand arrays
-    hipLaunchKernelGGL(mlp::mlp_pack_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<float4*>(packed));
+    const mlp::SelectArgs sel{table, nrows, row_floats, counter, override_, stride, offset, row_out};
+    hipLaunchKernelGGL(mlp::mlp_pack_kernel, dim3((nthreads + 255) / 256 + (table ? 1 : 0)), dim3(256), 0, s, w, reinterpret_cast<float4*>(packed), sel);
     mlp::FwdArgs a{};
     a.M = M; a.x = x; a.x_stride = x_stride; a.t = t; a.t_stride = t_stride;
     a.wp = reinterpret_cast<const float4*>(packed);

@@ -18,7 +18,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
             "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard",
-            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged")
+            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged", "dgs_mlp_forward_select")
 
 
 def _deps():
@@ -88,6 +88,8 @@ def load():
         lib.dgs_mlp_scratch_floats.argtypes = [ci]
         lib.dgs_mlp_forward.restype = ci
         lib.dgs_mlp_forward.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
+        lib.dgs_mlp_forward_select.restype = ci
+        lib.dgs_mlp_forward_select.argtypes = [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, ci, ci, vp, vp]
         lib.dgs_mlp_backward.restype = ci
         lib.dgs_mlp_backward.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp]
         lib.dgs_knn_points2.restype = ci
@@ -456,7 +458,8 @@ def node_mlp_params(net):
     return out
 
 
-def _mlp_forward_raw(x, t, rot_bias, params):
+def _mlp_forward_raw(x, t, rot_bias, params, select=None):
+    """select: None, or the arguments of select_row() -- the weight-packing launch then also picks the view (dgs_mlp_forward_select)."""
     lib = load()
     dev = x.device
     M = x.shape[0]
@@ -468,8 +471,16 @@ def _mlp_forward_raw(x, t, rot_bias, params):
     ptrs = (ctypes.c_void_p * 28)(*[p.data_ptr() for p in params])
     rb = (ctypes.c_float * 4)(*rot_bias)
     with torch.cuda.device(dev):
-        rc = lib.dgs_mlp_forward(M, x.data_ptr(), x.stride(0), t.data_ptr(), t.stride(0), ptrs, rb, packed.data_ptr(),
-                                 saved.data_ptr(), attrs.data_ptr(), _stream(dev))
+        if select is None:
+            rc = lib.dgs_mlp_forward(M, x.data_ptr(), x.stride(0), t.data_ptr(), t.stride(0), ptrs, rb, packed.data_ptr(),
+                                     saved.data_ptr(), attrs.data_ptr(), _stream(dev))
+        else:
+            table, counter, override, stride, offset, row_out = select
+            assert (table.dtype == torch.float32 and table.is_contiguous() and row_out.is_contiguous() and counter.dtype == torch.int32
+                    and override.dtype == torch.int32 and table.device == dev)
+            rc = lib.dgs_mlp_forward_select(M, x.data_ptr(), x.stride(0), t.data_ptr(), t.stride(0), ptrs, rb, packed.data_ptr(),
+                                            saved.data_ptr(), attrs.data_ptr(), table.data_ptr(), table.shape[0], table.shape[1],
+                                            counter.data_ptr(), override.data_ptr(), int(stride), int(offset), row_out.data_ptr(), _stream(dev))
     _check(lib, rc, "dgs_mlp_forward")
     return attrs, packed, saved
 
@@ -578,8 +589,8 @@ class DeferredNodeMLP:
         self.state = None
 
     @torch.no_grad()
-    def forward(self, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0)):
-        attrs, packed, saved = _mlp_forward_raw(x.detach(), t.detach(), tuple(float(v) for v in rot_bias), self.params)
+    def forward(self, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0), select=None):
+        attrs, packed, saved = _mlp_forward_raw(x.detach(), t.detach(), tuple(float(v) for v in rot_bias), self.params, select=select)
         self.state = (packed, saved)
         return attrs
 

@@ -377,6 +377,7 @@ class Trainer:
         # the view of a replay is chosen ON THE DEVICE by the first node of the graph (dgs_select_row): step counter + override word.
         # The host mirrors the counter; a step that asks for another view than the default order's writes the override first.
         self._dev_select = os.environ.get("DGS_DEVICE_VIEW_SELECT", "1") != "0"
+        self._select_rider = os.environ.get("DGS_SELECT_RIDER", "1") != "0"   # 0: the selection as a node of its own (A/B)
         self._vctr = torch.full((1,), int(self.iteration), dtype=torch.int32, device=dev)
         self._vovr = torch.full((1,), -1, dtype=torch.int32, device=dev)
         self._vctr_host = int(self.iteration)
@@ -410,6 +411,7 @@ class Trainer:
             with torch.cuda.graph(self._g1, **mode):
                 self._select_view_node()
                 self._sloss = self._fwd_bwd_a(self._scam, self._sgt)
+                self._select_consumed()
             self._g1b = torch.cuda.CUDAGraph()
             self._g1c = None
             if self.split3:
@@ -425,6 +427,7 @@ class Trainer:
             with torch.cuda.graph(self._g1, **mode):
                 self._select_view_node()
                 self._sloss = self._fwd_bwd(self._scam, self._sgt)   # lives in the graph's pool: rewritten by every replay
+                self._select_consumed()
                 if self.world == 1:
                     self._finish()
         self._g2 = self._g2a = self._g2b = None
@@ -473,7 +476,21 @@ class Trainer:
         """First node of a captured step (see enable_graph): the view row of this replay, chosen on the device."""
         if self._dev_select:
             from . import _ops
-            _ops.select_row(self._vtab, self._vctr, self._vovr, self.world, self.rank, self._scam.row)
+            args = (self._vtab, self._vctr, self._vovr, self.world, self.rank, self._scam.row)
+            s, d = self.surfels, self.deform
+            if (self._select_rider and self.rasterizer_cls is None and s.get_xyz.is_cuda and self.fuse_deform and hasattr(d, "_node_attrs")
+                    and d.can_assemble(s)):
+                # the deformation's node MLP is the first consumer of the view (its time): the selection rides in that path's first
+                # launch instead of being a node of its own (4 us + the fork behind it: 9 us of the step)
+                d.view_select = args
+            else:
+                _ops.select_row(*args)
+
+    def _select_consumed(self):
+        """A handed-over view selection (_select_view_node) must have been launched by the step that was just built."""
+        if getattr(self.deform, "view_select", None) is not None:
+            self.deform.view_select = None
+            raise RuntimeError("the captured step did not launch its view selection")
 
     def refresh_knn_mode(self):
         """Re-evaluate which seeded neighbour search fits the scene (ControlNodes.pick_knn_refine: one host read) and, if the

@@ -160,6 +160,12 @@ size_t dgs_mlp_saved_floats(int M);
 size_t dgs_mlp_scratch_floats(int M);
 int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
                     const float* rot_bias, float* packed, float* saved, float* attrs, void* stream);
+/* dgs_mlp_forward whose weight-packing launch also performs dgs_select_row(table .. row_out) (table may be NULL: then exactly
+ * dgs_mlp_forward): for a captured train step whose node MLP is the first consumer of the selected view (its time `t` points
+ * into row_out) -- the selection then costs no node of its own in front of the step. */
+int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
+                           const float* rot_bias, float* packed, float* saved, float* attrs, const float* table, int nrows, int row_floats,
+                           int* counter, int* override_, int stride, int offset, float* row_out, void* stream);
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream);
 
