@@ -410,12 +410,28 @@ __global__ void __launch_bounds__(kThreads) mlp_fwd_kernel(FwdArgs a)
 }
 
 // ---- backward chain ---------------------------------------------------------------------------------------------
+// Optional: the reduction of the skinning backward's node table (dgs_deform_reduce, lbs_reduce_raw_kernel) folded into the head of
+// this kernel.  The table row of a node is [13 attribute gradients | H hyper-coordinate gradients | radius | weight]; a workgroup
+// needs the attribute gradients of its own 8 nodes only, so it reads them from the table, finishes the other columns
+// (exp / sigmoid chain rules of the raw radius and weight), leaves the row zeroed for the next backward and stores the
+// attribute gradients for the weight-gradient kernel -- one launch (6 us in the step's tail, on its critical path) less.
+struct ReduceFold {
+    float* table;              // [M][G], or null: g_attrs is read as given
+    int G, H;                  // G = 13 + H + 2
+    const float* rad_raw; const float* w_raw;
+    float* g_nodes;            // [M][3 + H]
+    float* g_rad_raw; float* g_w_raw;
+    float* g_attrs_out;        // [M][13]
+    int accumulate, clear;
+};
+
 struct BwdArgs {
     int M;
     const float* g_attrs;      // [M][13]
     const float4* wq;          // packed dgrad operand (= packed + kFwdVecs)
     const float* saved;
     float* scratch;            // sc_* layout
+    ReduceFold fold;
 };
 
 __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
@@ -439,9 +455,35 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
     // the ReLU masks are the saved post-activation values of this thread's two outputs (rows fv and 4 + fv, column fc)
     const float* hs = a.saved + (size_t)(row0 + fv) * kW + fc;
     float h0 = hs[sv_h(M, 7)], h1 = hs[sv_h(M, 7) + 4 * kW];
-    for (int e = tid; e < kRows * 16; e += kThreads) {
-        int r = e >> 4, c = e & 15;
-        sG[r * kSG + c] = c < kHeads ? a.g_attrs[(size_t)(row0 + r) * kHeads + c] : 0.f;
+    if (a.fold.table) {
+        const ReduceFold& f = a.fold;
+        const int T = 3 + f.H;
+        for (int e = tid; e < kRows * f.G; e += kThreads) {
+            const int r = e / f.G, c = e - r * f.G, node = row0 + r;
+            const float acc = f.table[(size_t)node * f.G + c];
+            if (f.clear) f.table[(size_t)node * f.G + c] = 0.f;
+            if (c < kHeads) {
+                sG[r * kSG + c] = acc;
+                f.g_attrs_out[(size_t)node * kHeads + c] = acc;
+            } else if (c < kHeads + f.H) {
+                float* d = f.g_nodes + (size_t)node * T + 3 + (c - kHeads);
+                *d = f.accumulate ? *d + acc : acc;
+            } else if (c == kHeads + f.H) {
+                const float v = acc * expf(f.rad_raw[node]);
+                f.g_rad_raw[node] = f.accumulate ? f.g_rad_raw[node] + v : v;
+            } else {
+                const float w = 1.0f / (1.0f + expf(-f.w_raw[node]));
+                const float v = acc * w * (1.0f - w);
+                f.g_w_raw[node] = f.accumulate ? f.g_w_raw[node] + v : v;
+            }
+            if (c < 3 && !f.accumulate) f.g_nodes[(size_t)node * T + c] = 0.f;   // node positions are detached in the reference
+        }
+        for (int e = tid; e < kRows * (16 - kHeads); e += kThreads) sG[(e / (16 - kHeads)) * kSG + kHeads + e % (16 - kHeads)] = 0.f;
+    } else {
+        for (int e = tid; e < kRows * 16; e += kThreads) {
+            int r = e >> 4, c = e & 15;
+            sG[r * kSG + c] = c < kHeads ? a.g_attrs[(size_t)(row0 + r) * kHeads + c] : 0.f;
+        }
     }
     __syncthreads();
 

@@ -2259,11 +2259,25 @@ int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, 
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream)
 {
+    return dgs_mlp_backward_reduce(M, const_cast<float*>(g_attrs), packed, saved, scratch, grads, accumulate, 0, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, 0, nullptr, stream);
+}
+
+int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
+                            int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
+                            float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream)
+{
     if (M <= 0 || M % 64) return fail(-1, "dgs_mlp_backward: M must be a positive multiple of 64");
     if (!g_attrs || !packed || !saved || !scratch || !grads) return fail(-1, "dgs_mlp_backward: null pointer");
+    if (lbs_table && (H < 0 || H > kLbsHmax || !node_radius_raw || !node_weight_raw || !g_nodes || !g_radius_raw || !g_weight_raw))
+        return fail(-1, "dgs_mlp_backward_reduce: bad argument");
+    static_assert(kLbsAttr == mlp::kHeads, "the node table's attribute columns are the MLP's outputs");
     hipStream_t s = (hipStream_t)stream;
     mlp::BwdArgs b{};
     b.M = M; b.g_attrs = g_attrs; b.saved = saved; b.scratch = scratch;
+    if (lbs_table)   // flags as dgs_deform_reduce: bit 0 add to the gradients, bit 2 leave the table zeroed
+        b.fold = mlp::ReduceFold{(float*)lbs_table, kLbsAttr + H + 2, H, node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw,
+                                 g_attrs, reduce_flags & 1, (reduce_flags & 4) ? 1 : 0};
     b.wq = reinterpret_cast<const float4*>(packed) + (size_t)mlp::kFwdVecs;
     hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
 
@@ -2281,17 +2295,17 @@ int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const flo
         d.ntiles = ((out + mlp::kWgTileJ - 1) / mlp::kWgTileJ) * d.iblocks;
     };
     const int W = mlp::kW;
-    auto H = [&](int l) { return saved + mlp::sv_h(M, l); };
+    auto Hs = [&](int l) { return saved + mlp::sv_h(M, l); };
     auto dZ = [&](int l) { return scratch + mlp::sc_dz(M, l); };
-    add(g_attrs, mlp::kHeads, mlp::kHeads, H(7), W, W, nullptr, W, nullptr);                          // heads
+    add(g_attrs, mlp::kHeads, mlp::kHeads, Hs(7), W, W, nullptr, W, nullptr);                          // heads
     for (int l = 7; l >= 1; l--) {
         float* gw = grads[2 * (l + 2)];
         float* gb = grads[2 * (l + 2) + 1];
         if (l == 5) {
             add(dZ(5), W, W, saved + mlp::sv_inp(M), mlp::kInPad, mlp::kIn, gw, mlp::kIn + W, gb);    // [inp | .]
-            add(dZ(5), W, W, H(4), W, W, gw + mlp::kIn, mlp::kIn + W, nullptr);                       // [. | H4]
+            add(dZ(5), W, W, Hs(4), W, W, gw + mlp::kIn, mlp::kIn + W, nullptr);                       // [. | H4]
         } else {
-            add(dZ(l), W, W, H(l - 1), W, W, gw, W, gb);
+            add(dZ(l), W, W, Hs(l - 1), W, W, gw, W, gb);
         }
     }
     add(dZ(0), W, W, saved + mlp::sv_inp(M), mlp::kInPad, mlp::kIn, grads[4], mlp::kIn, grads[5]);   // L0

@@ -168,6 +168,13 @@ int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, 
                            int* counter, int* override_, int stride, int offset, float* row_out, void* stream);
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream);
+/* dgs_mlp_backward with dgs_deform_reduce folded into its first kernel (lbs_table may be NULL: then exactly dgs_mlp_backward):
+ * the skinning backward left its node table [M][13 + H + 2] unreduced (dgs_deform_backward, accumulate bit 3); every workgroup of
+ * the MLP's backward chain reduces the rows of its own nodes -- g_attrs[M][13] is WRITTEN here (and read by the weight-gradient
+ * kernel), g_nodes / g_radius_raw / g_weight_raw as dgs_deform_reduce writes them; reduce_flags as its `accumulate`. */
+int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
+                            int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
+                            float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream);
 
 /* dgs_knn_points with the query coordinates split over two arrays: [0,D1) from x1[N,D1], [D1,D1+D2) from
  * x2[N, x2_stride] (avoids materialising cat([xyz, feature[:, :hyper]]) every step). */
