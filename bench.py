@@ -616,10 +616,10 @@ def main():
             basis = "own" if name == "binning" else "survey"
             gbs = b[basis] / (ms * 1e-3) / 1e9
             kernels = {"preprocess_fwd": ["preprocess_fwd_kernel"], "surfel_bwd": ["surfel_bwd_kernel"],
-                       "binning": ["count_tiles_lds_kernel", "column_pass_kernel", "scan_tiles_kernel", "scatter_keys_lds_kernel", "sort_tiles_radix_kernel"]}[name]
+                       "binning": ["count_tiles_lds_kernel", "bin_offsets_kernel", "scatter_keys_lds_kernel", "sort_tiles_radix_kernel"]}[name]
             traffic = [pmc_of(k, "hbm_traffic_bytes_per_launch") for k in kernels]
             return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                    "traffic": None if any(t is None for t in traffic) else int(sum(t * (2 if k == "column_pass_kernel" else 1) for t, k in zip(traffic, kernels))),
+                    "traffic": None if any(t is None for t in traffic) else int(sum(traffic)),
                     "avg_ms": round(ms, 4), "frac_basis": "own_bytes_per_launch" if basis == "own" else "alg_bytes_per_launch (SURVEY 8d)",
                     "alg_bytes_per_launch": round(b["survey"]), "own_bytes_per_launch": round(b["own"]),
                     "own_GBs": round(b["own"] / (ms * 1e-3) / 1e9, 2), "survey_GBs": round(b["survey"] / (ms * 1e-3) / 1e9, 2),
