@@ -49,7 +49,8 @@ def test_fit_recovers_a_hidden_dynamic_scene(tmp_path):
     print("mean loss per 500 iterations:", np.round(blocks, 4))
     # ---- the stated margins
     # (the run is chaotic -- float atomics, 9000 Adam steps, densification decisions: seven runs of this test on one code state
-    # ended between 23.3 and 28.2 dB, the level of an untrained model is 7.7)
+    # ended between 23.3 and 28.2 dB, the level of an untrained model is 7.7; the test below shows that the spread is the order of the
+    # float atomics and nothing else)
     assert probes[9000] >= probes[1] + 10.0, probes                    # held-out PSNR rises by >= 10 dB over the run
     assert probes[9000] >= 21.0, probes                                # ... to a level at which the scene is recognisably recovered
     assert probes[6000] >= probes[3000] + 1.0, probes                  # the deformation (trained from iteration 3000) adds to the static fit
@@ -63,3 +64,53 @@ def test_fit_recovers_a_hidden_dynamic_scene(tmp_path):
     assert blocks[5] < 0.6 * blocks[0] and blocks[15] < blocks[5], blocks
     assert sum(1 for a, b in zip(blocks[:-1], blocks[1:]) if b > 1.05 * a) <= 4, blocks
     assert os.path.exists(os.path.join(str(tmp_path / "model"), "point_cloud/iteration_9000/point_cloud.ply"))
+
+
+def test_the_run_to_run_spread_is_the_float_atomics(tmp_path, monkeypatch):
+    """The learning test above ends anywhere between 23 and 28 dB from run to run.  Is that chaos seeded by the order of float
+    atomics, or a race?  With every atomic sum replaced by an ordered one -- the deterministic backward blend (rasterizer option
+    7) and the skinning backward's per-workgroup tables instead of its wave-level atomics (coherent_surfels off) -- two fits with
+    the same seed, through warm-up, densification, pruning and an opacity reset, must agree BIT FOR BIT in every loss and every
+    parameter; a third fit in the default configuration (atomics, captured step) starts from the same state and drifts away."""
+    from diff_surfel_rasterization import _C
+    from dgs_amd import train as dtrain
+    from dgs_amd.fit import fit
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    dev = torch.device("cuda:0")
+    data = str(tmp_path / "scene")
+    write_dynamic_dnerf(data, n_train=24, n_test=2, H=128, W=128, device=dev)
+    kw = dict(iterations=900, device=dev, num_pts=6000, node_num=128, seed=0, warm_up=300, regularize_from=600, densify_from=200,
+              opacity_reset_interval=500)
+
+    def run(tag, deterministic):
+        if deterministic:
+            sort = dtrain.Trainer.sort_surfels
+
+            def sort_ordered(self):
+                out = sort(self)
+                self.deform.coherent_surfels = False     # per-workgroup LDS tables + ordered reduction instead of wave-level float atomics
+                return out
+            monkeypatch.setattr(dtrain.Trainer, "sort_surfels", sort_ordered)
+            _C.set_option(7, 1)
+        try:
+            tr, losses = fit(data, str(tmp_path / tag), graph=not deterministic, **kw)
+        finally:
+            _C.set_option(7, 0)
+            monkeypatch.undo()
+        alive = tr.surfels.alive
+        state = [t.detach()[alive].clone() for t in (tr.surfels._xyz, tr.surfels._features, tr.surfels._opacity, tr.surfels._scaling, tr.surfels._rotation)]
+        state += [tr.deform.nodes.detach().clone()] + [p.detach().clone() for p in tr.deform.network.parameters()]
+        return np.asarray(losses, dtype=np.float64), state
+
+    la, sa = run("a", True)
+    lb, sb = run("b", True)
+    assert len(la) == 900 and np.isfinite(la).all()
+    assert np.array_equal(la, lb), int(np.argmax(la != lb))
+    assert len(sa) == len(sb) and all(x.shape == y.shape and torch.equal(x, y) for x, y in zip(sa, sb))
+    lc, _ = run("c", False)
+    assert lc[0] == pytest.approx(la[0], rel=1e-4)                       # the same first step, up to the summation order ...
+    assert np.abs(lc[:100] - la[:100]).max() <= 0.02 * la[:100].max()    # ... then the trajectories separate slowly
+    assert not np.array_equal(lc, la)
+    print("|delta loss| deterministic vs atomic run, mean over iterations 1-100 / 801-900: %.2e / %.2e; mean loss 801-900: %.4f vs %.4f"
+          % (np.abs(lc[:100] - la[:100]).mean(), np.abs(lc[800:] - la[800:]).mean(), la[800:].mean(), lc[800:].mean()))
+    assert lc[800:].mean() == pytest.approx(la[800:].mean(), rel=0.25)   # the same optimisation, not the same trajectory
