@@ -31,6 +31,13 @@ namespace dgs {
 #ifndef DGS_PIN_PREFETCH
 #define DGS_PIN_PREFETCH 1
 #endif
+#ifndef DGS_BWD_INTERLEAVE
+#define DGS_BWD_INTERLEAVE 0   // A/B only: 1 = 2-deep interleave of the backward walk (alpha of entry i + 1 in front of the step of entry i).
+// Measured (tools/ab_check.sh, 200k / 800x800, blend bwd per launch, two rounds on one lease): off 0.275 / 0.276 ms; on at 5 waves per SIMD
+// (96 registers, 7 -> 15 spills) 0.291 / 0.298; on at 4 waves per SIMD (111 registers, no spill) 0.303 / 0.301.  The next entry's
+// evaluation (11 floats) held across the step costs more in registers than a second chain inside the wave gives: five waves
+// per SIMD already are five such chains, and the kernel is issue-bound (3.6 cycles per VALU instruction), not stalled.
+#endif
 #ifndef DGS_DIAG_BWD
 #define DGS_DIAG_BWD 0   // development only (WRONG results): 1 no atomics, 2 no reduction either, 3 evaluation + loop only
 #endif
@@ -1167,7 +1174,20 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
             const int nhit = __builtin_popcountll(m);
             f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
             f32x4 tw = S.tw[0], tuv = S.tuv[0], q3 = S.q3[0], q4 = S.q4[0];
+#if DGS_BWD_INTERLEAVE
+            // A/B: the alpha evaluation of entry i + 1 is issued in front of the step of entry i -- two independent
+            // chains inside one wave.  Its result (11 floats) lives across the step: see the measurements at DGS_BWD_INTERLEAVE.
+            AlphaEval evn;
+            bool okn = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), evn);
+            a0 = S.a[0][1]; a1 = S.a[1][1]; a2 = S.a[2][1];
+#endif
             for (int i = 0; i < nhit; i++) {
+#if DGS_BWD_INTERLEAVE
+                const AlphaEval ev = evn;
+                bool ok = okn;
+                okn = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), evn);   // (slot nhit: stale planes, evaluated and dropped)
+                { const int n2 = min(i + 2, kChunkB); a0 = S.a[0][n2]; a1 = S.a[1][n2]; a2 = S.a[2][n2]; }
+#else
                 AlphaEval ev;
                 bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
 #if DGS_PIN_PREFETCH
@@ -1175,6 +1195,7 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
 #endif
                 a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
                 DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
+#endif
                 const int e = __builtin_amdgcn_readfirstlane(__float_as_int(q4.z));  // 0-based list index == the reference's `contributor`
                 ok = ok & (e < st.last_contributor);
                 if (__ballot(ok) != 0ull) {
