@@ -35,6 +35,46 @@ struct PreprocessArgs {
     unsigned row_inv;       // ceil(2^32 / (3 M)) (see surfel_bwd_kernel)
 };
 
+// The SH rows of a workgroup's surfels (`total` = rows x row floats, contiguous from `src`) -> LDS rows of `stride` floats.
+// 16 bytes per lane and load: at degree 3 the 64 rows are 768 float4, i.e. ONE batch of 12 loads per thread, all in flight
+// before the first LDS store -- the 4-byte version was four dependent batches of 12 (a 4-byte load keeps the CU's address unit busy as
+// long as a 16-byte one), a third of both per-surfel kernels' run time.  The 4-byte path stays for row counts / alignments
+// that do not divide.
+__device__ __forceinline__ void stage_sh_rows(const float* __restrict__ src, int total, int row, int stride, unsigned row_inv, float* __restrict__ s_sh)
+{
+    if ((row & 3) == 0 && (reinterpret_cast<size_t>(src) & 15) == 0) {   // (a float4 never straddles two rows: one row / column per load)
+        const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
+        const int nvec = total >> 2;
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += 12 * kSurfelBlock) {
+            float4 q[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const int v = v0 + i * kSurfelBlock; q[i] = v < nvec ? src4[v] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const int v = v0 + i * kSurfelBlock;
+                if (v < nvec) {
+                    const int e = 4 * v, r = (int)__umulhi((unsigned)e, row_inv);
+                    float* d = s_sh + (r * stride + (e - r * row));
+                    d[0] = q[i].x; d[1] = q[i].y; d[2] = q[i].z; d[3] = q[i].w;
+                }
+            }
+        }
+        return;
+    }
+    // batches of 12 elements per thread: all loads of a batch are in flight before the first LDS store (an
+    // element-wise copy loop is a chain of dependent global-load latencies)
+    for (int e0 = threadIdx.x; e0 < total; e0 += 12 * kSurfelBlock) {
+        float v[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) { const int e = e0 + i * kSurfelBlock; v[i] = e < total ? src[e] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int e = e0 + i * kSurfelBlock;
+            if (e < total) { const int r = (int)__umulhi((unsigned)e, row_inv); s_sh[r * stride + (e - r * row)] = v[i]; }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kSurfelBlock) preprocess_fwd_kernel(PreprocessArgs a)
 {
     // SH rows reach the threads through LDS with coalesced loads (see surfel_bwd_kernel)
@@ -43,35 +83,25 @@ __global__ void __launch_bounds__(kSurfelBlock) preprocess_fwd_kernel(Preprocess
     const int idx = base + threadIdx.x;
     const int row = a.M * 3, stride = row + 1;
     const bool use_sh = !a.colors_precomp && a.shs;
+    // the surfel's own parameters are requested in front of the staging (one memory round trip for both instead of two)
+    const int li = min(idx, a.P - 1);
+    float pos[3] = {a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]};
+    float sc[2] = {a.scales[2 * li], a.scales[2 * li + 1]};
+    const float4 qv = reinterpret_cast<const float4*>(a.rotations)[li];
+    const float opac = a.opacities[li];
     if (use_sh) {
         const int rows_here = min(kSurfelBlock, a.P - base);
-        const float* src = a.shs + (size_t)base * row;
-        // batches of 12 elements per thread: all loads of a batch are in flight before the first LDS store (an
-        // element-wise copy loop is a chain of dependent global-load latencies)
-        const int total = rows_here * row;
-        for (int e0 = threadIdx.x; e0 < total; e0 += 12 * kSurfelBlock) {
-            float v[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) { const int e = e0 + i * kSurfelBlock; v[i] = e < total ? src[e] : 0.f; }
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const int e = e0 + i * kSurfelBlock;
-                if (e < total) { const int r = (int)__umulhi((unsigned)e, a.row_inv); s_sh[r * stride + (e - r * row)] = v[i]; }
-            }
-        }
+        stage_sh_rows(a.shs + (size_t)base * row, rows_here * row, row, stride, a.row_inv, s_sh);
         __syncthreads();
     }
     if (idx >= a.P) return;
     SurfelRec rec;
-    float pos[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    float sc[2] = {a.scales[2 * idx], a.scales[2 * idx + 1]};
-    const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
     float q[4] = {qv.x, qv.y, qv.z, qv.w};
     const float* sh = use_sh ? s_sh + threadIdx.x * stride : nullptr;
     const float* cp = a.colors_precomp ? a.colors_precomp + 3 * idx : nullptr;
     TileRect tr;
     int tiles;
-    const int radius = preprocess_surfel(a.cam, pos, sc, q, a.opacities[idx], a.D, sh, cp, rec, tiles, tr, a.tight != 0);
+    const int radius = preprocess_surfel(a.cam, pos, sc, q, opac, a.D, sh, cp, rec, tiles, tr, a.tight != 0);
     a.radii[idx] = radius;
     a.rects[idx] = make_uint2(tr.xs, tr.ys);
     if (radius > 0) {
@@ -891,23 +921,11 @@ __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs 
     const int row = a.M * 3, stride = row + 1;
     const int rows_here = min(kSurfelBlock, a.P - base);
     if (a.shs) {
-        const float* src = a.shs + (size_t)base * row;
-        // batches of 12 elements per thread: all loads of a batch are in flight before the first LDS store (an
-        // element-wise copy loop is a chain of dependent global-load latencies)
-        const int total = rows_here * row;
-        for (int e0 = threadIdx.x; e0 < total; e0 += 12 * kSurfelBlock) {
-            float v[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) { const int e = e0 + i * kSurfelBlock; v[i] = e < total ? src[e] : 0.f; }
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const int e = e0 + i * kSurfelBlock;
-                if (e < total) { const int r = (int)__umulhi((unsigned)e, a.row_inv); s_sh[r * stride + (e - r * row)] = v[i]; }
-            }
-        }
+        stage_sh_rows(a.shs + (size_t)base * row, rows_here * row, row, stride, a.row_inv, s_sh);
         __syncthreads();
     }
     if (active) {
+        // (requesting these in front of the staging saves a memory round trip but costs the third wave per SIMD: 191 registers)
         SurfelRec rec;
         {
             float4* dst = reinterpret_cast<float4*>(&rec);
@@ -940,26 +958,28 @@ __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs 
         }
         for (int c = 0; c < 3; c++) {
             a.dL_dmean3D[3 * idx + c] = g.dmean3D[c];
-            a.dL_dcolor[3 * idx + c] = acc[kAccColor + c];
-            a.dL_dnormal[3 * idx + c] = acc[kAccNormal + c];
+            if (a.dL_dcolor) a.dL_dcolor[3 * idx + c] = acc[kAccColor + c];      // (optional outputs: dgs_surfel_rasterizer.h)
+            if (a.dL_dnormal) a.dL_dnormal[3 * idx + c] = acc[kAccNormal + c];
         }
         a.dL_dmean2D[3 * idx] = g.dmean2D[0];
         a.dL_dmean2D[3 * idx + 1] = g.dmean2D[1];
         a.dL_dmean2D[3 * idx + 2] = 0.f;
         a.dL_dopacity[idx] = acc[kAccOpacity];
-        for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = g.dT[c];
+        if (a.dL_dtransMat)
+            for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = g.dT[c];
         a.dL_dscale[2 * idx] = g.dscale[0];
         a.dL_dscale[2 * idx + 1] = g.dscale[1];
         reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(g.drot[0], g.drot[1], g.drot[2], g.drot[3]);
     } else if (idx < a.P) {
         for (int c = 0; c < 3; c++) {
             a.dL_dmean3D[3 * idx + c] = 0.f;
-            a.dL_dcolor[3 * idx + c] = 0.f;
-            a.dL_dnormal[3 * idx + c] = 0.f;
+            if (a.dL_dcolor) a.dL_dcolor[3 * idx + c] = 0.f;
+            if (a.dL_dnormal) a.dL_dnormal[3 * idx + c] = 0.f;
             a.dL_dmean2D[3 * idx + c] = 0.f;
         }
         a.dL_dopacity[idx] = 0.f;
-        for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = 0.f;
+        if (a.dL_dtransMat)
+            for (int c = 0; c < 9; c++) a.dL_dtransMat[9 * idx + c] = 0.f;
         a.dL_dscale[2 * idx] = 0.f;
         a.dL_dscale[2 * idx + 1] = 0.f;
         reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -967,14 +987,32 @@ __global__ void __launch_bounds__(kSurfelBlock) surfel_bwd_kernel(SurfelBwdArgs 
     if (a.shs) {
         // only visible surfels and only the first (D+1)^2 coefficients are written, as in the reference
         __syncthreads();
+        static_assert(kSurfelBlock == 64, "one wave per workgroup: the vote below is the workgroup's visibility mask");
+        const unsigned long long vis = __ballot(active);   // (was one radii load per element of the loop below)
         const int touched = 3 * (a.D + 1) * (a.D + 1);
         float* dst = a.dL_dsh + (size_t)base * row;
-        for (int e = threadIdx.x; e < rows_here * row; e += kSurfelBlock) {
-            const int r = (int)__umulhi((unsigned)e, a.row_inv);
-            const int c = e - r * row;
-            const bool live = c < touched && a.radii[base + r] > 0;
-            if (live) dst[e] = s_sh[r * stride + c];
-            else if (a.sh_all_rows) dst[e] = 0.f;   // option 8: the caller's buffer needs no fill (a gradient bucket that is stored, not added to)
+        const int total = rows_here * row;
+        if (a.sh_all_rows && (row & 3) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+            // option 8 (every element is stored: the caller's buffer needs no fill -- a gradient bucket that is stored, not added to):
+            // 16 bytes per lane and store
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            for (int v = threadIdx.x; v < (total >> 2); v += kSurfelBlock) {
+                const int e = 4 * v, r = (int)__umulhi((unsigned)e, a.row_inv), c = e - r * row;
+                const float* sp = s_sh + (r * stride + c);
+                const bool rv = (vis >> r) & 1ull;
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = (rv && c + k < touched) ? sp[k] : 0.f;
+                dst4[v] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            for (int e = threadIdx.x; e < total; e += kSurfelBlock) {
+                const int r = (int)__umulhi((unsigned)e, a.row_inv);
+                const int c = e - r * row;
+                const bool live = c < touched && ((vis >> r) & 1ull);
+                if (live) dst[e] = s_sh[r * stride + c];
+                else if (a.sh_all_rows) dst[e] = 0.f;   // option 8
+            }
         }
     }
 }

@@ -772,7 +772,7 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
     if (transMat_precomp) return fail(DGS_ERR_UNSUPPORTED, "transMat_precomp (cov3D_precomp) is not supported");
     if ((unsigned long long)P * dgs::kAccFloats * 4ull >= 0xffffffffull) return fail(DGS_ERR_UNSUPPORTED, "backward: more than 53 million surfels (32-bit accumulator offsets)");
     if (!geom_buffer || !img_buffer || (R > 0 && !binning_buffer)) return fail(DGS_ERR_INVALID_ARGUMENT, "scratch buffer is NULL");
-    if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dtransMat ||
+    if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dopacity || !dL_dmean3D ||   // (dL_dnormal, dL_dcolor, dL_dtransMat: NULL = not wanted)
         !dL_dscale || !dL_drot || !scales || !rotations || !viewmatrix || !campos || !background)
         return fail(DGS_ERR_INVALID_ARGUMENT, "NULL pointer");
     if (shs && colors_precomp == nullptr && !dL_dsh) return fail(DGS_ERR_INVALID_ARGUMENT, "dL_dsh is NULL");

@@ -276,9 +276,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, dL_dsh_out=None, context=None):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, dL_dsh_out=None, context=None,
+                                 want_colors=True, want_transmat=True):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
-    dL_dscales[P,2], dL_drotations[P,4])  -- rasterize_points.cu:239"""
+    dL_dscales[P,2], dL_drotations[P,4])  -- rasterize_points.cu:239.
+    want_colors / want_transmat = False: that array is not computed (None in its place): the autograd node passes what its inputs'
+    requires_grad says (dL_dcolors is the gradient of colors_precomp, dL_dtransMat of cov3Ds_precomp)."""
     lib = load()
     _need_device(background=background, means3D=means3D, radii=radii, colors=colors, scales=scales, rotations=rotations,
                  transMat_precomp=transMat_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix, sh=sh, campos=campos,
@@ -299,6 +302,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         views.append(flat[off:off + P * c].view(P, c))
         off += n
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal, dL_dopacity, dL_dtransMat, dL_dscales, dL_drotations = views
+    full = want_colors and want_transmat   # every array of the reference's call, its scratch (dL_dnormal) included
     dL_dsh = dL_dsh_out if dL_dsh_out is not None else torch.zeros((P, M, 3), **opts)  # caller-provided: written in place (extension)
     if P != 0:
         bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
@@ -312,12 +316,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             rc = entry(
                 P, int(degree), int(M), int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc), float(scale_modifier),
                 _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx), float(tan_fovy), _ptr(rad), _ptr(gb),
-                _ptr(bb), _ptr(ib), _ptr(gc), _ptr(go), dL_dmeans2D.data_ptr(), dL_dnormal.data_ptr(), dL_dopacity.data_ptr(),
-                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(),
+                _ptr(bb), _ptr(ib), _ptr(gc), _ptr(go), dL_dmeans2D.data_ptr(), dL_dnormal.data_ptr() if full else None, dL_dopacity.data_ptr(),
+                dL_dcolors.data_ptr() if want_colors else None, dL_dmeans3D.data_ptr(), dL_dtransMat.data_ptr() if want_transmat else None,
+                _ptr(dL_dsh), dL_dscales.data_ptr(),
                 dL_drotations.data_ptr(), int(bool(debug)), _stream(dev))
         if rc < 0:
             _raise(lib, rc, "rasterize_gaussians_backward")
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+    return (dL_dmeans2D, dL_dcolors if want_colors else None, dL_dopacity, dL_dmeans3D, dL_dtransMat if want_transmat else None, dL_dsh,
+            dL_dscales, dL_drotations)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

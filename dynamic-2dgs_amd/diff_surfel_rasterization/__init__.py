@@ -141,13 +141,15 @@ class _SurfelRasterFn(torch.autograd.Function):
         # set and the launches are issued under one lock per device (the kernels read it at launch time, on the host)
         with _bwd_lock(means3D.device):
             _C.set_option(8, 1 if (sink is not None and all_rows) else 0, device=means3D.device.index)
+            # arrays nobody differentiates are not computed: dL_dcolors is the gradient of colors_precomp, dL_dtransMat of cov3Ds_precomp
+            want = dict(want_colors=bool(ctx.needs_input_grad[3]), want_transmat=bool(ctx.needs_input_grad[7]))
             if sink is not None:
                 (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
-                    lambda *a: _C.rasterize_gaussians_backward(*a, dL_dsh_out=sink), call, cfg.debug, "snapshot_bw.dump", "backward")
+                    lambda *a: _C.rasterize_gaussians_backward(*a, dL_dsh_out=sink, **want), call, cfg.debug, "snapshot_bw.dump", "backward")
                 g_sh = None
             else:
                 (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
-                    _C.rasterize_gaussians_backward, call, cfg.debug, "snapshot_bw.dump", "backward")
+                    lambda *a: _C.rasterize_gaussians_backward(*a, **want), call, cfg.debug, "snapshot_bw.dump", "backward")
         return (g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_transMat, None)
 
 

@@ -80,7 +80,10 @@ int dgs_rasterizer_forward(dgs_alloc_fn geometry_alloc, void* geometry_ctx, dgs_
  * accumulate into: pass it zeroed, or pass the buffer the visible rows are to be overwritten in
  * (diff_surfel_rasterization.set_sh_grad_sink).  Shapes: dL_dpix[3,H,W], dL_depths[8,H,W], dL_dmean2D[P,3],
  * dL_dnormal[P,3], dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
- * dL_dscale[P,2], dL_drot[P,4].  Returns DGS_OK or a negative dgs_status. */
+ * dL_dscale[P,2], dL_drot[P,4].  Extension: dL_dnormal, dL_dcolor and dL_dtransMat may be NULL -- "not wanted".  In the reference
+ * they are intermediates of the backward (per-surfel colour / normal gradients in front of the SH and transform chains) or the
+ * gradient of an input this library does not take (transMat_precomp); a caller that trains SH coefficients reads none of the
+ * three, and their 60 bytes per surfel are the worst-coalesced stores of the per-surfel kernel.  Returns DGS_OK or a negative dgs_status. */
 int dgs_rasterizer_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                             const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                             const float* rotations, const float* transMat_precomp, const float* viewmatrix,
