@@ -128,11 +128,24 @@ __device__ __forceinline__ void tile_order_body(const uint2* ranges, const uint3
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
     __syncthreads();
-    // bin 0 = heaviest.  weight = list length (ranges) or traversed length (weights), 4 entries per bin, saturating
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = weights ? weights[t] : (ranges[t].y - ranges[t].x);
-        const uint32_t bin = kOrderBins - 1 - min(w >> 2, (uint32_t)(kOrderBins - 1));
-        atomicAdd(&s_hist[bin], 1u);
+    // bin 0 = heaviest.  weight = list length (ranges) or traversed length (weights), 4 entries per bin, saturating.
+    // Both passes take four tiles per thread and trip with all four loads in flight (this body is the serial tail of the launch it
+    // rides in -- one workgroup, the rest of the device idle: a load -> LDS atomic loop was one memory round trip per 1024 tiles
+    // and pass, five at 2500 tiles)
+    auto weight4 = [&](int t0, uint32_t (&w)[4]) {
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const int t = t0 + 1024 * l;
+            if (weights) w[l] = t < ntiles ? weights[t] : 0u;
+            else { const uint2 r = t < ntiles ? ranges[t] : make_uint2(0u, 0u); w[l] = r.y - r.x; }
+        }
+    };
+    for (int t0 = tid; t0 < ntiles; t0 += 4096) {
+        uint32_t w[4];
+        weight4(t0, w);
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+            if (t0 + 1024 * l < ntiles) atomicAdd(&s_hist[kOrderBins - 1 - min(w[l] >> 2, (uint32_t)(kOrderBins - 1))], 1u);
     }
     __syncthreads();
     // exclusive scan of the 1024 bins (one per thread)
@@ -151,11 +164,15 @@ __device__ __forceinline__ void tile_order_body(const uint2* ranges, const uint3
     __syncthreads();
     s_hist[tid] = base + inc - v;
     __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t w = weights ? weights[t] : (ranges[t].y - ranges[t].x);
-        const uint32_t bin = kOrderBins - 1 - min(w >> 2, (uint32_t)(kOrderBins - 1));
-        const uint32_t pos = atomicAdd(&s_hist[bin], 1u);
-        order[pos] = (uint32_t)t;
+    for (int t0 = tid; t0 < ntiles; t0 += 4096) {
+        uint32_t w[4], pos[4];
+        weight4(t0, w);
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+            pos[l] = t0 + 1024 * l < ntiles ? atomicAdd(&s_hist[kOrderBins - 1 - min(w[l] >> 2, (uint32_t)(kOrderBins - 1))], 1u) : 0u;
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+            if (t0 + 1024 * l < ntiles) order[pos[l]] = (uint32_t)(t0 + 1024 * l);
     }
 }
 
@@ -288,7 +305,12 @@ __global__ void __launch_bounds__(1024) prep_bwd_kernel(float4* __restrict__ acc
         {   // long-tile path of the backward blend: a tile is long from 512 traversed entries and (sum of the traversed lengths) / long_div on
             const int ntiles = tiles_x * tiles_y;
             uint32_t sum = 0;
-            for (int t = threadIdx.x; t < ntiles; t += 1024) sum += weights[t];
+            for (int t0 = threadIdx.x; t0 < ntiles; t0 += 4096) {   // four loads in flight per trip (tile_order_body)
+                uint32_t w[4];
+#pragma unroll
+                for (int l = 0; l < 4; l++) w[l] = t0 + 1024 * l < ntiles ? weights[t0 + 1024 * l] : 0u;
+                sum += (w[0] + w[1]) + (w[2] + w[3]);
+            }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
             if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = sum;

@@ -226,7 +226,13 @@ __global__ void __launch_bounds__(kBinThreads) scatter_keys_lds_kernel(BinArgs a
     extern __shared__ uint32_t s_cur[];
     const int g = blockIdx.x, tid = threadIdx.x;
     if (a.state[2] != 0u) return;  // capacity overflow: nothing may be written
-    for (int t = tid; t < a.ntiles; t += kBinThreads) s_cur[t] = a.M[(size_t)g * a.ntiles + t];
+    for (int t0 = tid; t0 < a.ntiles; t0 += 4 * kBinThreads) {   // four loads in flight per trip (2500 tiles: one trip)
+        uint32_t c[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) { const int t = t0 + l * kBinThreads; c[l] = t < a.ntiles ? a.M[(size_t)g * a.ntiles + t] : 0u; }
+#pragma unroll
+        for (int l = 0; l < 4; l++) { const int t = t0 + l * kBinThreads; if (t < a.ntiles) s_cur[t] = c[l]; }
+    }
     __syncthreads();
     const int end = min(a.P, (g + 1) * a.chunk);
     const int lane = tid & 63;
@@ -700,12 +706,23 @@ __global__ void __launch_bounds__(256) sort_tiles_radix_kernel(const uint2* rang
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- load, and the bits in which the bucket's depths differ
     uint32_t kand = 0xffffffffu, kor = 0u;
-    for (int i = tid; i < n; i += 256) {
-        const uint64_t k = gk[i];
-        const uint32_t d = (uint32_t)(k >> 32);
-        s_key[0][i] = d;
-        s_val[0][i] = (uint32_t)k;
-        kand &= d; kor |= d;
+    {
+        // all of the thread's keys are requested before the first is used (a load -> LDS store loop is one memory round trip per
+        // trip: three for the average list of the metric scene, of a kernel whose workgroups run in 2.4 rounds)
+        constexpr int kLoads = CAP / 256;
+        uint64_t kb[kLoads];
+#pragma unroll
+        for (int l = 0; l < kLoads; l++) { const int i = tid + 256 * l; kb[l] = i < n ? gk[i] : 0ull; }
+#pragma unroll
+        for (int l = 0; l < kLoads; l++) {
+            const int i = tid + 256 * l;
+            if (i < n) {
+                const uint32_t d = (uint32_t)(kb[l] >> 32);
+                s_key[0][i] = d;
+                s_val[0][i] = (uint32_t)kb[l];
+                kand &= d; kor |= d;
+            }
+        }
     }
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
