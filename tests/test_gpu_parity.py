@@ -120,6 +120,36 @@ def test_forward_backward_match_oracle(cfg):
         assert rel_l2(hip[k], og[k]) <= 2e-4, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
 
 
+@pytest.mark.parametrize("coeffs", [1, 4, 9, 16])
+def test_sh_tables_of_every_size_match_the_oracle(coeffs):
+    """shs[P, M, 3] with M = 1, 4, 9, 16 coefficients per channel (the reference allocates (max_degree + 1)^2: a model built for
+    degree 0 .. 3).  The per-surfel kernels stage the rows through LDS with 16-byte loads where 4 divides the row (M = 4, 16) and
+    with 4-byte loads otherwise (M = 1, 9), the last workgroup ragged (250 surfels = 3 x 64 + 58); with option 8 dL_dsh is stored
+    for every row (float4 stores where they divide): images, radii and gradients against the oracle on both paths, and the
+    culled rows of dL_dsh exactly zero under option 8."""
+    from diff_surfel_rasterization import _C
+    from gpu_utils import frac_close, rel_l2, run_hip
+    deg = int(round(coeffs ** 0.5)) - 1
+    case = small_case(P=250, H=56, W=72, seed=31, view=2, scale_mul=2.0, sh_degree=deg)
+    case["shs"] = case["shs"][:, :coeffs].contiguous()
+    gc, go = _cot(case)
+    orc = oracle_from_case(case)
+    og = orc.backward(gc, go)
+    for all_rows in (0, 1):
+        try:
+            _C.set_option(8, all_rows)
+            hip = run_hip(case, gc, go)
+        finally:
+            _C.set_option(8, 0)
+        assert np.array_equal(hip["radii"], orc.radii)
+        frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
+        frac_close(hip["allmap"], orc.allmap, 5e-5, 2e-5, 1e-4, 1e-1, "allmap")
+        for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
+            assert hip[k].shape == og[k].shape
+            assert rel_l2(hip[k], og[k]) <= 2e-4, "%s (option 8 = %d) rel-L2 %.3e" % (k, all_rows, rel_l2(hip[k], og[k]))
+        assert (hip["dL_dsh"][orc.radii == 0] == 0).all()
+
+
 def _degenerate_case():
     """A small scene in which a third of the surfels is made extreme: edge-on to within 1e-3 .. 1e-5 rad of the viewing ray (p.z of the
     ray-splat intersection ~ 0 on every pixel: 1 / p.z overflows towards the horizon line and the reference falls back to the
