@@ -136,6 +136,9 @@ struct BinArgs {
     uint64_t* keys;         // [R] (scatter only)
     uint32_t* sync;         // count only: nsync words cleared for bin_offsets_kernel (its workgroups' aggregates and ticket), or null
     int nsync;
+    // scatter only, rider (order != null): one more workgroup at the end of the grid clears tile_last and writes the forward blend's
+    // dispatch order from the ranges -- next to the scatter instead of as the serial tail of bin_offsets_kernel's last workgroup
+    const uint2* ranges; uint32_t* order; uint32_t* group_xcd; uint32_t* tile_last; int tiles_y, order_mode;
 };
 
 __global__ void __launch_bounds__(kBinThreads) count_tiles_lds_kernel(BinArgs a)
@@ -225,6 +228,15 @@ __global__ void __launch_bounds__(kBinThreads) scatter_keys_lds_kernel(BinArgs a
 {
     extern __shared__ uint32_t s_cur[];
     const int g = blockIdx.x, tid = threadIdx.x;
+    if (g == kBinGroups) {   // the rider (BinArgs::order); runs on an overflowed frame as well (its ranges are empty, the order still has to exist)
+        __shared__ uint32_t s_hist[8 * kOrderBins];
+        __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
+        __shared__ uint32_t s_osum[16];
+        for (int i = tid; i < a.ntiles; i += kBinThreads) a.tile_last[i] = 0u;
+        if (a.order_mode == 4) tile_order_xcd_body(a.ranges, nullptr, a.tiles_x, a.tiles_y, a.order, a.group_xcd, true, s_hist, s_gw, s_gx, s_osum);
+        else tile_order_body(a.ranges, nullptr, a.ntiles, a.order, s_hist, s_osum);
+        return;
+    }
     if (a.state[2] != 0u) return;  // capacity overflow: nothing may be written
     for (int t0 = tid; t0 < a.ntiles; t0 += 4 * kBinThreads) {   // four loads in flight per trip (2500 tiles: one trip)
         uint32_t c[4];
@@ -366,6 +378,7 @@ struct OffsetsArgs {
     int tiles_x, tiles_y, order_mode;
     uint32_t* group_xcd; uint32_t* tile_last; uint32_t* long_thr; uint32_t long_div;
     uint32_t* sync;
+    int order_later;        // tile_last and the dispatch order are left to the scatter launch's rider workgroup (capacity mode: it always runs)
 };
 
 __global__ void __launch_bounds__(64 * kColGroups) bin_offsets_kernel(OffsetsArgs a)
@@ -469,7 +482,8 @@ __global__ void __launch_bounds__(64 * kColGroups) bin_offsets_kernel(OffsetsArg
     const bool over = a.cap > 0 && (total > a.cap || (a.list_hint > 0 && longest > a.list_hint));
     if (over)
         for (int i = tid; i < a.ntiles; i += 64 * kColGroups) a.ranges[i] = make_uint2(0u, 0u);
-    for (int i = tid; i < a.ntiles; i += 64 * kColGroups) a.tile_last[i] = 0u;
+    if (!a.order_later)
+        for (int i = tid; i < a.ntiles; i += 64 * kColGroups) a.tile_last[i] = 0u;
     if (tid == 0) {
         a.state[0] = total;
         a.state[1] = longest;
@@ -477,7 +491,7 @@ __global__ void __launch_bounds__(64 * kColGroups) bin_offsets_kernel(OffsetsArg
         if (over && a.overflow) atomicOr(a.overflow, 1);
         a.long_thr[0] = max(768u, total / max(a.long_div, 1u));
     }
-    if (a.order) {
+    if (a.order && !a.order_later) {
         __threadfence_block();
         __syncthreads();
         if (a.order_mode == 4) tile_order_xcd_body(a.ranges, nullptr, a.tiles_x, a.tiles_y, a.order, a.group_xcd, true, s_hist, s_gw, s_gx, s_osum);

@@ -201,6 +201,7 @@ struct dgs_context {
     {
         if (const char* e = getenv("DGS_LONG_TILES")) long_tiles.store(atoi(e) != 0);   // A/B runs of whole programs (bench.py, the test suite)
         if (const char* e = getenv("DGS_MERGED_OFFSETS")) merged_offsets.store(atoi(e) != 0);
+        if (const char* e = getenv("DGS_ORDER_RIDER")) order_rider.store(atoi(e) != 0);
     }
     int device = 0;
     std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
@@ -216,6 +217,7 @@ struct dgs_context {
     // gains 7 %; an opaque knot (40 k of 100 k surfels on a few tiles) pays 2-4 % for the forward path (0.112 -> 0.114-0.116).
     std::atomic<int> long_div_fwd{400};  // key 10: a list is long from num_rendered / this (and 768 entries) on
     std::atomic<int> long_div_bwd{512};  // key 11: a tile is long from (sum of traversed lengths) / this (and 512 entries) on
+    std::atomic<int> order_rider{1};     // key 13: capacity mode: tile_last + the forward's dispatch order by a rider workgroup of the scatter launch (0: by bin_offsets_kernel's last workgroup)
     std::atomic<int> merged_offsets{1};  // key 12: tile counts -> ranges, bucket cursors and dispatch order in one launch (bin_offsets_kernel); 0 = column pass, scan, column pass
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
@@ -355,6 +357,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (key == 10 && value > 0) { c->long_div_fwd.store(value); return DGS_OK; }
     if (key == 11 && value > 0) { c->long_div_bwd.store(value); return DGS_OK; }
     if (key == 12) { c->merged_offsets.store(value != 0); return DGS_OK; }
+    if (key == 13) { c->order_rider.store(value != 0); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
@@ -588,6 +591,7 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     const bool merged_offsets = il.lds_bins && ctx->merged_offsets.load();
     ba_.sync = merged_offsets ? tile_counts : nullptr;
     ba_.nsync = 2 * off_blocks + 1;
+    ba_.ranges = nullptr; ba_.order = nullptr; ba_.group_xcd = nullptr; ba_.tile_last = nullptr; ba_.tiles_y = il.tiles_y; ba_.order_mode = 0;
     if (il.lds_bins) {
         hipLaunchKernelGGL(dgs::count_tiles_lds_kernel, dim3(dgs::kBinGroups), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
         if (!merged_offsets)
@@ -604,6 +608,7 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
     // ---- K3/K6 scan of the T tile counts -> tile ranges, num_rendered, longest list
     int tile_order = ctx->tile_order.load();
     if (tile_order == 4 && dgs::order_groups(il.tiles_x, il.tiles_y) > dgs::kOrderMaxGroups) tile_order = 3;   // > 128 x 128 tiles
+    bool order_later = false;
     if (merged_offsets) {
         // column sums + scan + bucket cursors + dispatch order in one launch (kernels_preprocess.h: bin_offsets_kernel)
         dgs::OffsetsArgs oa;
@@ -614,6 +619,9 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         oa.group_xcd = (uint32_t*)(img + il.group_xcd); oa.tile_last = (uint32_t*)(img + il.tile_last);
         oa.long_thr = (uint32_t*)(img + il.long_thr); oa.long_div = (uint32_t)ctx->long_div_fwd.load();
         oa.sync = tile_counts;
+        // capacity mode: the scatter launch always follows (R = capacity > 0) and carries the order as a rider workgroup
+        oa.order_later = (capacity > 0 && oa.order != nullptr && ctx->order_rider.load()) ? 1 : 0;
+        order_later = oa.order_later != 0;
         hipLaunchKernelGGL(dgs::bin_offsets_kernel, dim3(off_blocks), dim3(64 * dgs::kColGroups), 0, stream, oa);
     } else
     hipLaunchKernelGGL(dgs::scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_counts, il.ntiles, ranges,
@@ -656,7 +664,11 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
                 hipLaunchKernelGGL(dgs::column_pass_kernel, dim3(off_blocks), dim3(64 * dgs::kColGroups), 0, stream, cursor, il.ntiles,
                                    (const uint2*)ranges, (uint32_t*)nullptr);
             ba_.keys = keys;
-            hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
+            if (order_later) {
+                ba_.ranges = ranges; ba_.order = (uint32_t*)(img + il.order_fwd); ba_.group_xcd = (uint32_t*)(img + il.group_xcd);
+                ba_.tile_last = (uint32_t*)(img + il.tile_last); ba_.order_mode = tile_order;
+            }
+            hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups + (order_later ? 1 : 0)), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
         } else {
             dgs::ScatterArgs sa;
             sa.P = P; sa.radii = radii; sa.rec = pa.rec; sa.rects = pa.rects; sa.cursor = cursor;

@@ -164,6 +164,9 @@ void dgs_set_tight_rects(int on);
  * key 12 = binning offsets in one launch (1 [default] / 0): per-tile counts -> tile ranges, bucket write cursors, num_rendered, the
  *         capacity check and the forward's dispatch order by one kernel whose workgroups exchange their aggregates (decoupled
  *         look-back); 0 = the three launches (column pass, one-workgroup scan, column pass) it replaces.  Same results.
+ * key 13 = capacity mode only (1 [default] / 0): the forward blend's dispatch order and the cleared per-tile maxima are written by one more
+ *         workgroup of the key-scatter launch (next to its 256 working ones) instead of by the last workgroup of the offsets kernel
+ *         (a serial tail of that launch).  Same results.
  * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
  *         host read the library cannot know which of its per-tile sort kernels will find work and launches all four; with the
  *         promise it launches only those for lists up to `value` (2048: one launch; 57344 = 28 segments of 2048: three).  A frame that breaks the promise is treated exactly like a capacity overflow: background, flag raised,
