@@ -214,3 +214,22 @@ def test_trace_stages_are_noops_unless_enabled(monkeypatch):
     finally:
         monkeypatch.delenv("DGS_ROCTX")
         importlib.reload(trace)
+
+
+def test_list_promise_moves_up_one_tier_at_a_time():
+    """Trainer._next_list_hint: the promise of the longest tile list (rasterizer option 6) follows the tiers of the library's sort
+    launches -- 2048 entries (one launch), 57 344 = 28 segments of 2048 (three), none (four).  A view that breaks the promise moves
+    the trainer ONE tier up; anything that is not a tier, and the last tier, lead to 'no promise'."""
+    from dgs_amd.train import Trainer
+    t = Trainer.__new__(Trainer)
+    assert Trainer.LIST_HINT_TIERS == (2048, 57344, 0)
+    seen = []
+    t._list_hint = 2048
+    for _ in range(4):
+        t._list_hint = t._next_list_hint()
+        seen.append(t._list_hint)
+    assert seen == [57344, 0, 0, 0]
+    t._list_hint = 1234
+    assert t._next_list_hint() == 0
+    del t._list_hint
+    assert t._next_list_hint() == 0
