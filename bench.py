@@ -388,6 +388,16 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
 
     from diff_surfel_rasterization import _C
+    from dgs_amd import _ops as _train_ops
+    if world > 1:
+        # a stale or hash-less binary is rebuilt by whoever loads it (_C._refuse_stale); _dgs_build serialises that with a file lock
+        # and an atomic rename, and here one rank per node does the loading first so that the others never wait inside hipcc
+        if local_rank == 0:
+            _C.load()
+            _train_ops.load()
+        dist.barrier()
+    _C.load()
+    _train_ops.load()
     if args.tile_order is not None:
         _C.set_option(1, args.tile_order)
     P, H, W = WORKLOADS[args.workload]
