@@ -31,15 +31,24 @@ namespace dgs {
 #ifndef DGS_PIN_PREFETCH
 #define DGS_PIN_PREFETCH 1
 #endif
-#ifndef DGS_BWD_INTERLEAVE
-#define DGS_BWD_INTERLEAVE 0   // A/B only: 1 = 2-deep interleave of the backward walk (alpha of entry i + 1 in front of the step of entry i).
-// Measured (tools/ab_check.sh, 200k / 800x800, blend bwd per launch, two rounds on one lease): off 0.275 / 0.276 ms; on at 5 waves per SIMD
-// (96 registers, 7 -> 15 spills) 0.291 / 0.298; on at 4 waves per SIMD (111 registers, no spill) 0.303 / 0.301.  The next entry's
-// evaluation (11 floats) held across the step costs more in registers than a second chain inside the wave gives: five waves
-// per SIMD already are five such chains, and the kernel is issue-bound (3.6 cycles per VALU instruction), not stalled.
+// ---- A/B switches ------------------------------------------------------------------------------------------------------------
+// The product library is built with NONE of these set: the superseded kernels and reductions they select live in csrc/ab/ and are
+// only reachable with -DDGS_AB_BUILD (tools/ab_variants.sh builds such twins next to the product, tools/ab_check.sh runs the parity
+// file and the timing on each).  DGS_DIAG_BWD modes produce WRONG results by design (they remove work to price it).
+#ifndef DGS_FWD_ROWS
+#define DGS_FWD_ROWS 1       // 0: ab/blend_fwd_quadrant.h (one list per wave)
+#endif
+#ifndef DGS_BWD_ROWS
+#define DGS_BWD_ROWS 0       // 1: ab/blend_bwd_rows.h (one list per 16-lane row: 2.6 x slower on the L2's float-atomic rate)
+#endif
+#ifndef DGS_BWD_REDUCE
+#define DGS_BWD_REDUCE 4     // 0-3: ab/reduce_variants.h (3 = the DPP sum of wave_reduce.h), 4: transposition through the wave's own LDS (wave_reduce.h)
 #endif
 #ifndef DGS_DIAG_BWD
-#define DGS_DIAG_BWD 0   // development only (WRONG results): 1 no atomics, 2 no reduction either, 3 evaluation + loop only
+#define DGS_DIAG_BWD 0       // 1 no atomics, 2 no reduction either, 3 evaluation + loop only
+#endif
+#if !defined(DGS_AB_BUILD) && (DGS_FWD_ROWS != 1 || DGS_BWD_ROWS != 0 || DGS_BWD_REDUCE != 4 || DGS_DIAG_BWD != 0)
+#error "A/B variants and diagnostic modes are not part of the product library: build them with -DDGS_AB_BUILD (tools/ab_variants.sh)"
 #endif
 constexpr int kChunk = 64;   // list entries staged per wave and step: one per lane
 
@@ -347,13 +356,6 @@ inline int blend_grid_size(int tiles_x, int tiles_y, int mode)
 // built from plain FMAs on VGPR operands (entry constants arrive through LDS broadcasts, not SGPRs), one comparison decides the
 // alpha test (alpha_affine), finished and outside pixels are poisoned with NaN coordinates instead of being masked, and the
 // median bookkeeping is skipped once no pixel of the wave has T > 0.5.
-struct FwdStage {            // one wave's staging slice: the chunk's visited entries, compacted (+1: the visit loop reads one slot ahead)
-    f32x4 a[3][kChunk + 1];  // alpha part of the entry's affine image (tile_affine)
-    f32x4 tw[kChunk + 1];    // (Tw.x Tw.y Tw.z, 1-based list position as bits)
-    f32x4 q3[kChunk + 1];    // (n.x n.y n.z r)
-    f32x4 q4[kChunk + 1];    // (g b - -): a 16-byte plane like the others, so one address register serves all six
-};
-
 // does the record's exact pixel box (q5) reach a pixel centre of the 8x8 block whose first pixel is (qx, qy)?
 __device__ __forceinline__ bool block_box_hit(const float4& bx, float qx, float qy)
 {
@@ -366,161 +368,17 @@ __device__ __forceinline__ int lane_rank(unsigned long long m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-__global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(BlendFwdArgs a)
-{
-    __shared__ FwdStage s_stage[4];
-    __shared__ uint32_t s_max[4];
-
-    const int ntiles = a.tiles_x * a.tiles_y;
-    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
-    if (a.mode < 3 && tile >= ntiles) return;
-    if (a.mode >= 3) tile = (int)a.order[tile];
-    if (tile >= ntiles) return;   // mode 4: empty slot
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    int lx_, ly_;
-    lane_pixel(tid, lx_, ly_);
-    const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
-    const bool inside = px < a.W && py < a.H;
-    const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
-    const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
-    // this wave's quadrant: first pixel, and its span in the scaled tile-relative coordinates of the affine form
-    const float qx = tpx + (float)(8 * (wave & 1)), qy = tpy + (float)(8 * (wave >> 1));
-    const float qus0 = kSqrt2 * ((wave & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((wave & 2) ? 0.5f : -7.5f);
-    // sqrt2 x (pixel - tile centre); NaN = this pixel takes no further entry (outside the image, or saturated)
-    float us = inside ? kSqrt2 * ((float)lx_ - 7.5f) : __builtin_nanf("");
-    const float vs = kSqrt2 * ((float)ly_ - 7.5f);
-
-    const uint2 range = a.ranges[tile];
-    const uint32_t len = range.y - range.x;
-    FwdStage& S = s_stage[wave];
-
-    PixFwd st;
-    pixfwd_init(st);
-
-    // Visit, in list order, the nhit entries the wave has staged.  Every instruction of this loop is issued once per (wave, entry)
-    // visit, scalar ones included (the CU's scalar unit issues ~1 instruction per cycle for all four SIMDs: 25 scalar
-    // instructions per visit -- bit-scan of a visit mask, saturation ballots, early-out tests -- cost as much issue time as the
-    // arithmetic).  Hence: the staged entries are COMPACTED (a counted loop over consecutive slots), a pixel that saturates
-    // (forward.cu:402-406: it blends neither this entry nor any later one) is poisoned with one select, and whether the wave
-    // still has live pixels is tested per chunk, not per visit.
-    auto visit = [&](auto track_median, int nhit) {
-        f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
-        f32x4 tw = S.tw[0], q3 = S.q3[0], q4 = S.q4[0];
-        for (int i = 0; i < nhit; i++) {
-            AlphaEval e;
-            const bool pass = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
-            // Software pipeline over the visited entries with ONE register set: the next entry's alpha part is requested as soon
-            // as this one's has been consumed, its Tw / normal / colour at the end of the visit -- each INTO THE SAME registers,
-            // a good hundred cycles before it is needed.  The empty asm statements pin the order: left alone the compiler hoists
-            // the loads above the evaluation, needs a second register set and pays twelve moves per visit to rotate it.
-#if DGS_PIN_PREFETCH
-            asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");
+#if !DGS_FWD_ROWS
+#include "ab/blend_fwd_quadrant.h"   // (DGS_AB_BUILD only, checked above)
 #endif
-            a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
-            bool use3d;
-            const float depth = alpha_depth(e, tw.x, tw.y, tw.z, use3d);
-            float w, test_T;
-            pixfwd_weight(st, e.alpha, w, test_T);
-            const bool ok = pass & (depth >= kNear);      // forward.cu:388 (float 0.2f: same set as (double)depth < 0.2)
-            const bool blend = ok & !(test_T < kTmin);
-            if (blend) {
-                st.contributor = __float_as_uint(tw.w);   // 1-based list position (forward.cu:356)
-                pixfwd_accumulate<decltype(track_median)::value>(st, w, test_T, depth, as_quad(q3), Quad{q4.x, q4.y, 0.f, 0.f});
-            }
-            us = (ok ^ blend) ? __builtin_nanf("") : us;   // passed but saturated: the pixel is finished
-#if DGS_PIN_PREFETCH
-            asm volatile("" : "+v"(st.T), "+v"(us) : : "memory");
-#endif
-            tw = S.tw[i + 1]; q3 = S.q3[i + 1]; q4 = S.q4[i + 1];
-        }
-    };
-
-    uint32_t id_next = lane < len ? a.point_list[range.x + lane] : 0u;
-    unsigned long long alive = __ballot(inside);   // lanes that still take entries (wave-uniform)
-    for (uint32_t base = 0; base < len && alive != 0ull; base += kChunk) {
-        const uint32_t e_mine = base + (uint32_t)lane;
-        const uint32_t id = id_next;   // (lanes beyond the end of the list hold id 0: a valid record, masked out below)
-        // Straight-line staging: all six quads of the record are requested at once and every lane runs the whole test (a
-        // conditional ladder -- list end, box, footprint -- makes the compiler sink each load behind the test before it:
-        // five dependent trips to memory per chunk).  Entries that can touch the quadrant are compacted: slot = rank among them.
-        const float4* src = a.rec + (size_t)id * kRecQuads;
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], bx = src[5];
-        // the id of the lane's next entry travels while this chunk is visited (the record loads of the next step then start at once)
-        id_next = e_mine + kChunk < len ? a.point_list[range.x + e_mine + kChunk] : 0u;
-        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
-        const bool hit = (e_mine < len) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
-        const unsigned long long m = __ballot(hit);
-        if (m == 0ull) continue;
-        if (hit) {
-            const int slot = lane_rank(m);
-            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
-            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
-            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
-            S.tw[slot] = mk4(q1.z, q1.w, q2.x, __uint_as_float(e_mine + 1u));
-            S.q3[slot] = mk4(q3);
-            S.q4[slot] = mk4(q4);
-        }
-        __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
-        // median bookkeeping (forward.cu:421-425) only while some pixel of the wave still has T > 0.5
-        if (__ballot(st.T > 0.5f && us == us) != 0ull) visit(std::true_type{}, __builtin_popcountll(m));
-        else visit(std::false_type{}, __builtin_popcountll(m));
-        __builtin_amdgcn_wave_barrier();
-        alive = __ballot(us == us);   // wave-level early out (forward.cu:334-336 votes per block)
-    }
-
-    // per-tile maximum of the last contributor: the backward starts there instead of walking the
-    // whole list (backward.cu:276-279 skips those entries one by one)
-    uint32_t m = inside ? st.last : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = __shfl_xor(m, d, 64);
-        m = o > m ? o : m;
-    }
-    if (lane == 0) s_max[wave] = m;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t mm = s_max[0];
-        mm = s_max[1] > mm ? s_max[1] : mm;
-        mm = s_max[2] > mm ? s_max[2] : mm;
-        mm = s_max[3] > mm ? s_max[3] : mm;
-        a.tile_last[tile] = mm;
-    }
-
-    const size_t plane = (size_t)ntiles * kTilePix;
-    const size_t slot = (size_t)tile * kTilePix + tid;
-    a.final_T[slot] = st.T;
-    a.final_T[plane + slot] = st.dist1;
-    a.final_T[2 * plane + slot] = st.dist2;
-    a.n_contrib[slot] = st.last;
-    a.n_contrib[plane + slot] = st.med_c;
-    if (inside) {
-        const size_t HW = (size_t)a.H * a.W;
-        const size_t pix = (size_t)py * a.W + px;
-        a.out_color[pix] = st.C[0] + st.T * a.bg[0];
-        a.out_color[HW + pix] = st.C[1] + st.T * a.bg[1];
-        a.out_color[2 * HW + pix] = st.C[2] + st.T * a.bg[2];
-        a.out_others[pix] = st.D;                 // DEPTH_OFFSET 0   (auxiliary.h:25-30)
-        a.out_others[HW + pix] = 1.f - st.T;      // ALPHA_OFFSET 1
-        a.out_others[2 * HW + pix] = st.N[0];     // NORMAL_OFFSET 2..4
-        a.out_others[3 * HW + pix] = st.N[1];
-        a.out_others[4 * HW + pix] = st.N[2];
-        a.out_others[5 * HW + pix] = st.med_d;    // MIDDEPTH_OFFSET 5
-        a.out_others[6 * HW + pix] = st.distortion;  // DISTORTION_OFFSET 6
-        a.out_others[7 * HW + pix] = st.med_w;    // MEDIAN_WEIGHT_OFFSET 7
-    }
-}
 
 // ---- forward blend, one list per 16-lane row (round 4) ----------------------------------------------------------------------
-// Same idea as blend_bwd_rows_kernel below, where it is described; in the forward nothing is summed across lanes and nothing is
+// Same idea as ab/blend_bwd_rows.h, where it is described; in the forward nothing is summed across lanes and nothing is
 // added to global memory, so the design pays here: every DPP row of the wave -- one 4x4 pixel block of the quadrant -- walks the
 // list of the entries that can reach ITS block (blocks_hit_linear while staging; a block whose 16 pixels are all finished takes no
 // more entries), the planes of an entry are stored once per wave, and the visit loop runs max-over-rows(list length) times with
-// four slot addresses per LDS read instead of one.  Per-pixel arithmetic and entry order are those of blend_fwd_kernel: the results
+// four slot addresses per LDS read instead of one.  Per-pixel arithmetic and entry order are those of the round-3 forward (ab/blend_fwd_quadrant.h): the results
 // are bit-identical.  0.87 of that kernel's visits on the 200k / 800x800 scene (tools/blend_stats.py).
-#ifndef DGS_FWD_ROWS
-#define DGS_FWD_ROWS 1
-#endif
 
 // ---- long tiles (round 4) ---------------------------------------------------------------------------------------------------
 // A tile is one workgroup and a quadrant one wave that walks the tile's list serially, so a launch is never shorter than its longest
@@ -818,7 +676,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_ker
             AlphaEval e;
             const bool pass = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), e);
 #if DGS_PIN_PREFETCH
-            asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
+            asm volatile("" : "+v"(e.a), "+v"(e.alpha) : : "memory");   // see blend_fwd_rows_kernel: one register set, loads pinned behind their last use
 #endif
             sl = sl_next;
             a0 = S.a[0][sl]; a1 = S.a[1][sl]; a2 = S.a[2][sl];
@@ -943,140 +801,43 @@ struct BlendBwdArgs {
 };
 
 // ---- wave reduction of the 16 per-surfel partials of one (wave, entry) visit --------------------------------------------
-// DGS_BWD_REDUCE selects the implementation (A/B builds; the default is the measured best):
-//   0  halving butterfly on the LDS crossbar: 17 ds_bpermute + 30 v_cndmask + 17 v_add (round-1 kernel),
-//   1  matrix pipe: 16 x v_mfma_f32_16x16x4_f32 (exact fp32) with the partial as the A operand and a one-hot column
-//      selector as B:  D[i][n] += sum_k v_n[lane 16 k + i]  -- one instruction folds the four 16-lane rows of value n into
-//      column n of ONE 16x16 accumulator, so after the 16 instructions lane (q, n) holds four row sums of value n; three
-//      adds and two cross-row exchanges finish.  The blend kernels issue no other MFMA, the pipe is otherwise idle,
-//   2  hybrid: v_permlane32_swap folds the two wave halves first (values n and n + 8 share a register), then 8 MFMAs,
-//   3  VALU only: permlane swaps across rows, bank-masked DPP adds inside a row (wave_reduce.h),
-//   4  transposition through the wave's own LDS (wave_reduce.h: 16 ds_write_addtid_b32 + 4 ds_read_b128 + 17 VALU); DGS_RED_PHASES = 2
-//      does it in two rounds of 8 values through half the LDS.
-// Measured at 200k / 800x800 (blend bwd, ms): 0: 0.338, 1: 0.548 (the matrix pipe -- 16 x 32 cycles per visit -- becomes the
-// bottleneck), 2: 0.455, 3: 0.315 (round 2; 0.304 on the round-4 kernel), 4 (default since round 4): 0.267 with two rounds, 48 staged
-// entries per chunk and 5 workgroups per CU (30 KB of LDS); one round through 4 KB: 0.304 at 3 workgroups per CU (64 entries per chunk),
-// 0.277 at 4 (48), 0.272 at 5 (32); two rounds at 4 workgroups per CU (64): 0.281 -- the occupancy decides, the chunk size does not
-// (variant 3 with 48 entries: 0.304).  Where the 0.267 go (DGS_DIAG_BWD): atomics 0.009, reduction 0.056 (0.104 with variant 3),
-// gradient arithmetic 0.10, alpha evaluation + loop + staging 0.104.
-// On return lane l holds the wave total of v[l & 15] (variants 1, 2) / v[l >> 2] (variants 0, 3, 4 with one round); reduce16_slot() tells which.
-#ifndef DGS_BWD_REDUCE
-#define DGS_BWD_REDUCE 4
-#endif
+// Transposition through the wave's own LDS (wave_reduce.h: 16 ds_write_addtid_b32 + 4 ds_read_b128 + 17 VALU), in two rounds of
+// 8 values through 2 KB per wave.  The four earlier implementations (butterfly on the LDS crossbar 0.338 ms, matrix pipe 0.548,
+// permlane + MFMA hybrid 0.455, permlane + DPP 0.304-0.315; this one 0.267) and their measurements: ab/reduce_variants.h.
+// On return lane l with (l & 3) == 0 holds the wave total of v[(l >> 3) + 2 (l & 4)]; reduce16_slot() says so.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float wave_reduce16_butterfly(float (&v)[16], int lane)
-{
-    float a8[8], a4[4], a2[2], a1;
-    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const float keep = h5 ? v[i + 8] : v[i];
-        const float send = h5 ? v[i] : v[i + 8];
-        a8[i] = keep + __shfl_xor(send, 32, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float keep = h4 ? a8[i + 4] : a8[i];
-        const float send = h4 ? a8[i] : a8[i + 4];
-        a4[i] = keep + __shfl_xor(send, 16, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const float keep = h3 ? a4[i + 2] : a4[i];
-        const float send = h3 ? a4[i] : a4[i + 2];
-        a2[i] = keep + __shfl_xor(send, 8, 64);
-    }
-    {
-        const float keep = h2 ? a2[1] : a2[0];
-        const float send = h2 ? a2[0] : a2[1];
-        a1 = keep + __shfl_xor(send, 4, 64);
-    }
-    a1 += __shfl_xor(a1, 2, 64);
-    a1 += __shfl_xor(a1, 1, 64);
-    return a1;
-}
-
-__device__ __forceinline__ float mfma_rows_finish(const f32x4_t& d0, const f32x4_t& d1)
-{
-    float p = ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
-    p += __shfl_xor(p, 16, 64);
-    p += __shfl_xor(p, 32, 64);
-    return p;
-}
-
-__device__ __forceinline__ float wave_reduce16_mfma(float (&v)[16], int lane)
-{
-    // two accumulators (even / odd columns) so that consecutive MFMAs do not wait for each other's result
-    f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    const int col = lane & 15;
-#pragma unroll
-    for (int n = 0; n < 16; n += 2) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[n], col == n ? 1.f : 0.f, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[n + 1], col == n + 1 ? 1.f : 0.f, d1, 0, 0, 0);
-    }
-    return mfma_rows_finish(d0, d1);
-}
-
-__device__ __forceinline__ float wave_reduce16_hybrid(float (&v)[16], int lane)
-{
-    f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    const int col = (lane & 15) - ((lane & 32) >> 2);   // lanes 32..63 carry value n + 8 in register n
-#pragma unroll
-    for (int n = 0; n < 8; n += 2) {
-        float h[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            // after the swap x = (lower half of v[n], lower half of v[n+8]), y = (upper half of v[n], upper half of v[n+8])
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[n + u]), __float_as_uint(v[n + u + 8]), false, false);
-            h[u] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        }
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h[0], col == n ? 1.f : 0.f, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h[1], col == n + 1 ? 1.f : 0.f, d1, 0, 0, 0);
-    }
-    return mfma_rows_finish(d0, d1);
-}
-
 #ifndef DGS_RED_PHASES
-#define DGS_RED_PHASES 2
+#define DGS_RED_PHASES 2     // 1 (A/B): one round of 16 values through 4 KB -- 3 workgroups per CU instead of 5: 0.304 ms
 #endif
-#if DGS_BWD_REDUCE == 4
+#if !defined(DGS_AB_BUILD) && DGS_RED_PHASES != 2
+#error "DGS_RED_PHASES is an A/B switch: -DDGS_AB_BUILD"
+#endif
+
+#if DGS_BWD_REDUCE != 4
+#include "ab/reduce_variants.h"   // defines BwdRedCtx, wave_reduce16, reduce16_slot for variants 0-3
+#else
 struct BwdRed { float v[16 / DGS_RED_PHASES][64]; };   // one wave's transposition buffer
 typedef RedLds<DGS_RED_PHASES> BwdRedCtx;
-#else
-struct BwdRedCtx {};
-#endif
 
 __device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane, const BwdRedCtx& rc)
 {
-#if DGS_BWD_REDUCE == 4
 #if DGS_RED_PHASES == 1
     return wave_reduce16_lds(v, rc);
 #else
     return wave_reduce16_lds(v, rc, lane);
-#endif
-#elif DGS_BWD_REDUCE == 3
-    return wave_reduce16_dpp(v);   // wave_reduce.h: permlane swaps + bank-masked DPP adds, no LDS
-#elif DGS_BWD_REDUCE == 0
-    return wave_reduce16_butterfly(v, lane);
-#elif DGS_BWD_REDUCE == 1
-    return wave_reduce16_mfma(v, lane);
-#else
-    return wave_reduce16_hybrid(v, lane);
 #endif
 }
 
 // which of the 16 values lane `lane` holds after wave_reduce16, or -1 if the lane holds a duplicate
 __device__ __forceinline__ int reduce16_slot(int lane)
 {
-#if DGS_BWD_REDUCE == 4 && DGS_RED_PHASES == 2
+#if DGS_RED_PHASES == 2
     return (lane & 3) == 0 ? (lane >> 3) + 2 * (lane & 4) : -1;
-#elif DGS_BWD_REDUCE == 0 || DGS_BWD_REDUCE == 3 || DGS_BWD_REDUCE == 4
-    return (lane & 3) == 0 ? (lane >> 2) : -1;
 #else
-    return lane < 16 ? lane : -1;
+    return (lane & 3) == 0 ? (lane >> 2) : -1;
 #endif
 }
+#endif
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -1085,9 +846,6 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-#ifndef DGS_BWD_ROWS
-#define DGS_BWD_ROWS 0   // 1: the row-per-block backward kernel (measured, not the default: see blend_bwd_rows_kernel)
-#endif
 constexpr int kDetRows = DGS_BWD_ROWS ? 16 : 4;   // rows of det_part per list entry: one per (wave, 16-lane row) or per wave
 
 #ifndef DGS_BWD_MINWAVES
@@ -1174,7 +932,7 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
         for (int top = hi - 1; top >= lo; top -= kChunkB) {
             const int e_mine = top - lane;
             const uint32_t id = id_next;   // (lanes beyond the front of the range hold id 0: a valid record, masked out below)
-            // straight-line staging, see blend_fwd_kernel
+            // straight-line staging, see blend_fwd_rows_kernel
             const float4* src = a.rec + (size_t)id * kRecQuads;
             const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3s = src[3], q4s = src[4], bx = src[5];
             id_next = stager && e_mine - kChunkB >= lo ? a.point_list[range.x + (uint32_t)(e_mine - kChunkB)] : 0u;
@@ -1196,28 +954,14 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
             const int nhit = __builtin_popcountll(m);
             f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
             f32x4 tw = S.tw[0], tuv = S.tuv[0], q3 = S.q3[0], q4 = S.q4[0];
-#if DGS_BWD_INTERLEAVE
-            // A/B: the alpha evaluation of entry i + 1 is issued in front of the step of entry i -- two independent
-            // chains inside one wave.  Its result (11 floats) lives across the step: see the measurements at DGS_BWD_INTERLEAVE.
-            AlphaEval evn;
-            bool okn = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), evn);
-            a0 = S.a[0][1]; a1 = S.a[1][1]; a2 = S.a[2][1];
-#endif
             for (int i = 0; i < nhit; i++) {
-#if DGS_BWD_INTERLEAVE
-                const AlphaEval ev = evn;
-                bool ok = okn;
-                okn = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), evn);   // (slot nhit: stale planes, evaluated and dropped)
-                { const int n2 = min(i + 2, kChunkB); a0 = S.a[0][n2]; a1 = S.a[1][n2]; a2 = S.a[2][n2]; }
-#else
                 AlphaEval ev;
                 bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
 #if DGS_PIN_PREFETCH
-                asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
+                asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_rows_kernel: one register set, loads pinned behind their last use
 #endif
                 a0 = S.a[0][i + 1]; a1 = S.a[1][i + 1]; a2 = S.a[2][i + 1];
                 DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
-#endif
                 const int e = __builtin_amdgcn_readfirstlane(__float_as_int(q4.z));  // 0-based list index == the reference's `contributor`
                 ok = ok & (e < st.last_contributor);
                 if (__ballot(ok) != 0ull) {
@@ -1334,206 +1078,9 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
     bwd_quadrant<DET, false>(a, tile, wave, 0, s_stage[wave], rc, nullptr);
 }
 
-// ---- backward blend, one list per 16-lane row (round 4) -------------------------------------------------------------------
-// In blend_bwd_kernel above all 64 lanes of a wave visit the same entry, and 30 of them blend it on the 200k / 800x800 scene
-// (tools/blend_stats.py).  Here every DPP row of the wave -- one 4x4 pixel block of the quadrant (surfel_math.h lane_pixel) --
-// walks the list of the entries that can reach ITS block: while staging, a lane tests its entry against the four blocks
-// (blocks_hit_linear: the record's pixel box, then a tangent-plane bound of the footprint's conic; also what decides whether the
-// entry is staged at all), the entry's planes are stored once per wave, compacted as before, and each block it reaches gets the
-// slot number appended to its row's byte list (rank among the ballot of that block).  One wave-instruction of the visit loop then
-// serves four (entry, block) pairs: lane l reads the planes of the slot its row is at (four addresses per ds_read_b128), rows that
-// have run out of entries read the null slot (opacity 0: fails the alpha test, contributes exact zeros).  A row's list also stops
-// at ITS pixels' last contributor instead of the wave's.  The 16 partials are summed per row (wave_reduce.h rows_reduce16) and all
-// 64 lanes issue one atomic each: row r' = (l >> 1) & 3 of value (l >> 3) + 8 (l & 1), to the surfel of row r's entry.
-// Per-pixel arithmetic and entry order are those of blend_bwd_kernel; the sums reach the accumulator rows in 16 instead of 4
-// pieces per (tile, entry).  Iterations per wave: 0.87 of the visits of the kernel above on the 200k / 800x800 scene (tools/blend_stats.py:
-// a splat that reaches a quadrant reaches 2.9 of its 4 blocks, and the four rows of a wave wait for the longest list of the chunk).
-//
-// MEASURED AND NOT THE DEFAULT (round 4; parity suite green; same lease, 200k / 800x800, ms per launch):
-//     blend_bwd_kernel, DPP reduction (round 3)      0.304
-//     blend_bwd_kernel, LDS reduction (the default)  0.269
-//     this kernel                                    0.704     without its atomics 0.253, without reduction + atomics 0.189
-// The float atomics, free in the kernel above (0.271 -> 0.262 without them), are what this design cannot afford: a visit there ends
-// in 16 lanes adding to ONE 64-byte accumulator row -- the wave-wide sum has already merged the up to four blocks an entry reaches in
-// the quadrant -- while an iteration here ends in 64 lanes adding to up to four rows, and whenever the rows of the wave sit on the same
-// entry (large splats: most of the time) four lanes of one instruction hit the same address.  3.5 M (entry, block) pairs x 16 lanes
-// instead of 1.2 M visits x 16: the L2's atomic units are the bound (0.45 ms).  Merging equal targets across the four rows before
-// the atomic costs ~14 DPP-class instructions per iteration (two exchange steps of value + target) -- as much as the 13 % fewer
-// iterations save, and the upper bound without any atomic is only 6 % under the default.  Kept as the committed A/B
-// (-DDGS_BWD_ROWS=1, tools/ab_variants.sh); lane_pixel keeps the block layout, which costs the default nothing.
-#ifndef DGS_BWD_ROWS
-#define DGS_BWD_ROWS 0
+#if DGS_BWD_ROWS
+#include "ab/blend_bwd_rows.h"
 #endif
-static_assert(kChunkB <= 60, "a row's byte list holds 64 slots and is read two ahead");
-constexpr int kNullSlot = kChunkB;   // the slot behind the staged ones: the entry that contributes nothing
-template <bool DET>
-struct BwdRowStage {
-    f32x4 a[3][kChunkB + 1];
-    f32x4 tw[kChunkB + 1];     // (Tw.x Tw.y Tw.z opacity)
-    f32x4 tuv[kChunkB + 1];    // (Tu.x Tu.y Tv.x Tv.y)
-    f32x4 q3[kChunkB + 1];     // (n.x n.y n.z r)
-    f32x4 q4[kChunkB + 1];     // (g b, 0-based list index as bits, byte offset of the surfel's accumulator row; null slot: index INT_MAX, offset ~0)
-    uint32_t idx[4][16];       // row r: the slots of its block's entries in visit order, one byte each
-    float red[DET ? 10 : 9][64];   // rows_reduce16: 8 values per round + one row of per-lane words (two in the deterministic variant)
-};
-
-template <bool DET>
-__global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_rows_kernel(BlendBwdArgs a)
-{
-    __shared__ BwdRowStage<DET> s_stage[4];
-
-    const int ntiles = a.tiles_x * a.tiles_y;
-    int tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
-    if (a.mode < 3 && tile >= ntiles) return;
-    if (a.mode >= 3) tile = (int)a.order[tile];
-    if (tile >= ntiles) return;   // mode 4: empty slot
-    if (a.tile_last[tile] == 0u) return;   // no pixel of the tile blended anything
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    int lx_, ly_;
-    lane_pixel(tid, lx_, ly_);
-    const int px = tx * kTileX + lx_, py = ty * kTileY + ly_;
-    const bool inside = px < a.W && py < a.H;
-    const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
-    const float tpx = (float)(tx * kTileX), tpy = (float)(ty * kTileY);
-    const float X0 = tpx + 8.0f, Y0 = tpy + 8.0f;
-    const float qx = tpx + (float)(8 * (wave & 1)), qy = tpy + (float)(8 * (wave >> 1));
-    const float qus0 = kSqrt2 * ((wave & 1) ? 0.5f : -7.5f), qvs0 = kSqrt2 * ((wave & 2) ? 0.5f : -7.5f);
-    const float us = kSqrt2 * ((float)lx_ - 7.5f), vs = kSqrt2 * ((float)ly_ - 7.5f);
-    const uint2 range = a.ranges[tile];
-    BwdRowStage<DET>& S = s_stage[wave];
-
-    const size_t plane = (size_t)ntiles * kTilePix;
-    const size_t slot_px = (size_t)tile * kTilePix + tid;
-    PixBwdA st;
-    {
-        float gpix[3] = {0.f, 0.f, 0.f}, goth[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (inside) {
-            const size_t HW = (size_t)a.H * a.W;
-            const size_t pix = (size_t)py * a.W + px;
-#pragma unroll
-            for (int c = 0; c < 3; c++) gpix[c] = a.dL_dpix[c * HW + pix];
-#pragma unroll
-            for (int c = 0; c < 8; c++) goth[c] = a.dL_dothers[c * HW + pix];
-        }
-        const int last = inside ? (int)a.n_contrib[slot_px] : 0;
-        const int medc = inside ? (int)a.n_contrib[plane + slot_px] : 0;
-        pixbwd_init_affine(st, inside ? a.final_T[slot_px] : 0.f, a.final_T[plane + slot_px], a.final_T[2 * plane + slot_px], last, medc, gpix,
-                           goth, a.bg);
-    }
-    // a row's list ends at its own pixels' last contributor; the wave walks the tile's list back to front from the largest of the four
-    const int row_last = row_max16(st.last_contributor);
-    const int rl0 = __builtin_amdgcn_readlane(row_last, 0), rl1 = __builtin_amdgcn_readlane(row_last, 16);
-    const int rl2 = __builtin_amdgcn_readlane(row_last, 32), rl3 = __builtin_amdgcn_readlane(row_last, 48);
-    const int wave_last = max(max(rl0, rl1), max(rl2, rl3));
-    RedRows rc;
-    rc.init(&S.red[0][0], lane);
-    // the null slot: planes of an entry that fails the alpha test for every pixel and whose other constants are finite
-    if (lane < 7) {
-        f32x4* planes[7] = {&S.a[0][kNullSlot], &S.a[1][kNullSlot], &S.a[2][kNullSlot], &S.tw[kNullSlot], &S.tuv[kNullSlot], &S.q3[kNullSlot], &S.q4[kNullSlot]};
-        f32x4 z = mk4(0.f, 0.f, 0.f, 0.f);
-        if (lane == 6) z = mk4(0.f, 0.f, __int_as_float(0x7fffffff), __uint_as_float(0xffffffffu));
-#pragma unroll
-        for (int k = 0; k < 7; k++)
-            if (lane == k) *planes[k] = z;
-    }
-    const uint8_t* my_list = (const uint8_t*)&S.idx[row][0];
-    const int kk = (lane >> 3) + 8 * (lane & 1);   // the value this lane finishes (rows_reduce16)
-
-    const bool stager = lane < kChunkB;
-    uint32_t id_next = stager && wave_last - 1 - lane >= 0 ? a.point_list[range.x + (uint32_t)(wave_last - 1 - lane)] : 0u;
-    for (int top = wave_last - 1; top >= 0; top -= kChunkB) {
-        const int e_mine = top - lane;
-        const uint32_t id = id_next;   // (lanes beyond the front of the list hold id 0: a valid record, masked out below)
-        const float4* src = a.rec + (size_t)id * kRecQuads;
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3s = src[3], q4s = src[4], bx = src[5];
-        id_next = stager && e_mine - kChunkB >= 0 ? a.point_list[range.x + (uint32_t)(e_mine - kChunkB)] : 0u;
-        const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
-        const uint32_t bm = (stager & (e_mine >= 0)) ? blocks_hit_linear(ta, qus0, qvs0, as_quad(bx), qx, qy) : 0u;
-        const bool h0 = (bm & 1u) && e_mine < rl0, h1 = (bm & 2u) && e_mine < rl1, h2 = (bm & 4u) && e_mine < rl2, h3 = (bm & 8u) && e_mine < rl3;
-        const bool hit = h0 | h1 | h2 | h3;
-        const unsigned long long m = __ballot(hit);
-        if (m == 0ull) continue;
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-        ((uint32_t*)&S.idx[0][0])[lane] = 0x01010101u * (uint32_t)kNullSlot;   // every list: null slots behind its entries
-        if (hit) {
-            const int slot = lane_rank(m);
-            S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
-            S.a[1][slot] = mk4(ta.a1.x, ta.a1.y, ta.a1.z, ta.a1.w);
-            S.a[2][slot] = mk4(ta.a2.x, ta.a2.y, ta.a2.z, ta.a2.w);
-            S.tw[slot] = mk4(q1.z, q1.w, q2.x, q2.w);
-            S.tuv[slot] = mk4(q0.x, q0.y, q0.w, q1.x);
-            S.q3[slot] = mk4(q3s);
-            S.q4[slot] = mk4(q4s.x, q4s.y, __int_as_float(e_mine), __uint_as_float(id * (uint32_t)(kAccFloats * 4)));
-            uint8_t* lists = (uint8_t*)&S.idx[0][0];
-            if (h0) lists[lane_rank(m0)] = (uint8_t)slot;
-            if (h1) lists[64 + lane_rank(m1)] = (uint8_t)slot;
-            if (h2) lists[128 + lane_rank(m2)] = (uint8_t)slot;
-            if (h3) lists[192 + lane_rank(m3)] = (uint8_t)slot;
-        }
-        __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
-        const int n01 = max(__builtin_popcountll(m0), __builtin_popcountll(m1)), n23 = max(__builtin_popcountll(m2), __builtin_popcountll(m3));
-        const int niter = __builtin_amdgcn_readfirstlane(max(n01, n23));   // (ballot popcounts: uniform, the loop counter belongs on the scalar unit)
-        int sl = my_list[0];
-        int sl_next = my_list[1];
-        f32x4 a0 = S.a[0][sl], a1 = S.a[1][sl], a2 = S.a[2][sl];
-        f32x4 tw = S.tw[sl], tuv = S.tuv[sl], q3 = S.q3[sl], q4 = S.q4[sl];
-        for (int i = 0; i < niter; i++) {
-            AlphaEval ev;
-            bool ok = alpha_affine(us, vs, as_quad(a0), as_quad(a1), as_quad(a2), ev);
-#if DGS_PIN_PREFETCH
-            asm volatile("" : "+v"(ev.a), "+v"(ev.alpha) : : "memory");   // see blend_fwd_kernel: one register set, loads pinned behind their last use
-#endif
-            sl = sl_next;
-            a0 = S.a[0][sl]; a1 = S.a[1][sl]; a2 = S.a[2][sl];
-            DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
-            const int e = __float_as_int(q4.z);   // 0-based list index of the row's entry == the reference's `contributor`
-            ok = ok & (e < st.last_contributor);
-            if (__ballot(ok) != 0ull) {
-                bool use3d;
-                const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
-                ok = ok & (depth >= kNear);
-                float out[16], out2d[2];
-                pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
-                                   Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
-                uint32_t rid, re;
-#if DGS_DIAG_BWD >= 2
-                float tot = 0.f; rid = __float_as_uint(q4.w); re = 0;
-                for (int k = 0; k < 16; k++) asm volatile("" : : "v"(out[k]));
-#else
-                const float tot = rows_reduce16<DET>(out, __float_as_uint(q4.w), __float_as_uint(q4.z), rc, lane, rid, re);
-#endif
-#if DGS_DIAG_BWD >= 1
-                asm volatile("" : : "v"(tot), "v"(rid));
-                if (false) {
-#else
-                if (rid != 0xffffffffu && tot != 0.0f) {
-#endif   // (a row without an entry, or one none of whose pixels blended it, adds nothing)
-                    if (DET) a.det_part[(((size_t)(range.x + re) * 4 + wave) * 4 + ((lane >> 1) & 3)) * kAccFloats + kk] = tot;
-                    else atomicAdd((float*)((char*)a.acc + (rid + 4u * (uint32_t)kk)), tot);   // rid = byte offset of the surfel's accumulator row
-                }
-                if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
-                    const float mx = row_sum16(out2d[0]);
-                    const float my = row_sum16(out2d[1]);
-                    if ((lane & 15) == 0 && (mx != 0.0f || my != 0.0f)) {
-                        float* dst = DET ? a.det_part + (((size_t)(range.x + (uint32_t)e) * 4 + wave) * 4 + row) * kAccFloats
-                                         : (float*)((char*)a.acc + __float_as_uint(q4.w));
-                        if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
-                        else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
-                    }
-                }
-            }
-#if DGS_PIN_PREFETCH
-            asm volatile("" : "+v"(st.T) : : "memory");
-#endif
-            tw = S.tw[sl]; tuv = S.tuv[sl]; q3 = S.q3[sl]; q4 = S.q4[sl];
-            DGS_PIN4(tw); DGS_PIN4(tuv); DGS_PIN4(q3); DGS_PIN4(q4);
-            sl_next = my_list[i + 2];
-            asm volatile("" : "+v"(sl_next));   // requested here, a visit before the address is formed from it
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
 
 // Deterministic reduction of the backward blend (test option): one thread per surfel walks the tiles of its rectangle in
 // row-major order, finds its entry in the tile's sorted list and adds the four waves' rows in order 0..3.  Same sums as the

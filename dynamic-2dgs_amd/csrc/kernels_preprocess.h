@@ -224,14 +224,19 @@ __global__ void __launch_bounds__(64 * kColGroups) column_pass_kernel(uint32_t* 
 
 // duplicateWithKeys (rasterizer_impl.cu:70-111) for the tile-bucketed sort: the tile id is implied by the bucket, so
 // the key only carries (depth, surfel index) -- the tie-break order of the reference's stable radix sort.
+constexpr size_t kScatterRiderLds = (8 * kOrderBins + 2 * kOrderMaxGroups + 16) * sizeof(uint32_t);   // the rider workgroup's tables (below)
 __global__ void __launch_bounds__(kBinThreads) scatter_keys_lds_kernel(BinArgs a)
 {
     extern __shared__ uint32_t s_cur[];
     const int g = blockIdx.x, tid = threadIdx.x;
     if (g == kBinGroups) {   // the rider (BinArgs::order); runs on an overflowed frame as well (its ranges are empty, the order still has to exist)
-        __shared__ uint32_t s_hist[8 * kOrderBins];
-        __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
-        __shared__ uint32_t s_osum[16];
+        // its tables live in the DYNAMIC buffer (the rider never uses the cursors; the host sizes the buffer for whichever is larger,
+        // kScatterRiderLds): static arrays here would add 40 KB to every workgroup of the launch and push a 3840 x 2160 image
+        // (32 400 tiles = 127 KB of cursors) past the 160 KB a workgroup can have
+        uint32_t* s_hist = s_cur;
+        uint32_t* s_gw = s_hist + 8 * kOrderBins;
+        uint32_t* s_gx = s_gw + kOrderMaxGroups;
+        uint32_t* s_osum = s_gx + kOrderMaxGroups;
         for (int i = tid; i < a.ntiles; i += kBinThreads) a.tile_last[i] = 0u;
         if (a.order_mode == 4) tile_order_xcd_body(a.ranges, nullptr, a.tiles_x, a.tiles_y, a.order, a.group_xcd, true, s_hist, s_gw, s_gx, s_osum);
         else tile_order_body(a.ranges, nullptr, a.ntiles, a.order, s_hist, s_osum);

@@ -668,7 +668,8 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
                 ba_.ranges = ranges; ba_.order = (uint32_t*)(img + il.order_fwd); ba_.group_xcd = (uint32_t*)(img + il.group_xcd);
                 ba_.tile_last = (uint32_t*)(img + il.tile_last); ba_.order_mode = tile_order;
             }
-            hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups + (order_later ? 1 : 0)), dim3(dgs::kBinThreads), hist_bytes, stream, ba_);
+            const size_t scatter_lds = order_later && hist_bytes < dgs::kScatterRiderLds ? dgs::kScatterRiderLds : hist_bytes;
+            hipLaunchKernelGGL(dgs::scatter_keys_lds_kernel, dim3(dgs::kBinGroups + (order_later ? 1 : 0)), dim3(dgs::kBinThreads), scatter_lds, stream, ba_);
         } else {
             dgs::ScatterArgs sa;
             sa.P = P; sa.radii = radii; sa.rec = pa.rec; sa.rects = pa.rects; sa.cursor = cursor;

@@ -1,16 +1,18 @@
-// wave_reduce.h -- sum of 16 per-lane values over the 64 lanes of a gfx950 wave without touching LDS.
-//
+// wave_reduce.h -- sum of 16 per-lane values over the 64 lanes of a gfx950 wave: in registers (permlane swaps + DPP; used by the
+// skinning backward of train_ops.hip) and through the wave's own LDS (the backward blend).
+// (The row-wise sums of the row-per-block backward are in ab/blend_bwd_rows.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dgs {
+
+// ---- in registers --------------------------------------------------------------------------------------------------------
 // v_permlane32_swap / v_permlane16_swap fold the wave halves and the row pairs (after them row r holds value i + 4 r in
 // register i), then DPP adds with bank-masked writes fold a 16-lane row: row_mirror (lane l + lane 15-l -> lanes 0..7 keep
 // registers 0,1, lanes 8..15 registers 2,3), row_half_mirror, two quad permutes.  Any pairing works for a sum; the mirrors
 // are the ones DPP offers across 8 and 4 lanes.  On return every lane of quad k (lanes 4k .. 4k+3) holds the wave total of
 // v[k].  36 VALU instructions, no ds_bpermute (measured on MI355X against the halving butterfly on the LDS crossbar --
 // 17 ds_bpermute + 30 v_cndmask + 17 v_add -- inside the backward blend kernel: 0.338 -> 0.315 ms).
-#pragma once
-#include <hip/hip_runtime.h>
-
-namespace dgs {
-
 __device__ __forceinline__ float wave_reduce16_dpp(float (&v)[16])
 {
     float h[8], g[4];
@@ -44,7 +46,38 @@ __device__ __forceinline__ float wave_reduce16_dpp(float (&v)[16])
     return e;
 }
 
-// ---- the same sum through LDS (DGS_BWD_REDUCE == 4) ------------------------------------------------------------------
+
+// Eight values: on return the eight lanes 8k .. 8k+7 hold the wave total of v[k].
+__device__ __forceinline__ float wave_reduce8_dpp(float (&v)[8])
+{
+    float h[4], g[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        h[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // lanes 0..31: value i, lanes 32..63: value i + 4
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[i]), __float_as_uint(h[i + 2]), false, false);
+        g[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // row r: value i + 2 r
+    }
+    float f, e;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"       // lanes 0..7 of a row: value 2 r
+        "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xc\n\t"       // lanes 8..15:         value 2 r + 1
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %1, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(f), "=&v"(e)
+        : "v"(g[0]), "v"(g[1]));
+    return e;
+}
+
+// ---- the sum through LDS ---------------------------------------------------------------------------------------------
 // The DPP / permlane version above is 36 VALU instructions of the expensive classes (v_permlane*_swap 8.5 cycles, DPP adds
 // 4.4-4.8) = ~170 of a backward visit's ~500 issue cycles, while the LDS pipe of the blend kernels is 22 % busy
 // (SQ_LDS_IDX_ACTIVE, profiles/r03_pmc_metric.json).  Here the wave TRANSPOSES the 64 x 16 partials through its own 4 KB of
@@ -153,120 +186,6 @@ __device__ __forceinline__ float wave_reduce16_lds(float (&v)[16], const RedLds<
     const float lo = red_row8(red_sum4(x0) + red_sum4(x1));
     const float hi = red_row8(red_sum4(y0) + red_sum4(y1));
     return (lane & 4) ? hi : lo;
-}
-
-// ---- row-wise sums for the row-per-block backward (kernels_blend.h blend_bwd_rows_kernel) ----------------------------------
-// Every 16-lane row r of the wave holds the 16 partials of ITS OWN list entry; wanted: for every row the 16 sums over its 16
-// lanes.  Same transposition as above, in two rounds of 8 values through 2 KB: all lanes store value k into row k
-// (ds_write_addtid_b32), then lane l -- value k = l >> 3, source row r' = (l >> 1) & 3, half h = l & 1 -- reads the 8 numbers of
-// (k, r', h) with two ds_read_b128 (rotated by (l >> 4) & 1: conflict free, see above), adds them (7 v_add_f32) and joins the two
-// halves with one quad DPP add.  After the two rounds lane l keeps the total of value (l >> 3) + 8 (l & 1) of row (l >> 1) & 3:
-// 64 results, 64 lanes, one global atomic each -- no lane carries a duplicate.  Row 8 of the buffer transports one 32-bit word
-// per lane (the surfel id of the row's entry) to the lanes that finish that row; row 9 a second one (deterministic variant).
-struct RedRows {
-    uint32_t m0;                 // LDS byte address of this wave's buffer
-    const red_f32x4* rd[2];      // this lane's two read addresses
-    const uint32_t* meta;        // word of source row (lane >> 1) & 3 in row 8 (row 9: + 64)
-    __device__ __forceinline__ void init(float* buf /* [10][64] */, int lane)
-    {
-        m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)buf);
-        const int k = lane >> 3, r = (lane >> 1) & 3, h = lane & 1, s = (lane >> 4) & 1;
-#pragma unroll
-        for (int i = 0; i < 2; i++) rd[i] = (const red_f32x4*)(buf + k * 64) + 4 * r + 2 * h + ((i + s) & 1);
-        meta = (const uint32_t*)(buf + 8 * 64) + 16 * r;
-    }
-};
-
-__device__ __forceinline__ void red_store_word(uint32_t w, int row /* 8 or 9 */)   // M0 as left by red_store8
-{
-    if (row == 8) asm volatile("ds_write_addtid_b32 %0 offset:2048" : : "v"(w) : "memory");
-    else asm volatile("ds_write_addtid_b32 %0 offset:2304" : : "v"(w) : "memory");
-}
-
-__device__ __forceinline__ float red_pair(float t)   // t + the neighbouring lane's t (lanes 2 j, 2 j + 1)
-{
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(t));
-    return t;
-}
-
-// on return: the total of value (lane >> 3) + 8 (lane & 1) over the 16 lanes of row (lane >> 1) & 3, and in w8 (w9) the word that
-// row's lanes passed as word8 (word9; only transported when TWO)
-template <bool TWO>
-__device__ __forceinline__ float rows_reduce16(float (&v)[16], uint32_t word8, uint32_t word9, const RedRows& r, int lane, uint32_t& w8, uint32_t& w9)
-{
-    red_store8(r.m0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-    red_store_word(word8, 8);
-    if (TWO) red_store_word(word9, 9);
-    const red_f32x4 x0 = *r.rd[0], x1 = *r.rd[1];
-    w8 = r.meta[0];
-    w9 = TWO ? r.meta[64] : 0u;
-    red_store8(r.m0, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);   // (LDS operations of a wave execute in order: the reads above see round 1)
-    const red_f32x4 y0 = *r.rd[0], y1 = *r.rd[1];
-    const float lo = red_pair(red_sum4(x0) + red_sum4(x1));
-    const float hi = red_pair(red_sum4(y0) + red_sum4(y1));
-    return (lane & 1) ? hi : lo;
-}
-
-// sum over the 16 lanes of a row, on every lane of the row (rare 2-D filter branch of the backward)
-__device__ __forceinline__ float row_sum16(float t)
-{
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
-        : "+v"(t));
-    return t;
-}
-
-// maximum over the 16 lanes of a row, on every lane of the row
-__device__ __forceinline__ int row_max16(int t)
-{
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
-        : "+v"(t));
-    return t;
-}
-
-// Eight values: on return the eight lanes 8k .. 8k+7 hold the wave total of v[k].
-__device__ __forceinline__ float wave_reduce8_dpp(float (&v)[8])
-{
-    float h[4], g[2];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
-        h[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // lanes 0..31: value i, lanes 32..63: value i + 4
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[i]), __float_as_uint(h[i + 2]), false, false);
-        g[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // row r: value i + 2 r
-    }
-    float f, e;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"       // lanes 0..7 of a row: value 2 r
-        "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xc\n\t"       // lanes 8..15:         value 2 r + 1
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %1, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-        : "=&v"(f), "=&v"(e)
-        : "v"(g[0]), "v"(g[1]));
-    return e;
 }
 
 }  // namespace dgs

@@ -9,7 +9,7 @@ if [ "$1" = build ]; then
   rm -f $D/ab_*.so
   for v in "$@"; do
     name=${v%%:*}; flags=${v#*:}
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -fno-slp-vectorize $flags $D/surfel_rasterizer.hip -o $D/ab_$name.so 2>&1 | grep -v warning | grep -v "^$" &
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -fno-slp-vectorize -DDGS_AB_BUILD $flags $D/surfel_rasterizer.hip -o $D/ab_$name.so 2>&1 | grep -v warning | grep -v "^$" &
   done
   wait
   ls $D/ab_*.so
