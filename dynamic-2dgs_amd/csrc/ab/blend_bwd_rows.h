@@ -203,9 +203,9 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_rows_ker
         const uint32_t bm = (stager & (e_mine >= 0)) ? blocks_hit_linear(ta, qus0, qvs0, as_quad(bx), qx, qy) : 0u;
         const bool h0 = (bm & 1u) && e_mine < rl0, h1 = (bm & 2u) && e_mine < rl1, h2 = (bm & 4u) && e_mine < rl2, h3 = (bm & 8u) && e_mine < rl3;
         const bool hit = h0 | h1 | h2 | h3;
-        const unsigned long long m = __ballot(hit);
+        const unsigned long long m = ballot64(hit);
         if (m == 0ull) continue;
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        const unsigned long long m0 = ballot64(h0), m1 = ballot64(h1), m2 = ballot64(h2), m3 = ballot64(h3);
         ((uint32_t*)&S.idx[0][0])[lane] = 0x01010101u * (uint32_t)kNullSlot;   // every list: null slots behind its entries
         if (hit) {
             const int slot = lane_rank(m);
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_rows_ker
             DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
             const int e = __float_as_int(q4.z);   // 0-based list index of the row's entry == the reference's `contributor`
             ok = ok & (e < st.last_contributor);
-            if (__ballot(ok) != 0ull) {
+            if (ballot64(ok) != 0ull) {
                 bool use3d;
                 const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
                 ok = ok & (depth >= kNear);
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_rows_ker
                     if (DET) a.det_part[(((size_t)(range.x + re) * 4 + wave) * 4 + ((lane >> 1) & 3)) * kAccFloats + kk] = tot;
                     else atomicAdd((float*)((char*)a.acc + (rid + 4u * (uint32_t)kk)), tot);   // rid = byte offset of the surfel's accumulator row
                 }
-                if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                if (ballot64(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
                     const float mx = row_sum16(out2d[0]);
                     const float my = row_sum16(out2d[1]);
                     if ((lane & 15) == 0 && (mx != 0.0f || my != 0.0f)) {

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(B
     };
 
     uint32_t id_next = lane < len ? a.point_list[range.x + lane] : 0u;
-    unsigned long long alive = __ballot(inside);   // lanes that still take entries (wave-uniform)
+    unsigned long long alive = ballot64(inside);   // lanes that still take entries (wave-uniform)
     for (uint32_t base = 0; base < len && alive != 0ull; base += kChunk) {
         const uint32_t e_mine = base + (uint32_t)lane;
         const uint32_t id = id_next;   // (lanes beyond the end of the list hold id 0: a valid record, masked out below)
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(B
         id_next = e_mine + kChunk < len ? a.point_list[range.x + e_mine + kChunk] : 0u;
         const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
         const bool hit = (e_mine < len) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
-        const unsigned long long m = __ballot(hit);
+        const unsigned long long m = ballot64(hit);
         if (m == 0ull) continue;
         if (hit) {
             const int slot = lane_rank(m);
@@ -107,10 +107,10 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_kernel(B
         }
         __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
         // median bookkeeping (forward.cu:421-425) only while some pixel of the wave still has T > 0.5
-        if (__ballot(st.T > 0.5f && us == us) != 0ull) visit(std::true_type{}, __builtin_popcountll(m));
+        if (ballot64(st.T > 0.5f && us == us) != 0ull) visit(std::true_type{}, __builtin_popcountll(m));
         else visit(std::false_type{}, __builtin_popcountll(m));
         __builtin_amdgcn_wave_barrier();
-        alive = __ballot(us == us);   // wave-level early out (forward.cu:334-336 votes per block)
+        alive = ballot64(us == us);   // wave-level early out (forward.cu:334-336 votes per block)
     }
 
     // per-tile maximum of the last contributor: the backward starts there instead of walking the

@@ -62,6 +62,10 @@ __device__ __forceinline__ f32x4 mk4(float x, float y, float z, float w) { retur
 __device__ __forceinline__ f32x4 mk4(const float4& v) { return f32x4{v.x, v.y, v.z, v.w}; }
 #define DGS_PIN4(v) asm volatile("" : "+v"(v))
 
+// __ballot() takes an int: the bool -> int -> "!= 0" round trip is not always folded back (a v_cndmask 0/1 + v_cmp_ne per use in the
+// blend loops when the predicate is an AND of lane masks); the builtin takes the i1 as it is
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long long v)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -480,7 +484,7 @@ __device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, 
         const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3r = src[3], q4r = src[4], bx = src[5];
         const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
         const bool hit = (e_mine < len) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
-        const unsigned long long m = __ballot(hit);
+        const unsigned long long m = ballot64(hit);
         if (hit) {
             const int slot = lane_rank(m);
             S.a[0][slot] = mk4(ta.a0.x, ta.a0.y, ta.a0.z, ta.a0.w);
@@ -523,7 +527,7 @@ __device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, 
         const uint32_t last_before = st.last;
         st.T = T_in;
         st.dist1 = 0.f; st.dist2 = 0.f;    // the round's own sums; the sums in front of the chunk are added in below
-        if (__ballot(took) != 0ull) {
+        if (ballot64(took) != 0ull) {
             f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
             f32x4 tw = S.tw[0], q3 = S.q3[0], q4 = S.q4[0];
             for (int i = 0; i < nhit; i++) {
@@ -549,7 +553,7 @@ __device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, 
         __builtin_amdgcn_wave_barrier();
         const float W_own = T_in - st.T, d1_own = st.dist1, d2_own = st.dist2;   // (T only moves by the blending weights)
         X.W[seg][lane] = W_own; X.d1[seg][lane] = d1_own; X.d2[seg][lane] = d2_own;
-        const unsigned long long sat = __ballot(took && !(us == us));   // pixels that saturated in this chunk
+        const unsigned long long sat = ballot64(took && !(us == us));   // pixels that saturated in this chunk
         if (lane == 0) X.done[seg] = sat;
         if (st.last != last_before) T_final = st.T;
         __syncthreads();
@@ -563,7 +567,7 @@ __device__ __forceinline__ void blend_fwd_long(const BlendFwdArgs& a, int tile, 
         const unsigned long long any_sat = X.done[0] | X.done[1] | X.done[2] | X.done[3];
         done_pix = done_pix | (((any_sat >> lane) & 1ull) != 0ull);
         T_round = T_in3 - X.W[3][lane];   // T behind the last wave's chunk (its T_in minus its weights: the operation it performed)
-        if (__ballot(!done_pix && T_round >= kTmin) == 0ull) break;   // (the same verdict in all four waves: same data)
+        if (ballot64(!done_pix && T_round >= kTmin) == 0ull) break;   // (the same verdict in all four waves: same data)
     }
 
     __syncthreads();   // every wave is done with its staging slice: the waves' states go there
@@ -701,7 +705,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_ker
     };
 
     uint32_t id_next = (uint32_t)lane < len ? a.point_list[range.x + lane] : 0u;
-    unsigned long long alive = __ballot(inside);   // lanes that still take entries
+    unsigned long long alive = ballot64(inside);   // lanes that still take entries
     for (uint32_t base = 0; base < len && alive != 0ull; base += kChunkF) {
         const uint32_t e_mine = base + (uint32_t)lane;
         const uint32_t id = id_next;   // (lanes beyond the end of the list hold id 0: a valid record, masked out below)
@@ -714,9 +718,9 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_ker
         bm &= (((uint32_t)alive & 0xffffu) ? 1u : 0u) | (((uint32_t)(alive >> 16) & 0xffffu) ? 2u : 0u) |
               (((uint32_t)(alive >> 32) & 0xffffu) ? 4u : 0u) | (((uint32_t)(alive >> 48) & 0xffffu) ? 8u : 0u);
         const bool hit = bm != 0u;
-        const unsigned long long m = __ballot(hit);
+        const unsigned long long m = ballot64(hit);
         if (m == 0ull) continue;
-        const unsigned long long m0 = __ballot((bm & 1u) != 0u), m1 = __ballot((bm & 2u) != 0u), m2 = __ballot((bm & 4u) != 0u), m3 = __ballot((bm & 8u) != 0u);
+        const unsigned long long m0 = ballot64((bm & 1u) != 0u), m1 = ballot64((bm & 2u) != 0u), m2 = ballot64((bm & 4u) != 0u), m3 = ballot64((bm & 8u) != 0u);
         ((uint32_t*)&S.idx[0][0])[lane] = 0x01010101u * (uint32_t)kNullSlotF;   // every list: null slots behind its entries
         if (lane < 4) ((uint32_t*)&S.idx[0][0])[64 + lane] = 0x01010101u * (uint32_t)kNullSlotF;
         if (hit) {
@@ -737,10 +741,10 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_ker
         const int n01 = max(__builtin_popcountll(m0), __builtin_popcountll(m1)), n23 = max(__builtin_popcountll(m2), __builtin_popcountll(m3));
         const int niter = __builtin_amdgcn_readfirstlane(max(n01, n23));
         // median bookkeeping (forward.cu:421-425) only while some pixel of the wave still has T > 0.5
-        if (__ballot(st.T > 0.5f && us == us) != 0ull) visit(std::true_type{}, niter);
+        if (ballot64(st.T > 0.5f && us == us) != 0ull) visit(std::true_type{}, niter);
         else visit(std::false_type{}, niter);
         __builtin_amdgcn_wave_barrier();
-        alive = __ballot(us == us);   // wave-level early out (forward.cu:334-336 votes per block)
+        alive = ballot64(us == us);   // wave-level early out (forward.cu:334-336 votes per block)
     }
 
     uint32_t mx = inside ? st.last : 0u;
@@ -938,7 +942,7 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
             id_next = stager && e_mine - kChunkB >= lo ? a.point_list[range.x + (uint32_t)(e_mine - kChunkB)] : 0u;
             const TileAffine ta = tile_affine(as_quad(q0), as_quad(q1), as_quad(q2), X0, Y0);
             const bool hit = stager & (e_mine >= lo) & block_box_hit(bx, qx, qy) & block_hit_affine(ta, qus0, qus0 + 7.0f * kSqrt2, qvs0, qvs0 + 7.0f * kSqrt2);
-            const unsigned long long m = __ballot(hit);
+            const unsigned long long m = ballot64(hit);
             if (m == 0ull) continue;
             if (hit) {
                 const int slot = lane_rank(m);
@@ -964,7 +968,7 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
                 DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
                 const int e = __builtin_amdgcn_readfirstlane(__float_as_int(q4.z));  // 0-based list index == the reference's `contributor`
                 ok = ok & (e < st.last_contributor);
-                if (__ballot(ok) != 0ull) {
+                if (ballot64(ok) != 0ull) {
                     bool use3d;
                     const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
                     ok = ok & (depth >= kNear);
@@ -986,6 +990,8 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
                     pixbwd_step_affine(st, ev, ok, use3d, depth, e, pfx, pfy, tw.x, tw.y, as_quad(tuv), tw.w, as_quad(q3),
                                        Quad{q4.x, q4.y, 0.f, 0.f}, out, out2d);
 #endif
+                    // (two ballots of plain comparisons and scalar logic: ballot64(ok && !use3d) compiled to a select and a compare per visit)
+                    const bool any2d = (ballot64(ok) & ~ballot64(use3d)) != 0ull;
                     // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
                     float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * kDetRows + q) * kAccFloats
                                      : a.acc + (size_t)__builtin_amdgcn_readfirstlane(__float_as_uint(q4.w)) * kAccFloats;
@@ -1004,7 +1010,7 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
 #else
                     asm volatile("" : : "v"(tot));
 #endif
-                    if (__ballot(ok && !use3d) != 0ull) {  // rare 2-D filter branch (backward.cu:436-443)
+                    if (any2d) {  // rare 2-D filter branch (backward.cu:436-443)
                         const float mx = wave_sum(out2d[0]);
                         const float my = wave_sum(out2d[1]);
                         if (lane == 0) {

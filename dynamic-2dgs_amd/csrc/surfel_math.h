@@ -772,31 +772,40 @@ DGS_HD void pixbwd_step(PixBwd& s, const PairEval& e, bool ok, int contributor, 
 // Backward of one list entry in the affine form (blend_bwd_kernel since round 3).  Same contract as pixbwd_step: branch-free, a
 // pixel that does not blend the entry (`ok` false) runs on neutral values and contributes exact zeros.  Differences:
 //   * the alpha part comes from alpha_affine (e: s, 1/p.z, G, a, ds) and the pair's depth from alpha_depth;
-//   * k.xy, l.xy of the pixel (needed for dL_dk.z, dL_dl.z) are rebuilt from Tu.xy, Tv.xy, Tw.xy: 4 FMAs, only here;
 //   * the distortion terms use the per-pixel products gA = g_dist A, gD = g_dist D, gD2 = g_dist D2 (pixbwd_init_affine):
 //         dL_dweight = g_dist (D2 + m^2 A - 2 m D) = gD2 + m (tz - gD),  tz = m gA - gD
 //         dL_dz      = w (2 tz dm/dd + g_depth)
 //   * u is one FMA chain; 1 / (1 - alpha) needs no select (alpha = 0 gives exactly 1).
+// Round 5 (instruction count; the visit is VALU-issue bound):
+//   * the median contributor's two extra terms cost one comparison and two selects: u's chain STARTS from g_alpha or from the
+//     precomputed g_alpha + g_medw, and dL_dz ends in an FMA onto g_meddepth or 0 (were: compare, two selects, two adds);
+//   * the background term uses the per-pixel product Tf_bg = T_final dot(bg, g_pix);
+//   * dL_dk.z, dL_dl.z and the third row's factor without k.xy, l.xy: with (ax, ay) = dL_dp.xy and c_r = ax r.y - ay r.x for the rows
+//     r = Tu, Tv, Tw of the matrix,  n1 = -dL_dk.z = pfy c_w - c_v,  n2 = -dL_dl.z = c_u - pfx c_w,  and
+//     pfx n1 + pfy n2 = pfy c_u - pfx c_v  (the c_w terms cancel): 10 operations on shorter chains instead of 11;
 struct PixBwdA {
-    float T, T_final, acc;
+    float T, acc;
     float gA, gD, gD2;            // g_dist * (final_A, final_D, final_D2)
-    float g_pix[3], g_depth, g_alpha, g_normal[3], g_meddepth, g_medw, bg_dot;
-    int last_contributor, med_c;
+    float g_pix[3], g_depth, g_alpha, g_normal[3];
+    float g_alpha_med;            // g_alpha + g_medw: where the median contributor's u starts
+    float g_meddepth;
+    float Tf_bg;                  // T_final * dot(bg, g_pix)
+    int last_contributor, med_e;  // med_e: 0-based list index of the median contributor (-1: none)
 };
 
 DGS_HD void pixbwd_init_affine(PixBwdA& s, float T_final, float dist1, float dist2, int last, int med_c, const float* gpix,
                                const float* gothers /*8*/, const float* bg)
 {
-    s.T = s.T_final = T_final;
+    s.T = T_final;
     s.acc = 0.f;
     for (int c = 0; c < 3; c++) s.g_pix[c] = gpix[c];
     const float g_dist = gothers[6];
     s.gA = g_dist * (1.f - T_final); s.gD = g_dist * dist1; s.gD2 = g_dist * dist2;
     s.g_depth = gothers[0]; s.g_alpha = gothers[1];
     s.g_normal[0] = gothers[2]; s.g_normal[1] = gothers[3]; s.g_normal[2] = gothers[4];
-    s.g_meddepth = gothers[5]; s.g_medw = gothers[7];
-    s.bg_dot = bg[0] * gpix[0] + bg[1] * gpix[1] + bg[2] * gpix[2];
-    s.last_contributor = last; s.med_c = med_c;
+    s.g_meddepth = gothers[5]; s.g_alpha_med = gothers[1] + gothers[7];
+    s.Tf_bg = T_final * (bg[0] * gpix[0] + bg[1] * gpix[1] + bg[2] * gpix[2]);
+    s.last_contributor = last; s.med_e = med_c - 1;
 }
 
 // The `u` of pixbwd_step_affine alone (same expressions): what the entry contributes to the "behind" recurrence acc <- acc + alpha (u - acc).
@@ -806,10 +815,9 @@ DGS_HD float pixbwd_u_affine(const PixBwdA& s, bool ok, float depth, int contrib
     const float c_d = ok ? depth : 1.f;
     const float r_d = fast_rcp(c_d);
     const float m_d = kDepthC1 - kDepthC2 * r_d;
-    const bool is_med = ok & (contributor == s.med_c - 1);
+    const bool is_med = ok & (contributor == s.med_e);
     const float tz = m_d * s.gA - s.gD;
-    float u = s.gD2 + m_d * (tz - s.gD) + s.g_alpha;
-    u += is_med ? s.g_medw : 0.f;
+    float u = s.gD2 + m_d * (tz - s.gD) + (is_med ? s.g_alpha_med : s.g_alpha);
     u = q3.w * s.g_pix[0] + (q4.x * s.g_pix[1] + (q4.y * s.g_pix[2] + (q3.x * s.g_normal[0] + (q3.y * s.g_normal[1] + (q3.z * s.g_normal[2] + (c_d * s.g_depth + u))))));
     return u;
 }
@@ -819,10 +827,10 @@ DGS_HD void pixbwd_step_affine(PixBwdA& s, const AlphaEval& e, bool ok, bool use
                                float Twx, float Twy, const Quad& tuv, float opacity, const Quad& q3, const Quad& q4, float* out /*[16]*/,
                                float* out2d /*[2]*/)
 {
-    const bool m3 = ok & use3d;
     const float alpha = ok ? e.alpha : 0.f;
     const float G = ok ? e.G : 0.f;
     const float c_d = ok ? depth : 1.f;
+    const bool m3 = ok & use3d;
     const float sx = m3 ? e.sx : 0.f, sy = m3 ? e.sy : 0.f, inv_pz = m3 ? e.inv_pz : 0.f;
     const float inv_1ma = fast_rcp(1.f - alpha);   // alpha <= 0.99: well conditioned; alpha = 0 gives exactly 1
     s.T = s.T * inv_1ma;
@@ -830,26 +838,24 @@ DGS_HD void pixbwd_step_affine(PixBwdA& s, const AlphaEval& e, bool ok, bool use
     const float r_d = fast_rcp(c_d);
     const float m_d = kDepthC1 - kDepthC2 * r_d;
     const float dmd2 = (2.0f * kDepthC2) * (r_d * r_d);     // 2 d(mapped)/d(depth), backward.cu:352
-    const bool is_med = ok & (contributor == s.med_c - 1);
+    const bool is_med = ok & (contributor == s.med_e);
     const float tz = m_d * s.gA - s.gD;
-    float u = s.gD2 + m_d * (tz - s.gD) + s.g_alpha;
-    u += is_med ? s.g_medw : 0.f;
+    float u = s.gD2 + m_d * (tz - s.gD) + (is_med ? s.g_alpha_med : s.g_alpha);
     u = q3.w * s.g_pix[0] + (q4.x * s.g_pix[1] + (q4.y * s.g_pix[2] + (q3.x * s.g_normal[0] + (q3.y * s.g_normal[1] + (q3.z * s.g_normal[2] + (c_d * s.g_depth + u))))));
     const float d = u - s.acc;
-    const float dL_dalpha = d * s.T - (s.T_final * inv_1ma) * s.bg_dot;
+    const float dL_dalpha = d * s.T - inv_1ma * s.Tf_bg;
     s.acc += alpha * d;
-    float dL_dz = w * (tz * dmd2 + s.g_depth);
-    dL_dz += is_med ? s.g_meddepth : 0.f;
+    const float dL_dz = w * (tz * dmd2 + s.g_depth) + (is_med ? s.g_meddepth : 0.f);
     out[kAccColor + 0] = w * s.g_pix[0]; out[kAccColor + 1] = w * s.g_pix[1]; out[kAccColor + 2] = w * s.g_pix[2];
     out[kAccNormal + 0] = w * s.g_normal[0]; out[kAccNormal + 1] = w * s.g_normal[1]; out[kAccNormal + 2] = w * s.g_normal[2];
     out[kAccOpacity] = G * dL_dalpha;
     const float nGdG = -(G * (opacity * dL_dalpha));   // -G dL_dG
     const float dsx = nGdG * sx + dL_dz * Twx, dsy = nGdG * sy + dL_dz * Twy;
     const float ax = dsx * inv_pz, ay = dsy * inv_pz;   // dL_dp.xy; dL_dp.z = -(ax s.x + ay s.y)
-    const float kx = pfx * Twx - tuv.x, ky = pfx * Twy - tuv.y, lx = pfy * Twx - tuv.z, ly = pfy * Twy - tuv.w;
-    const float n1 = ly * ax - lx * ay;             // -dL_dk.z
-    const float n2 = ay * kx - ax * ky;             // -dL_dl.z
-    const float m3w = dL_dz - (pfx * n1 + pfy * n2);
+    const float c_w = ax * Twy - ay * Twx, c_u = ax * tuv.y - ay * tuv.x, c_v = ax * tuv.w - ay * tuv.z;
+    const float n1 = pfy * c_w - c_v;               // -dL_dk.z
+    const float n2 = c_u - pfx * c_w;               // -dL_dl.z
+    const float m3w = (dL_dz - pfy * c_u) + pfx * c_v;
     out[kAccT + 0] = n1 * sx; out[kAccT + 1] = n1 * sy; out[kAccT + 2] = n1;
     out[kAccT + 3] = n2 * sx; out[kAccT + 4] = n2 * sy; out[kAccT + 5] = n2;
     out[kAccT + 6] = m3w * sx; out[kAccT + 7] = m3w * sy; out[kAccT + 8] = m3w;

@@ -183,9 +183,24 @@ __device__ __forceinline__ float wave_reduce16_lds(float (&v)[16], const RedLds<
     const red_f32x4 x0 = *r.rd[0], x1 = *r.rd[1];
     red_store8(r.m0, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);   // (LDS operations of a wave execute in order: the reads above see round 1)
     const red_f32x4 y0 = *r.rd[0], y1 = *r.rd[1];
-    const float lo = red_row8(red_sum4(x0) + red_sum4(x1));
-    const float hi = red_row8(red_sum4(y0) + red_sum4(y1));
-    return (lane & 4) ? hi : lo;
+    // lane 8 k + p holds an eighth of value k (round 1) and of value k + 8 (round 2).  The two 8-lane sums share their three exchange
+    // steps (round 5; were three DPP adds each + one select): the first step crosses the halves of the group -- lanes p < 4 keep their
+    // round-1 number and receive the round-1 number of lane 7 - p, lanes p >= 4 the same for round 2 -- and the two quad steps then add
+    // like with like.  Two selects + three DPP adds; lanes 8 k .. 8 k + 3 end with the total of v[k], lanes 8 k + 4 .. 8 k + 7 with v[k + 8].
+    const float lo = red_sum4(x0) + red_sum4(x1), hi = red_sum4(y0) + red_sum4(y1);
+    const bool upper = (lane & 4) != 0;
+    const float send = upper ? lo : hi;
+    float keep = upper ? hi : lo;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(keep)
+        : "v"(send));
+    return keep;
 }
 
 }  // namespace dgs
