@@ -18,7 +18,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
             "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard",
-            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged", "dgs_mlp_forward_select", "dgs_mlp_backward_reduce")
+            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged", "dgs_mlp_forward_select", "dgs_mlp_backward_reduce", "dgs_train_ops_set_option")
 
 
 def _deps():
@@ -152,8 +152,12 @@ def load():
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         lib.dgs_densify_accumulate_guarded.restype = ci
         lib.dgs_densify_accumulate_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]
-        if lib.dgs_train_ops_abi_version() != 1:
-            raise RuntimeError("libdgs_train_ops.so ABI version mismatch")
+        lib.dgs_train_ops_set_option.restype = ci
+        lib.dgs_train_ops_set_option.argtypes = [ci, ci]
+        if lib.dgs_train_ops_abi_version() != 2:
+            raise RuntimeError("libdgs_train_ops.so ABI version mismatch (want 2, library says %d): rebuild it" % lib.dgs_train_ops_abi_version())
+        if os.environ.get("DGS_MLP_SPLIT") == "0":   # development A/B (tools/ab_env.sh): the one-stream backward of the node MLP
+            lib.dgs_train_ops_set_option(0, 0)
         _lib = lib
     return _lib
 
@@ -540,6 +544,14 @@ class _FusedNodeMLP(torch.autograd.Function):
             ret = outs
         _mlp_backward_raw(g_attrs, packed, saved, outs, ctx.sink is not None)
         return (None, None, None, None) + tuple(ret)
+
+
+def set_mlp_backward_split(on):
+    """dgs_train_ops_set_option(DGS_TRAIN_OPT_MLP_SPLIT): on (default) = the node MLP's backward chain in two launches with the
+    weight gradients of the first half's layers on a library-owned second stream next to the second half; off = one stream.
+    Bit-identical gradients either way (tests/test_train_ops_gpu.py)."""
+    lib = load()
+    _check(lib, lib.dgs_train_ops_set_option(0, 1 if on else 0), "dgs_train_ops_set_option")
 
 
 def fused_node_mlp(net, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0), grad_sink=False):

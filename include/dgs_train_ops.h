@@ -18,7 +18,8 @@
 extern "C" {
 #endif
 
-#define DGS_TRAIN_OPS_ABI_VERSION 1
+#define DGS_TRAIN_OPS_ABI_VERSION 2   /* 2: dgs_train_ops_set_option; the round-4 additions (dgs_adam_step_origin, dgs_select_row,
+                                         dgs_loss_forward_merged, dgs_mlp_forward_select, dgs_mlp_backward_reduce) are required */
 
 int dgs_train_ops_abi_version(void);
 const char* dgs_train_ops_last_error(void);
@@ -166,6 +167,12 @@ int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_s
 int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
                            const float* rot_bias, float* packed, float* saved, float* attrs, const float* table, int nrows, int row_floats,
                            int* counter, int* override_, int stride, int offset, float* row_out, void* stream);
+/* The backward runs as two halves of the chain on `stream` with the weight gradients of the first half's layers on a second,
+ * library-owned stream next to the second half (forked and joined through events: everything is complete on `stream` when it is,
+ * and a stream capture records the fork as graph edges).  dgs_train_ops_set_option(DGS_TRAIN_OPT_MLP_SPLIT, 0) runs chain and
+ * weight gradients one after the other on `stream` alone; the results are bit-identical either way. */
+#define DGS_TRAIN_OPT_MLP_SPLIT 0
+int dgs_train_ops_set_option(int option, int value);
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream);
 /* dgs_mlp_backward with dgs_deform_reduce folded into its first kernel (lbs_table may be NULL: then exactly dgs_mlp_backward):

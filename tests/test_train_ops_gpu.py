@@ -402,6 +402,60 @@ def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
             close(ref_grads[n], got, "grad %s (sink=%s)" % (n, sink), 2e-4)
 
 
+@pytest.mark.parametrize("M", [64, 1024])
+def test_node_mlp_backward_split_is_bit_identical(M):
+    """The two-stream backward of the node MLP (chain in two launches, the first half's weight gradients on the library's side
+    stream) against the one-stream one: every gradient bit for bit, eagerly and as a replayed graph capture."""
+    from dgs_amd import _ops
+    from dgs_amd.deform import DeformMLP
+    torch.manual_seed(7)
+    net = DeformMLP().cuda()
+    nodes = torch.randn(M, 11, device="cuda") * 0.8
+    t = torch.rand(M, 1, device="cuda")
+    cot = torch.randn(M, 13, device="cuda")
+
+    def grads():
+        for p in net.parameters():
+            p.grad = None
+        out = _ops.fused_node_mlp(net, nodes, t)
+        (out * cot).sum().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net.parameters()]
+
+    try:
+        _ops.set_mlp_backward_split(False)
+        one = grads()
+        _ops.set_mlp_backward_split(True)
+        two = grads()
+        again = grads()
+        for a, b, c, (n, _) in zip(one, two, again, net.named_parameters()):
+            assert torch.equal(a, b), n
+            assert torch.equal(b, c), n
+        # captured: the fork and the join become edges of the graph
+        sink = [torch.zeros_like(p) for p in net.parameters()]
+        for p, g in zip(net.parameters(), sink):
+            p.grad = g
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                out = _ops.fused_node_mlp(net, nodes, t, grad_sink=True)
+                (out * cot).sum().backward()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = _ops.fused_node_mlp(net, nodes, t, grad_sink=True)
+            (out * cot).sum().backward()
+        for g in sink:
+            g.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, g, (n, _) in zip(one, sink, net.named_parameters()):
+            assert torch.equal(a, g), n
+    finally:
+        _ops.set_mlp_backward_split(True)
+
+
 def test_fused_deform_assembled_matches_torch_autograd():
     """ControlNodes.forward_assembled (KNN on split inputs, MFMA node MLP, skinning + surfel activations in one kernel
     per direction, gradients written or added in place) against the PyTorch formulation feeding render()."""
