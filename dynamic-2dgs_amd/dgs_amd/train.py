@@ -343,7 +343,7 @@ class Trainer:
         if self.arap:
             from .arap import lambda_arap
             assert lambda_arap(self.iteration + 1) == 0, "the ARAP regulariser is still active: capture the step after iteration 20000"
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" and os.environ.get("DGS_ALLOW_GRAPH_PACKET_CAPTURE") != "1":   # (the second: tools/diag/graph_knob_probe.py)
             # ROCm 7.2: the AQL-packet-capture replay path intermittently runs the step's memset nodes out of order
             # (observed: an L1 loss term of exactly 0, 1e18 gradients).  The knob is read when the HIP runtime starts.
             raise RuntimeError("set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE importing torch to use "

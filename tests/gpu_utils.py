@@ -89,6 +89,29 @@ def run_hip_raw(case, dev="cuda:0"):
     return out
 
 
+# ---- observed parity margins -----------------------------------------------------------------------------------------------------
+# Every comparison below also RECORDS what it measured (per test and call site), next to what it asserted; tests/conftest.py writes
+# the records to gpurun_out/parity_r05.json at the end of a GPU session and the summary committed under profiles/ is what the
+# asserted tolerances are held against (<= 3x the observed value).
+PARITY_LOG = []
+
+
+def _where():
+    import inspect
+    import os
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    for fr in inspect.stack(0)[2:]:
+        fn = os.path.basename(fr.filename)
+        if fn not in ("gpu_utils.py",):
+            return test, "%s:%d" % (fn, fr.lineno)
+    return test, ""
+
+
+def _record(kind, name, observed, asserted):
+    test, site = _where()
+    PARITY_LOG.append({"test": test, "site": site, "kind": kind, "name": name, "observed": observed, "asserted": asserted})
+
+
 def frac_close(a, b, atol, rtol=0.0, max_bad_frac=0.0, hard_atol=None, name=""):
     """|a-b| <= atol + rtol*|b| everywhere except a fraction max_bad_frac of entries (discrete
     contributor flips at the 1/255 and 1e-4 thresholds), which must still be within hard_atol."""
@@ -97,15 +120,24 @@ def frac_close(a, b, atol, rtol=0.0, max_bad_frac=0.0, hard_atol=None, name=""):
     err = np.abs(a - b)
     bad = err > (atol + rtol * np.abs(b))
     frac = float(bad.mean()) if bad.size else 0.0
+    if err.size:
+        scaled = err / np.maximum(1.0, np.abs(b))   # abs <= 1e-5 max(1, |x|)
+        _record("frac_close", name,
+                {"max_err": float(err.max()), "p9999_err": float(np.quantile(err, 0.9999)), "p999_err": float(np.quantile(err, 0.999)),
+                 "frac_over_asserted": frac, "frac_over_survey_1e-5": float((scaled > 1e-5).mean()), "n": int(err.size)},
+                {"atol": atol, "rtol": rtol, "max_bad_frac": max_bad_frac, "hard_atol": hard_atol})
     assert frac <= max_bad_frac, "%s: %.3e of entries off (max err %.3e)" % (name, frac, float(err.max()))
     if hard_atol is not None and err.size:
         assert float(err.max()) <= hard_atol, "%s: max err %.3e > hard %.3e" % (name, float(err.max()), hard_atol)
 
 
-def rel_l2(a, b):
+def rel_l2(a, b, record=True):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    v = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    if record:
+        _record("rel_l2", "", {"rel_l2": v}, None)   # (the bound is in the assert at the recorded call site)
+    return v
 
 
 def grad_close(a, b, name, tol_trim=2e-4, tol_all=5e-3, trim_frac=1e-3):
@@ -121,6 +153,7 @@ def grad_close(a, b, name, tol_trim=2e-4, tol_all=5e-3, trim_frac=1e-3):
     full = float(np.linalg.norm(e) / denom)
     k = int(np.ceil(trim_frac * e.shape[0]))
     trimmed = float(np.linalg.norm(np.sort(e)[:e.shape[0] - k]) / denom) if e.shape[0] > k else 0.0
+    _record("grad_close", name, {"rel_l2_trimmed": trimmed, "rel_l2_all": full}, {"tol_trim": tol_trim, "tol_all": tol_all, "trim_frac": trim_frac})
     assert trimmed <= tol_trim, "%s: trimmed rel-L2 %.3e" % (name, trimmed)
     assert full <= tol_all, "%s: rel-L2 %.3e" % (name, full)
 

@@ -553,3 +553,27 @@ def test_config_c2_static_forward_only_50k_800():
     frac_close(hip["allmap"], orc.allmap, 1e-4, 5e-5, 1e-4, 2e-1, "allmap")
     mse = float(((hip["color"] - orc.color) ** 2).mean())
     assert mse < 1e-9      # PSNR > 90 dB for a [0, 1] image
+
+
+@pytest.mark.parametrize("H,W", [(2160, 3840), (2400, 3840)])
+def test_uhd_images_bin_in_lds_with_the_order_rider(H, W):
+    """3840 x 2160 is 32 400 tiles = 127 KB of per-workgroup tile cursors, 3840 x 2400 is 36 000 = 141 KB (the most the LDS path takes):
+    the scatter launch of capacity mode carries the dispatch order as a rider workgroup, whose tables have to live INSIDE that dynamic
+    buffer (as static arrays they pushed the launch past the 160 KB a workgroup can have and the launch failed).  Capacity
+    mode (no host read) against the exact-size mode bit for bit, and against the oracle."""
+    from diff_surfel_rasterization import _C
+    from gpu_utils import frac_close, run_hip
+    case = small_case(P=1500, H=H, W=W, seed=21, view=2, scale_mul=6.0)
+    gc, go = _cot(case)
+    exact = run_hip(case, gc, go)
+    _C.set_capacity(4_000_000)
+    try:
+        cap = run_hip(case, gc, go)
+        assert not _C.read_overflow()
+    finally:
+        _C.set_capacity(0)
+    assert np.array_equal(exact["radii"], cap["radii"])
+    assert np.array_equal(exact["color"], cap["color"]) and np.array_equal(exact["allmap"], cap["allmap"])
+    orc = oracle_from_case(case)
+    assert np.array_equal(cap["radii"], orc.radii)
+    frac_close(cap["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
