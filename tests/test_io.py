@@ -204,3 +204,36 @@ def test_scene_from_point_cloud_matches_reference_create_from_pcd():
                            (scene.opacity_logit, "opacity", 1e-6), (scene.feature, "feature", 0), (scene.log_scale, "scaling", 2e-5)):
         assert mine.shape == g[key].shape, key
         np.testing.assert_allclose(mine.numpy(), g[key], rtol=tol, atol=tol, err_msg=key)
+
+
+def test_point_cloud_ply_fields_match_what_the_reference_hands_to_plyfile(tmp_path):
+    """Reference-side half of the PLY pin (tests/golden/make_ply_golden.py): the structured array GaussianModel.save_ply gives
+    to plyfile's PlyElement.describe -- 69 little-endian float32 fields, their names and ORDER, the channel-major SH flattening, zero
+    normals -- is what dgs_amd.io.save_surfels writes, field for field and value for value; and what GaussianModel.load_ply rebuilds
+    from such an element is what load_surfels returns.  (The byte layout of the file itself rests on the PLY specification:
+    `plyfile` is not in the image.)"""
+    g = np.load(os.path.join(GOLD, "ply_golden.npz"))
+    from dgs_amd.synthetic import SurfelScene
+    t = lambda n: torch.from_numpy(g["in_" + n].copy())
+    scene = SurfelScene(t("xyz"), t("scaling"), t("rotation"), t("opacity"), t("f_dc"), t("f_rest"), t("feature"))
+    model = SurfelModel(scene)
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    dio.save_surfels(model, path)
+    v = dio.read_ply(path)
+    assert list(v.dtype.names) == list(g["field_names"])                          # names and order
+    assert [v.dtype[n].str for n in v.dtype.names] == list(g["field_dtypes"])     # '<f4' each
+    mine = np.stack([np.asarray(v[n], np.float64) for n in v.dtype.names], axis=1)
+    assert np.array_equal(mine, g["table"])
+    # header text: what plyfile writes for PlyData([el]) with its defaults (binary, native = little endian), property per field
+    with open(path, "rb") as f:
+        head = f.read(4096).split(b"end_header\n")[0].decode("ascii").split("\n")
+    assert head[0] == "ply" and head[1] == "format binary_little_endian 1.0"
+    assert [h for h in head if h.startswith("element")] == ["element vertex %d" % mine.shape[0]]
+    assert [h.split()[1:] for h in head if h.startswith("property")] == [["float", n] for n in g["field_names"]]
+    # the load side
+    back = dio.load_surfels(path, sh_degree=3, fea_dim=8)
+    for name, got in (("xyz", back.xyz), ("f_dc", back.f_dc), ("f_rest", back.f_rest), ("opacity", back.opacity_logit),
+                      ("scaling", back.log_scale), ("rotation", back.rotation), ("feature", back.feature)):
+        assert got.shape == g["loaded_" + name].shape, name
+        assert np.array_equal(got.numpy(), g["loaded_" + name]), name
+    assert int(g["loaded_active_sh_degree"]) == 3
