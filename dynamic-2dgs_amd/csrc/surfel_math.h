@@ -832,15 +832,10 @@ DGS_HD void pixbwd_step_affine(PixBwdA& s, const AlphaEval& e, bool ok, bool use
     const float c_d = ok ? depth : 1.f;
     const bool m3 = ok & use3d;
     const float sx = m3 ? e.sx : 0.f, sy = m3 ? e.sy : 0.f, inv_pz = m3 ? e.inv_pz : 0.f;
-#if defined(DGS_BWD_ONE_RCP) && DGS_BWD_ONE_RCP
-    // A/B: one reciprocal for 1 / (1 - alpha) and 1 / depth -- r = 1 / ((1 - alpha) depth), two multiplies recover both
-    const float om = 1.f - alpha;
-    const float r_both = fast_rcp(om * c_d);
-    const float inv_1ma = r_both * c_d, r_d = r_both * om;
-#else
+    // (one reciprocal for both -- r = 1 / ((1 - alpha) depth), two multiplies recover 1 / (1 - alpha) and 1 / depth -- was built and
+    // measured in round 5: 0.257 / 0.256 ms against 0.259 / 0.255 for this form, same lease: three multiplies for one v_rcp is a wash)
     const float inv_1ma = fast_rcp(1.f - alpha);   // alpha <= 0.99: well conditioned; alpha = 0 gives exactly 1
     const float r_d = fast_rcp(c_d);
-#endif
     s.T = s.T * inv_1ma;
     const float w = alpha * s.T;
     const float m_d = kDepthC1 - kDepthC2 * r_d;

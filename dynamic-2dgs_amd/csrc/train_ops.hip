@@ -1955,13 +1955,14 @@ long long adam_blocks(int nseg, const long long* off)
     return nb;
 }
 
-// ---- the second stream of the node MLP's backward (dgs_mlp_backward_reduce) -------------------------------------------------------
-// One side stream + two events per device, created on first use and kept: the fork and the join are event dependencies, so they are
-// recorded as edges when the caller's stream is being captured into a graph and cost nothing to re-create per call.  Calls on one
-// device take turns (the mutex covers the enqueue sequence only).
+// ---- the two streams of the node MLP's backward (dgs_mlp_backward_reduce2) --------------------------------------------------------
+// The second stream is the CALLER's: a library-owned one, forked with an event from `stream`, crashes hipStreamEndCapture on ROCm 7.2
+// when `stream` is itself a forked branch of the capture (the trainer runs this backward on a side stream of its captured step) --
+// a stream that joins a capture through an event recorded on a non-origin stream is not unwound.  Both streams the caller passes are
+// branches of the same capture origin (or plain streams), and the two dependencies between them below are ordinary event edges.
+// One pair of events per device, created on first use and kept; calls on one device take turns (the mutex covers the enqueue only).
 std::atomic<bool> g_mlp_split{true};
 struct MlpFork {
-    hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
 std::mutex g_fork_mu;
@@ -1972,11 +1973,10 @@ MlpFork* mlp_fork_for_current_device()
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     MlpFork& f = g_forks[dev];
-    if (!f.side) {
-        if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamDestroy(f.side);
+    if (!f.fork) {
+        if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess) { f = MlpFork{}; return nullptr; }
+        if (hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipEventDestroy(f.fork);
             f = MlpFork{};
             return nullptr;
         }
@@ -2297,13 +2297,21 @@ int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, 
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream)
 {
-    return dgs_mlp_backward_reduce(M, const_cast<float*>(g_attrs), packed, saved, scratch, grads, accumulate, 0, nullptr, nullptr, nullptr, nullptr,
-                                   nullptr, 0, nullptr, stream);
+    return dgs_mlp_backward_reduce2(M, const_cast<float*>(g_attrs), packed, saved, scratch, grads, accumulate, 0, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, 0, nullptr, stream, nullptr);
 }
 
 int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                             int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
                             float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream)
+{
+    return dgs_mlp_backward_reduce2(M, g_attrs, packed, saved, scratch, grads, accumulate, H, node_radius_raw, node_weight_raw, g_nodes, g_radius_raw,
+                                    g_weight_raw, reduce_flags, lbs_table, stream, nullptr);
+}
+
+int dgs_mlp_backward_reduce2(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
+                             int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
+                             float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream, void* stream2)
 {
     if (M <= 0 || M % 64) return fail(-1, "dgs_mlp_backward: M must be a positive multiple of 64");
     if (!g_attrs || !packed || !saved || !scratch || !grads) return fail(-1, "dgs_mlp_backward: null pointer");
@@ -2360,8 +2368,9 @@ int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const fl
     };
 
     MlpFork* f = nullptr;
+    hipStream_t s2 = (hipStream_t)stream2;
     std::unique_lock<std::mutex> lk(g_fork_mu, std::defer_lock);
-    if (g_mlp_split.load()) {
+    if (s2 && s2 != s && g_mlp_split.load()) {
         lk.lock();
         f = mlp_fork_for_current_device();
     }
@@ -2372,14 +2381,14 @@ int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const fl
         launch_wgrad(0, nd, s);
     } else {
         // two streams (node_mlp.h, mlp_bwd_kernel):   s:    chain heads..dZ4 -> chain dZ3..dT1 -> weight gradients L3..T1 -> join
-        //                                              side:                 \-> weight gradients heads..L4 ------------------/
+        //                                              s2:                   \-> weight gradients heads..L4 ------------------/
         hipLaunchKernelGGL(mlp::mlp_bwd_kernel<1>, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
-        if (hipEventRecord(f->fork, s) != hipSuccess || hipStreamWaitEvent(f->side, f->fork, 0) != hipSuccess)
+        if (hipEventRecord(f->fork, s) != hipSuccess || hipStreamWaitEvent(s2, f->fork, 0) != hipSuccess)
             return fail(-2, "dgs_mlp_backward: fork failed");
-        launch_wgrad(0, n_first, f->side);
+        launch_wgrad(0, n_first, s2);
         hipLaunchKernelGGL(mlp::mlp_bwd_kernel<2>, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
         launch_wgrad(n_first, nd - n_first, s);
-        if (hipEventRecord(f->join, f->side) != hipSuccess || hipStreamWaitEvent(s, f->join, 0) != hipSuccess)
+        if (hipEventRecord(f->join, s2) != hipSuccess || hipStreamWaitEvent(s, f->join, 0) != hipSuccess)
             return fail(-2, "dgs_mlp_backward: join failed");
     }
     if (hipGetLastError() != hipSuccess) return fail(-2, "dgs_mlp_backward: launch failed");

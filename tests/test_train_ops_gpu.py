@@ -404,56 +404,68 @@ def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
 
 @pytest.mark.parametrize("M", [64, 1024])
 def test_node_mlp_backward_split_is_bit_identical(M):
-    """The two-stream backward of the node MLP (chain in two launches, the first half's weight gradients on the library's side
-    stream) against the one-stream one: every gradient bit for bit, eagerly and as a replayed graph capture."""
+    """dgs_mlp_backward_reduce2: the backward chain in two launches with the first half's weight gradients on a second stream, against the
+    one-stream call -- every gradient bit for bit; eagerly, and captured in the topology the trainer uses (the backward on a side branch
+    of the capture, the second stream another branch forked from the capture's ORIGIN: a second stream forked from the side branch
+    crashed hipStreamEndCapture on ROCm 7.2, which is why the caller supplies it)."""
     from dgs_amd import _ops
     from dgs_amd.deform import DeformMLP
     torch.manual_seed(7)
     net = DeformMLP().cuda()
     nodes = torch.randn(M, 11, device="cuda") * 0.8
     t = torch.rand(M, 1, device="cuda")
-    cot = torch.randn(M, 13, device="cuda")
+    cot = torch.randn(M, 13, device="cuda").contiguous()
+    mlp = _ops.DeferredNodeMLP(net)
+    sink = [torch.zeros_like(p) for p in net.parameters()]
+    for p, g in zip(net.parameters(), sink):
+        p.grad = g
+    s2 = torch.cuda.Stream()
 
-    def grads():
-        for p in net.parameters():
-            p.grad = None
-        out = _ops.fused_node_mlp(net, nodes, t)
-        (out * cot).sum().backward()
+    def run(stream2):
+        mlp.forward(nodes, t)
+        if stream2 is not None:
+            stream2.wait_stream(torch.cuda.current_stream())
+        mlp.backward(cot, store=True, stream2=stream2)
         torch.cuda.synchronize()
-        return [p.grad.clone() for p in net.parameters()]
+        return [g.clone() for g in sink]
 
+    one = run(None)
+    two = run(s2)
+    again = run(s2)
+    for a, b, c, (n, _) in zip(one, two, again, net.named_parameters()):
+        assert float(a.abs().max()) > 0, n
+        assert torch.equal(a, b), n
+        assert torch.equal(b, c), n
+    _ops.set_mlp_backward_split(False)     # the option: the second stream is ignored
     try:
-        _ops.set_mlp_backward_split(False)
-        one = grads()
+        off = run(s2)
+    finally:
         _ops.set_mlp_backward_split(True)
-        two = grads()
-        again = grads()
-        for a, b, c, (n, _) in zip(one, two, again, net.named_parameters()):
-            assert torch.equal(a, b), n
-            assert torch.equal(b, c), n
-        # captured: the fork and the join become edges of the graph
-        sink = [torch.zeros_like(p) for p in net.parameters()]
-        for p, g in zip(net.parameters(), sink):
-            p.grad = g
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                out = _ops.fused_node_mlp(net, nodes, t, grad_sink=True)
-                (out * cot).sum().backward()
-        torch.cuda.current_stream().wait_stream(side)
+    assert all(torch.equal(a, b) for a, b in zip(one, off))
+
+    # captured like the trainer's step: origin -> side (the backward) and origin -> s2, both joined back into the origin
+    side = torch.cuda.Stream()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        mlp.forward(nodes, t)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = _ops.fused_node_mlp(net, nodes, t, grad_sink=True)
-            (out * cot).sum().backward()
+        with torch.cuda.graph(graph, stream=cap, capture_error_mode="thread_local"):
+            cur = torch.cuda.current_stream()
+            s2.wait_stream(cur)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                packed, saved = mlp.state
+                _ops._mlp_backward_raw(cot, packed, saved, sink, False, stream2=s2)
+            cur.wait_stream(side)
+    torch.cuda.current_stream().wait_stream(cap)
+    for rep in range(3):
         for g in sink:
             g.zero_()
         graph.replay()
         torch.cuda.synchronize()
         for a, g, (n, _) in zip(one, sink, net.named_parameters()):
-            assert torch.equal(a, g), n
-    finally:
-        _ops.set_mlp_backward_split(True)
+            assert torch.equal(a, g), (rep, n)
 
 
 def test_fused_deform_assembled_matches_torch_autograd():
