@@ -665,13 +665,17 @@ class Trainer:
         # explicit unit gradient: loss.backward() alone launches a fill for it every step
         with trace.stage("dgs.backward"):
             self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
+        self._mlp_in_finish = False
         if hasattr(d, "finish_backward") and not self.warmup:   # (warm-up: nothing behind the deformation's outputs trains)
-            d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
+            if self.world == 1 and self.opt_deform is None and fused and d.can_overlap_backward():
+                # single GPU: _finish launches the node-MLP backward, with the surfels' update and the statistics kernels (three
+                # launches, ~25 us of a mostly idle device) on a side branch next to it
+                self._mlp_in_finish = True
+            else:
+                d.finish_backward()
         elif hasattr(d, "run_pending_reduce"):
             d.run_pending_reduce()
-        if getattr(d, "_join_pending", False) and fused:
-            # single GPU: the node-MLP backward now runs on the side stream and is the longer branch; the statistics kernels
-            # (three launches, ~25 us of a mostly idle device) go behind the surfel update instead of in front of it (_finish)
+        if self._mlp_in_finish:
             self._late_stats = (pkg, fused)
         else:
             self._statistics(pkg, fused)
@@ -868,15 +872,18 @@ class Trainer:
                     self.opt_surfels.step(first, n_train, advance=False)
             elif self.warmup:
                 self.opt_surfels.step(0, n_train, advance=adv)
-            elif getattr(self.deform, "_join_pending", False):
-                # the node-MLP backward is still running on the side stream: update the surfels, which do
-                # not depend on it, meanwhile; then join and update the deformation parameters
-                self.opt_surfels.step(0, self.n_surfel_params, advance=adv)
-                if late is not None:
-                    self._statistics(*late)
-                    accumulate()
-                    late = None
-                self.deform.join_backward()
+            elif getattr(self, "_mlp_in_finish", False):
+                # the surfels do not depend on the node-MLP backward: their update (and the statistics) on a side branch next to it,
+                # then the deformation parameters
+                self._mlp_in_finish = False
+                late_now, late = late, None
+
+                def meanwhile():
+                    self.opt_surfels.step(0, self.n_surfel_params, advance=adv)
+                    if late_now is not None:
+                        self._statistics(*late_now)
+                        accumulate()
+                self.deform.finish_backward(meanwhile=meanwhile)
                 self.opt_surfels.step(self.n_surfel_params, None, advance=False)
             else:
                 self.opt_surfels.step(advance=adv)

@@ -405,9 +405,9 @@ def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
 @pytest.mark.parametrize("M", [64, 1024])
 def test_node_mlp_backward_split_is_bit_identical(M):
     """dgs_mlp_backward_reduce2: the backward chain in two launches with the first half's weight gradients on a second stream, against the
-    one-stream call -- every gradient bit for bit; eagerly, and captured in the topology the trainer uses (the backward on a side branch
-    of the capture, the second stream another branch forked from the capture's ORIGIN: a second stream forked from the side branch
-    crashed hipStreamEndCapture on ROCm 7.2, which is why the caller supplies it)."""
+    one-stream call -- every gradient bit for bit; eagerly, and captured in the topology the trainer uses (the chain on the capture's
+    origin stream, every branch forked from and joined into the origin: ROCm 7.2's hipStreamEndCapture crashed on branches of
+    branches, which is why the chain runs on the origin and the caller supplies the second stream)."""
     from dgs_amd import _ops
     from dgs_amd.deform import DeformMLP
     torch.manual_seed(7)
@@ -443,8 +443,10 @@ def test_node_mlp_backward_split_is_bit_identical(M):
         _ops.set_mlp_backward_split(True)
     assert all(torch.equal(a, b) for a, b in zip(one, off))
 
-    # captured like the trainer's step: origin -> side (the backward) and origin -> s2, both joined back into the origin
-    side = torch.cuda.Stream()
+    # captured like the trainer's step: the chain on the capture's origin stream, its second stream and an unrelated branch (the
+    # trainer: the surfels' update) both forked from and joined into the origin
+    other = torch.cuda.Stream()
+    busy = torch.zeros(1 << 20, device="cuda")
     cap = torch.cuda.Stream()
     cap.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(cap):
@@ -452,12 +454,13 @@ def test_node_mlp_backward_split_is_bit_identical(M):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=cap, capture_error_mode="thread_local"):
             cur = torch.cuda.current_stream()
+            other.wait_stream(cur)
+            with torch.cuda.stream(other):
+                busy.add_(1.0)
             s2.wait_stream(cur)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                packed, saved = mlp.state
-                _ops._mlp_backward_raw(cot, packed, saved, sink, False, stream2=s2)
-            cur.wait_stream(side)
+            packed, saved = mlp.state
+            _ops._mlp_backward_raw(cot, packed, saved, sink, False, stream2=s2)
+            cur.wait_stream(other)
     torch.cuda.current_stream().wait_stream(cap)
     for rep in range(3):
         for g in sink:
@@ -466,6 +469,7 @@ def test_node_mlp_backward_split_is_bit_identical(M):
         torch.cuda.synchronize()
         for a, g, (n, _) in zip(one, sink, net.named_parameters()):
             assert torch.equal(a, g), (rep, n)
+    assert float(busy[0]) == 3.0
 
 
 def test_fused_deform_assembled_matches_torch_autograd():
