@@ -166,8 +166,14 @@ def trained_trainer(P, H, W, device, pre_iterations):
     try:
         write_dynamic_dnerf(os.path.join(tmp, "scene"), n_train=48, n_test=2, H=H, W=W, device=device, truth=DynamicTruth(24000, 16000, detail=0.3))
         warm_up, reg_from = (3000, 8000) if pre_iterations >= 10000 else (3 * pre_iterations // 10, 8 * pre_iterations // 10)
+        # deterministic pre-fit (order-free sums instead of float atomics, Trainer.set_deterministic): every run of this workload times the
+        # SAME scene -- with the float atomics the fit's outcome, and with it the timed step, varied by +-6 % from run to run (round 4)
+        det = os.environ.get("DGS_TRAINED_DETERMINISTIC", "1") != "0"
         tr, losses = fit(os.path.join(tmp, "scene"), os.path.join(tmp, "model"), iterations=pre_iterations, device=device, num_pts=P, node_num=512,
-                         seed=0, warm_up=warm_up, regularize_from=reg_from, node_densify_at=10 ** 9)
+                         seed=0, warm_up=warm_up, regularize_from=reg_from, node_densify_at=10 ** 9, deterministic=det)
+        if det:
+            tr.set_deterministic(False)   # the timed steps are the product's default kernels
+        tr.pre_fit_mode = "deterministic" if det else "float atomics"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return tr, losses
@@ -665,6 +671,10 @@ def main():
         if pre_losses is not None:
             k = max(len(pre_losses) // 10, 1)
             out["config"]["pre_training_loss"] = {"first_tenth_mean": round(sum(pre_losses[:k]) / k, 5), "last_tenth_mean": round(sum(pre_losses[-k:]) / k, 5)}
+            out["config"]["pre_fit"] = getattr(tr, "pre_fit_mode", "float atomics")
+            # fingerprint of the fitted scene: equal from run to run exactly when the pre-fit is reproducible
+            out["config"]["pre_fit_fingerprint"] = {"live_surfels": int(tr.surfels.num_surfels), "last_loss": float("%.9g" % pre_losses[-1]),
+                                                    "loss_sum": float("%.12g" % sum(pre_losses))}
         if args.densify_every:
             out["densify"] = {"every": args.densify_every, "calls": len(densify_log), "ms_per_call": [round(m, 3) for m, _ in densify_log],
                               "cloned_split_pruned": [list(map(int, c)) for _, c in densify_log], "slots": tr.P,

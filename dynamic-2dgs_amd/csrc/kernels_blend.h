@@ -800,7 +800,8 @@ struct BlendBwdArgs {
     const float* dL_dpix;     // [3,H,W]
     const float* dL_dothers;  // [8,H,W]
     float* acc;               // [P, kAccFloats], zeroed
-    float* det_part;          // deterministic variant only: [num_rendered][4 waves][kAccFloats], zeroed (see det_reduce_kernel)
+    float* det_part;          // deterministic variant 1 only: [num_rendered][4 waves][kAccFloats], zeroed (see det_reduce_kernel)
+    unsigned long long* acc64; // deterministic variant 2 only: [P, kAccFloats] fixed-point sums (2^-44), zero on entry (fixed_to_acc_kernel)
     const LongThr* long_thr;  // thresholds of the long-tile path, or null (path off: grid = blend_grid_size)
 };
 
@@ -855,9 +856,21 @@ constexpr int kDetRows = DGS_BWD_ROWS ? 16 : 4;   // rows of det_part per list e
 #ifndef DGS_BWD_MINWAVES
 #define DGS_BWD_MINWAVES 5
 #endif
-// DET = false: the per-(wave, entry) sums go into the surfel's accumulator row with hardware float atomics (order of arrival:
-// results differ at the rounding level from run to run, like the reference's).  DET = true (dgs_set_option(7, 1), tests): every
+// DET = 0: the per-(wave, entry) sums go into the surfel's accumulator row with hardware float atomics (order of arrival:
+// results differ at the rounding level from run to run, like the reference's).  DET = 1 (dgs_set_option(7, 1), tests): every
 // (list entry, wave) owns a row of det_part and stores its sums there; det_reduce_kernel adds the rows of a surfel in a fixed order.
+// DET = 2 (dgs_set_option(7, 2), round 5): the sums are added as 64-bit FIXED-POINT numbers (units of 2^-44, |sum| < 2^18) with
+// integer atomics -- integer addition is associative, so the result does not depend on the order of arrival: bit-identical
+// gradients from run to run at the speed of the default kernel, legal inside a captured graph (variant 1 is neither: it allocates
+// per call and searches lists).  The price is the fixed quantum: a partial sum below 6e-14 is lost and one of 1e-9 keeps 4-5
+// digits, where fp32 keeps 7 -- a different (slightly noisier) optimisation than the default, which is why it is an option:
+// reproducible pre-fits (bench.py --workload trained, fit(deterministic=True)) and tests.
+__device__ __forceinline__ unsigned long long to_fixed44(float v)
+{
+    v = fminf(fmaxf(v, -262144.0f), 262144.0f);
+    return (unsigned long long)__float2ll_rn(v * 17592186044416.0f);   // 2^44; two's complement: unsigned wrap-around adds signed numbers
+}
+
 #ifndef DGS_BWD_CHUNK
 #define DGS_BWD_CHUNK 48
 #endif
@@ -878,7 +891,7 @@ struct BwdStage {            // one wave's staging slice: the chunk's visited en
 // wave then composes the quarters behind its own (they were walked by the other waves at the same time) and runs the real pass from
 // the state that reaches it.  1.4 x the arithmetic on a quarter of the critical path; the gradients differ from the serial walk in
 // rounding only (products and sums taken quarter-wise), like two runs of the atomic backward do.
-template <bool DET, bool LONG>
+template <int DET, bool LONG>
 __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, int q, int seg, BwdStage& S, const BwdRedCtx& rc, float* xfer /*LONG: [4][3][64]*/)
 {
     const int ntiles = a.tiles_x * a.tiles_y;
@@ -993,8 +1006,10 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
                     // (two ballots of plain comparisons and scalar logic: ballot64(ok && !use3d) compiled to a select and a compare per visit)
                     const bool any2d = (ballot64(ok) & ~ballot64(use3d)) != 0ull;
                     // wave-uniform row address: keep it on the scalar unit (SGPR base + per-lane offset in the atomic)
-                    float* dst = DET ? a.det_part + ((size_t)(range.x + (uint32_t)e) * kDetRows + q) * kAccFloats
-                                     : a.acc + (size_t)__builtin_amdgcn_readfirstlane(__float_as_uint(q4.w)) * kAccFloats;
+                    const size_t row = DET == 1 ? ((size_t)(range.x + (uint32_t)e) * kDetRows + q) * kAccFloats
+                                                : (size_t)__builtin_amdgcn_readfirstlane(__float_as_uint(q4.w)) * kAccFloats;
+                    float* dst = (DET == 1 ? a.det_part : a.acc) + row;
+                    unsigned long long* dst64 = DET == 2 ? a.acc64 + row : nullptr;
 #if DGS_DIAG_BWD >= 2
                     float tot = 0.f;
                     for (int k = 0; k < 16; k++) asm volatile("" : : "v"(out[k]));
@@ -1004,7 +1019,8 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
 #endif
 #if DGS_DIAG_BWD == 0
                     if (rslot >= 0) {
-                        if (DET) dst[rslot] = tot;
+                        if (DET == 1) dst[rslot] = tot;
+                        else if (DET == 2) atomicAdd(dst64 + rslot, to_fixed44(tot));
                         else atomicAdd(dst + rslot, tot);
                     }
 #else
@@ -1014,7 +1030,8 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
                         const float mx = wave_sum(out2d[0]);
                         const float my = wave_sum(out2d[1]);
                         if (lane == 0) {
-                            if (DET) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
+                            if (DET == 1) { dst[kAccMean2D] = mx; dst[kAccMean2D + 1] = my; }
+                            else if (DET == 2) { atomicAdd(dst64 + kAccMean2D, to_fixed44(mx)); atomicAdd(dst64 + kAccMean2D + 1, to_fixed44(my)); }
                             else { atomicAdd(dst + kAccMean2D, mx); atomicAdd(dst + kAccMean2D + 1, my); }
                         }
                     }
@@ -1049,7 +1066,7 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
     walk(std::false_type{});
 }
 
-template <bool DET>
+template <int DET>
 __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(BlendBwdArgs a)  // workgroups per CU = waves per SIMD the register allocator must allow
 {
     __shared__ BwdStage s_stage[4];
@@ -1087,6 +1104,17 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
 #if DGS_BWD_ROWS
 #include "ab/blend_bwd_rows.h"
 #endif
+
+// Deterministic variant 2: the fixed-point rows -> the float accumulator rows the per-surfel kernel reads; the fixed-point rows are
+// left zeroed for the next backward.
+__global__ void __launch_bounds__(256) fixed_to_acc_kernel(unsigned long long* __restrict__ acc64, float* __restrict__ acc, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long v = (long long)acc64[i];
+    acc64[i] = 0ull;
+    acc[i] = (float)((double)v * (1.0 / 17592186044416.0));
+}
 
 // Deterministic reduction of the backward blend (test option): one thread per surfel walks the tiles of its rectangle in
 // row-major order, finds its entry in the tile's sorted list and adds the four waves' rows in order 0..3.  Same sums as the

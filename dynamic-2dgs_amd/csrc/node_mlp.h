@@ -434,15 +434,6 @@ struct BwdArgs {
     ReduceFold fold;
 };
 
-// PART: 0 the whole chain; 1 heads .. dZ4 (and the L5 stage's part of the time-net gradient, parked in the dT2 rows of the scratch);
-// 2 dZ3 .. dT1 from the stored dZ4.  The two halves are one launch each (dgs_mlp_backward_reduce): the weight gradients of the
-// layers the first half has finished run on a second stream NEXT TO the second half instead of behind the whole chain -- the tail of
-// the train step is this chain, then the weight gradients, then the deformation's Adam update, all on one critical path.
-// (Why not one launch of both with per-layer device flags: a waiting weight-gradient workgroup and a chain workgroup never share a CU
-// -- 4 x 120 and 4 x 128 registers per SIMD -- so waiters that get dispatched first can keep the chain off the device for good, and
-// inside ONE launch, where dispatch order would protect the chain, the two roles fill all 256 CUs and starve the surfels' Adam update
-// that runs next to them)
-template <int PART>
 __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sA[kRows * kSA];
@@ -459,15 +450,11 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
 #define BW(l, row) (a.wq + (BOff<l>::v + (row) * b_C(l) + cg * 64))
 #define BN(l, col0) (a.wq + (BOff<l>::v + wave * 4 * b_C(l) + (col0)))
     float4 q0[kChunk], q1[kChunk];
-    f32x4 acc[2];
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* hs = a.saved + (size_t)(row0 + fv) * kW + fc;
-    float h0, h1;
-    if constexpr (PART != 2) {
     frag_load<1>(q0, BW(10, kq), kW, lane);                  // heads
     frag_load<8>(q1, BW(9, kq * 16), kW, lane);              // L7, first half
     // the ReLU masks are the saved post-activation values of this thread's two outputs (rows fv and 4 + fv, column fc)
-    h0 = hs[sv_h(M, 7)]; h1 = hs[sv_h(M, 7) + 4 * kW];
+    const float* hs = a.saved + (size_t)(row0 + fv) * kW + fc;
+    float h0 = hs[sv_h(M, 7)], h1 = hs[sv_h(M, 7) + 4 * kW];
     if (a.fold.table) {
         const ReduceFold& f = a.fold;
         const int T = 3 + f.H;
@@ -499,20 +486,9 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
         }
     }
     __syncthreads();
-    } else {
-        // second half: dZ4 of this workgroup's rows back into LDS (what finish_dz left there), the L5 stage's share of the time-net
-        // gradient, the masks of H3 and the first operand chunks of L4 -- the state the whole chain has at this point
-        const float* dz4 = a.scratch + sc_dz(M, 4) + (size_t)row0 * kW;
-        sB[fv * kSA + fc] = dz4[fv * kW + fc];
-        sB[(4 + fv) * kSA + fc] = dz4[(4 + fv) * kW + fc];
-        if (tid < 512 && lane < 32) sD[(tid >> 6) * kSD + lane] = a.scratch[sc_dt2(M) + (size_t)(row0 + (tid >> 6)) * 32 + lane];
-        h0 = hs[sv_h(M, 3)]; h1 = hs[sv_h(M, 3) + 4 * kW];
-        frag_load<8>(q0, BW(6, kq * 16), kW, lane);
-        frag_load<8>(q1, BW(6, kq * 16 + 8), kW, lane);
-        acc[0] = zero; acc[1] = zero;
-        __syncthreads();
-    }
 
+    f32x4 acc[2];
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     // partial sums -> ReLU mask -> dZ to LDS (when the chain goes on) and to the scratch; then the mask of the next stage
     auto finish_dz = [&](float* __restrict__ sdst, float* __restrict__ gdst /* + row0 * 256 */, size_t next_mask) {
         part_store(sPart, wave, lane, acc);
@@ -532,7 +508,6 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
     const float* rA = sA + r8 * kSA;
     const float* rB = sB + r8 * kSA;
 
-    if constexpr (PART != 2) {
     // heads: dZ7 = (g_attrs[8 x 16] * Wh) * [H7 > 0]
     acc[0] = zero; acc[1] = zero;
     frag_mma<1>(q0, sG + r8 * kSG + kq * 4, acc);
@@ -553,21 +528,15 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
         frag_mma<8>(q1, rA + kq * 64, acc);
         frag_load<4>(q1, BN(7, kW), b_C(7), lane);
         frag_mma<8>(q0, rA + kq * 64 + 32, acc);
-        if constexpr (PART == 0) frag_load<8>(q0, BW(6, kq * 16), kW, lane);          // L4, first half
+        frag_load<8>(q0, BW(6, kq * 16), kW, lane);          // L4, first half
         f32x4 accn[2] = {zero, zero};
         frag_mma<4>(q1, rA + wave * 16, accn);
-        if constexpr (PART == 0) frag_load<8>(q1, BW(6, kq * 16 + 8), kW, lane);
+        frag_load<8>(q1, BW(6, kq * 16 + 8), kW, lane);
         part_store(sPartN, wave, lane, accn);
         finish_dz(sB, a.scratch + sc_dz(M, 4) + (size_t)row0 * kW, sv_h(M, 3));
         // (sPartN is complete after the first barrier of finish_dz; sD is read two stages later)
-        if (tid < 512 && lane < 32) {
-            const float v = part_sum_narrow(sPartN, tid >> 6, lane);
-            if constexpr (PART == 1) a.scratch[sc_dt2(M) + (size_t)(row0 + (tid >> 6)) * 32 + lane] = v;   // parked for the second half
-            else sD[(tid >> 6) * kSD + lane] = v;
-        }
+        if (tid < 512 && lane < 32) sD[(tid >> 6) * kSD + lane] = part_sum_narrow(sPartN, tid >> 6, lane);
     }
-    }
-    if constexpr (PART == 1) return;
     DGRAD(rB, sA, 4, frag_load<8>(q0, BW(5, kq * 16), kW, lane), frag_load<8>(q1, BW(5, kq * 16 + 8), kW, lane), q0, q1);
     DGRAD(rA, sB, 3, frag_load<8>(q0, BW(4, kq * 16), kW, lane), frag_load<8>(q1, BW(4, kq * 16 + 8), kW, lane), q0, q1);
     DGRAD(rB, sA, 2, frag_load<8>(q0, BW(3, kq * 16), kW, lane), frag_load<8>(q1, BW(3, kq * 16 + 8), kW, lane), q0, q1);

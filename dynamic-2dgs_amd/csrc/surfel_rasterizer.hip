@@ -207,7 +207,9 @@ struct dgs_context {
     std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
     std::atomic<int> sort_regs{2};    // per-tile sort: 2 LSD radix in LDS (default), 1 bitonic network in registers, 0 bitonic in LDS
     std::atomic<int> tile_order{3};   // kernels_blend.h tile_for_block (3 = longest tile first)
-    std::atomic<int> deterministic{0};   // key 7: backward blend without atomics, fixed summation order (tests)
+    std::atomic<int> deterministic{0};   // key 7: 1 backward blend without atomics, fixed summation order (tests); 2 fixed-point integer atomics
+    unsigned long long* acc64 = nullptr; // key 7 = 2: [P, kAccFloats] fixed-point accumulator rows, zero between backward passes
+    size_t acc64_rows = 0;
     std::atomic<int> sh_all_rows{0};     // key 8: dL_dsh written for every row (zeros for culled surfels / unused bands)
     std::atomic<int> long_tiles{1};      // key 9: four workgroups (one per quadrant, four list quarters each) for the longest tiles
     // Measured (tools/diag/long_tune.py, blend fwd / bwd in ms; uniform 200k scene | ONE densified scene, 88 k surfels, kept as a checkpoint):
@@ -337,6 +339,7 @@ void dgs_context_destroy(dgs_context* c)
             if (d == c) d = nullptr;
     }
     if (c->overflow_owned) (void)hipFree(c->overflow_owned);
+    if (c->acc64) (void)hipFree(c->acc64);
     if (c->stage.u) (void)hipHostFree(c->stage.u);
     if (c->prof.counters) (void)hipFree(c->prof.counters);
     if (c->prof.ring) (void)hipFree(c->prof.ring);
@@ -351,7 +354,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
     if (key == 0) { c->tight_rects.store(value != 0); return DGS_OK; }
     if (key == 1 && value >= 0 && value <= 4) { c->tile_order.store(value); return DGS_OK; }
-    if (key == 7) { c->deterministic.store(value != 0); return DGS_OK; }
+    if (key == 7 && value >= 0 && value <= 2) { c->deterministic.store(value); return DGS_OK; }
     if (key == 8) { c->sh_all_rows.store(value != 0); return DGS_OK; }
     if (key == 9) { c->long_tiles.store(value != 0); return DGS_OK; }
     if (key == 10 && value > 0) { c->long_div_fwd.store(value); return DGS_OK; }
@@ -848,7 +851,32 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         if (const int lim = ctx->grid_limit_bwd.load()) grid = lim < grid ? lim : grid;
         Prof::Pair pp;
         const bool timed = prof_begin(ctx, 1, stream, pp);
-        if (ctx->deterministic.load()) {
+        const int det = ctx->deterministic.load();
+        if (det == 2) {
+            // fixed-point sums with integer atomics: order-free, capturable.  The rows live in the context (zero between backward
+            // passes: fixed_to_acc_kernel clears what it converts); they are (re)allocated outside a capture only
+            {
+                std::lock_guard<std::mutex> lk(ctx->mu);
+                if (ctx->acc64_rows < (size_t)P) {
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    (void)hipStreamIsCapturing(stream, &cs);
+                    if (cs != hipStreamCaptureStatusNone)
+                        return fail(DGS_ERR_INVALID_ARGUMENT, "deterministic backward (option 7 = 2): the fixed-point rows must exist before a capture (run one eager backward at this size first)");
+                    DGS_HIP(hipStreamSynchronize(stream));
+                    if (ctx->acc64) (void)hipFree(ctx->acc64);
+                    ctx->acc64 = nullptr; ctx->acc64_rows = 0;
+                    const size_t rows = (size_t)P + (size_t)P / 4 + 1024;
+                    DGS_HIP(hipMalloc((void**)&ctx->acc64, rows * dgs::kAccFloats * sizeof(unsigned long long)));
+                    DGS_HIP(hipMemset(ctx->acc64, 0, rows * dgs::kAccFloats * sizeof(unsigned long long)));
+                    ctx->acc64_rows = rows;
+                }
+            }
+            ba.det_part = nullptr;
+            ba.acc64 = ctx->acc64;
+            hipLaunchKernelGGL(dgs::blend_bwd_kernel<2>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+            const size_t n = (size_t)P * dgs::kAccFloats;
+            hipLaunchKernelGGL(dgs::fixed_to_acc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ctx->acc64, acc, n);
+        } else if (det == 1) {
             // test option: every (list entry, wave) stores its sums in a row of its own, a per-surfel kernel adds them in a fixed
             // order.  R x 320 bytes of scratch from the stream-ordered allocator (not capturable: tests run eagerly)
             float* part = nullptr;
@@ -859,17 +887,18 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
 #if DGS_BWD_ROWS
             hipLaunchKernelGGL(dgs::blend_bwd_rows_kernel<true>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
 #else
-            hipLaunchKernelGGL(dgs::blend_bwd_kernel<true>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+            hipLaunchKernelGGL(dgs::blend_bwd_kernel<1>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
 #endif
             hipLaunchKernelGGL(dgs::det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, radii,
                                (const uint2*)(geom_buffer + gl.rects), il.tiles_x, ba.ranges, ba.point_list, (const float*)part, acc);
             DGS_HIP(hipFreeAsync(part, stream));
         } else {
             ba.det_part = nullptr;
+            ba.acc64 = nullptr;
 #if DGS_BWD_ROWS
             hipLaunchKernelGGL(dgs::blend_bwd_rows_kernel<false>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
 #else
-            hipLaunchKernelGGL(dgs::blend_bwd_kernel<false>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
+            hipLaunchKernelGGL(dgs::blend_bwd_kernel<0>, dim3(grid), dim3(dgs::kTilePix), 0, stream, ba);
 #endif
         }
         if (timed) prof_end(ctx, stream, pp, ba.tile_last, il.ntiles);

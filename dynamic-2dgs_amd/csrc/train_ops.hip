@@ -8,10 +8,7 @@
 // (<= 1024 x 16 floats) live in LDS, one thread per query point keeps its K best in registers.
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <cmath>
-#include <map>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1955,47 +1952,12 @@ long long adam_blocks(int nseg, const long long* off)
     return nb;
 }
 
-// ---- the two streams of the node MLP's backward (dgs_mlp_backward_reduce2) --------------------------------------------------------
-// The second stream is the CALLER's: a library-owned one, forked with an event from `stream`, crashes hipStreamEndCapture on ROCm 7.2
-// when `stream` is itself a forked branch of the capture (the trainer runs this backward on a side stream of its captured step) --
-// a stream that joins a capture through an event recorded on a non-origin stream is not unwound.  Both streams the caller passes are
-// branches of the same capture origin (or plain streams), and the two dependencies between them below are ordinary event edges.
-// One pair of events per device, created on first use and kept; calls on one device take turns (the mutex covers the enqueue only).
-std::atomic<bool> g_mlp_split{true};
-struct MlpFork {
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-std::mutex g_fork_mu;
-std::map<int, MlpFork> g_forks;
-
-MlpFork* mlp_fork_for_current_device()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    MlpFork& f = g_forks[dev];
-    if (!f.fork) {
-        if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess) { f = MlpFork{}; return nullptr; }
-        if (hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipEventDestroy(f.fork);
-            f = MlpFork{};
-            return nullptr;
-        }
-    }
-    return &f;
-}
-
 }  // namespace
 
 extern "C" {
 
 int dgs_train_ops_abi_version(void) { return DGS_TRAIN_OPS_ABI_VERSION; }
 const char* dgs_train_ops_last_error(void) { return g_err.c_str(); }
-
-int dgs_train_ops_set_option(int option, int value)
-{
-    if (option == DGS_TRAIN_OPT_MLP_SPLIT) { g_mlp_split.store(value != 0); return 0; }
-    return fail(-1, "dgs_train_ops_set_option: unknown option");
-}
 
 int dgs_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_sum, float* dm_dmu1,
                      float* dm_dsigma1_sq, float* dm_dsigma12, void* stream)
@@ -2297,21 +2259,13 @@ int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, 
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream)
 {
-    return dgs_mlp_backward_reduce2(M, const_cast<float*>(g_attrs), packed, saved, scratch, grads, accumulate, 0, nullptr, nullptr, nullptr, nullptr,
-                                    nullptr, 0, nullptr, stream, nullptr);
+    return dgs_mlp_backward_reduce(M, const_cast<float*>(g_attrs), packed, saved, scratch, grads, accumulate, 0, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, 0, nullptr, stream);
 }
 
 int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                             int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
                             float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream)
-{
-    return dgs_mlp_backward_reduce2(M, g_attrs, packed, saved, scratch, grads, accumulate, H, node_radius_raw, node_weight_raw, g_nodes, g_radius_raw,
-                                    g_weight_raw, reduce_flags, lbs_table, stream, nullptr);
-}
-
-int dgs_mlp_backward_reduce2(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
-                             int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
-                             float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream, void* stream2)
 {
     if (M <= 0 || M % 64) return fail(-1, "dgs_mlp_backward: M must be a positive multiple of 64");
     if (!g_attrs || !packed || !saved || !scratch || !grads) return fail(-1, "dgs_mlp_backward: null pointer");
@@ -2325,15 +2279,15 @@ int dgs_mlp_backward_reduce2(int M, float* g_attrs, const float* packed, const f
         b.fold = mlp::ReduceFold{(float*)lbs_table, kLbsAttr + H + 2, H, node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw,
                                  g_attrs, reduce_flags & 1, (reduce_flags & 4) ? 1 : 0};
     b.wq = reinterpret_cast<const float4*>(packed) + (size_t)mlp::kFwdVecs;
+    hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
 
-    // weight-gradient descriptors in the order the chain finishes their dZ: heads, L7 .. L1, L0, time net 2, time net 1
     mlp::WgArgs g{};
     g.M = M; g.accumulate = accumulate;
     int r = 0;
     for (int h = 0; h < 4; h++)
         for (int k = 0; k < kHeadRows[h]; k++, r++) { g.hw[r] = grads[20 + 2 * h] + (size_t)k * mlp::kW; g.hb[r] = grads[21 + 2 * h] + k; }
     for (; r < 16; r++) { g.hw[r] = g.hw[0]; g.hb[r] = g.hb[0]; }
-    int nd = 0;
+    int nd = 0, block = 0;
     auto add = [&](const float* dz, int dzs, int out, const float* x, int xs, int in, float* dw, int dws, float* db) {
         mlp::WgDesc& d = g.d[nd++];
         d.dz = dz; d.dz_stride = dzs; d.out = out; d.x = x; d.x_stride = xs; d.in = in; d.dw = dw; d.dw_stride = dws; d.db = db;
@@ -2344,7 +2298,6 @@ int dgs_mlp_backward_reduce2(int M, float* g_attrs, const float* packed, const f
     auto Hs = [&](int l) { return saved + mlp::sv_h(M, l); };
     auto dZ = [&](int l) { return scratch + mlp::sc_dz(M, l); };
     add(g_attrs, mlp::kHeads, mlp::kHeads, Hs(7), W, W, nullptr, W, nullptr);                          // heads
-    int n_first = 0;   // descriptors whose dZ the first half of the chain writes: heads, L7, L6, L5 (two), L4
     for (int l = 7; l >= 1; l--) {
         float* gw = grads[2 * (l + 2)];
         float* gb = grads[2 * (l + 2) + 1];
@@ -2354,43 +2307,13 @@ int dgs_mlp_backward_reduce2(int M, float* g_attrs, const float* packed, const f
         } else {
             add(dZ(l), W, W, Hs(l - 1), W, W, gw, W, gb);
         }
-        if (l == 4) n_first = nd;
     }
     add(dZ(0), W, W, saved + mlp::sv_inp(M), mlp::kInPad, mlp::kIn, grads[4], mlp::kIn, grads[5]);   // L0
     add(scratch + mlp::sc_dt2(M), 32, mlp::kTOut, saved + mlp::sv_t1(M), W, W, grads[2], W, grads[3]);        // time net 2
     add(scratch + mlp::sc_dt1(M), W, W, saved + mlp::sv_et(M), mlp::kTPad, mlp::kTCh, grads[0], mlp::kTCh, grads[1]);  // time net 1
-    auto launch_wgrad = [&](int first, int count, hipStream_t st) {
-        mlp::WgArgs part = g;
-        for (int i = 0; i < count; i++) part.d[i] = g.d[first + i];
-        part.ndesc = count;
-        const int blocks = mlp::wg_place(part);
-        hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(blocks), dim3(mlp::kWgThreads), 0, st, part);
-    };
-
-    MlpFork* f = nullptr;
-    hipStream_t s2 = (hipStream_t)stream2;
-    std::unique_lock<std::mutex> lk(g_fork_mu, std::defer_lock);
-    if (s2 && s2 != s && g_mlp_split.load()) {
-        lk.lock();
-        f = mlp_fork_for_current_device();
-    }
-    if (!f) {
-        // one stream: the whole chain, then all weight gradients
-        if (lk.owns_lock()) lk.unlock();
-        hipLaunchKernelGGL(mlp::mlp_bwd_kernel<0>, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
-        launch_wgrad(0, nd, s);
-    } else {
-        // two streams (node_mlp.h, mlp_bwd_kernel):   s:    chain heads..dZ4 -> chain dZ3..dT1 -> weight gradients L3..T1 -> join
-        //                                              s2:                   \-> weight gradients heads..L4 ------------------/
-        hipLaunchKernelGGL(mlp::mlp_bwd_kernel<1>, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
-        if (hipEventRecord(f->fork, s) != hipSuccess || hipStreamWaitEvent(s2, f->fork, 0) != hipSuccess)
-            return fail(-2, "dgs_mlp_backward: fork failed");
-        launch_wgrad(0, n_first, s2);
-        hipLaunchKernelGGL(mlp::mlp_bwd_kernel<2>, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
-        launch_wgrad(n_first, nd - n_first, s);
-        if (hipEventRecord(f->join, s2) != hipSuccess || hipStreamWaitEvent(s, f->join, 0) != hipSuccess)
-            return fail(-2, "dgs_mlp_backward: join failed");
-    }
+    g.ndesc = nd;
+    block = mlp::wg_place(g);
+    hipLaunchKernelGGL(mlp::mlp_wgrad_kernel, dim3(block), dim3(mlp::kWgThreads), 0, s, g);
     if (hipGetLastError() != hipSuccess) return fail(-2, "dgs_mlp_backward: launch failed");
     return 0;
 }

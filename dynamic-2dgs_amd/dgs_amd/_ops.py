@@ -18,7 +18,7 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
             "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard",
-            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged", "dgs_mlp_forward_select", "dgs_mlp_backward_reduce", "dgs_train_ops_set_option", "dgs_mlp_backward_reduce2")
+            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged", "dgs_mlp_forward_select", "dgs_mlp_backward_reduce")
 
 
 def _deps():
@@ -94,8 +94,6 @@ def load():
         lib.dgs_mlp_backward.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp]
         lib.dgs_mlp_backward_reduce.restype = ci
         lib.dgs_mlp_backward_reduce.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp]
-        lib.dgs_mlp_backward_reduce2.restype = ci
-        lib.dgs_mlp_backward_reduce2.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp]
         lib.dgs_knn_points2.restype = ci
         lib.dgs_knn_points2.argtypes = [ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
         lib.dgs_knn_refine.restype = ci
@@ -154,12 +152,8 @@ def load():
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         lib.dgs_densify_accumulate_guarded.restype = ci
         lib.dgs_densify_accumulate_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]
-        lib.dgs_train_ops_set_option.restype = ci
-        lib.dgs_train_ops_set_option.argtypes = [ci, ci]
         if lib.dgs_train_ops_abi_version() != 2:
             raise RuntimeError("libdgs_train_ops.so ABI version mismatch (want 2, library says %d): rebuild it" % lib.dgs_train_ops_abi_version())
-        if os.environ.get("DGS_MLP_SPLIT") == "0":   # development A/B (tools/ab_env.sh): the one-stream backward of the node MLP
-            lib.dgs_train_ops_set_option(0, 0)
         _lib = lib
     return _lib
 
@@ -493,29 +487,26 @@ def _mlp_forward_raw(x, t, rot_bias, params, select=None):
     return attrs, packed, saved
 
 
-def _mlp_backward_raw(g_attrs, packed, saved, outs, accumulate, fold=None, stream2=None):
+def _mlp_backward_raw(g_attrs, packed, saved, outs, accumulate, fold=None):
     """fold: None, or the arguments of a deferred node-table reduction (the closure's fold_args, see _FusedDeform.backward):
     (M, H, node_radius, node_weight, g_nodes, g_radius, g_weight, g_attrs, flags, table) -- dgs_mlp_backward_reduce then reduces the
-    table inside the backward chain's first kernel and WRITES g_attrs.
-    stream2: a second torch stream for the weight gradients of the chain's first half (dgs_mlp_backward_reduce2: under capture it must
-    have been forked from the capture's ORIGIN stream by the caller); None = everything on the current stream."""
+    table inside the backward chain's first kernel and WRITES g_attrs."""
     lib = load()
     dev = packed.device
     M = g_attrs.shape[0]
     scratch = torch.empty(int(lib.dgs_mlp_scratch_floats(M)), dtype=torch.float32, device=dev)
     ptrs = (ctypes.c_void_p * 28)(*[o.data_ptr() for o in outs])
-    s2 = None if stream2 is None else ctypes.c_void_p(stream2.cuda_stream)
     with torch.cuda.device(dev):
         if fold is None:
-            rc = lib.dgs_mlp_backward_reduce2(M, g_attrs.data_ptr(), packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(), ptrs,
-                                              1 if accumulate else 0, 0, None, None, None, None, None, 0, None, _stream(dev), s2)
+            rc = lib.dgs_mlp_backward(M, g_attrs.data_ptr(), packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(), ptrs,
+                                      1 if accumulate else 0, _stream(dev))
         else:
             fM, H, nr, nw, g_nodes, g_rad, g_w, fg, flags, table = fold
             if fM != M or fg.data_ptr() != g_attrs.data_ptr():
                 raise RuntimeError("node MLP backward: the deferred reduction belongs to another attribute table")
-            rc = lib.dgs_mlp_backward_reduce2(M, g_attrs.data_ptr(), packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(), ptrs,
-                                              1 if accumulate else 0, H, nr.data_ptr(), nw.data_ptr(), g_nodes.data_ptr(), g_rad.data_ptr(),
-                                              g_w.data_ptr(), int(flags), table.data_ptr(), _stream(dev), s2)
+            rc = lib.dgs_mlp_backward_reduce(M, g_attrs.data_ptr(), packed.data_ptr(), saved.data_ptr(), scratch.data_ptr(), ptrs,
+                                             1 if accumulate else 0, H, nr.data_ptr(), nw.data_ptr(), g_nodes.data_ptr(), g_rad.data_ptr(),
+                                             g_w.data_ptr(), int(flags), table.data_ptr(), _stream(dev))
     _check(lib, rc, "dgs_mlp_backward")
 
 
@@ -549,14 +540,6 @@ class _FusedNodeMLP(torch.autograd.Function):
             ret = outs
         _mlp_backward_raw(g_attrs, packed, saved, outs, ctx.sink is not None)
         return (None, None, None, None) + tuple(ret)
-
-
-def set_mlp_backward_split(on):
-    """dgs_train_ops_set_option(DGS_TRAIN_OPT_MLP_SPLIT): on (default) = a caller that hands the node MLP's backward a second stream
-    gets the chain in two launches with the weight gradients of the first half's layers on that stream next to the second half; off =
-    the second stream is ignored.  Bit-identical gradients either way (tests/test_train_ops_gpu.py)."""
-    lib = load()
-    _check(lib, lib.dgs_train_ops_set_option(0, 1 if on else 0), "dgs_train_ops_set_option")
 
 
 def fused_node_mlp(net, x, t, rot_bias=(1.0, 0.0, 0.0, 0.0), grad_sink=False):
@@ -625,14 +608,14 @@ class DeferredNodeMLP:
         return attrs
 
     @torch.no_grad()
-    def backward(self, g_attrs, store=False, fold=None, stream2=None):
+    def backward(self, g_attrs, store=False, fold=None):
         """store=True: the parameter gradients are overwritten instead of added to (a buffer that is never cleared).
-        fold: a deferred node-table reduction to run inside the first kernel; stream2: see _mlp_backward_raw."""
+        fold: a deferred node-table reduction to run inside the first kernel (_mlp_backward_raw)."""
         packed, saved = self.state
         sink = [p.grad for p in self.params]
         if any(g is None or not g.is_contiguous() for g in sink):
             raise RuntimeError("DeferredNodeMLP.backward: every parameter needs a contiguous .grad")
-        _mlp_backward_raw(g_attrs, packed, saved, sink, not store, fold=fold, stream2=stream2)
+        _mlp_backward_raw(g_attrs, packed, saved, sink, not store, fold=fold)
         self.state = None
 
 

@@ -22,11 +22,13 @@ from .train import Trainer
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
-        arap=False, warm_up=3000, regularize_from=8000, on_iteration=None):
+        arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot).  warm_up / regularize_from: the
     reference's stages (train_gui.py:282-285: deformation detached while iteration < opt.warm_up; :292-293: normal and
-    distortion regularisers off until iteration 8000).  on_iteration(it, trainer): optional hook after every iteration."""
+    distortion regularisers off until iteration 8000).  on_iteration(it, trainer): optional hook after every iteration.
+    deterministic=True (HIP path): Trainer.set_deterministic -- order-free sums instead of float atomics; two fits with the same
+    arguments end bit-identical.  The trainer is returned in that mode (set_deterministic(False) restores the float atomics)."""
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
@@ -44,6 +46,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True, arap=arap)
     if graph is None:
         graph = on_gpu
+    if deterministic:
+        tr.set_deterministic(True)
     if on_gpu:
         tr.sort_surfels()
     tr.arap_from = warm_up                                             # opt.warm_up (arguments/__init__.py:102)

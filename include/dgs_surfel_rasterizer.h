@@ -150,7 +150,10 @@ void dgs_set_tight_rects(int on);
  *         hipStreamBeginCapture / torch.cuda.graph; dgs_rasterizer_forward then returns `value`.  A frame whose lists do
  *         not fit renders as background and raises the overflow flag; value 0 restores the exact-size mode,
  * key 3 = per-tile sort: 2 LSD radix sort in LDS [default], 1 bitonic network with the keys in registers, 0 bitonic network in LDS,
- * key 7 = deterministic backward (0 [default] / 1): the backward blend stores its per-(list entry, wave) sums instead of adding them
+ * key 7 = deterministic backward (0 [default] / 1 / 2).  2: the sums are added as 64-bit fixed-point numbers (2^-44) with integer
+ *         atomics -- order-free, hence bit-identical from run to run, at the default kernel's speed and legal under stream capture
+ *         (the context keeps [P, 20] 64-bit rows; they must exist before a capture: run one eager backward first); partial sums are
+ *         quantised to 6e-14.  1: the backward blend stores its per-(list entry, wave) sums instead of adding them
  *         with float atomics and a per-surfel kernel adds them in a fixed order -- bit-identical gradients from run to run.  For
  *         tests: R x 320 bytes of scratch (R x 1280 with the row-per-block A/B kernel) from hipMallocAsync (not capturable), a linear search per (surfel, tile).
  * key 8 = dL_dsh of the backward written for EVERY row and coefficient (0 [default]: visible rows and the active bands only, as the

@@ -18,8 +18,8 @@
 extern "C" {
 #endif
 
-#define DGS_TRAIN_OPS_ABI_VERSION 2   /* 2: dgs_train_ops_set_option, dgs_mlp_backward_reduce2; the round-4 additions (dgs_adam_step_origin, dgs_select_row,
-                                         dgs_loss_forward_merged, dgs_mlp_forward_select, dgs_mlp_backward_reduce) are required */
+#define DGS_TRAIN_OPS_ABI_VERSION 2   /* 2: the round-4 additions (dgs_adam_step_origin, dgs_select_row, dgs_loss_forward_merged,
+                                         dgs_mlp_forward_select, dgs_mlp_backward_reduce) are required exports */
 
 int dgs_train_ops_abi_version(void);
 const char* dgs_train_ops_last_error(void);
@@ -167,9 +167,6 @@ int dgs_mlp_forward(int M, const float* x, int x_stride, const float* t, int t_s
 int dgs_mlp_forward_select(int M, const float* x, int x_stride, const float* t, int t_stride, const float* const* params,
                            const float* rot_bias, float* packed, float* saved, float* attrs, const float* table, int nrows, int row_floats,
                            int* counter, int* override_, int stride, int offset, float* row_out, void* stream);
-/* dgs_train_ops_set_option(DGS_TRAIN_OPT_MLP_SPLIT, 0): dgs_mlp_backward_reduce2 ignores its second stream (A/B, tests). */
-#define DGS_TRAIN_OPT_MLP_SPLIT 0
-int dgs_train_ops_set_option(int option, int value);
 int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                      int accumulate, void* stream);
 /* dgs_mlp_backward with dgs_deform_reduce folded into its first kernel (lbs_table may be NULL: then exactly dgs_mlp_backward):
@@ -179,16 +176,6 @@ int dgs_mlp_backward(int M, const float* g_attrs, const float* packed, const flo
 int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
                             int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
                             float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream);
-/* dgs_mlp_backward_reduce on TWO streams of the caller (stream2 NULL or == stream: exactly dgs_mlp_backward_reduce): the chain runs
- * as two launches on `stream`, the weight gradients of the layers its first half has finished on `stream2` NEXT TO the second half,
- * the others on `stream` behind it.  On entry stream2 must not be ahead of anything the backward reads; on return everything is
- * ordered on `stream` (stream2 waits for the first half through an event, `stream` for stream2 through another).  Under stream
- * capture both streams must be branches of the SAME capture already (fork stream2 from the capture's origin stream, not from
- * `stream`: ROCm 7.2 does not unwind a stream that joined a capture through a non-origin branch).  Gradients are bit-identical
- * to the one-stream call. */
-int dgs_mlp_backward_reduce2(int M, float* g_attrs, const float* packed, const float* saved, float* scratch, float* const* grads,
-                             int accumulate, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes,
-                             float* g_radius_raw, float* g_weight_raw, int reduce_flags, void* lbs_table, void* stream, void* stream2);
 
 /* dgs_knn_points with the query coordinates split over two arrays: [0,D1) from x1[N,D1], [D1,D1+D2) from
  * x2[N, x2_stride] (avoids materialising cat([xyz, feature[:, :hyper]]) every step). */

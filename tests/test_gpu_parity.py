@@ -315,6 +315,37 @@ def test_deterministic_backward_is_reproducible_and_equals_the_atomic_one(cfg):
         grad_close(det[0][k], og[k], k)
 
 
+@pytest.mark.parametrize("cfg", [CASES[0], CASES[3], CASES[4]])
+def test_fixed_point_backward_is_reproducible_fast_path(cfg):
+    """dgs_set_option(7, 2): the backward blend adds its per-(wave, entry) sums as 64-bit fixed-point numbers (2^-44) with integer
+    atomics -- integer addition is associative, so three runs are bit-identical in every gradient array whatever order the sums
+    arrive in; the float-atomic backward computes the same sums to rounding + the 6e-14 quantum; and the oracle bounds of the
+    default kernel are met.  Unlike variant 1 it allocates nothing per call: legal under stream capture (checked below)."""
+    from diff_surfel_rasterization import _C
+    from gpu_utils import grad_close, run_hip
+    case = small_case(**cfg)
+    gc, go = _cot(case)
+    keys = ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh")
+    atomic = run_hip(case, gc, go, debug=False)
+    try:
+        _C.set_option(7, 2)
+        det = [run_hip(case, gc, go, debug=False) for _ in range(3)]
+    finally:
+        _C.set_option(7, 0)
+    for k in keys:
+        assert np.array_equal(det[0][k], det[1][k]) and np.array_equal(det[0][k], det[2][k]), k
+        scale = np.abs(det[0][k]).max()
+        assert np.abs(det[0][k] - atomic[k]).max() <= 1e-4 * scale + 1e-12, k
+    assert np.array_equal(det[0]["color"], atomic["color"])
+    og = oracle_from_case(case).backward(gc, go)
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity"):
+        grad_close(det[0][k], og[k], k)
+    again = run_hip(case, gc, go, debug=False)   # back on float atomics: the fixed-point rows were left zeroed, nothing leaks
+    for k in keys:
+        scale = np.abs(atomic[k]).max()
+        assert np.abs(again[k] - atomic[k]).max() <= 1e-4 * scale + 1e-12, k
+
+
 def test_backward_needs_no_zero_filled_outputs():
     """The eight per-surfel gradient arrays are written for every row (culled surfels: zeros), so the binding allocates them
     uninitialised.  Poison the allocator's free blocks with NaN first: the gradients of a scene with culled surfels must come

@@ -114,3 +114,37 @@ def test_the_run_to_run_spread_is_the_float_atomics(tmp_path, monkeypatch):
     print("|delta loss| deterministic vs atomic run, mean over iterations 1-100 / 801-900: %.2e / %.2e; mean loss 801-900: %.4f vs %.4f"
           % (np.abs(lc[:100] - la[:100]).mean(), np.abs(lc[800:] - la[800:]).mean(), la[800:].mean(), lc[800:].mean()))
     assert lc[800:].mean() == pytest.approx(la[800:].mean(), rel=0.25)   # the same optimisation, not the same trajectory
+
+
+def test_deterministic_captured_fits_are_bit_identical(tmp_path):
+    """fit(deterministic=True): order-free sums (fixed-point integer atomics in the backward blend, ordered skinning tables) INSIDE the
+    captured step -- two fits from the same seed through warm-up, densification, pruning and an opacity reset agree bit for bit in
+    every loss and every parameter, at the speed of the default step (bench.py --workload trained pre-fits this way so that every
+    run times the same scene).  A third fit with the float atomics starts at the same loss and ends elsewhere."""
+    from dgs_amd.fit import fit
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    dev = torch.device("cuda:0")
+    data = str(tmp_path / "scene")
+    write_dynamic_dnerf(data, n_train=24, n_test=2, H=128, W=128, device=dev)
+    kw = dict(iterations=900, device=dev, num_pts=6000, node_num=128, seed=0, warm_up=300, regularize_from=600, densify_from=200,
+              opacity_reset_interval=500)
+
+    def run(tag, deterministic):
+        tr, losses = fit(data, str(tmp_path / tag), deterministic=deterministic, **kw)
+        assert tr._graph, "the step was captured"
+        alive = tr.surfels.alive
+        state = [t.detach()[alive].clone() for t in (tr.surfels._xyz, tr.surfels._features, tr.surfels._opacity, tr.surfels._scaling, tr.surfels._rotation)]
+        state += [tr.deform.nodes.detach().clone()] + [p.detach().clone() for p in tr.deform.network.parameters()]
+        tr.set_deterministic(False)
+        return np.asarray(losses, dtype=np.float64), state
+
+    la, sa = run("a", True)
+    lb, sb = run("b", True)
+    assert len(la) == 900 and np.isfinite(la).all()
+    assert np.array_equal(la, lb), int(np.argmax(la != lb))
+    assert len(sa) == len(sb) and all(x.shape == y.shape and torch.equal(x, y) for x, y in zip(sa, sb))
+    lc, _ = run("c", False)
+    assert lc[0] == pytest.approx(la[0], rel=1e-4)
+    assert not np.array_equal(lc, la)
+    assert la[800:].mean() < 0.5 * la[:50].mean()                       # it learns like the default does
+    assert lc[800:].mean() == pytest.approx(la[800:].mean(), rel=0.25)

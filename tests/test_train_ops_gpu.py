@@ -402,76 +402,6 @@ def test_fused_node_mlp_matches_torch_autograd(M, per_node_t):
             close(ref_grads[n], got, "grad %s (sink=%s)" % (n, sink), 2e-4)
 
 
-@pytest.mark.parametrize("M", [64, 1024])
-def test_node_mlp_backward_split_is_bit_identical(M):
-    """dgs_mlp_backward_reduce2: the backward chain in two launches with the first half's weight gradients on a second stream, against the
-    one-stream call -- every gradient bit for bit; eagerly, and captured in the topology the trainer uses (the chain on the capture's
-    origin stream, every branch forked from and joined into the origin: ROCm 7.2's hipStreamEndCapture crashed on branches of
-    branches, which is why the chain runs on the origin and the caller supplies the second stream)."""
-    from dgs_amd import _ops
-    from dgs_amd.deform import DeformMLP
-    torch.manual_seed(7)
-    net = DeformMLP().cuda()
-    nodes = torch.randn(M, 11, device="cuda") * 0.8
-    t = torch.rand(M, 1, device="cuda")
-    cot = torch.randn(M, 13, device="cuda").contiguous()
-    mlp = _ops.DeferredNodeMLP(net)
-    sink = [torch.zeros_like(p) for p in net.parameters()]
-    for p, g in zip(net.parameters(), sink):
-        p.grad = g
-    s2 = torch.cuda.Stream()
-
-    def run(stream2):
-        mlp.forward(nodes, t)
-        if stream2 is not None:
-            stream2.wait_stream(torch.cuda.current_stream())
-        mlp.backward(cot, store=True, stream2=stream2)
-        torch.cuda.synchronize()
-        return [g.clone() for g in sink]
-
-    one = run(None)
-    two = run(s2)
-    again = run(s2)
-    for a, b, c, (n, _) in zip(one, two, again, net.named_parameters()):
-        assert float(a.abs().max()) > 0, n
-        assert torch.equal(a, b), n
-        assert torch.equal(b, c), n
-    _ops.set_mlp_backward_split(False)     # the option: the second stream is ignored
-    try:
-        off = run(s2)
-    finally:
-        _ops.set_mlp_backward_split(True)
-    assert all(torch.equal(a, b) for a, b in zip(one, off))
-
-    # captured like the trainer's step: the chain on the capture's origin stream, its second stream and an unrelated branch (the
-    # trainer: the surfels' update) both forked from and joined into the origin
-    other = torch.cuda.Stream()
-    busy = torch.zeros(1 << 20, device="cuda")
-    cap = torch.cuda.Stream()
-    cap.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(cap):
-        mlp.forward(nodes, t)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=cap, capture_error_mode="thread_local"):
-            cur = torch.cuda.current_stream()
-            other.wait_stream(cur)
-            with torch.cuda.stream(other):
-                busy.add_(1.0)
-            s2.wait_stream(cur)
-            packed, saved = mlp.state
-            _ops._mlp_backward_raw(cot, packed, saved, sink, False, stream2=s2)
-            cur.wait_stream(other)
-    torch.cuda.current_stream().wait_stream(cap)
-    for rep in range(3):
-        for g in sink:
-            g.zero_()
-        graph.replay()
-        torch.cuda.synchronize()
-        for a, g, (n, _) in zip(one, sink, net.named_parameters()):
-            assert torch.equal(a, g), (rep, n)
-    assert float(busy[0]) == 3.0
-
-
 def test_fused_deform_assembled_matches_torch_autograd():
     """ControlNodes.forward_assembled (KNN on split inputs, MFMA node MLP, skinning + surfel activations in one kernel
     per direction, gradients written or added in place) against the PyTorch formulation feeding render()."""
