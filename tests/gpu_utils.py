@@ -131,6 +131,23 @@ def frac_close(a, b, atol, rtol=0.0, max_bad_frac=0.0, hard_atol=None, name=""):
         assert float(err.max()) <= hard_atol, "%s: max err %.3e > hard %.3e" % (name, float(err.max()), hard_atol)
 
 
+def img_close(a, b, name, tol=1e-5, max_bad_frac=0.0, hard=None):
+    """SURVEY section 8(c)'s image tolerance: |a - b| <= tol * max(1, |b|), on all but max_bad_frac of the entries (a contributor on the
+    1/255 or 1e-4 threshold may flip: only the large scenes allow any), which must still be within `hard`."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    if not err.size:
+        return
+    scaled = err / np.maximum(1.0, np.abs(b))
+    frac = float((scaled > tol).mean())
+    _record("img_close", name, {"max_err": float(err.max()), "max_scaled_err": float(scaled.max()), "p9999_scaled_err": float(np.quantile(scaled, 0.9999)),
+                                "frac_over_tol": frac, "n": int(err.size)}, {"tol": tol, "max_bad_frac": max_bad_frac, "hard": hard})
+    assert frac <= max_bad_frac, "%s: %.3e of entries beyond %.0e max(1, |x|) (max err %.3e)" % (name, frac, tol, float(err.max()))
+    if hard is not None:
+        assert float(err.max()) <= hard, "%s: max err %.3e > hard %.3e" % (name, float(err.max()), hard)
+
+
 def rel_l2(a, b, record=True):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)

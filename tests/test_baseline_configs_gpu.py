@@ -26,7 +26,7 @@ def _cot(H, W, seed=5):
 
 @pytest.mark.parametrize("name", ["c3", "c4", "c5"])
 def test_config_matches_oracle_and_properties(name):
-    from gpu_utils import frac_close, grad_close, median_flips, rel_l2, run_hip, hip_median_contrib
+    from gpu_utils import frac_close, img_close, grad_close, median_flips, rel_l2, run_hip, hip_median_contrib
     cfg = CONFIGS[name]
     case = small_case(P=cfg["P"], H=cfg["H"], W=cfg["W"], seed=0, view=cfg["view"], n_views=64)
     gc, go = _cot(cfg["H"], cfg["W"])
@@ -38,7 +38,7 @@ def test_config_matches_oracle_and_properties(name):
     assert alpha.min() >= 0.0 and alpha.max() <= 1.0 and np.isfinite(a["allmap"]).all() and np.isfinite(a["color"]).all()
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh", "dL_dmeans2D"):
         assert np.isfinite(a[k]).all(), k
-        assert rel_l2(b[k], 2.0 * a[k]) <= 1e-5, k                       # backward is linear in the cotangent
+        assert rel_l2(b[k], 2.0 * a[k]) <= 1e-6, k                       # backward is linear in the cotangent
     w = run_hip(dict(case, bg=torch.tensor([1.0, 1.0, 1.0])), debug=False)
     assert np.abs((w["color"] - a["color"]) - (1.0 - alpha)[None]).max() <= 1e-6   # colour = C + T * bg
     vis = a["radii"] > 0
@@ -48,7 +48,7 @@ def test_config_matches_oracle_and_properties(name):
     # ---- against the oracle (OpenMP, same inputs)
     orc = oracle_from_case(case)
     assert float((a["radii"] != orc.radii).mean()) <= 1e-4
-    frac_close(a["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
+    img_close(a["color"], orc.color, "color", max_bad_frac=6e-4, hard=6e-3)   # observed (C3 / C4 / C5) <= 1.9e-4 of the pixels, max 1.7e-3
     # Channels 5 and 7 (median depth, median weight) are the depth / weight of ONE contributor, the last one blended while
     # T > 0.5 (forward.cu:416-420): a pixel whose T sits on 0.5 to rounding picks a neighbouring contributor and jumps by the
     # difference between the two (seen at 1 M / 1600x1600: weight 0.500001 vs 0.028).  median_flips proves, pixel by pixel
@@ -56,9 +56,9 @@ def test_config_matches_oracle_and_properties(name):
     # from the oracle's pick only across entries blended at T = 0.5 +- 2e-4; all other pixels are held to the tolerance of
     # the summed channels.
     sums, medians = [0, 1, 2, 3, 4, 6], [5, 7]
-    frac_close(a["allmap"][sums], orc.allmap[sums], 1e-4, 5e-5, 1e-4, 2e-1, "allmap")
+    frac_close(a["allmap"][sums], orc.allmap[sums], 1e-4, 5e-5, 8e-5, 1.5e-2, "allmap")   # observed 2.7e-5 of the entries, max 5.0e-3; C5 sums 1-3 k terms: 1.2e-3 of them beyond 1e-5 max(1, |x|)
     flips = median_flips(hip_median_contrib(case), orc)
-    frac_close(a["allmap"][medians][:, ~flips], orc.allmap[medians][:, ~flips], 1e-4, 5e-5, 1e-4, 2e-1, "median depth / weight")
+    frac_close(a["allmap"][medians][:, ~flips], orc.allmap[medians][:, ~flips], 1e-4, 5e-5, 4e-5, 8e-3, "median depth / weight")   # observed 1.1e-5, max 2.7e-3
     mse = float(((a["color"] - orc.color) ** 2).mean())
     assert mse < 1e-9                                                     # PSNR > 90 dB for a [0, 1] image
     og = orc.backward(gc, go)
@@ -70,7 +70,7 @@ def test_config_matches_oracle_and_properties(name):
     og64 = o64.backward(gc.astype(np.float64), go.astype(np.float64))
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
         own = rel_l2(og[k], og64[k])
-        grad_close(a[k], og[k], k, tol_all=max(5e-3, 4.0 * own))
+        grad_close(a[k], og[k], k, tol_trim=5e-5, tol_all=max(5e-3, 4.0 * own))   # trimmed: observed <= 1.6e-5
         assert rel_l2(a[k], og64[k]) <= max(5e-3, 4.0 * own), "%s: HIP vs fp64 oracle %.3e, fp32 oracle vs fp64 oracle %.3e" % (
             k, rel_l2(a[k], og64[k]), own)
 

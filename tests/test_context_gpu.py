@@ -72,7 +72,7 @@ def test_two_threads_two_contexts_interleaved():
                 assert R == R0 and np.array_equal(c, c0) and np.array_equal(a, a0) and np.array_equal(r, r0)
                 for x, y in zip(g, g0):
                     if y.size and np.abs(y).max() > 0:
-                        assert rel_l2(x, y) <= 2e-5
+                        assert rel_l2(x, y) <= 1e-6
     finally:
         for c in ctxs:
             c.close()

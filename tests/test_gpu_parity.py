@@ -1,14 +1,16 @@
 """-m gpu parity tests: the HIP path (through the drop-in Python surface -> C ABI -> gfx950 kernels)
 against the CPU oracle on identical seeded inputs.
 
-Tolerances (stated per SURVEY.md section 8c):
+Tolerances (since round 5 every bound is at most 3x what the suite measured -- gpu_utils records the
+observed errors of every comparison, profiles/r05_parity_margins.md is the summary of one GPU session):
   * per-surfel preprocess (transMat, centre, normal, rgb, depth, radii, tile counts): bit-exact,
   * sorted lists / tile ranges: exact,
-  * images: |err| <= 2e-5 (+1e-5 rel) on all but <= 1e-4 of the pixels (a contributor whose alpha or
-    transmittance sits within an ulp of the 1/255 / 1e-4 thresholds may flip), hard cap 2e-2,
-  * per-surfel gradients: relative L2 <= 2e-4 per tensor on the small scenes (fp32 atomics order + fast
-    rcp/exp); at 200k/800x800 the same bound after trimming the 1e-3 worst-conditioned surfels and
-    5e-3 overall (gpu_utils.grad_close explains why: the oracle's own f32 vs f64 builds differ more).
+  * images, small scenes: |err| <= 1e-5 max(1, |x|) on EVERY pixel -- SURVEY's bound (observed: colour 1.4e-6, allmap 5.8e-6);
+    20 k surfels and up: the same bound on all but a stated fraction of the pixels (2e-5 .. 4e-4 observed: a contributor whose alpha
+    or transmittance sits within an ulp of the 1/255 / 1e-4 thresholds flips), with a hard cap at 3x the largest flip seen,
+  * per-surfel gradients: relative L2 <= 1e-4 per tensor on the small scenes (SURVEY's bound; observed 4.2e-5: fp32 atomics order +
+    fast rcp/exp); at 200k/800x800 4.5e-5 after trimming the 1e-3 worst-conditioned surfels (observed 1.4e-5) and 2.5e-3 overall
+    (observed 7.5e-4; gpu_utils.grad_close explains why the tail is what it is: the oracle's own f32 vs f64 builds differ more).
 """
 import numpy as np
 import pytest
@@ -46,7 +48,7 @@ def reference_rects():
 def test_tight_lists_are_ordered_sublists(cfg):
     """Default policy: per tile, the list is an order-preserving sub-list of the reference's list (pairs that cannot
     reach alpha >= 1/255 are never emitted), and the images still match the oracle."""
-    from gpu_utils import frac_close, run_hip_raw
+    from gpu_utils import frac_close, img_close, run_hip_raw
     case = small_case(**cfg)
     orc = oracle_from_case(case)
     hip = run_hip_raw(case)
@@ -61,13 +63,13 @@ def test_tight_lists_are_ordered_sublists(cfg):
         assert all(any(v == w for w in it) for v in mine.tolist()), "tile %d: not an ordered sub-list" % t
         dropped += len(ref) - len(mine)
     assert dropped == orc.num_rendered - hip["R"]
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-    frac_close(hip["allmap"], orc.allmap, 5e-5, 2e-5, 1e-4, 1e-1, "allmap")
+    img_close(hip["color"], orc.color, "color")                 # observed 1.4e-6 (profiles/r05_parity_margins.md)
+    img_close(hip["allmap"], orc.allmap, "allmap")              # observed 5.8e-6
 
 
 @pytest.mark.parametrize("cfg", CASES)
 def test_stages_match_oracle(cfg, reference_rects):
-    from gpu_utils import frac_close, run_hip_raw
+    from gpu_utils import frac_close, img_close, run_hip_raw
     case = small_case(**cfg)
     orc = oracle_from_case(case)
     hip = run_hip_raw(case)
@@ -100,24 +102,24 @@ def test_stages_match_oracle(cfg, reference_rects):
         ty, tx = divmod(t, tiles_x)
         blk = last[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]
         assert hip["tile_last"][t] == (blk.max() if blk.size else 0)
-    frac_close(hip["final_T"], orc.field("final_T"), 2e-5, 1e-5, 1e-4, 2e-2, "final_T")
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-    frac_close(hip["allmap"], orc.allmap, 5e-5, 2e-5, 1e-4, 1e-1, "allmap")
+    img_close(hip["final_T"], orc.field("final_T"), "final_T", tol=4e-6)   # observed 1.3e-6
+    img_close(hip["color"], orc.color, "color")                 # observed 1.4e-6 (profiles/r05_parity_margins.md)
+    img_close(hip["allmap"], orc.allmap, "allmap")              # observed 5.8e-6
 
 
 @pytest.mark.parametrize("cfg", CASES)
 def test_forward_backward_match_oracle(cfg):
-    from gpu_utils import frac_close, rel_l2, run_hip
+    from gpu_utils import frac_close, img_close, rel_l2, run_hip
     case = small_case(**cfg)
     gc, go = _cot(case)
     orc = oracle_from_case(case)
     og = orc.backward(gc, go)
     hip = run_hip(case, gc, go)
     assert np.array_equal(hip["radii"], orc.radii)
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-    frac_close(hip["allmap"], orc.allmap, 5e-5, 2e-5, 1e-4, 1e-1, "allmap")
+    img_close(hip["color"], orc.color, "color")                 # observed 1.4e-6 (profiles/r05_parity_margins.md)
+    img_close(hip["allmap"], orc.allmap, "allmap")              # observed 5.8e-6
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
-        assert rel_l2(hip[k], og[k]) <= 2e-4, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
+        assert rel_l2(hip[k], og[k]) <= 1e-4, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
 
 
 @pytest.mark.parametrize("coeffs", [1, 4, 9, 16])
@@ -128,7 +130,7 @@ def test_sh_tables_of_every_size_match_the_oracle(coeffs):
     for every row (float4 stores where they divide): images, radii and gradients against the oracle on both paths, and the
     culled rows of dL_dsh exactly zero under option 8."""
     from diff_surfel_rasterization import _C
-    from gpu_utils import frac_close, rel_l2, run_hip
+    from gpu_utils import frac_close, img_close, rel_l2, run_hip
     deg = int(round(coeffs ** 0.5)) - 1
     case = small_case(P=250, H=56, W=72, seed=31, view=2, scale_mul=2.0, sh_degree=deg)
     case["shs"] = case["shs"][:, :coeffs].contiguous()
@@ -142,11 +144,11 @@ def test_sh_tables_of_every_size_match_the_oracle(coeffs):
         finally:
             _C.set_option(8, 0)
         assert np.array_equal(hip["radii"], orc.radii)
-        frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-        frac_close(hip["allmap"], orc.allmap, 5e-5, 2e-5, 1e-4, 1e-1, "allmap")
+        img_close(hip["color"], orc.color, "color")                 # observed 1.4e-6 (profiles/r05_parity_margins.md)
+        img_close(hip["allmap"], orc.allmap, "allmap")              # observed 5.8e-6
         for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
             assert hip[k].shape == og[k].shape
-            assert rel_l2(hip[k], og[k]) <= 2e-4, "%s (option 8 = %d) rel-L2 %.3e" % (k, all_rows, rel_l2(hip[k], og[k]))
+            assert rel_l2(hip[k], og[k]) <= 1e-4, "%s (option 8 = %d) rel-L2 %.3e" % (k, all_rows, rel_l2(hip[k], og[k]))
         assert (hip["dL_dsh"][orc.radii == 0] == 0).all()
 
 
@@ -199,7 +201,7 @@ def test_degenerate_splats_match_oracle():
     """Edge-on, needle, sub-pixel, image-filling and near-plane surfels: bounds the documented departure of alpha_affine
     (a pair whose rho3d overflows is skipped where the reference would fall back to the low-pass disc) and exercises the conservative
     footprint tests (block_hit_affine: not-an-ellipse branches) on real degenerate conics.  Same tolerances as the regular scenes."""
-    from gpu_utils import frac_close, hip_median_contrib, median_flips, rel_l2, run_hip
+    from gpu_utils import frac_close, img_close, hip_median_contrib, median_flips, rel_l2, run_hip
     case = _degenerate_case()
     gc, go = _cot(case)
     orc = oracle_from_case(case)
@@ -210,26 +212,26 @@ def test_degenerate_splats_match_oracle():
     og = orc.backward(gc, go)
     hip = run_hip(case, gc, go)
     assert np.array_equal(hip["radii"], orc.radii)
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 2e-4, 2e-2, "color")
+    img_close(hip["color"], orc.color, "color")                 # observed 2.4e-7
     am, om = hip["allmap"].copy(), orc.allmap.copy()
     for ch in (5, 7):
         am[ch][flips] = om[ch][flips]
-    frac_close(am, om, 5e-5, 2e-5, 2e-4, 2e-1, "allmap")
+    img_close(am, om, "allmap")                                   # observed 1.9e-6
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
-        assert rel_l2(hip[k], og[k]) <= 1e-3, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
+        assert rel_l2(hip[k], og[k]) <= 1e-4, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
 
 
 def test_precomputed_colors_and_no_grad_path():
-    from gpu_utils import frac_close, rel_l2, run_hip
+    from gpu_utils import frac_close, img_close, rel_l2, run_hip
     case = small_case(P=500, H=64, W=64, seed=12, view=3, scale_mul=2.0)
     cp = np.random.default_rng(5).random((500, 3)).astype(np.float32)
     gc, go = _cot(case)
     orc = oracle_from_case(case, colors_precomp=cp)
     og = orc.backward(gc, go)
     hip = run_hip(case, gc, go, colors_precomp=cp)
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-    assert rel_l2(hip["dL_dcolors"], og["dL_dcolors"]) <= 2e-4
-    assert rel_l2(hip["dL_dmeans3D"], og["dL_dmeans3D"]) <= 2e-4
+    img_close(hip["color"], orc.color, "color")                 # observed 1.4e-6 (profiles/r05_parity_margins.md)
+    assert rel_l2(hip["dL_dcolors"], og["dL_dcolors"]) <= 1e-5
+    assert rel_l2(hip["dL_dmeans3D"], og["dL_dmeans3D"]) <= 1e-5
 
 
 @pytest.mark.parametrize("shape", [(96, 80), (200, 136)])
@@ -312,7 +314,7 @@ def test_deterministic_backward_is_reproducible_and_equals_the_atomic_one(cfg):
     assert np.array_equal(det[0]["color"], atomic["color"])
     og = oracle_from_case(case).backward(gc, go)
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity"):
-        grad_close(det[0][k], og[k], k)
+        grad_close(det[0][k], og[k], k, tol_trim=4e-5, tol_all=1.3e-3)   # observed 1.3e-5 / 4.1e-4
 
 
 @pytest.mark.parametrize("cfg", [CASES[0], CASES[3], CASES[4]])
@@ -339,7 +341,7 @@ def test_fixed_point_backward_is_reproducible_fast_path(cfg):
     assert np.array_equal(det[0]["color"], atomic["color"])
     og = oracle_from_case(case).backward(gc, go)
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity"):
-        grad_close(det[0][k], og[k], k)
+        grad_close(det[0][k], og[k], k, tol_trim=4e-5, tol_all=1.3e-3)
     again = run_hip(case, gc, go, debug=False)   # back on float atomics: the fixed-point rows were left zeroed, nothing leaks
     for k in keys:
         scale = np.abs(atomic[k]).max()
@@ -402,15 +404,15 @@ def test_edge_cases():
 
 def test_mid_size_against_oracle():
     """20k surfels, 256x256: many batches per tile, exercises the early-out and the atomics under load."""
-    from gpu_utils import frac_close, rel_l2, run_hip
+    from gpu_utils import frac_close, img_close, rel_l2, run_hip
     case = small_case(P=20000, H=256, W=256, seed=21, view=11, n_views=16, scale_mul=1.5)
     gc, go = _cot(case)
     orc = oracle_from_case(case)
     og = orc.backward(gc, go)
     hip = run_hip(case, gc, go, debug=False)
     assert float((hip["radii"] != orc.radii).mean()) <= 1e-4
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-    frac_close(hip["allmap"], orc.allmap, 1e-4, 5e-5, 1e-4, 2e-1, "allmap")
+    img_close(hip["color"], orc.color, "color", max_bad_frac=6e-5, hard=2e-3)      # observed 2.0e-5 of the pixels, max 5.3e-4
+    img_close(hip["allmap"], orc.allmap, "allmap", max_bad_frac=1.4e-4, hard=7e-3)  # observed 4.4e-5, max 2.1e-3
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
         assert rel_l2(hip[k], og[k]) <= 5e-4, "%s rel-L2 %.3e" % (k, rel_l2(hip[k], og[k]))
 
@@ -420,7 +422,7 @@ def test_full_size_properties():
     Forward determinism (bitwise), alpha in [0,1], colour == sum + T*bg consistency with a second
     background (linearity in bg), backward linearity in the cotangent, and parity of the image with the
     oracle (the oracle finishes this size in seconds with OpenMP)."""
-    from gpu_utils import frac_close, grad_close, rel_l2, run_hip
+    from gpu_utils import frac_close, img_close, grad_close, rel_l2, run_hip
     case = small_case(P=200000, H=800, W=800, seed=0, view=5, n_views=64, scale_mul=1.0)
     gc, go = _cot(case)
     a = run_hip(case, gc, go, debug=False)
@@ -429,18 +431,18 @@ def test_full_size_properties():
     alpha = a["allmap"][1]
     assert alpha.min() >= 0.0 and alpha.max() <= 1.0
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh", "dL_dmeans2D"):
-        assert rel_l2(b[k], 2.0 * a[k]) <= 1e-5, k
+        assert rel_l2(b[k], 2.0 * a[k]) <= 1e-6, k
     case_w = dict(case, bg=torch.tensor([1.0, 1.0, 1.0]))
     w = run_hip(case_w, debug=False)
     T = 1.0 - alpha
     assert np.abs((w["color"] - a["color"]) - T[None]).max() <= 1e-6
     orc = oracle_from_case(case)
     assert float((a["radii"] != orc.radii).mean()) <= 1e-4
-    frac_close(a["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-    frac_close(a["allmap"], orc.allmap, 1e-4, 5e-5, 1e-4, 2e-1, "allmap")
+    img_close(a["color"], orc.color, "color", max_bad_frac=2.7e-4, hard=4e-3)        # observed 8.8e-5 of the pixels, max 1.2e-3
+    img_close(a["allmap"], orc.allmap, "allmap", max_bad_frac=1.3e-3, hard=0.19)     # observed 4.1e-4, max 6.1e-2 (a median flip)
     og = orc.backward(gc, go)
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
-        grad_close(a[k], og[k], k)
+        grad_close(a[k], og[k], k, tol_trim=4.5e-5, tol_all=2.5e-3)    # observed <= 1.4e-5 / 7.5e-4
 
 
 @pytest.mark.parametrize("sort_mode", [2, 1, 0])
@@ -477,7 +479,7 @@ def test_long_tile_lists_use_all_sort_paths(sort_mode, P):
     the global-memory fallback above 8192; bitonic mode: the 128 KB LDS network and, above 16384, the fallback); P = 9000:
     4 k .. 7 k per tile (the 128 KB radix kernel).  The lists must still equal the reference order."""
     from diff_surfel_rasterization import _C
-    from gpu_utils import frac_close, run_hip_raw
+    from gpu_utils import frac_close, img_close, run_hip_raw
     case = small_case(P=P, H=96, W=96, seed=41, view=2, scale_mul=6.0, sh_degree=0, radius=2.2)
     orc = oracle_from_case(case)
     lens = (orc.field("ranges")[:, 1] - orc.field("ranges")[:, 0])
@@ -494,7 +496,7 @@ def test_long_tile_lists_use_all_sort_paths(sort_mode, P):
         _C.set_option(3, 2)
     assert hip["R"] == orc.num_rendered
     assert np.array_equal(hip["point_list"], orc.field("point_list"))
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 5e-4, 2e-2, "color")  # 96x96 image: one flipped pixel is 1.1e-4
+    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 3.5e-4, 1e-2, "color")  # 96x96 image: one flipped pixel is 1.1e-4 of it (observed: one, max 3.1e-3)
 
 
 def _clustered_case(P=7000, n_cluster=3000, H=128, W=160, seed=51):
@@ -518,7 +520,7 @@ def test_long_tile_path_matches_the_serial_walk_and_the_oracle():
     (T at the quarter boundaries is a product of products, the sums are added quarter by quarter); against the oracle it meets the
     same bounds; two runs are bit-identical."""
     from diff_surfel_rasterization import _C
-    from gpu_utils import frac_close, hip_median_contrib, median_flips, rel_l2, run_hip, run_hip_raw
+    from gpu_utils import frac_close, img_close, hip_median_contrib, median_flips, rel_l2, run_hip, run_hip_raw
     case = _clustered_case()
     gc, go = _cot(case)
     orc = oracle_from_case(case)
@@ -548,7 +550,7 @@ def test_long_tile_path_matches_the_serial_walk_and_the_oracle():
         d = np.abs(l1[k] - s0[k])[:, ~differ]
         assert d.max() <= tol * max(1.0, float(np.abs(s0[k]).max())), (k, float(d.max()))
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
-        assert rel_l2(l1[k], s0[k]) <= 1e-4, "%s rel-L2 %.3e" % (k, rel_l2(l1[k], s0[k]))
+        assert rel_l2(l1[k], s0[k]) <= 1e-6, "%s rel-L2 %.3e" % (k, rel_l2(l1[k], s0[k]))
         assert not np.array_equal(l1[k], s0[k])
     # the backward's long path alone (serial forward feeding it is the same forward: option 9 switches both, so compare the gradients
     # of two long runs with the deterministic reduction: the quarter-wise recurrences must reproduce themselves bit for bit)
@@ -559,29 +561,29 @@ def test_long_tile_path_matches_the_serial_walk_and_the_oracle():
         _C.set_option(7, 0); _C.set_option(10, 400); _C.set_option(11, 512)
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
         assert np.array_equal(d1[k], d2[k]), k
-        assert rel_l2(d1[k], l1[k]) <= 1e-4, k
+        assert rel_l2(d1[k], l1[k]) <= 1e-6, k
     og = orc.backward(gc, go)
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
-        assert rel_l2(l1[k], og[k]) <= 1e-3, "%s vs oracle rel-L2 %.3e" % (k, rel_l2(l1[k], og[k]))
+        assert rel_l2(l1[k], og[k]) <= 2.5e-4, "%s vs oracle rel-L2 %.3e" % (k, rel_l2(l1[k], og[k]))
     # long path vs oracle
     flips = median_flips(hip_median_contrib(case), orc)
     am, om = l1["allmap"].copy(), orc.allmap.copy()
     for ch in (5, 7):
         am[ch][flips] = om[ch][flips]
-    frac_close(l1["color"], orc.color, 2e-5, 1e-5, 2e-4, 2e-2, "color")
-    frac_close(am, om, 5e-5, 2e-5, 2e-4, 1e-1, "allmap")
+    img_close(l1["color"], orc.color, "color")                  # observed 5.5e-6
+    img_close(am, om, "allmap", max_bad_frac=8e-5, hard=6e-5)    # observed 2.4e-5 of the entries beyond 1e-5, max 2.0e-5
 
 
 def test_config_c2_static_forward_only_50k_800():
     """BASELINE.json configs[1]: static canonical render, 50 k surfels, 800x800, forward only -- every output against the
     oracle at the stated tolerance (colour |err| <= 2e-5 on all but 1e-4 of the pixels, i.e. PSNR > 90 dB), radii exact."""
-    from gpu_utils import frac_close, run_hip
+    from gpu_utils import frac_close, img_close, run_hip
     case = small_case(P=50000, H=800, W=800, seed=0, view=11, n_views=64)
     orc = oracle_from_case(case)
     hip = run_hip(case, debug=False)
     assert float((hip["radii"] != orc.radii).mean()) <= 1e-4
-    frac_close(hip["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
-    frac_close(hip["allmap"], orc.allmap, 1e-4, 5e-5, 1e-4, 2e-1, "allmap")
+    img_close(hip["color"], orc.color, "color", max_bad_frac=1.5e-4, hard=2.5e-3)    # observed 4.8e-5, max 7.9e-4
+    img_close(hip["allmap"], orc.allmap, "allmap", max_bad_frac=6e-4, hard=0.14)   # observed 1.8e-4, max 4.5e-2
     mse = float(((hip["color"] - orc.color) ** 2).mean())
     assert mse < 1e-9      # PSNR > 90 dB for a [0, 1] image
 
@@ -593,7 +595,7 @@ def test_uhd_images_bin_in_lds_with_the_order_rider(H, W):
     buffer (as static arrays they pushed the launch past the 160 KB a workgroup can have and the launch failed).  Capacity
     mode (no host read) against the exact-size mode bit for bit, and against the oracle."""
     from diff_surfel_rasterization import _C
-    from gpu_utils import frac_close, run_hip
+    from gpu_utils import frac_close, img_close, run_hip
     case = small_case(P=1500, H=H, W=W, seed=21, view=2, scale_mul=2.0)
     gc, go = _cot(case)
     exact = run_hip(case, gc, go)
@@ -607,4 +609,4 @@ def test_uhd_images_bin_in_lds_with_the_order_rider(H, W):
     assert np.array_equal(exact["color"], cap["color"]) and np.array_equal(exact["allmap"], cap["allmap"])
     orc = oracle_from_case(case)
     assert np.array_equal(cap["radii"], orc.radii)
-    frac_close(cap["color"], orc.color, 2e-5, 1e-5, 1e-4, 2e-2, "color")
+    img_close(cap["color"], orc.color, "color", max_bad_frac=3e-5, hard=5e-3)       # observed 7.9e-6, max 1.5e-3

@@ -568,7 +568,9 @@ def test_stored_gradients_equal_cleared_and_added_ones():
         a, b, c = fa[off:off + n], fb[off:off + n], fc[off:off + n]
         off += n
         noise = float((b - c).norm()) + 1e-12 * float(b.norm()) + 1e-30        # two cleared runs: float atomics + three Adam steps apart
-        assert float((a - b).norm()) <= 4.0 * noise + 1e-4 * float(b.norm()), (i, n, float((a - b).norm()), noise, float(b.norm()))
+        # (1e-3 of the segment's norm: a producer that added would be off by a multiple of it; the 4-element segments -- head biases --
+        # have been seen 4e-4 apart between two runs whose own pair happened to agree to 6e-5: one pair's noise is a draw, not a bound)
+        assert float((a - b).norm()) <= 4.0 * noise + 1e-3 * float(b.norm()), (i, n, float((a - b).norm()), noise, float(b.norm()))
     # Parameters after three Adam steps: Adam turns a gradient that is zero to rounding into a full step of either sign, so a few
     # elements per run land 2 lr apart between ANY two runs (float atomics); the maximum difference of one pair of runs is a draw
     # from that tail, not a yardstick for another pair (tools/diag/store_probe.py: pairwise maxima of one configuration spread over
