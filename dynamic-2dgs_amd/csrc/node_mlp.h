@@ -423,6 +423,7 @@ struct ReduceFold {
     float* g_rad_raw; float* g_w_raw;
     float* g_attrs_out;        // [M][13]
     int accumulate, clear;
+    int fixed;                 // the table holds 64-bit fixed-point sums (units of 2^-44: dgs_deform_backward accumulate bit 4)
 };
 
 struct BwdArgs {
@@ -460,8 +461,15 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a)
         const int T = 3 + f.H;
         for (int e = tid; e < kRows * f.G; e += kThreads) {
             const int r = e / f.G, c = e - r * f.G, node = row0 + r;
-            const float acc = f.table[(size_t)node * f.G + c];
-            if (f.clear) f.table[(size_t)node * f.G + c] = 0.f;
+            float acc;
+            if (f.fixed) {
+                unsigned long long* t64 = reinterpret_cast<unsigned long long*>(f.table) + (size_t)node * f.G + c;
+                acc = (float)((double)(long long)*t64 * (1.0 / 17592186044416.0));
+                if (f.clear) *t64 = 0ull;
+            } else {
+                acc = f.table[(size_t)node * f.G + c];
+                if (f.clear) f.table[(size_t)node * f.G + c] = 0.f;
+            }
             if (c < kHeads) {
                 sG[r * kSG + c] = acc;
                 f.g_attrs_out[(size_t)node * kHeads + c] = acc;

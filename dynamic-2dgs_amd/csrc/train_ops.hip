@@ -1271,7 +1271,16 @@ inline size_t lbs_bwd_lds_bytes(int M, int H)
 // Correct for any order; an unsorted cloud makes the loop below run once per DISTINCT node of a wave (up to 64 times).
 constexpr int kCohThreads = 256;
 
-template <int CVN>
+// FIXED (dgs_deform_backward accumulate bit 4): the table holds 64-bit fixed-point sums (units of 2^-44) added with INTEGER
+// atomics -- order-free, so the node gradients are bit-identical from run to run (Trainer.set_deterministic); the reduce converts.
+__device__ __forceinline__ unsigned long long lbs_to_fixed44(float v)
+{
+    v = fminf(fmaxf(v, -262144.0f), 262144.0f);
+    return (unsigned long long)__float2ll_rn(v * 17592186044416.0f);
+}
+__device__ __forceinline__ float lbs_from_fixed44(unsigned long long v) { return (float)((double)(long long)v * (1.0 / 17592186044416.0)); }
+
+template <bool FIXED, int CVN>
 __device__ __forceinline__ void lbs_combine(bool valid, int j, const float (&cv)[CVN], int G, float* __restrict__ table)
 {
     const int lane = threadIdx.x & 63;
@@ -1301,13 +1310,17 @@ __device__ __forceinline__ void lbs_combine(bool valid, int j, const float (&cv)
         }
         const int sub4 = lane & 3, sub8 = lane & 7;
         const int col = sub4 == 0 ? (lane >> 2) : (sub8 == 1 ? 16 + (lane >> 3) : (sub8 == 2 ? 24 + (lane >> 3) : -1));
-        if (col >= 0 && col < G) atomicAdd(table + (size_t)jl * G + col, sub4 == 0 ? r0 : (sub8 == 1 ? r1 : r2));
+        if (col >= 0 && col < G) {
+            const float tot = sub4 == 0 ? r0 : (sub8 == 1 ? r1 : r2);
+            if (FIXED) atomicAdd(reinterpret_cast<unsigned long long*>(table) + (size_t)jl * G + col, lbs_to_fixed44(tot));
+            else atomicAdd(table + (size_t)jl * G + col, tot);
+        }
         todo &= ~__ballot(sel);
     }
 }
 
 // HT > 0: hyper dimension known at compile time (a.H == HT): arrays sized for it, static indexing (the trainer's H = 8)
-template <bool ASM, bool COH, int HT = 0>
+template <bool ASM, bool COH, int HT = 0, bool FIXED = false>
 __global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_kernel(LbsArgs a, const float* g_xyz, const float* g_rot, const float* g_scale,
                                                       float* g_feature, int gf_stride, int accumulate,
                                                       float* partial /*[kLbsBlocks][M][G], COH: [M][G] zeroed*/, int chunk, AsmArgs s_)
@@ -1447,7 +1460,7 @@ __global__ void __launch_bounds__(COH ? kCohThreads : kLbsBwdThreads) lbs_bwd_ke
 #pragma unroll
             for (int h = HM; h < HM + 2; h++) cv[kLbsAttr + h] = h == H ? d_rad : (h == H + 1 ? d_w : 0.f);
             }
-            if (COH) lbs_combine(valid, j, cv, G, partial);
+            if (COH) lbs_combine<FIXED>(valid, j, cv, G, partial);
             else lbs_deliver(valid, j, cv, G, GS, a.M, s_tab, s_exch, s_cnt, s_slot, s_over);
         }
         if (valid)
@@ -1481,14 +1494,20 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(const float* partial, i
 // (through sigmoid), written or added in place; the attribute gradients are always written (the node MLP consumes them)
 __global__ void __launch_bounds__(256) lbs_reduce_raw_kernel(const float* partial, int M, int H, const float* rad_raw,
                                                              const float* w_raw, float* g_nodes, float* g_rad_raw, float* g_w_raw,
-                                                             float* g_attrs, int accumulate, int nparts, float* clear)
+                                                             float* g_attrs, int accumulate, int nparts, float* clear, int fixed = 0)
 {
     const int G = kLbsAttr + H + 2, T = 3 + H;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M * G) return;
     float acc = 0.f;
+    if (fixed) {   // one [M][G] table of 64-bit fixed-point sums (lbs_combine<FIXED>)
+        unsigned long long* t64 = reinterpret_cast<unsigned long long*>(const_cast<float*>(partial));
+        acc = lbs_from_fixed44(t64[i]);
+        if (clear) t64[i] = 0ull;
+    } else {
     for (int b = 0; b < nparts; b++) acc += partial[(size_t)b * M * G + i];
     if (clear) clear[i] = 0.f;   // coherent variant with a persistent table: leave it zeroed for the next backward (no memset launch)
+    }
     const int node = i / G, c = i - node * G;
     if (c < kLbsAttr) { g_attrs[(size_t)node * kLbsAttr + c] = acc; }
     else if (c < kLbsAttr + H) {
@@ -2076,7 +2095,7 @@ int dgs_deform_reduce(int M, int H, const float* node_radius_raw, const float* n
     const int G = kLbsAttr + H + 2;
     hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
                        node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1,
-                       (accumulate & 4) ? (float*)scratch : (float*)nullptr);
+                       (accumulate & 4) ? (float*)scratch : (float*)nullptr, (accumulate & 16) ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : fail(-4, "lbs_reduce_raw_kernel: launch failed");
 }
 
@@ -2277,7 +2296,7 @@ int dgs_mlp_backward_reduce(int M, float* g_attrs, const float* packed, const fl
     b.M = M; b.g_attrs = g_attrs; b.saved = saved; b.scratch = scratch;
     if (lbs_table)   // flags as dgs_deform_reduce: bit 0 add to the gradients, bit 2 leave the table zeroed
         b.fold = mlp::ReduceFold{(float*)lbs_table, kLbsAttr + H + 2, H, node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw,
-                                 g_attrs, reduce_flags & 1, (reduce_flags & 4) ? 1 : 0};
+                                 g_attrs, reduce_flags & 1, (reduce_flags & 4) ? 1 : 0, (reduce_flags & 16) ? 1 : 0};
     b.wq = reinterpret_cast<const float4*>(packed) + (size_t)mlp::kFwdVecs;
     hipLaunchKernelGGL(mlp::mlp_bwd_kernel, dim3(M / mlp::kRows), dim3(mlp::kThreads), 0, s, b);
 
@@ -2379,19 +2398,22 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
         // coherent variant (surfels stored by nearest node): one zeroed [M][G] table, wave-level sums, global atomics
         // accumulate bit 2 (value 4): `scratch` is a persistent table that is zero on entry and must be zero on exit
         const bool persistent = (accumulate & 4) != 0;
+        const bool fixed = (accumulate & 16) != 0;   // bit 4: 64-bit fixed-point table, integer atomics (order-free sums)
         if (!persistent) {
-            const hipError_t me = hipMemsetAsync(scratch, 0, (size_t)M * G * sizeof(float), (hipStream_t)stream);
+            const hipError_t me = hipMemsetAsync(scratch, 0, (size_t)M * G * (fixed ? sizeof(unsigned long long) : sizeof(float)), (hipStream_t)stream);
             if (me != hipSuccess) return fail(-4, std::string("dgs_deform_backward: ") + hipGetErrorString(me));
         }
-        auto kern = H == 8 ? lbs_bwd_kernel<true, true, 8> : lbs_bwd_kernel<true, true, 0>;   // the trainer's hyper_dim, specialised
+        auto kern = fixed ? (H == 8 ? lbs_bwd_kernel<true, true, 8, true> : lbs_bwd_kernel<true, true, 0, true>)
+                          : (H == 8 ? lbs_bwd_kernel<true, true, 8> : lbs_bwd_kernel<true, true, 0>);   // the trainer's hyper_dim, specialised
         hipLaunchKernelGGL(kern, dim3((N + kCohThreads - 1) / kCohThreads), dim3(kCohThreads), 0, (hipStream_t)stream, a,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, g_feature, feature_stride, accumulate & 1,
                            (float*)scratch, kCohThreads, s);
         if (!(accumulate & 8))      // bit 3: the caller reduces the table later (dgs_deform_reduce), e.g. on another stream
             hipLaunchKernelGGL(lbs_reduce_raw_kernel, dim3((M * G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, M, H,
                                node_radius_raw, node_weight_raw, g_nodes, g_radius_raw, g_weight_raw, g_attrs, accumulate & 1, 1,
-                               persistent ? (float*)scratch : (float*)nullptr);
+                               persistent ? (float*)scratch : (float*)nullptr, fixed ? 1 : 0);
     } else {
+        if (accumulate & 16) return fail(-1, "dgs_deform_backward: the fixed-point table (bit 4) needs the coherent variant (bit 1)");
         if (accumulate & 8) return fail(-1, "dgs_deform_backward: the deferred reduce (bit 3) needs the coherent variant (bit 1)");
         const int chunk = (N + kLbsBlocks - 1) / kLbsBlocks;
         hipLaunchKernelGGL((lbs_bwd_kernel<true, false>), dim3(kLbsBlocks), dim3(kLbsBwdThreads), lds, (hipStream_t)stream, a, (const float*)nullptr,

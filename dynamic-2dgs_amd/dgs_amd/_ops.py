@@ -654,7 +654,7 @@ class _FusedDeform(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                g_attrs_out=None, coherent=False, reduce_later=None, sink_store=False, tables=None):
+                g_attrs_out=None, coherent=False, reduce_later=None, sink_store=False, tables=None, fixed=False):
         lib = load()
         dev = xyz.device
         N, M = xyz.shape[0], nodes.shape[0]
@@ -681,6 +681,7 @@ class _FusedDeform(torch.autograd.Function):
         ctx.reduce_later = reduce_later if (g_attrs_out is not None and sink is not None) else None
         ctx.sink_store = bool(sink_store) and sink is not None and feature.shape[1] == H
         ctx.tables = tables if tables is not None else _DEFAULT_TABLES
+        ctx.fixed = bool(fixed) and bool(coherent)   # the coherent table as 64-bit fixed-point sums (order-free integer atomics)
         return means3D, scales, rots, opac
 
     @staticmethod
@@ -708,7 +709,7 @@ class _FusedDeform(torch.autograd.Function):
             ret, acc = outs, 0
         mask = ctx.mask
         defer = ctx.reduce_later is not None and ctx.coherent and persistent == 4
-        flags = acc | (2 if ctx.coherent else 0) | persistent | (8 if defer else 0)
+        flags = acc | (2 if ctx.coherent else 0) | persistent | (8 if defer else 0) | (16 if ctx.fixed else 0)
         with torch.cuda.device(dev):
             rc = lib.dgs_deform_backward(
                 N, M, H, xyz.data_ptr(), feature.data_ptr(), feature.shape[1], idx.data_ptr(), nodes.data_ptr(), node_radius.data_ptr(),
@@ -724,18 +725,18 @@ class _FusedDeform(torch.autograd.Function):
             def reduce(M=M, H=H, nr=node_radius, nw=node_weight, outs=outs, g_attrs=g_attrs, flags=flags, scratch=scratch, dev=dev):
                 with torch.cuda.device(dev):
                     _check(lib, lib.dgs_deform_reduce(M, H, nr.data_ptr(), nw.data_ptr(), outs[5].data_ptr(), outs[6].data_ptr(), outs[7].data_ptr(),
-                                                      g_attrs.data_ptr(), flags & 5, scratch.data_ptr(), _stream(dev)), "dgs_deform_reduce")
+                                                      g_attrs.data_ptr(), flags & 21, scratch.data_ptr(), _stream(dev)), "dgs_deform_reduce")
                 tables.mark(tkey, False)
             # a caller that launches the node MLP's backward next may fold the reduction into it (DeferredNodeMLP.backward(fold=...))
             # and call done() instead of the closure
-            reduce.fold_args = (M, H, node_radius, node_weight, outs[5], outs[6], outs[7], g_attrs, flags & 5, scratch)
+            reduce.fold_args = (M, H, node_radius, node_weight, outs[5], outs[6], outs[7], g_attrs, flags & 21, scratch)
             reduce.done = lambda: tables.mark(tkey, False)
             ctx.reduce_later.append(reduce)
-        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None, None, None, None)
+        return tuple(ret) + (g_attrs if ctx.g_attrs_out is None else None, None, None, None, None, None, None, None, None, None, None)
 
 
 def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, grad_sink=False,
-                 g_attrs_out=None, coherent=False, reduce_later=None, tables=None):
+                 g_attrs_out=None, coherent=False, reduce_later=None, tables=None, fixed=False):
     # grad_sink: False, True (ADD into the .grad tensors) or "store" (OVERWRITE them: every element of the eight tensors is written by
     # every backward, so a gradient buffer that only ever receives stores needs no clearing; needs feature.shape[1] == H)
     """Raw surfel parameters + node tables + node attributes -> (means3D, scales, rotations, opacity) for the rasterizer.
@@ -745,7 +746,8 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
     reduce_later: a list (coherent + grad_sink + g_attrs_out only).  The backward then leaves its node table unreduced and appends
     ONE callable to the list; the caller must run it (on any stream ordered behind the backward) before the node gradients or
     g_attrs_out are read -- ControlNodes.finish_backward does, on the node-MLP backward's side stream.
-    tables: the CoherentTables that own the persistent node table of the coherent backward (default: a process-wide one)."""
+    tables: the CoherentTables that own the persistent node table of the coherent backward (default: a process-wide one).
+    fixed (coherent only): the node table as 64-bit fixed-point sums added with integer atomics -- order-free, bit-reproducible."""
     params = (xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight)
     sink = None
     if grad_sink and torch.is_grad_enabled():
@@ -753,7 +755,7 @@ def fused_deform(xyz, scaling, rotation, opacity, feature, nodes, node_radius, n
         if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in sink):
             raise RuntimeError("fused_deform(grad_sink=True): every parameter needs a contiguous fp32 .grad")
     return _FusedDeform.apply(xyz, scaling, rotation, opacity, feature, nodes, node_radius, node_weight, attrs, idx, mask, H, sink,
-                              g_attrs_out, coherent, reduce_later, grad_sink == "store", tables)
+                              g_attrs_out, coherent, reduce_later, grad_sink == "store", tables, fixed)
 
 
 _ONES = {}

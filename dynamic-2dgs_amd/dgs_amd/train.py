@@ -992,13 +992,12 @@ class Trainer:
         near = torch.cat([torch.cdist(x[i:i + 16384], nodes).argmin(1) for i in range(0, x.shape[0], 16384)])
         near = torch.where(s.alive, near, torch.full_like(near, nodes.shape[0]))
         self.reorder_surfels(torch.argsort(near, stable=True))
-        d._sorted_once = True
-        d.coherent_surfels = bool(x.is_cuda and self.rasterizer_cls is None) and not getattr(self, "_deterministic", False)
+        d.coherent_surfels = bool(x.is_cuda and self.rasterizer_cls is None)
 
     def set_deterministic(self, on=True):
         """Bit-reproducible training on the HIP path: every float-atomic sum of the step is replaced by an order-free one -- the
-        backward blend adds 64-bit fixed-point numbers with integer atomics (rasterizer option 7 = 2) and the skinning backward uses
-        its per-workgroup tables + ordered reduction instead of wave-level float atomics.  Two runs from the same seed then agree
+        backward blend and the skinning backward's node table add 64-bit fixed-point numbers (units of 2^-44) with INTEGER atomics
+        (rasterizer option 7 = 2; dgs_deform_backward accumulate bit 4) instead of float atomics.  Two runs from the same seed then agree
         bit for bit through densification and opacity resets (tests/test_learning_gpu.py).  Costs ~5-10 % of a step and quantises
         the blend's partial sums to 6e-14 (a different, equally valid optimisation: kernels_blend.h).  The option lives in the
         rasterizer context of this trainer's DEVICE; a captured step is re-captured."""
@@ -1011,11 +1010,7 @@ class Trainer:
         self._flush_guard()
         self._deterministic = on
         _C.set_option(7, 2 if on else 0, device=dev)
-        d = self.deform
-        if on:
-            d.coherent_surfels = False
-        elif getattr(d, "_sorted_once", False):
-            d.coherent_surfels = True
+        self.deform.fixed_point_tables = on   # the coherent skinning backward's node table: 64-bit fixed-point sums, integer atomics
         if self._graph:
             # (the fixed-point rows of the backward are allocated by the eager warm-up steps enable_graph runs before it captures)
             self._graph = None

@@ -195,7 +195,10 @@ int dgs_knn_points2(int N, int M, int D1, int D2, int K, const float* x1, const 
  * contributions are summed across the wave and one 23-lane global atomic per (wave, node) goes into a single [M][13+H+2]
  * table -- instead of 256 per-workgroup LDS tables of 94 KB.  Same results for any order (float summation order aside);
  * an unsorted set makes it slow, not wrong.  accumulate bit 2 (value 4, coherent variant only): `scratch` is a persistent
- * table that is all zero on entry and is left all zero (no memset launch).  scratch: dgs_lbs_scratch_bytes(M, H) bytes. */
+ * table that is all zero on entry and is left all zero (no memset launch).  accumulate bit 4 (value 16, coherent variant only):
+ * the table holds 64-bit FIXED-POINT sums (units of 2^-44) added with integer atomics -- order-free, so the node gradients are
+ * bit-identical from run to run (the float atomics of the default are not); pass the same bit to dgs_deform_reduce /
+ * dgs_mlp_backward_reduce, which convert.  scratch: dgs_lbs_scratch_bytes(M, H) bytes (enough for either table). */
 int dgs_deform_forward(int N, int M, int H, const float* xyz, const float* feature, int feature_stride, const long long* idx,
                        const float* nodes, const float* node_radius_raw, const float* node_weight_raw, const float* attrs,
                        const float* mask, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
@@ -208,7 +211,7 @@ int dgs_deform_backward(int N, int M, int H, const float* xyz, const float* feat
                         float* g_nodes, float* g_radius_raw, float* g_weight_raw, float* g_attrs, int accumulate, void* scratch,
                         void* stream);
 /* accumulate bit 3 (value 8, coherent variant only) makes dgs_deform_backward leave its [M][13+H+2] table unreduced: g_nodes,
- * g_radius_raw, g_weight_raw and g_attrs are then produced by this call (same accumulate bits 0 and 2), which the caller may
+ * g_radius_raw, g_weight_raw and g_attrs are then produced by this call (same accumulate bits 0, 2 and 4), which the caller may
  * launch on another stream -- the train step runs it in front of the node-MLP backward on that backward's side stream, so that
  * the surfels' Adam update starts right behind the skinning backward. */
 int dgs_deform_reduce(int M, int H, const float* node_radius_raw, const float* node_weight_raw, float* g_nodes, float* g_radius_raw,

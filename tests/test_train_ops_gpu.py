@@ -415,7 +415,7 @@ def test_fused_deform_assembled_matches_torch_autograd():
     # "coherent": the wave-sum + global-atomic backward for node-sorted storage order -- on the unsorted cloud (worst case:
     # ~64 distinct nodes per wave) and on the cloud sorted by nearest node ("sorted": the torch result is permuted to compare)
     near_perm = None
-    for mode in ("torch", "fused", "sink", "coherent", "sorted"):
+    for mode in ("torch", "fused", "sink", "coherent", "sorted", "fixed", "fixed2"):
         torch.manual_seed(1)
         scene = make_scene(N, seed=3)
         if mode == "sorted":
@@ -443,7 +443,8 @@ def test_fused_deform_assembled_matches_torch_autograd():
         else:
             assert m.can_assemble(pc)
             m.grad_sink = mode == "sink"
-            m.coherent_surfels = mode in ("coherent", "sorted")
+            m.coherent_surfels = mode in ("coherent", "sorted", "fixed", "fixed2")
+            m.fixed_point_tables = mode in ("fixed", "fixed2")   # the node table as 64-bit fixed-point sums (order-free integer atomics)
             if m.grad_sink:
                 for p in params.values():
                     p.grad = torch.full_like(p, 0.5)
@@ -470,7 +471,9 @@ def test_fused_deform_assembled_matches_torch_autograd():
         err = float((u - v).abs().max())
         assert err <= tol * scale, "%s: err %.3e scale %.3e" % (name, err, scale)
 
-    for mode in ("fused", "sink", "coherent", "sorted"):
+    for n, ga in res["fixed"][1].items():   # two runs of the fixed-point table: bit-identical node (and every other) gradient
+        assert torch.equal(ga, res["fixed2"][1][n]), n
+    for mode in ("fused", "sink", "coherent", "sorted", "fixed"):
         for i, (a, b) in enumerate(zip(res["torch"][0], res[mode][0])):
             close(a, b, "%s out %d" % (mode, i), 2e-5)
         for n, ga in res["torch"][1].items():
