@@ -1010,6 +1010,10 @@ class Trainer:
         self._flush_guard()
         self._deterministic = on
         _C.set_option(7, 2 if on else 0, device=dev)
+        # the long-tile path (four workgroups share a tile's list: sums taken stretch-wise, i.e. other roundings than the serial walk) is
+        # given to the first 256 slots of the longest-first dispatch order, and the order of tiles of EQUAL length class in that
+        # order comes from LDS atomics -- which tiles get it is not reproducible once more than 256 qualify.  Serial walks only.
+        _C.set_option(9, 0 if on else 1, device=dev)
         self.deform.fixed_point_tables = on   # the coherent skinning backward's node table: 64-bit fixed-point sums, integer atomics
         if self._graph:
             # (the fixed-point rows of the backward are allocated by the eager warm-up steps enable_graph runs before it captures)
