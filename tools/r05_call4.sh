@@ -1,6 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-echo "== deform + learning tests"; timeout 900 python -m pytest tests/test_train_ops_gpu.py tests/test_learning_gpu.py -m gpu -x -q -k "deform or deterministic or spread" 2>&1 | tail -3
 echo "== trained, deterministic pre-fit, three times"
 for i in 1 2 3; do timeout 900 python bench.py --workload trained --no-cpu-baseline --no-roofline-legs 2> $O/trained_$i.err | tee $O/trained_$i.json | python -c "
 import sys, json
