@@ -694,10 +694,11 @@ __global__ void __launch_bounds__(256) sort_tiles_reg_kernel(const uint2* ranges
 // SEG = true (lists longer than CAP): blockIdx.y = segment; the workgroup sorts entries [y CAP, (y + 1) CAP) of every list of
 // more than CAP and at most CAP * gridDim.y entries and writes the sorted (depth, index) KEYS into the list's scratch area;
 // merge_segments_kernel then ranks every key among the other segments.  `seg_out` = scratch of 2 R keys (list at 2 * range.x).
-// CAP = 3584: 60 KB of LDS.  The 8192-entry / 132-KB instantiation of this kernel that round 2 used for lists of 2 k - 8 k entries
-// never took less than ~73 us per launch, with or without work (36 workgroups that find nothing to sort: 73 us; this one: 2 us).
-// The cause was not isolated -- bare allocations of 16 .. 160 KB launch in 2.5 us whatever their size
-// (tools/micro/lds_launch_bench.hip) -- but the 60-KB instantiation does not show it, and its segments run side by side.
+// CAP = kSegCap = 2048 (36 KB of LDS), up to kMaxSegs = 28 segments per list.  History: round 3 used segments of 3584 (60 KB); the
+// 8192-entry / 132-KB instantiation that round 2 used for lists of 2 k - 8 k entries never took less than ~73 us per launch, with or
+// without work (36 workgroups that find nothing to sort: 73 us; the segment kernel: 2 us).  The cause was not isolated -- bare
+// allocations of 16 .. 160 KB launch in 2.5 us whatever their size (tools/micro/lds_launch_bench.hip) -- the smaller instantiations do
+// not show it, and their segments run side by side.
 // Round 4: the segments are as long as the main kernel's lists (2048) and EVERY list beyond that is cut into them -- the 3584-entry
 // single-workgroup instantiation that used to take the lists of 2 049 .. 3 584 entries is gone: one workgroup of four waves needs
 // 25-50 us for such a list (the launch a densified scene waited for), two or more segments side by side + the rank / merge step half.

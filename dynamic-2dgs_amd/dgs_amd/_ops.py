@@ -357,6 +357,7 @@ class FlatAdam:
         step must be re-captured afterwards."""
         for i in range(first, self._n if last is None else last):
             self._origin[i] = float(t0)
+        self.__dict__.pop("_origin_slices", None)
 
     def moments(self, p):
         """(exp_avg, exp_avg_sq) of parameter p as views shaped like p (state surgery of dgs_amd/densify.py)."""
@@ -394,7 +395,11 @@ class FlatAdam:
         dev = self.grad.device
         last = self._n if last is None else last
         k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, plan = self._range(first, last)
-        origin = (ctypes.c_float * k)(*list(self._origin)[first:last])
+        okey = (first, last)
+        cache = self.__dict__.setdefault("_origin_slices", {})
+        origin = cache.get(okey)
+        if origin is None:   # (one ctypes array per (first, last), like _range: an eager step makes no Python list of all origins)
+            origin = cache[okey] = (ctypes.c_float * k)(*[self._origin[i] for i in range(first, last)])
         skip = None if self.skip is None else self.skip.data_ptr()
         with torch.cuda.device(dev):
             if advance:

@@ -218,9 +218,17 @@ class Trainer:
             self.opt_surfels = _ops.FlatAdam(plist, [lr_of[id(p)] for p in plist], self.bucket.flat, patterns=patterns,
                                              schedules=schedules, sched_t0=float(self._steps_done))
             self.opt_deform = None
-            if old is not None and hasattr(old, "_origin") and len(old._origin) == len(plist):
-                for i in range(len(plist)):   # rebuilt state (grow / node densification): the parameters keep their step origins
-                    self.opt_surfels._origin[i] = old._origin[i]
+            if old is not None and hasattr(old, "_origin"):
+                # rebuilt state (grow / node densification): the parameters keep their step origins -- by position when the list is
+                # the same length (a rebuild replaces the tensors), by identity for whatever survives a changed list
+                if len(old._origin) == len(plist):
+                    for i in range(len(plist)):
+                        self.opt_surfels._origin[i] = old._origin[i]
+                else:
+                    was = {id(p): old._origin[i] for i, p in enumerate(getattr(old, "params", []))}
+                    for i, p in enumerate(plist):
+                        if id(p) in was:
+                            self.opt_surfels._origin[i] = was[id(p)]
             self.opt_surfels.zero_grads = False  # True: step + zero_grad in one pass, see _forward for why it is off
             self._bucket_clean = False
             self._init_guard(old)
@@ -510,6 +518,8 @@ class Trainer:
         opt = (self.opt_surfels.exp_avg.clone(), self.opt_surfels.exp_avg_sq.clone(), self.opt_surfels.t.clone(),
                self.opt_surfels.status.clone())
         stats = (sf.xyz_gradient_accum.clone(), sf.denom.clone(), sf.max_radii2D.clone())
+        if hasattr(self.opt_surfels, "_origin"):   # the per-parameter Adam step origins are optimiser state too (host side)
+            opt = opt + (list(self.opt_surfels._origin),)
         return state, opt, stats
 
     @torch.no_grad()
@@ -522,6 +532,11 @@ class Trainer:
         self.opt_surfels.exp_avg_sq.copy_(opt[1])
         self.opt_surfels.t.copy_(opt[2])
         self.opt_surfels.status.copy_(opt[3])
+        if len(opt) > 4 and hasattr(self.opt_surfels, "_origin") and len(opt[4]) == len(self.opt_surfels._origin):
+            if list(self.opt_surfels._origin) != opt[4]:
+                for i, v in enumerate(opt[4]):
+                    self.opt_surfels._origin[i] = v
+                self.opt_surfels.__dict__.pop("_origin_slices", None)
         sf.xyz_gradient_accum.copy_(stats[0])
         sf.denom.copy_(stats[1])
         sf.max_radii2D.copy_(stats[2])
