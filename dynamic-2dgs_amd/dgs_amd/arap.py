@@ -7,6 +7,10 @@ device the nodes live on.  Active for iterations < 20000 in the reference (weigh
 of this package is the regime after that, so the regulariser runs eagerly (Trainer(arap=True)).
 The random draws of the reference (the time samples, the 512-node subsample) can be passed in, so that results are
 reproducible and comparable with the reference's.
+
+Also here (round 5): the two node regularisers of the reference's node PRE-TRAINING stage (train_gui.py:502-504, which this package
+does not run: SURVEY section 2, trainer shell) -- elastic_loss and acc_loss (utils/time_utils.py:1091-1120), pinned by the imported
+reference like arap_loss.  ControlNodeWarp.arap_loss_with_rot (:1035-1043) has no caller in the reference and is not restated.
 """
 import math
 
@@ -124,3 +128,68 @@ def arap_loss(deform, t=None, delta_t=0.05, t_samp_num=2, t_samp=None, sample_id
     nodes_t = nodes[:, None, :3].detach() + d_xyz
     ii, jj, nn, _ = connectivity_from_points(nodes_t[:, 0], K=10)
     return arap_error(nodes_t.permute(1, 0, 2), ii, jj, nn, sample_idx=sample_idx, generator=generator)
+
+
+# ---- the two node regularisers of the node pre-training stage (train_gui.py:502-504) --------------------------------------------
+def _node_positions_at(deform, t_samp):
+    """nodes[:, None, :3].detach() + node_deform(t)['d_xyz'] for the time samples t_samp [T] -> [M, T, 3] (live nodes only)."""
+    nodes = deform.nodes
+    live = getattr(deform, "live_nodes", None)
+    if live is not None and not bool(live.all()):
+        nodes = nodes[live]
+    M, T = nodes.shape[0], t_samp.shape[0]
+    x = nodes[:, None, :3].detach().expand(M, T, 3).reshape(-1, 3)
+    d_xyz = deform.network(x, t_samp[None, :, None].expand(M, T, 1).reshape(-1, 1))["d_xyz"].view(M, T, 3)
+    return nodes, nodes[:, None, :3].detach() + d_xyz
+
+
+def _sample_times(t, delta_t, n, generator, dev, t_samp):
+    if t_samp is not None:
+        return t_samp
+    rnd = lambda *s: torch.rand(*s, generator=generator, device=dev)
+    t0 = rnd([]) if t is None else t.reshape(-1)[0] + delta_t * (rnd([]) - 0.5)
+    return rnd(n) * delta_t + t0 - 0.5 * delta_t
+
+
+def elastic_loss(deform, t=None, delta_t=0.005, K=2, t_samp_num=8, t_samp=None, generator=None):
+    """ControlNodeWarp.elastic_loss (utils/time_utils.py:1091-1108): the lengths of every node's edges to its K nearest other nodes
+    (11-D neighbour search with the skinning weights of cal_nn_weight) should not vary over `t_samp_num` times within delta_t of t;
+    each edge's variance is normalised by its own detached value (so the LOSS is ~ the weighted edge count and only its gradient
+    matters), weighted by the skinning weight of the neighbour, summed per node, averaged."""
+    dev = deform.nodes.device
+    t_samp = _sample_times(t, delta_t, t_samp_num, generator, dev, t_samp)
+    nodes, nodes_t = _node_positions_at(deform, t_samp)
+    # cal_nn_weight(x = node positions, feature = node hyper coordinates, K + 1): the node itself comes first and is dropped
+    live = getattr(deform, "live_nodes", None)
+    if live is not None and not bool(live.all()):
+        raise NotImplementedError("elastic_loss with padding nodes: call it before ControlNodes.pad_nodes / on the unpadded module")
+    K0 = deform.K
+    try:
+        deform.K = K + 1
+        w, _, idx = deform.nn_weights(nodes[:, :3].detach(), nodes[:, 3:])
+    finally:
+        deform.K = K0
+    # nn_weights leaves the neighbours in approximately ascending order: put the node itself first like pytorch3d does
+    self_col = (idx == torch.arange(nodes.shape[0], device=dev)[:, None]).float().argmax(1)
+    order = torch.arange(K + 1, device=dev)[None].expand(nodes.shape[0], K + 1).clone()
+    order[torch.arange(nodes.shape[0]), self_col] = -1
+    order = order.sort(dim=1).indices            # the self column first, the others in their order
+    w, idx = torch.gather(w, 1, order)[:, 1:], torch.gather(idx, 1, order)[:, 1:]
+    edge_t = (nodes_t[idx] - nodes_t[:, None]).norm(dim=-1)        # [M, K, T]
+    var = edge_t.var(dim=2)
+    var = var / (var.detach() + 1e-5)
+    return (var * w).sum(dim=1).mean()
+
+
+def acc_loss(deform, t=None, delta_t=0.005, t0=None, generator=None):
+    """ControlNodeWarp.acc_loss (utils/time_utils.py:1110-1120): |x(t - dt) + x(t + dt) - 2 x(t)| of every node, normalised by its
+    own detached value, averaged.  t0: the (already jittered) centre time, for reproducible comparisons."""
+    dev = deform.nodes.device
+    if t0 is None:
+        rnd = torch.rand([], generator=generator, device=dev)
+        t0 = rnd if t is None else t.reshape(-1)[0] + delta_t * (rnd - 0.5)
+    t3 = torch.stack([t0 - delta_t, t0, t0 + delta_t]).to(dev)
+    _, nodes_t = _node_positions_at(deform, t3)
+    acc = (nodes_t[:, 0] + nodes_t[:, 2] - 2 * nodes_t[:, 1]).norm(dim=-1)
+    acc = acc / (acc.detach() + 1e-5)
+    return acc.mean()

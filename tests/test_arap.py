@@ -123,3 +123,31 @@ def test_padding_nodes_are_invisible_to_arap_and_checkpoints(tmp_path):
     saved = torch.load(path, weights_only=True)
     assert saved["nodes"].shape[0] == 40 and saved["_node_radius"].shape[0] == 40 and saved["_node_weight"].shape[0] == 40
     assert torch.equal(saved["nodes"], d.nodes.detach()[:40])
+
+
+def test_elastic_and_acc_loss_match_reference():
+    """The two node regularisers of the reference's node pre-training stage (train_gui.py:502-504; ControlNodeWarp.elastic_loss /
+    acc_loss, utils/time_utils.py:1091-1120) against what the imported reference computes (tests/golden/make_node_reg_golden.py):
+    value and gradient with respect to the translation head, same time samples."""
+    g = np.load(os.path.join(HERE, "golden", "node_reg_golden.npz"))
+    M = g["nodes"].shape[0]
+    d = ControlNodes(node_num=M, K=3, hyper_dim=8, local_frame=True)
+    fill_params(d)
+    with torch.no_grad():
+        d.network.gaussian_warp.weight.mul_(50.0)
+        d.nodes.copy_(torch.from_numpy(g["nodes"].copy()))
+        d._node_radius.copy_(torch.from_numpy(g["node_radius_raw"].copy()))
+        d._node_weight.copy_(torch.from_numpy(g["node_weight_raw"].copy()))
+    for name, loss in (("elastic", arap.elastic_loss(d, delta_t=0.02, t_samp=torch.from_numpy(g["elastic_t_samp"].copy()))),
+                       ("acc", arap.acc_loss(d, delta_t=0.06, t0=torch.from_numpy(g["acc_t0"].copy())))):
+        d.zero_grad()
+        loss.backward()
+        want = float(g[name + "_loss"])
+        assert abs(float(loss) - want) <= 2e-4 * abs(want), (name, float(loss), want)
+        gw, ww = d.network.gaussian_warp.weight.grad.numpy(), g[name + "_grad_warp"]
+        assert np.abs(gw - ww).max() <= 2e-3 * np.abs(ww).max(), (name, np.abs(gw - ww).max(), np.abs(ww).max())
+    # drawing their own samples: reproducible per generator, different for different ones
+    a = arap.elastic_loss(d, t=torch.tensor([0.4]), delta_t=0.02, generator=torch.Generator().manual_seed(5))
+    b = arap.elastic_loss(d, t=torch.tensor([0.4]), delta_t=0.02, generator=torch.Generator().manual_seed(5))
+    c = arap.acc_loss(d, t=torch.tensor([0.4]), generator=torch.Generator().manual_seed(6))
+    assert float(a) == float(b) and torch.isfinite(c)
