@@ -121,8 +121,13 @@ class Trainer:
     SCHED_DEFORM = (0.00016 * 5, 0.0000016, 40_000)
 
     def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=LATE_DEFORM_LR, position_lr=LATE_POSITION_LR,
-                 fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False):
+                 fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False, views_per_rank=1):
         self.surfels, self.deform = surfels, deform
+        # k > 1 (opt-in, data parallelism): every rank renders k views per step and ADDS their gradients before the one exchange of the
+        # step -- neighbour search, the all-reduces and the Adam update once per k views instead of once per view; a step then trains on
+        # k * world views (gradient = their mean), `iteration` counts steps.  See _multi_view_step.
+        self.views_per_rank = int(views_per_rank)
+        assert self.views_per_rank >= 1
         # ARAP regulariser of the control nodes with the reference's weight schedule (dgs_amd/arap.py; non-zero for
         # iterations < 20000).  Eager only: it draws random times and runs a batched SVD, neither belongs in a captured step.
         self.arap = bool(arap)
@@ -396,7 +401,11 @@ class Trainer:
             # ... on a snapshot: the warm-up steps must not train (enable_graph is also called mid-run, by Trainer.grow)
             snap = self._snapshot()
             for _ in range(3):
-                if self._split_ok():
+                if self.views_per_rank > 1:
+                    for j in range(self.views_per_rank):
+                        self._view_of_step(j, self._scam, self._sgt)
+                    self._finish()
+                elif self._split_ok():
                     self._split_step(self._scam, self._sgt)
                 else:
                     self._fwd_bwd(self._scam, self._sgt)
@@ -413,7 +422,28 @@ class Trainer:
         # _ops._FusedDeform.backward) are found again instead of being allocated -- and zero-filled on every replay -- inside the graph
         mode = {"capture_error_mode": "thread_local", "stream": s}
         self._split = self._split_ok()
-        if self._split:
+        self._gk = None
+        if self.views_per_rank > 1:
+            # k views per step: one captured graph per KIND of view -- the first (gradients stored or the bucket cleared, neighbour
+            # search), the middle ones (gradients added), the last (added; statistics and loss of the k views closed; single GPU: the
+            # update) -- replayed in that order by _step_views; the exchange and, under data parallelism, the update follow
+            k = self.views_per_rank
+            self._gk = [None, None, None]
+            for which, j in ((0, 0), (1, 1), (2, k - 1)):
+                if which == 1 and k < 3:
+                    continue
+                g = torch.cuda.CUDAGraph()
+                kw = dict(mode) if which == 0 else dict(mode, pool=self._gk[0].pool())
+                with torch.cuda.graph(g, **kw):
+                    self._select_view_node()
+                    self._view_of_step(j, self._scam, self._sgt)
+                    self._select_consumed()
+                    if which == 2 and self.world == 1:
+                        self._finish()
+                self._gk[which] = g
+            self._g1 = self._gk[0]
+            self._sloss = self._kloss
+        elif self._split:
             # data parallel: graph 1a = forward + backward down to the rasterizer inputs (SH gradients final), eager async
             # all-reduce of the SH segment, graph 1b = rest of the backward, eager all-reduce of the rest, graph 2 = update
             with torch.cuda.graph(self._g1, **mode):
@@ -565,11 +595,14 @@ class Trainer:
         t = d.expand_time(cam.fid)
         fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
         assemble = fused and self.fuse_deform and d.can_assemble(s)
-        self._store_now = bool(assemble and torch.is_grad_enabled() and self._store_ok())
+        adding = getattr(self, "_accum_view", 0) > 0   # view 2 .. k of a multi-view step: every producer ADDS to what the earlier views left
+        self._store_now = bool(assemble and torch.is_grad_enabled() and self._store_ok()) and not adding
         if hasattr(d, "grad_sink") and d.grad_sink:
             d.grad_sink = "store" if self._store_now else True
-        if not self._store_now and not (getattr(self, "_bucket_clean", False) and self.opt_deform is None and self.opt_surfels.zero_grads):
+        if not adding and not self._store_now and not (getattr(self, "_bucket_clean", False) and self.opt_deform is None and self.opt_surfels.zero_grads):
             self.bucket.zero()
+        if hasattr(d, "reuse_knn"):
+            d.reuse_knn = adding             # the surfels and nodes have not moved since the step's first view: its neighbours stand
         self._bucket_clean = False
         asm = None
         if assemble:
@@ -589,7 +622,7 @@ class Trainer:
         # single GPU: the step guard rides in the loss node (the thread that writes the loss runs it): everything it reads exists
         # then, and the surfels' Adam update later starts right behind the skinning backward (_finish: advance=False)
         ride = (fused and torch.is_grad_enabled() and self.world == 1 and self.opt_deform is None and getattr(self, "_oflag", None) is not None
-                and not self._arap_active() and _losses.FUSE_PHOTOMETRIC)
+                and not self._arap_active() and _losses.FUSE_PHOTOMETRIC and self.views_per_rank == 1)
         with trace.stage("dgs.loss"):
             loss = (training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, unit_grad=True, guard=self.opt_surfels if ride else None, **lam)
                     if fused else training_loss(pkg, gt, **lam))
@@ -681,7 +714,8 @@ class Trainer:
         with trace.stage("dgs.backward"):
             self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
         if hasattr(d, "finish_backward") and not self.warmup:   # (warm-up: nothing behind the deformation's outputs trains)
-            d.finish_backward(join=self.world > 1 or self.opt_deform is not None)  # single GPU: joined inside _finish
+            # single GPU, one view per step: joined inside _finish
+            d.finish_backward(join=self.world > 1 or self.opt_deform is not None or self.views_per_rank > 1)
         elif hasattr(d, "run_pending_reduce"):
             d.run_pending_reduce()
         if getattr(d, "_join_pending", False) and fused:
@@ -704,7 +738,7 @@ class Trainer:
         s = self.surfels
         hip_fused = (self.rasterizer_cls is None and s.get_xyz.is_cuda and self.fuse_deform and getattr(s, "packed_sh", False)
                      and self.sh_grad_sink and self.n_sh > 0 and self.deform.can_assemble(s))
-        return split_step_allowed(self.world, self.overlap_allreduce, hip_fused, self._arap_active())
+        return self.views_per_rank == 1 and split_step_allowed(self.world, self.overlap_allreduce, hip_fused, self._arap_active())
 
     def _fwd_bwd_a(self, cam, gt):
         """Forward, loss and the backward down to the rasterizer's inputs: afterwards the SH segment of the bucket is final."""
@@ -842,8 +876,11 @@ class Trainer:
         with torch.no_grad():
             if reduce:
                 self._reduce()
+            k = self.views_per_rank
             if self.opt_deform is None:
-                self.opt_surfels.grad_scale = 1.0 / self.world if self._fold_mean else 1.0
+                self.opt_surfels.grad_scale = (1.0 / self.world if self._fold_mean else 1.0) / k
+            elif k > 1:
+                self.bucket.flat[:self.bucket.n_grad].mul_(1.0 / k)   # (torch.optim.Adam path: the bucket holds the mean over the ranks of the SUM over the k views)
 
             def accumulate():
                 if self.rasterizer_cls is None and s.get_xyz.is_cuda:
@@ -1183,9 +1220,59 @@ class Trainer:
             return self.opt_surfels.moments(p)
         return (None, None)
 
-    def view_for(self, iteration):
-        """Shared deterministic schedule: step i renders views {i*world + rank} mod V."""
-        return (iteration * self.world + self.rank) % len(self.cameras)
+    def view_for(self, iteration, j=0):
+        """Shared deterministic schedule: step i renders views {(i k + j) world + rank} mod V, j = 0 .. k - 1 (k = views_per_rank)."""
+        return ((iteration * self.views_per_rank + j) * self.world + self.rank) % len(self.cameras)
+
+    # ---- k views per rank and step (opt-in lever of the data-parallel step, VERDICT r04 item 4c) -------------------------------
+    def _stats_accumulate(self, j):
+        """The densification statistics of the step's j-th view into side buffers: the kernels of _statistics OVERWRITE the bucket
+        tail and the radii; a multi-view step needs the SUM of the gradient norms and visibility counts and the MAX of the radii
+        (add_densification_stats once per view, gaussian_model.py:484-486)."""
+        if getattr(self, "_kx", None) is None or self._kx.shape != self.bucket.extra.shape:
+            self._kx = torch.zeros_like(self.bucket.extra)
+            self._kr = torch.zeros_like(self._radii)
+        if j == 0:
+            self._kx.copy_(self.bucket.extra)
+            self._kr.copy_(self._radii)
+        else:
+            self._kx.add_(self.bucket.extra)
+            torch.maximum(self._kr, self._radii, out=self._kr)   # (element P, the overflow flag, is sticky: MAX keeps it)
+        if j == self.views_per_rank - 1:
+            self.bucket.extra.copy_(self._kx)
+            self._radii.copy_(self._kr)
+
+    def _loss_accumulate(self, j, loss):
+        if getattr(self, "_kloss", None) is None:
+            self._kloss = torch.zeros(1, dtype=loss.dtype, device=loss.device)
+        if j == 0:
+            self._kloss.copy_(loss.reshape(1))
+        else:
+            self._kloss.add_(loss.reshape(1))
+        if j == self.views_per_rank - 1:
+            self._kloss.mul_(1.0 / self.views_per_rank)
+            self._note_loss(self._kloss)
+
+    def _view_of_step(self, j, cam, gt):
+        """Forward + backward of the step's j-th view (views 1 .. k - 1 add to the gradients of view 0) and its statistics."""
+        self._accum_view = j
+        try:
+            loss = self._fwd_bwd(cam, gt)
+        finally:
+            self._accum_view = 0
+        with torch.no_grad():
+            self._stats_accumulate(j)
+            self._loss_accumulate(j, loss)
+        return loss
+
+    def _multi_view_step(self, views):
+        """One step over k views of this rank: gradients added view by view, then ONE exchange and ONE update -- the neighbour search,
+        every all-reduce and the Adam kernels once per k views.  Not split (the SH all-reduce of the split step hides under ONE view's
+        remaining backward; here k - 1 whole views run after the first one's gradients exist, and the exchange waits for the last)."""
+        for j, v in enumerate(views):
+            self._view_of_step(j, self.cameras[v], self.targets[v % len(self.targets)])
+        self._finish()
+        return self._kloss[0].detach().clone() if not self._graph else self._kloss
 
     def step(self):
         guarded = self.opt_deform is None and getattr(self, "_oflag", None) is not None
@@ -1194,9 +1281,14 @@ class Trainer:
             if not self._graph:   # eager launches read the context's current flag (a captured step has its own baked in)
                 from diff_surfel_rasterization import _C
                 _C.set_overflow_flag(self._oflag)
-        v = self.view_for(self.iteration)
-        self.iteration += 1
-        loss = self._step_view(v)
+        if self.views_per_rank > 1:
+            views = [self.view_for(self.iteration, j) for j in range(self.views_per_rank)]
+            self.iteration += 1
+            loss = self._step_views(views)
+        else:
+            v = self.view_for(self.iteration)
+            self.iteration += 1
+            loss = self._step_view(v)
         if guarded:
             self._guard_steps += 1
             ev = torch.cuda.Event()
@@ -1205,6 +1297,30 @@ class Trainer:
             if len(self._guard_events) > 2 * self.GUARD_RING:
                 self._guard_events.pop(min(self._guard_events))
         return loss
+
+    def _step_views(self, views):
+        """A multi-view step (views_per_rank > 1): replay the captured per-view graphs, or run eagerly."""
+        if not self._graph:
+            with trace.stage("dgs.step(%d views)" % len(views)):
+                return self._multi_view_step(views)
+        k = self.views_per_rank
+        base = (self.iteration - 1) * k              # what the device's view counter must read in front of this step
+        if self._dev_select:
+            if base != self._vctr_host:
+                self._vctr.fill_(base)
+                self._vctr_host = base
+        for j, v in enumerate(views):
+            if self._dev_select:
+                if v != ((base + j) * self.world + self.rank) % len(self.cameras):
+                    self._vovr.fill_(v)
+                self._vctr_host += 1
+            else:
+                self._scam.load(self._vtab[v])
+            self._gk[0 if j == 0 else (2 if j == k - 1 else 1)].replay()   # first (stores) / middle (adds) / last (adds, closes the statistics)
+        if self._g2 is not None:
+            self._reduce()
+            self._g2.replay()
+        return self._kloss
 
     def _step_view(self, v):
         if self._graph:
