@@ -72,7 +72,7 @@ WORKLOADS = {
 
 
 def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None, packed_sh=None, slots=None,
-                  sort_surfels=None):
+                  sort_surfels=None, views_per_rank=1):
     from dgs_amd.cameras import orbit_cameras
     from dgs_amd.deform import ControlNodes
     from dgs_amd.model import SurfelModel
@@ -88,7 +88,7 @@ def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None,
     cams = [c.to(device) for c in orbit_cameras(n_views, W, H)]
     targets = [target_image(H, W, seed=1 + v).to(device) for v in range(n_targets)]
     bg = torch.zeros(3, device=device)
-    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam)
+    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam, views_per_rank=views_per_rank)
     if sort_surfels is None:
         sort_surfels = torch.device(device).type == "cuda" and rasterizer_cls is None and os.environ.get("DGS_SORT_SURFELS", "1") != "0"
     if sort_surfels:
@@ -367,6 +367,9 @@ def main():
                     help="also run the in-place densification every N timed steps (off by default: the metric is the plain step)")
     ap.add_argument("--slots-factor", type=float, default=1.5, help="surfel slots per initial surfel when --densify-every is on")
     ap.add_argument("--pre-iterations", type=int, default=10000, help="--workload trained: fit() iterations before the timed region")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="opt-in lever of the data-parallel step (Trainer.views_per_rank): k views per rank added before ONE exchange and update; "
+                         "the line then reports views_per_step = k * N and the metric counts views, not steps")
     ap.add_argument("--drift-gap", type=int, default=100, help="steps between the headline window and the second (drift) window; 0: skip")
     args = ap.parse_args()
     # the per-step losses of the timed steps are read back from the step guard's pinned ring: size it for the run asked for
@@ -430,7 +433,7 @@ def main():
             tr.enable_graph(capacity=96 * tr.P)
         P = tr.P
     else:
-        tr = build_trainer(P, H, W, device, slots=int(args.slots_factor * P) if args.densify_every else None)
+        tr = build_trainer(P, H, W, device, slots=int(args.slots_factor * P) if args.densify_every else None, views_per_rank=args.views_per_rank)
         if use_graph:
             # whole-step HIP graphs: the rasterizer runs in capacity mode (no device->host read), 24 list entries per
             # surfel is ~3x what this scene needs
@@ -645,7 +648,7 @@ def main():
         out = {
             "metric": "train views/sec (fwd+bwd), 800x800, 200k surfels" if args.workload == "metric"
             else "train views/sec (fwd+bwd), %dx%d, %dk surfels" % (W, H, P // 1000),
-            "value": round(world * args.steps / dt, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "value": round(args.views_per_rank * world * args.steps / dt, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("%s: synthetic scene S(%d surfels, %dx%d, seed 0), full train step (node deform + surfel "
@@ -656,7 +659,8 @@ def main():
                         "(%d live surfels in %d slots now); the timed step is the same full late-regime train step as 'metric', "
                         "on the dataset's target views" % (W, H, args.pre_iterations, tr.surfels.num_surfels, tr.P)),
                        "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "control_nodes": int(tr.deform.node_num),
-                       "views_per_step": world, "parallelism": "dp%d (views sharded, one flat all-reduce)" % world,
+                       "views_per_step": args.views_per_rank * world, "views_per_rank": args.views_per_rank,
+                       "parallelism": "dp%d (views sharded, one flat all-reduce)" % world,
                        "launch": "whole-step HIP graph replay" if use_graph else "eager",
                        "neighbour_search": "%s (spatial share of the K-th neighbour distance %.2f)"
                                            % (tr.deform.knn_refine_mode, getattr(tr.deform, "knn_spatial_share", float("nan")))},

@@ -158,6 +158,54 @@ def test_graph_captured_step_matches_eager():
     assert float((pe - pg).abs().median()) < 1e-6
 
 
+def test_views_per_rank_on_the_fused_path():
+    """Trainer(views_per_rank=2) on the HIP path: the first view of a step STORES its gradients (nothing is cleared), the second one
+    goes through the ADD flavour of every producer (SH sink, skinning backward, node-table fold, weight gradients) and reuses the
+    first view's neighbour search -- the bucket the Adam kernel then reads is the SUM of the two single-view gradients (it divides by
+    k itself), the statistics tail their sum; and the captured form (one graph per kind of view) trains like the eager one."""
+    import bench
+    from diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+
+    def bucket_of(views_per_rank, views):
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2, views_per_rank=views_per_rank)
+        order = list(views)
+        tr.view_for = lambda it, j=0: order[j]
+        rec = []
+        tr.opt_surfels.step = lambda *a, **k: rec.append(tr.bucket.flat.clone())
+        tr.step()
+        torch.cuda.synchronize()
+        return rec[-1], tr.bucket.n_grad, float(tr.opt_surfels.grad_scale)
+
+    f0, n, s0 = bucket_of(1, [0])
+    f1, _, _ = bucket_of(1, [1])
+    fk, _, sk = bucket_of(2, [0, 1])
+    assert s0 == 1.0 and sk == 0.5
+    off = 0
+    tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2)
+    for i, m in enumerate([p.numel() for p in tr.bucket.params] + [fk.numel() - n]):
+        a, b = fk[off:off + m], (f0 + f1)[off:off + m]
+        off += m
+        assert float((a - b).norm()) <= 2e-4 * float(b.norm()) + 1e-12, (i, m, float((a - b).norm()), float(b.norm()))
+    res = {}
+    for graph in (False, True):
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2, views_per_rank=2)
+        try:
+            if graph:
+                tr.enable_graph(capacity=24 * 20000)
+            losses = [float(tr.step()) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert not _C.read_overflow()
+            assert tr.iteration == 3 and int(tr.surfels.denom.max()) == 6     # three steps of two views
+        finally:
+            _C.set_capacity(0)
+        res[graph] = (losses, torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu())
+    (le, pe), (lg, pg) = res[False], res[True]
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-4 * abs(a), (le, lg)
+    assert torch.isfinite(pg).all() and float((pe - pg).abs().median()) < 1e-6
+
+
 def test_device_side_view_selection_follows_the_host_order():
     """The view of a replayed step is chosen by the graph's first node (dgs_select_row: device step counter, default order
     (i * world + rank) mod V).  It must render what the host's order asks for: in the default order without any host copy, under a

@@ -170,7 +170,7 @@ def test_data_parallel_two_ranks_gloo():
     for view in range(world):
         surfels, deform, cams, targets, bg = _build()
         tr = Trainer(surfels, deform, cams, targets, bg)
-        tr.view_for = lambda it, v=view: v
+        tr.view_for = lambda it, j=0, v=view: v
         tr.opt_surfels.step = lambda: None
         tr.opt_deform.step = lambda: None
         tr.step()
@@ -178,6 +178,99 @@ def test_data_parallel_two_ranks_gloo():
     n = tr.bucket.n_grad
     expect = torch.cat([(flats[0][:n] + flats[1][:n]) / 2, flats[0][n:] + flats[1][n:]])
     assert torch.allclose(flat_dp, expect, rtol=1e-4, atol=1e-7)
+
+
+def _single_view_flats(views):
+    """Gradient bucket (+ statistics tail) of one single-view step per view, optimisers stubbed."""
+    flats = []
+    for view in views:
+        surfels, deform, cams, targets, bg = _build()
+        tr = Trainer(surfels, deform, cams, targets, bg)
+        tr.view_for = lambda it, j=0, v=view: v
+        tr.opt_surfels.step = lambda: None
+        tr.opt_deform.step = lambda: None
+        tr.step()
+        flats.append(tr.bucket.flat.clone())
+    return flats, tr.bucket.n_grad
+
+
+def test_views_per_rank_accumulates_k_views_before_one_update():
+    """Trainer(views_per_rank=2), one process: a step renders views 0 and 1, ADDS their gradients and updates once -- the bucket the
+    optimiser sees is the mean of the two single-view gradients, the statistics tail their sum, the radii their maximum; the schedule
+    is view_for(i, j) = ((i k + j) world + rank) mod V; the neighbour search of the second view is the first one's."""
+    surfels, deform, cams, targets, bg = _build()
+    tr = Trainer(surfels, deform, cams, targets, bg, views_per_rank=2)
+    assert [tr.view_for(0, 0), tr.view_for(0, 1), tr.view_for(1, 0), tr.view_for(1, 1), tr.view_for(2, 0)] == [0, 1, 2, 3, 0]
+    seen = []
+    tr.opt_surfels.step = lambda: seen.append(tr.bucket.flat.clone())
+    tr.opt_deform.step = lambda: None
+    loss = tr.step()
+    assert tr.iteration == 1 and len(seen) == 1
+    flats, n = _single_view_flats([0, 1])
+    expect = torch.cat([(flats[0][:n] + flats[1][:n]) / 2, flats[0][n:] + flats[1][n:]])
+    assert torch.allclose(seen[0], expect, rtol=1e-4, atol=1e-7)
+    assert float(loss) == float(loss) and float(surfels.denom.sum()) > 0
+    # ... and a real run updates everything once per step
+    surfels, deform, cams, targets, bg = _build()
+    tr = Trainer(surfels, deform, cams, targets, bg, views_per_rank=2)
+    before = [p.detach().clone() for p in tr.bucket.params]
+    tr.step()
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, tr.bucket.params))
+    assert int(surfels.denom.max()) == 2          # two views counted by the statistics of ONE step
+
+
+def _dp_k_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    render_mod.GaussianRasterizer = OracleRasterizer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        surfels, deform, cams, targets, bg = _build()
+        tr = Trainer(surfels, deform, cams, targets, bg, views_per_rank=2)
+        assert [tr.view_for(0, 0), tr.view_for(0, 1)] == [rank, 2 + rank]
+        sent = []
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(t, *a, **k):
+            sent.append(t.numel() * t.element_size())
+            return real_all_reduce(t, *a, **k)
+        dist.all_reduce = counting_all_reduce
+        seen = []
+        real_step = tr.opt_surfels.step
+        tr.opt_surfels.step = lambda: (seen.append(tr.bucket.flat.clone()), real_step())[1]
+        tr.step()
+        dist.all_reduce = real_all_reduce
+        tr.step()
+        params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params])
+        gathered = [torch.zeros_like(params) for _ in range(world)]
+        dist.all_gather(gathered, params)
+        same = all(torch.equal(gathered[0], g) for g in gathered)
+        if rank == 0:
+            q.put((same, len(sent), sum(sent), tr.wire_bytes_per_step()["total"], seen[0].numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_views_per_rank_two_ranks_one_exchange_per_step():
+    """Two ranks x two views per rank: ONE exchange per step (the same two all-reduces and bytes as a single-view step), replicas
+    bit-identical, and the bucket the optimisers see is the mean of the FOUR views' gradients."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_k_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, n_calls, n_bytes, wire, flat = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert same
+    assert n_calls == 2 and n_bytes == wire, (n_calls, n_bytes, wire)
+    render_mod.GaussianRasterizer = OracleRasterizer
+    flats, n = _single_view_flats([0, 1, 2, 3])
+    expect = torch.cat([sum(f[:n] for f in flats) / 4, sum(f[n:] for f in flats)])
+    assert torch.allclose(torch.from_numpy(flat), expect, rtol=1e-4, atol=1e-7)
 
 
 def test_trainer_lr_schedule_sets_the_reference_rates():
