@@ -667,7 +667,9 @@ class Trainer:
         """fn() under the SH gradient sink when it applies (the rasterizer's backward then writes dL/dSH straight into the
         bucket view of the packed parameter)."""
         s = self.surfels
-        if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink:
+        # (views 2 .. k of a multi-view step: the sink STORES the rows of the visible surfels, it does not add to them -- those views
+        # take the operator's own dL/dSH tensor and autograd adds it to the bucket view: one 4 P M-byte pass more per extra view)
+        if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink and not getattr(self, "_accum_view", 0):
             import diff_surfel_rasterization as dsr
             # the sink belongs to THIS trainer's SH parameter (keyed by the tensor the forward was given): other trainers on the
             # device keep theirs, and removing it afterwards removes nothing else
