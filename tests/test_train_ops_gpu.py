@@ -179,14 +179,20 @@ def test_views_per_rank_on_the_fused_path():
 
     f0, n, s0 = bucket_of(1, [0])
     f1, _, _ = bucket_of(1, [1])
+    f0b, _, _ = bucket_of(1, [0])     # the yardstick: two runs of ONE configuration differ by the float atomics of the backward
+    f1b, _, _ = bucket_of(1, [1])     # (the hyper-coordinate gradients are small differences of large terms: ~50 % noise)
     fk, _, sk = bucket_of(2, [0, 1])
     assert s0 == 1.0 and sk == 0.5
     off = 0
     tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2)
+    bad = []
     for i, m in enumerate([p.numel() for p in tr.bucket.params] + [fk.numel() - n]):
         a, b = fk[off:off + m], (f0 + f1)[off:off + m]
+        noise = float((f0 - f0b)[off:off + m].norm()) + float((f1 - f1b)[off:off + m].norm())
+        if not float((a - b).norm()) <= 4.0 * noise + 2e-4 * float(b.norm()) + 1e-12:
+            bad.append((i, m, float((a - b).norm()), noise, float(b.norm())))
         off += m
-        assert float((a - b).norm()) <= 2e-4 * float(b.norm()) + 1e-12, (i, m, float((a - b).norm()), float(b.norm()))
+    assert not bad, bad
     res = {}
     for graph in (False, True):
         tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2, views_per_rank=2)
