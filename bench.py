@@ -348,6 +348,8 @@ def comm_report(tr, args, world, device, ms_headline, split_choice):
             tr._oflag.zero_()
     out["ms_per_step_no_collectives"] = round(ms_free, 4)
     out["exposed_ms_per_step"] = round(ms_headline - ms_free, 4)
+    out["views_per_rank"] = int(args.views_per_rank)
+    out["exposed_ms_per_view"] = round((ms_headline - ms_free) / args.views_per_rank, 4)   # what Trainer.views_per_rank divides
     out["sum_of_slices_ms"] = round(sum(v["ms"] for v in out["slices"].values()), 4)
     return out
 

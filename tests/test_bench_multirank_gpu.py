@@ -47,3 +47,28 @@ def test_bench_two_ranks_prints_one_valid_line():
     assert set(c["slices"]) >= {"sh", "rest", "radii"} and all(v["ms"] > 0 and v["bus_GBs"] > 0 for v in c["slices"].values())
     assert 0 < c["ms_per_step_no_collectives"] < r["ms_per_step"] and abs(c["exposed_ms_per_step"] - (r["ms_per_step"] - c["ms_per_step_no_collectives"])) < 1e-3
     assert c["split3"]["chosen"] in ("two", "three") and c["split3"]["ms_per_step_two_pieces"] > 0 and c["split3"]["ms_per_step_three_pieces"] > 0
+
+
+def test_bench_two_ranks_two_views_per_rank():
+    """The same launch with --views-per-rank 2 (Trainer.views_per_rank: two views per rank added before the one exchange of a step):
+    four views per step, the rate counts views, one exchange per step (no split: the SH slice is part of `rest`), and the
+    communication object reports what stays exposed per VIEW."""
+    world, port = 2, _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DGS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
+                                       "--no-cpu-baseline", "--no-roofline-legs", "--views-per-rank", "2"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["views_per_step"] == 4 and r["config"]["views_per_rank"] == 2
+    assert r["value"] > 0 and abs(r["value"] - 4 * 1e3 / r["ms_per_step"]) <= 1e-2 * r["value"]
+    c = r["comm"]
+    assert c["views_per_rank"] == 2 and c["split3"] is None and "sh" not in c["slices"] and set(c["slices"]) >= {"rest", "radii"}
+    assert abs(c["exposed_ms_per_view"] - c["exposed_ms_per_step"] / 2) < 1e-3
