@@ -41,8 +41,12 @@ def test_fit_recovers_a_hidden_dynamic_scene(tmp_path):
         return float(np.mean(vals))
 
     probes = {}
+    # deterministic=True (round 5): order-free sums instead of float atomics -- the run is the same trajectory every time, so the
+    # margins below are checked on ONE known outcome instead of on a draw from a 5-dB spread (which failed this test once in ~15 runs)
     tr, losses = fit(data, str(tmp_path / "model"), iterations=9000, device=dev, num_pts=20_000, node_num=256, seed=0,
+                     deterministic=os.environ.get("DGS_LEARNING_TEST_ATOMICS", "0") != "1",
                      on_iteration=lambda it, t: probes.__setitem__(it, heldout_psnr(t)) if it in (1, 3000, 6000, 9000) else None)
+    tr.set_deterministic(False)
     print("held-out PSNR by iteration:", {k: round(v, 2) for k, v in sorted(probes.items())})
     losses = np.asarray(losses)
     blocks = losses[:9000].reshape(18, 500).mean(1)
