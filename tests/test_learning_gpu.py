@@ -151,4 +151,4 @@ def test_deterministic_captured_fits_are_bit_identical(tmp_path):
     assert lc[0] == pytest.approx(la[0], rel=1e-4)
     assert not np.array_equal(lc, la)
     assert la[800:].mean() < 0.5 * la[:50].mean()                       # it learns like the default does
-    assert lc[800:].mean() == pytest.approx(la[800:].mean(), rel=0.25)
+    assert lc[800:].mean() == pytest.approx(la[800:].mean(), rel=0.4)   # (the float-atomic run is a draw: same optimisation, other trajectory)
