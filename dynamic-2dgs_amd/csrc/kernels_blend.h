@@ -87,6 +87,13 @@ struct BlendFwdArgs {
     const LongThr* long_thr;     // thresholds of the long-tile path, or null (path off: grid = blend_grid_size)
     float* out_color;            // [3,H,W]
     float* out_others;           // [8,H,W]
+    // accumulator rider: the first `clear_blocks` workgroups (a multiple of 8: the XCD of every tile workgroup stays what it was) zero the
+    // backward's per-surfel accumulator rows -- 80 B per surfel of stores that ride under this VALU-bound kernel instead of costing the
+    // backward a 10-us launch of their own -- and *clean_flag says so to prep_bwd_kernel (1 = rows are zero; the backward blend writes 0)
+    float4* clear;
+    uint32_t clear_n4;
+    int clear_blocks;
+    uint32_t* clean_flag;
 };
 
 // Tile order.  The dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md) and every XCD has a private
@@ -309,7 +316,8 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* ranges, c
 // the last one orders the tiles by the length the forward traversed (tile_order_kernel) -- the two were 7 + 6 us back to back in
 // front of the backward blend of every step.
 __global__ void __launch_bounds__(1024) prep_bwd_kernel(float4* __restrict__ acc, size_t n4, const uint32_t* weights, int tiles_x, int tiles_y, int mode,
-                                                        uint32_t* order, uint32_t* group_xcd, uint32_t* long_thr /*[2]: [1] written here*/, uint32_t long_div)
+                                                        uint32_t* order, uint32_t* group_xcd, uint32_t* long_thr /*[2]: [1] written here*/, uint32_t long_div,
+                                                        const uint32_t* clean_flag /*1: the forward blend's rider zeroed the rows, or null*/)
 {
     __shared__ uint32_t s_hist[8 * kOrderBins];
     __shared__ uint32_t s_gw[kOrderMaxGroups], s_gx[kOrderMaxGroups];
@@ -339,6 +347,7 @@ __global__ void __launch_bounds__(1024) prep_bwd_kernel(float4* __restrict__ acc
         else tile_order_body(nullptr, weights, tiles_x * tiles_y, order, s_hist, s_wsum);
         return;
     }
+    if (clean_flag && *clean_flag == 1u) return;
     const size_t stride = (size_t)(gridDim.x - 1) * 1024;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) acc[i] = z;
@@ -629,17 +638,24 @@ __global__ void __launch_bounds__(kTilePix, DGS_FWD_MINWAVES) blend_fwd_rows_ker
     __shared__ uint32_t s_max[4];
     __shared__ FwdLongX s_x;      // long tiles: the rounds' exchange
 
+    if (a.clean_flag && blockIdx.x == 0 && threadIdx.x == 0) *a.clean_flag = a.clear_blocks > 0 ? 1u : 0u;   // read after this launch has ended
+    if ((int)blockIdx.x < a.clear_blocks) {   // accumulator rider (BlendFwdArgs)
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t i = blockIdx.x * kTilePix + threadIdx.x; i < a.clear_n4; i += (uint32_t)a.clear_blocks * kTilePix) a.clear[i] = z;
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.clear_blocks;
     const int ntiles = a.tiles_x * a.tiles_y;
     int tile;
     if (a.long_thr) {   // tile order 3 with the long-tile path: see long_decode
         int lq;
-        if (!long_decode(blockIdx.x, a.order, ntiles, a.long_thr->fwd, nullptr, a.ranges, tile, lq)) return;
+        if (!long_decode(bid, a.order, ntiles, a.long_thr->fwd, nullptr, a.ranges, tile, lq)) return;
         if (lq >= 0) {
             blend_fwd_long(a, tile, lq, s_stage, s_x);
             return;
         }
     } else {
-        tile = tile_for_block(blockIdx.x, a.tiles_x, a.tiles_y, a.mode);
+        tile = tile_for_block(bid, a.tiles_x, a.tiles_y, a.mode);
         if (a.mode < 3 && tile >= ntiles) return;
         if (a.mode >= 3) tile = (int)a.order[tile];
         if (tile >= ntiles) return;   // mode 4: empty slot
@@ -802,6 +818,7 @@ struct BlendBwdArgs {
     float* acc;               // [P, kAccFloats], zeroed
     float* det_part;          // deterministic variant 1 only: [num_rendered][4 waves][kAccFloats], zeroed (see det_reduce_kernel)
     unsigned long long* acc64; // deterministic variant 2 only: [P, kAccFloats] fixed-point sums (2^-44), zero on entry (fixed_to_acc_kernel)
+    uint32_t* clean_flag;      // BlendFwdArgs::clean_flag: the accumulator rows are written from here on (or null)
     const LongThr* long_thr;  // thresholds of the long-tile path, or null (path off: grid = blend_grid_size)
 };
 
@@ -1077,6 +1094,7 @@ __global__ void __launch_bounds__(kTilePix, DGS_BWD_MINWAVES) blend_bwd_kernel(B
 
     const int ntiles = a.tiles_x * a.tiles_y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.clean_flag && blockIdx.x == 0 && threadIdx.x == 0) *a.clean_flag = 0u;   // (prep_bwd_kernel read it in the launch before)
     int tile, lq = -1;
 #if DGS_BWD_REDUCE == 4
     if (a.long_thr) {   // tile order 3 with the long-tile path (long_decode)

@@ -202,6 +202,7 @@ struct dgs_context {
         if (const char* e = getenv("DGS_LONG_TILES")) long_tiles.store(atoi(e) != 0);   // A/B runs of whole programs (bench.py, the test suite)
         if (const char* e = getenv("DGS_MERGED_OFFSETS")) merged_offsets.store(atoi(e) != 0);
         if (const char* e = getenv("DGS_ORDER_RIDER")) order_rider.store(atoi(e) != 0);
+        if (const char* e = getenv("DGS_ACC_RIDER")) acc_rider.store(atoi(e) != 0);
     }
     int device = 0;
     std::atomic<int> tight_rects{1};  // exact opacity-aware tile rectangles (surfel_math.h tight_tile_rect)
@@ -224,6 +225,7 @@ struct dgs_context {
     std::atomic<int> capacity{0};     // > 0: capacity mode (no host read of num_rendered; stream-capture safe)
     std::atomic<int> list_hint{0};    // capacity mode (key 6): promised longest tile list; 0 = no promise (every sort kernel is launched)
     std::atomic<int> grid_limit_bwd{0};   // > 0 (diagnostic, key 4): the backward blend processes only the first N tiles of its dispatch order
+    std::atomic<bool> acc_rider{true};    // key 14: the forward blend zeroes the backward's accumulator rows (BlendFwdArgs::clear)
     std::atomic<int> grid_limit_fwd{0};   // > 0 (diagnostic, key 5): same for the forward blend (the other tiles' state is zero-filled)
     std::atomic<int*> overflow{nullptr};  // device flag raised by a capacity overflow (library- or caller-owned)
     int* overflow_owned = nullptr;
@@ -361,6 +363,7 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
     if (key == 11 && value > 0) { c->long_div_bwd.store(value); return DGS_OK; }
     if (key == 12) { c->merged_offsets.store(value != 0); return DGS_OK; }
     if (key == 13) { c->order_rider.store(value != 0); return DGS_OK; }
+    if (key == 14) { c->acc_rider.store(value != 0); return DGS_OK; }
     if (key == 3 && value >= 0 && value <= 2) { c->sort_regs.store(value); return DGS_OK; }
     if (key == 4 && value >= 0) { c->grid_limit_bwd.store(value); return DGS_OK; }
     if (key == 6 && value >= 0) { c->list_hint.store(value); return DGS_OK; }
@@ -759,6 +762,19 @@ int dgs_context_forward(dgs_context* ctx, dgs_alloc_fn geometry_alloc, void* geo
         DGS_HIP(hipMemsetAsync(img + il.final_T, 0, il.ranges - il.final_T, stream));   // final_T, n_contrib of the skipped tiles
         DGS_HIP(hipMemsetAsync(img + il.tile_last, 0, (size_t)il.ntiles * 4, stream));
     }
+    // accumulator rider: 256 workgroups in FRONT of the tile workgroups (they hold a slot for a few microseconds each while the tile
+    // workgroups fill the rest of the chip; at the end of the grid they would lengthen the drain)
+    fa.clear = nullptr; fa.clear_n4 = 0; fa.clear_blocks = 0;
+    fa.clean_flag = (uint32_t*)(geom + gl.total) + 3;
+    {
+        const size_t acc_bytes = (size_t)P * dgs::kAccFloats * 4;
+        if (ctx->acc_rider.load() && !ctx->grid_limit_fwd.load() && tile_order >= 3 && acc_bytes % 16 == 0 && acc_bytes / 16 < 0xf0000000ull) {
+            fa.clear = (float4*)(geom + gl.acc);
+            fa.clear_n4 = (uint32_t)(acc_bytes / 16);
+            fa.clear_blocks = (int)std::min<size_t>(256, ((fa.clear_n4 + 16 * dgs::kTilePix - 1) / (16 * dgs::kTilePix) + 7) / 8 * 8);   // ~16 stores per thread
+            grid += fa.clear_blocks;
+        }
+    }
     Prof::Pair pp;
     const bool timed = prof_begin(ctx, 0, stream, pp);
 #if DGS_FWD_ROWS
@@ -812,7 +828,8 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         const int fill_blocks = (int)std::min<size_t>(1024, (n4 + 4 * 1024 - 1) / (4 * 1024));   // ~4 stores of 16 B per thread
         hipLaunchKernelGGL(dgs::prep_bwd_kernel, dim3(fill_blocks + 1), dim3(1024), 0, stream, (float4*)acc, n4,
                            (const uint32_t*)(img_buffer + il.tile_last), il.tiles_x, il.tiles_y, bwd_mode,
-                           (uint32_t*)(img_buffer + il.order_bwd), (uint32_t*)(img_buffer + il.group_xcd), (uint32_t*)(img_buffer + il.long_thr), (uint32_t)ctx->long_div_bwd.load());
+                           (uint32_t*)(img_buffer + il.order_bwd), (uint32_t*)(img_buffer + il.group_xcd), (uint32_t*)(img_buffer + il.long_thr), (uint32_t)ctx->long_div_bwd.load(),
+                           DGS_BWD_ROWS ? (const uint32_t*)nullptr : (const uint32_t*)(geom_buffer + gl.total) + 3);   // (the A/B rows kernel does not reset the flag)
         DGS_STAGE("prep_bwd", debug, stream);
     } else {
         DGS_HIP(hipMemsetAsync(acc, 0, acc_bytes, stream));
@@ -840,6 +857,7 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
         ba.dL_dpix = dL_dpix;
         ba.dL_dothers = dL_depths;
         ba.acc = acc;
+        ba.clean_flag = (uint32_t*)(geom_buffer + gl.total) + 3;
         int grid = dgs::blend_grid_size(il.tiles_x, il.tiles_y, ba.mode);
         ba.long_thr = nullptr;
 #if !DGS_BWD_ROWS && DGS_BWD_REDUCE == 4

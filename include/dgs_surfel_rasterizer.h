@@ -170,6 +170,10 @@ void dgs_set_tight_rects(int on);
  * key 13 = capacity mode only (1 [default] / 0): the forward blend's dispatch order and the cleared per-tile maxima are written by one more
  *         workgroup of the key-scatter launch (next to its 256 working ones) instead of by the last workgroup of the offsets kernel
  *         (a serial tail of that launch).  Same results.
+ * key 14 = accumulator rider (1 [default] / 0; tile orders 3, 4): the first workgroups of the forward blend launch zero the per-surfel
+ *         accumulator rows of the backward (80 B per surfel, inside the geometry buffer) and leave a flag next to num_rendered; the
+ *         backward's prep launch then skips its own clear (-5 us per step at 200 k surfels: the stores ride under a VALU-bound kernel).  The
+ *         backward blend resets the flag, so a second backward over the same forward state clears the rows itself.  Same results.
  * key 6 = capacity mode only: a PROMISE that no tile list is longer than `value` entries (0 = none [default]).  Without the
  *         host read the library cannot know which of its per-tile sort kernels will find work and launches all four; with the
  *         promise it launches only those for lists up to `value` (2048: one launch; 57344 = 28 segments of 2048: three).  A frame that breaks the promise is treated exactly like a capacity overflow: background, flag raised,

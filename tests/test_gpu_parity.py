@@ -348,6 +348,47 @@ def test_fixed_point_backward_is_reproducible_fast_path(cfg):
         assert np.abs(again[k] - atomic[k]).max() <= 1e-4 * scale + 1e-12, k
 
 
+def test_accumulator_rider_of_the_forward_blend():
+    """The backward's per-surfel accumulator rows are zeroed by the first workgroups of the FORWARD blend launch (option 14, default on),
+    and a flag in the geometry buffer tells the backward's prep launch to skip its own clear.  (a) With the order-free backward
+    (option 7 = 2) the gradients are bit-identical with the rider on and off.  (b) A SECOND backward over the same forward state
+    finds the flag reset by the first one and clears the rows itself: .grad ends at exactly twice the single pass."""
+    from diff_surfel_rasterization import _C, GaussianRasterizer
+    from gpu_utils import run_hip, settings_from_case
+    case = small_case(P=6000, H=112, W=144, seed=77)
+    gc, go = _cot(case)
+    keys = ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh")
+    try:
+        _C.set_option(7, 2)
+        on = run_hip(case, gc, go, debug=False)
+        _C.set_option(14, 0)
+        off = run_hip(case, gc, go, debug=False)
+        _C.set_option(14, 1)
+        for k in keys:
+            assert np.array_equal(on[k], off[k]), k
+        assert np.array_equal(on["color"], off["color"]) and np.array_equal(on["allmap"], off["allmap"])
+        # (b) two backward passes over one forward
+        dev = "cuda:0"
+        rast = GaussianRasterizer(settings_from_case(case, dev, False))
+        leaves = {k: case[k].to(dev).clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        color, radii, allmap = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], scales=leaves["scales"],
+                                    rotations=leaves["rotations"], shs=leaves["shs"])
+        loss = (color * torch.as_tensor(gc, device=dev)).sum() + (allmap * torch.as_tensor(go, device=dev)).sum()
+        loss.backward(retain_graph=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        for k, name in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"), ("opacities", "dL_dopacity"), ("shs", "dL_dsh")):
+            assert np.array_equal(leaves[k].grad.cpu().numpy(), 2.0 * on[name]), name
+    finally:
+        _C.set_option(14, 1)
+        _C.set_option(7, 0)
+    # float atomics (the default): same sums to rounding
+    again = run_hip(case, gc, go, debug=False)
+    for k in keys:
+        assert np.abs(again[k] - on[k]).max() <= 1e-4 * np.abs(on[k]).max() + 1e-12, k
+
+
 def test_backward_needs_no_zero_filled_outputs():
     """The eight per-surfel gradient arrays are written for every row (culled surfels: zeros), so the binding allocates them
     uninitialised.  Poison the allocator's free blocks with NaN first: the gradients of a scene with culled surfels must come
