@@ -293,6 +293,16 @@ __global__ void __launch_bounds__(kSurfelBlock) count_tiles_global_kernel(int P,
         for (int x = x0; x < x1; x++) atomicAdd(&tile_counts[y * tiles_x + x], 1u);
 }
 
+// What is OR-ed into the overflow flag (dgs_set_overflow_flag): bit 0 the lists do not fit the capacity, bit 1 a list is longer than
+// promised (option 6), bit 2 that list is longer than the segmented sort reaches (kSegCap * kMaxSegs) -- the caller picks its next
+// configuration from the bits instead of trying the tiers one skipped step at a time.
+__device__ __forceinline__ int overflow_reason(uint32_t total, uint32_t cap, uint32_t longest, uint32_t list_hint)
+{
+    int r = total > cap ? 1 : 0;
+    if (list_hint > 0 && longest > list_hint) r |= longest > 57344u ? 6 : 2;
+    return r;
+}
+
 // Exclusive scan of the per-tile counts (T = 2500 at 800x800, 10000 at 1600x1600) by ONE workgroup:
 // ranges[t] = [start, end) (identifyTileRanges, rasterizer_impl.cu:116-138), cursor[t] = start (scatter cursors),
 // *total_out = num_rendered (rasterizer_impl.cu:281).
@@ -350,7 +360,7 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(const uint32_t* counts
             total_out[0] = total;
             total_out[1] = longest;
             total_out[2] = over ? 1u : 0u;
-            if (over && overflow) atomicOr(overflow, 1);
+            if (over && overflow) atomicOr(overflow, overflow_reason(total, cap, longest, list_hint));
             // long-tile path of the forward blend (kernels_blend.h): worth its extra arithmetic only where ONE tile's serial walk is as
             // long as the whole launch's throughput-bound time -- a list is long from 768 entries and num_rendered / long_div on
             long_thr[0] = max(768u, total / max(long_div, 1u));
@@ -493,7 +503,7 @@ __global__ void __launch_bounds__(64 * kColGroups) bin_offsets_kernel(OffsetsArg
         a.state[0] = total;
         a.state[1] = longest;
         a.state[2] = over ? 1u : 0u;
-        if (over && a.overflow) atomicOr(a.overflow, 1);
+        if (over && a.overflow) atomicOr(a.overflow, overflow_reason(total, a.cap, longest, a.list_hint));
         a.long_thr[0] = max(768u, total / max(a.long_div, 1u));
     }
     if (a.order && !a.order_later) {

@@ -329,13 +329,11 @@ class Trainer:
         if not self._graph or getattr(self, "_capacity", 0) <= 0:
             raise RuntimeError("rasterizer capacity overflow outside capacity mode")
         self.iteration -= redo          # the skipped steps changed nothing: their views are rendered again
+        reason = int(self._oflag.item())   # kernels_preprocess.h overflow_reason: 1 capacity, 2 promised list length, 4 beyond the segmented sort
         self._oflag.zero_()
         self._guard_events.clear()
         self.overflow_recoveries += 1
-        if getattr(self, "_list_hint", 0):
-            self._list_hint = self._next_list_hint()   # first suspect: a tile list longer than promised (enable_graph re-captures with the next tier)
-        else:
-            self._capacity = 2 * self._capacity
+        self._after_overflow(reason)
         self._graph = None
         self._in_recovery = True
         try:
@@ -492,18 +490,34 @@ class Trainer:
                     self._forward(self._scam, self._sgt)
             self._scam.load(self._vtab[0])
             torch.cuda.synchronize()
-        if _C.read_overflow(device=dev):
-            if self._list_hint:            # perhaps only the promised list length was exceeded: next tier and capture again
-                self._list_hint = self._next_list_hint()
+        reason = _C.read_overflow(device=dev)
+        if reason:
+            if reason & 1 and validate:    # (a broken promise next to it would not change that)
+                raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
+            if self._list_hint and (reason & 6 or not reason & 1):   # only the promised list length was exceeded: the tier that fits, capture again
+                self._list_hint = 0 if reason & 4 else self._next_list_hint()
                 self._graph = None
                 return self.enable_graph(capacity, validate=validate)
-            if validate:
-                raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
 
     # Promise of the longest tile list (dgs_set_option key 6) in the tiers of the library's sort kernels: up to 2048 entries one
     # launch, up to 57 344 (28 segments of 2048 + merge) three, no promise (0) four.  A view that breaks the promise
     # moves the trainer one tier up -- a densified scene with lists of a few thousand entries keeps the cheap tiers it fits.
     LIST_HINT_TIERS = (2048, 57344, 0)
+
+    def _after_overflow(self, reason):
+        """The next configuration after a frame that did not fit, from the reason bits the kernels left in the flag: a broken promise
+        moves the list-length tier (straight to 'no promise' when the list is beyond the segmented sort), a full buffer doubles the
+        capacity -- both in ONE recovery when both happened.  reason == 0 (flag already consumed): the order of rounds 3-4, promise first."""
+        hint = getattr(self, "_list_hint", 0)
+        if reason & 6 and hint:
+            self._list_hint = 0 if reason & 4 else self._next_list_hint()
+        if reason & 1:
+            self._capacity = 2 * self._capacity
+        if not reason & 7:
+            if hint:
+                self._list_hint = self._next_list_hint()
+            else:
+                self._capacity = 2 * self._capacity
 
     def _next_list_hint(self):
         t = self.LIST_HINT_TIERS

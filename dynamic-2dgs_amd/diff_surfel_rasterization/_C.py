@@ -220,7 +220,7 @@ class Context:
         self._flag = tensor   # keep it alive
 
     def read_overflow(self, reset=True):
-        return bool(load().dgs_context_read_overflow(self.handle, 1 if reset else 0))
+        return int(load().dgs_context_read_overflow(self.handle, 1 if reset else 0))   # 0, or the reason bits (dgs_set_overflow_flag)
 
     def close(self):
         if self.handle:
@@ -388,7 +388,7 @@ def set_capacity(n_entries, device=None):
 
 def read_overflow(reset=True, device=None):
     with _on(device):
-        return bool(load().dgs_read_overflow(1 if reset else 0))
+        return int(load().dgs_read_overflow(1 if reset else 0))   # 0, or the reason bits (dgs_set_overflow_flag)
 
 
 _OVERFLOW_FLAGS = {}   # device index -> the caller-owned flag tensor its default context points at (kept alive here)

@@ -182,12 +182,14 @@ void dgs_set_tight_rects(int on);
  * Returns DGS_OK or an error. */
 int dgs_set_option(int key, int value);
 
-/* The capacity-overflow flag is one int32 in device memory, OR-ed to 1 by the forward whose lists did not fit.  By default
+/* The capacity-overflow flag is one int32 in device memory, OR-ed by the forward whose lists did not fit with the reason: bit 0 the
+ * lists exceed the capacity, bit 1 a list is longer than promised (option 6), bit 2 that list is also beyond the segmented sort's
+ * 57 344 entries (the caller can pick its next capacity / promise from the bits; any non-zero value = the frame rendered as background).  By default
  * the library owns it (dgs_read_overflow).  A trainer that must not act on such a frame hands in its own flag here and lets
  * its optimiser kernels read it on the device (skip the update) -- no host round trip; NULL returns to the library's. */
 int dgs_set_overflow_flag(int* device_flag);
 
-/* 1 if a capacity overflow happened since the last reset (blocking device read; call it outside hot loops). */
+/* Non-zero (the reason bits above) if a capacity overflow happened since the last reset (blocking device read; call it outside hot loops). */
 int dgs_read_overflow(int reset);
 
 /* Kernel timing hook for bench.py.  mode 1: the library brackets its kernels with HIP events on the launch stream (eager

@@ -260,11 +260,25 @@ def test_capacity_overflow_is_flagged_not_fatal():
     try:
         out = run_hip(case, debug=False)
         torch.cuda.synchronize()
-        assert _C.read_overflow()
+        assert _C.read_overflow() == 1  # reason bit 0: the lists exceed the capacity (include/dgs_surfel_rasterizer.h, dgs_set_overflow_flag)
         bg = case["bg"].numpy()[:, None, None]
         assert abs(out["color"] - bg).max() == 0.0  # the frame rendered as background, nothing was written out of bounds
         assert not _C.read_overflow()  # flag was reset by the read
+        # a broken promise of the longest list (option 6) says so: bit 1; together with a full buffer: both bits
+        _C.set_capacity(1 << 20)
+        _C.set_option(6, 4)
+        out = run_hip(case, debug=False)
+        assert _C.read_overflow() == 2 and abs(out["color"] - bg).max() == 0.0
+        _C.set_capacity(100)
+        _C.set_option(6, 4)
+        run_hip(case, debug=False)
+        assert _C.read_overflow() == 3
+        _C.set_capacity(1 << 20)            # (set_capacity keeps no promise across a 0; here the promise is withdrawn explicitly)
+        _C.set_option(6, 0)
+        out = run_hip(case, debug=False)
+        assert not _C.read_overflow() and abs(out["color"] - bg).max() > 0.0
     finally:
+        _C.set_option(6, 0)
         _C.set_capacity(0)
     out = run_hip(case, debug=False)
     assert abs(out["color"]).max() > 0

@@ -326,3 +326,27 @@ def test_list_promise_moves_up_one_tier_at_a_time():
     assert t._next_list_hint() == 0
     del t._list_hint
     assert t._next_list_hint() == 0
+
+
+def test_overflow_reason_bits_pick_the_next_configuration_in_one_recovery():
+    """Trainer._after_overflow: the kernels leave the REASON of an overflow in the flag (kernels_preprocess.h overflow_reason: bit 0
+    capacity, bit 1 promised list length, bit 2 list beyond the segmented sort's 57 344 entries), so one recovery lands on the
+    configuration that fits -- a capacity overflow doubles the capacity and keeps the promise (rounds 3-4 walked the tiers first: up to
+    three skipped steps), a broken promise moves the tier and keeps the capacity, a 60 000-entry list goes straight to 'no promise'."""
+    from dgs_amd.train import Trainer
+
+    def after(hint, cap, reason):
+        t = Trainer.__new__(Trainer)
+        t._list_hint, t._capacity = hint, cap
+        t._after_overflow(reason)
+        return t._list_hint, t._capacity
+
+    assert after(2048, 1000, 1) == (2048, 2000)
+    assert after(2048, 1000, 2) == (57344, 1000)
+    assert after(2048, 1000, 6) == (0, 1000)
+    assert after(57344, 1000, 6) == (0, 1000)
+    assert after(2048, 1000, 3) == (57344, 2000)
+    assert after(0, 1000, 1) == (0, 2000)
+    # flag already consumed (reason 0): the promise is the first suspect, then the capacity
+    assert after(2048, 1000, 0) == (57344, 1000)
+    assert after(0, 1000, 0) == (0, 2000)
