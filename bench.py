@@ -313,8 +313,12 @@ def comm_report(tr, args, world, device, ms_headline, split_choice):
         snapshot that is restored afterwards (the replicas diverge without their all-reduce);
       exposed_ms_per_step: headline - that = communication the step does not hide."""
     wire = tr.wire_bytes_per_step()
-    out = {"world": world, "backend": dist.get_backend(), "wire_bytes_per_step": wire, "wire_bf16": bool(tr.wire_bf16), "split3": split_choice, "slices": {}}
+    shard = bool(tr._shard_ok())
+    out = {"world": world, "backend": dist.get_backend(), "wire_bytes_per_step": wire, "wire_bf16": bool(tr.wire_bf16), "split3": split_choice,
+           "sh_collective": ("reduce_scatter(gradients) -> Adam on P/N rows -> all_gather(parameter), the all-gather under the next step's "
+                             "deformation head" if shard else "all_reduce(gradients), Adam on all rows on every rank"), "slices": {}}
     reps = 10
+    rank = dist.get_rank()
     for name, nbytes in wire.items():
         if name == "total" or not nbytes:
             continue
@@ -322,17 +326,26 @@ def comm_report(tr, args, world, device, ms_headline, split_choice):
         half = tr.wire_bf16 and name in ("sh", "mid")   # these slices cross as bfloat16 (Trainer.wire_bf16)
         buf = torch.zeros(nbytes // (2 if half else 4), dtype=torch.int32 if is_radii else (torch.bfloat16 if half else torch.float32), device=device)
         op = dist.ReduceOp.MAX if is_radii else dist.ReduceOp.SUM
-        for _ in range(3):
-            dist.all_reduce(buf, op=op)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            dist.all_reduce(buf, op=op)
-        torch.cuda.synchronize()
-        ms = _max_over_ranks(time.perf_counter() - t0, device) / reps * 1e3
-        out["slices"][name] = {"bytes": int(nbytes), "ms": round(ms, 4), "bus_GBs": round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 2)}
+        c = buf.numel() // world
+        kinds = [(name, lambda: dist.all_reduce(buf, op=op), 2.0 * (world - 1) / world)]
+        if name == "sh" and shard:   # the sharded SH update: the two halves of the all-reduce as collectives of their own, in place
+            gbuf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device) if half else buf   # (the parameter rows always cross as fp32)
+            cg = gbuf.numel() // world
+            kinds = [("sh_reduce_scatter", lambda: dist.reduce_scatter_tensor(buf[rank * c:(rank + 1) * c], buf, op=op), (world - 1.0) / world),
+                     ("sh_all_gather", lambda: dist.all_gather_into_tensor(gbuf, gbuf[rank * cg:(rank + 1) * cg]), (world - 1.0) / world)]
+        for kname, fn, factor in kinds:
+            kbytes = int(nbytes) if kname != "sh_all_gather" else int(4 * (nbytes // (2 if half else 4)))
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            ms = _max_over_ranks(time.perf_counter() - t0, device) / reps * 1e3
+            out["slices"][kname] = {"bytes": kbytes, "ms": round(ms, 4), "bus_GBs": round(factor * kbytes / (ms * 1e-3) / 1e9, 2)}
         del buf
     snap, it0 = tr._snapshot(), tr.iteration
     tr.no_collectives = True
@@ -351,7 +364,53 @@ def comm_report(tr, args, world, device, ms_headline, split_choice):
     out["views_per_rank"] = int(args.views_per_rank)
     out["exposed_ms_per_view"] = round((ms_headline - ms_free) / args.views_per_rank, 4)   # what Trainer.views_per_rank divides
     out["sum_of_slices_ms"] = round(sum(v["ms"] for v in out["slices"].values()), 4)
+    out["levers"] = comm_levers(tr, args, world, device, ms_headline)
     return out
+
+
+def comm_levers(tr, args, world, device, ms_headline):
+    """N > 1: the two levers that trade something for less exposed communication, timed in THIS run (W + K steps each, from a snapshot
+    that is restored afterwards -- the headline and everything after it are unaffected), so that "which of them pays on these links"
+    needs no second run:  wire_bf16 -- the big slices cross as bfloat16 (a change of the numerics; eager collectives, no re-capture);
+    views_per_rank 2 -- two views per rank added before ONE exchange and update (k x N views per step; re-captured and captured back)."""
+    if args.views_per_rank != 1 or os.environ.get("DGS_NO_LEVERS", "0") == "1":
+        return None
+    res = {"ms_per_view_headline": round(ms_headline, 4)}
+
+    def window():
+        for _ in range(args.warmup):
+            tr.step()
+        return _max_over_ranks(timed_steps(tr, args.steps, world), device) / args.steps * 1e3
+
+    def rewind(snap, it0):
+        tr._restore(snap)
+        tr.iteration = it0
+        if getattr(tr, "_oflag", None) is not None:
+            tr._oflag.zero_()
+
+    snap, it0 = tr._snapshot(), tr.iteration
+    was = tr.wire_bf16
+    try:
+        tr.wire_bf16 = not was
+        ms = window()
+        res["wire_bf16_%s" % ("off" if was else "on")] = {"ms_per_view": round(ms, 4), "wire_bytes_per_step": tr.wire_bytes_per_step()["total"]}
+    finally:
+        tr.wire_bf16 = was
+        rewind(snap, it0)
+    if tr._graph:
+        cap = tr._capacity
+        try:
+            tr.views_per_rank = 2
+            tr._graph = None
+            tr.enable_graph(cap, validate=False)
+            ms = window()
+            res["views_per_rank_2"] = {"ms_per_step": round(ms, 4), "ms_per_view": round(ms / 2, 4), "views_per_step": 2 * world}
+        finally:
+            tr.views_per_rank = 1
+            rewind(snap, it0)
+            tr._graph = None
+            tr.enable_graph(cap, validate=False)
+    return res
 
 
 def main():
@@ -445,6 +504,12 @@ def main():
     # capture promised the rasterizer (longest tile list, list capacity): the trainer's step guard then skips that step,
     # re-captures and renders the view again (Trainer._recover_overflow).  A timed region in which that happened contains a
     # re-capture and is not reported: warm-up + timed region are run again on the re-captured step (at most twice).
+    views_first_step = [tr.view_for(0, j) for j in range(args.views_per_rank)]
+    if world > 1:   # the views every rank renders in step 0 (the shared schedule must give every rank its own)
+        vt = torch.tensor(views_first_step, dtype=torch.int64, device=device)
+        vall = [torch.zeros_like(vt) for _ in range(world)]
+        dist.all_gather(vall, vt)
+        views_first_step = [int(x) for v in vall for x in v.tolist()]
     split_choice = choose_split3(tr, args, world, device, use_graph)
     attempts = 0
     while True:
@@ -661,8 +726,9 @@ def main():
                         "(%d live surfels in %d slots now); the timed step is the same full late-regime train step as 'metric', "
                         "on the dataset's target views" % (W, H, args.pre_iterations, tr.surfels.num_surfels, tr.P)),
                        "surfels": P, "image": "%dx%d" % (W, H), "sh_degree": 3, "control_nodes": int(tr.deform.node_num),
-                       "views_per_step": args.views_per_rank * world, "views_per_rank": args.views_per_rank,
-                       "parallelism": "dp%d (views sharded, one flat all-reduce)" % world,
+                       "views_per_step": args.views_per_rank * world, "views_per_rank": args.views_per_rank, "views_first_step": views_first_step,
+                       "parallelism": ("dp%d (views sharded; SH gradients reduce-scattered to the rows' owners, updated rows all-gathered; the rest all-reduced)"
+                                       if (comm or {}).get("sh_collective", "").startswith("reduce_scatter") else "dp%d (views sharded, one flat all-reduce)") % world,
                        "launch": "whole-step HIP graph replay" if use_graph else "eager",
                        "neighbour_search": "%s (spatial share of the K-th neighbour distance %.2f)"
                                            % (tr.deform.knn_refine_mode, getattr(tr.deform, "knn_spatial_share", float("nan")))},

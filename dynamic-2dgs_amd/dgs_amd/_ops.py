@@ -410,6 +410,43 @@ class FlatAdam:
                                         self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
         _check(lib, rc, "dgs_adam_step")
 
+    @torch.no_grad()
+    def step_slice(self, index, lo, hi, advance=True):
+        """Adam update of ELEMENTS [lo, hi) of parameter `index` only: the share of a rank that owns these rows of the parameter
+        (Trainer.shard_optimizer: reduce-scatter of the gradient -> this -> all-gather of the parameter).  Gradient and moments are
+        read at the same flat offsets as a full step; the moments outside [lo, hi) are not touched (and go stale on this rank).
+        A periodic learning-rate pattern keeps its phase only if lo is a multiple of the period."""
+        lib = load()
+        dev = self.grad.device
+        n = self._offsets[index + 1] - self._offsets[index]
+        assert 0 <= lo <= hi <= n, (lo, hi, n)
+        assert self._period[index] == 0 or lo % self._period[index] == 0, "slice start must keep the phase of the learning-rate pattern"
+        key = ("slice", index, lo, hi)
+        if key not in self._plans:
+            off = (ctypes.c_longlong * 2)(self._offsets[index] + lo, self._offsets[index] + hi)
+            plan = torch.empty(int(lib.dgs_adam_plan_bytes(hi - lo)), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _check(lib, lib.dgs_adam_plan(1, off, plan.data_ptr(), _stream(dev)), "dgs_adam_plan")
+            one = lambda arr, typ: (typ * 1)(arr[index])
+            self._plans[key] = ((ctypes.c_void_p * 1)(self.params[index].data_ptr() + 4 * lo), off, one(self._lr, ctypes.c_float),
+                                one(self._lr2, ctypes.c_float), one(self._period, ctypes.c_int), one(self._split, ctypes.c_int),
+                                one(self._lr_final, ctypes.c_float), one(self._sched_steps, ctypes.c_float), plan)
+        ptrs, off, lr, lr2, period, split, lr_final, sched_steps, plan = self._plans[key]
+        if hi == lo:
+            if advance:
+                self.guard()
+            return
+        origin = (ctypes.c_float * 1)(self._origin[index])
+        skip = None if self.skip is None else self.skip.data_ptr()
+        with torch.cuda.device(dev):
+            if advance:
+                self.guard()
+            rc = lib.dgs_adam_step_origin(1, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, origin, float(self.grad_scale),
+                                        self.grad.data_ptr(), 1 if self.zero_grads else 0,
+                                        self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
+                                        self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
+        _check(lib, rc, "dgs_adam_step (slice)")
+
 
 class _FusedRegLoss(torch.autograd.Function):
     @staticmethod

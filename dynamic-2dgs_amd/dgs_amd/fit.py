@@ -77,6 +77,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
         else:
             losses.append(float(loss))
         if on_iteration is not None:
+            tr._wait_gather()   # (data parallel, sharded SH update: the hook sees complete parameters)
             on_iteration(it, tr)
         if graph_from and it == graph_from - 1:
             tr.enable_graph(int(list_capacity or 96 * tr.P))

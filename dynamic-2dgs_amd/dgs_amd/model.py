@@ -60,12 +60,22 @@ class SurfelModel(nn.Module):
     get_opacity = property(lambda self: torch.sigmoid(self._opacity))
     @property
     def get_features(self):
+        self._settle_sh()
         if self.packed_sh:
             return self._features
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
+    def _settle_sh(self):
+        """A data-parallel trainer with the sharded SH update keeps the all-gather of the last update's rows in flight between steps
+        (Trainer._gather_sh_start); it registers its wait here so that every reader of the coefficients through the model's accessors
+        (render, save) sees complete rows.  Raw access to `_features` needs Trainer.settle_shards()."""
+        hook = self.__dict__.get("_before_sh_read")
+        if hook is not None:
+            hook()
+
     def __getattr__(self, name):
         if name in ("_features_dc", "_features_rest") and self.__dict__.get("packed_sh"):
+            self._settle_sh()
             f = self._parameters["_features"]
             return f[:, :1] if name == "_features_dc" else f[:, 1:]
         return super().__getattr__(name)

@@ -121,8 +121,20 @@ class Trainer:
     SCHED_DEFORM = (0.00016 * 5, 0.0000016, 40_000)
 
     def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=LATE_DEFORM_LR, position_lr=LATE_POSITION_LR,
-                 fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False, views_per_rank=1):
+                 fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False, views_per_rank=1, shard_optimizer=True):
         self.surfels, self.deform = surfels, deform
+        # Data parallel (N > 1), split step: the SH coefficients -- 2/3 of the bucket -- are updated by the rank that OWNS their rows
+        # (contiguous slot range rank * P / N ...): reduce-scatter of the SH gradients instead of their all-reduce, Adam on P / N rows
+        # instead of P (the update is HBM-bound and was replicated on every rank), all-gather of the updated rows IN PLACE into the
+        # parameter -- the same bytes on the wire as the all-reduce, but the second half of them (the all-gather) is only needed by
+        # the NEXT step's preprocess kernel and rides under that step's deformation head (_shard_ok, _gather_sh_start).  No change of
+        # the numerics: every element sees the same sum and the same update, from one rank instead of N.  The SH moments of rows a
+        # rank does not own go stale there; whoever reads moments across rows (densification, reordering, growth) goes through
+        # _moments(), which gathers them first.
+        self.shard_optimizer = bool(shard_optimizer)
+        self._ag_work = None            # the all-gather of the last step's SH update, waited for where the next reader of SH starts
+        surfels.__dict__["_before_sh_read"] = self._wait_gather   # ... including readers outside the trainer (SurfelModel._settle_sh)
+        self._sh_moments_local = False  # True: only this rank's rows of the SH moments are current
         # k > 1 (opt-in, data parallelism): every rank renders k views per step and ADDS their gradients before the one exchange of the
         # step -- neighbour search, the all-reduces and the Adam update once per k views instead of once per view; a step then trains on
         # k * world views (gradient = their mean), `iteration` counts steps.  See _multi_view_step.
@@ -297,7 +309,8 @@ class Trainer:
             # the device's step counter and the host's disagree (something advanced FlatAdam outside step()): resynchronise
             # and look at the flag itself -- silently ignoring the report would hide an overflow for good
             self._resync_guard()
-            if bool(self._oflag.item()) or float(self.opt_surfels.status[0].item()) > 0:
+            # (data parallel: only what EVERY rank sees may decide -- the guard kernel's copy of the MAX-reduced flag, not this rank's own)
+            if float(self.opt_surfels.status[0].item()) > 0 or (self.world == 1 and bool(self._oflag.item())):
                 self._recover_overflow()
             return
         if float(e[1]) > 0:
@@ -308,12 +321,15 @@ class Trainer:
         them -- or the sticky flag itself -- says a step was skipped.  Called wherever the trainer is about to re-capture, change
         the slot layout or save: an overflow of the last two steps must not be captured into a fresh graph as a stale flag, withdraw
         the list-length promise for good, or be lost with the steps it skipped."""
+        self._wait_gather()
         if self.opt_deform is not None or getattr(self, "_oflag", None) is None or getattr(self, "_in_recovery", False):
             return False
         torch.cuda.synchronize()
         self._guard_events.clear()
         skipped = int(self.opt_surfels.status[1].item())
-        if bool(self._oflag.item()) or skipped != self._skipped_seen:
+        # data parallel: the skipped-step count comes from the MAX-reduced flag and is the same on every rank; this rank's own flag is
+        # not (a recovery is collective: every rank must take this branch, or none)
+        if skipped != self._skipped_seen or (self.world == 1 and bool(self._oflag.item())):
             if self._graph and getattr(self, "_capacity", 0) > 0:
                 self._recover_overflow()
                 return True
@@ -329,7 +345,10 @@ class Trainer:
         if not self._graph or getattr(self, "_capacity", 0) <= 0:
             raise RuntimeError("rasterizer capacity overflow outside capacity mode")
         self.iteration -= redo          # the skipped steps changed nothing: their views are rendered again
-        reason = int(self._oflag.item())   # kernels_preprocess.h overflow_reason: 1 capacity, 2 promised list length, 4 beyond the segmented sort
+        # kernels_preprocess.h overflow_reason: 1 capacity, 2 promised list length, 4 beyond the segmented sort -- the bits of EVERY rank's
+        # flag (the step's MAX all-reduce only says that some rank overflowed, and max(1, 2) drops a bit): all ranks must move to the
+        # same capacity and the same promise, or their captures -- and the collectives inside the capture's warm-up steps -- diverge
+        reason = self._agree_reason(int(self._oflag.item()))
         self._oflag.zero_()
         self._guard_events.clear()
         self.overflow_recoveries += 1
@@ -340,6 +359,16 @@ class Trainer:
             self.enable_graph(self._capacity, validate=False)
         finally:
             self._in_recovery = False
+
+    def _agree_reason(self, reason):
+        """Overflow reason bits OR-ed over the ranks (collective: every rank calls it at the same point).  The bits travel as three
+        0/1 words through a MAX all-reduce -- RCCL has no bitwise OR reduction."""
+        if self.world > 1 and not self.no_collectives and dist.is_initialized():
+            bits = torch.tensor([reason & 1, (reason >> 1) & 1, (reason >> 2) & 1], dtype=torch.int32, device=self.bucket.flat.device)
+            dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+            b = bits.tolist()
+            reason = (reason & ~7) | b[0] | (b[1] << 1) | (b[2] << 2)
+        return reason
 
     # ---- whole-step HIP graph ------------------------------------------------------------------------------------
     def enable_graph(self, capacity, validate=True):
@@ -360,6 +389,7 @@ class Trainer:
         # (round 5: twin 8.6e-6 / 1.2e-5, the same two guard-recovery steps in both series), so the requirement is gone; bench.py and
         # the tests still default the knob to 0, the configuration every committed number was measured in.)
         dev = self.surfels.get_xyz.device
+        self._wait_gather()        # (sharded data-parallel step: the SH rows of the last step's update may still be on the wire)
         if self._graph:            # a live capture is being replaced: settle what its last steps reported first
             if self._flush_guard():
                 return             # the recovery re-captured already (with a larger capacity / without the promise)
@@ -413,6 +443,7 @@ class Trainer:
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
         self._g1b = None
+        self._g0 = None
         # thread-local capture mode: with a process group alive, the collective library's watchdog thread polls events while
         # this thread captures; under the default ("global") mode such a call from ANOTHER thread invalidates the capture
         # and the watchdog dies with the error (seen once in three runs on ROCm 7 / RCCL 2.26)
@@ -444,10 +475,21 @@ class Trainer:
         elif self._split:
             # data parallel: graph 1a = forward + backward down to the rasterizer inputs (SH gradients final), eager async
             # all-reduce of the SH segment, graph 1b = rest of the backward, eager all-reduce of the rest, graph 2 = update
-            with torch.cuda.graph(self._g1, **mode):
-                self._select_view_node()
-                self._sloss = self._fwd_bwd_a(self._scam, self._sgt)
-                self._select_consumed()
+            if self._shard_ok():
+                # sharded SH update: the deformation head is a graph of its own (graph 0) -- it reads no SH coefficient, so the wait for
+                # the all-gather of the previous step's SH rows sits BEHIND it and that transfer rides under the head's ~75 us
+                self._g0 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g0, **mode):
+                    self._select_view_node()
+                    self._head = self._forward_head(self._scam)
+                    self._select_consumed()
+                with torch.cuda.graph(self._g1, pool=self._g0.pool(), **mode):
+                    self._sloss = self._fwd_bwd_a(self._scam, self._sgt, self._head)
+            else:
+                with torch.cuda.graph(self._g1, **mode):
+                    self._select_view_node()
+                    self._sloss = self._fwd_bwd_a(self._scam, self._sgt)
+                    self._select_consumed()
             self._g1b = torch.cuda.CUDAGraph()
             self._g1c = None
             if self.split3:
@@ -490,7 +532,7 @@ class Trainer:
                     self._forward(self._scam, self._sgt)
             self._scam.load(self._vtab[0])
             torch.cuda.synchronize()
-        reason = _C.read_overflow(device=dev)
+        reason = self._agree_reason(_C.read_overflow(device=dev))   # (data parallel: one verdict -- a rank re-capturing alone would pair its warm-up collectives with the others' training steps)
         if reason:
             if reason & 1 and validate:    # (a broken promise next to it would not change that)
                 raise RuntimeError("rasterizer capacity %d too small for this scene" % capacity)
@@ -558,10 +600,13 @@ class Trainer:
 
     def _snapshot(self):
         sf = self.surfels
+        self._wait_gather()
         state = [p.detach().clone() for p in self.bucket.params]
         opt = (self.opt_surfels.exp_avg.clone(), self.opt_surfels.exp_avg_sq.clone(), self.opt_surfels.t.clone(),
                self.opt_surfels.status.clone())
-        stats = (sf.xyz_gradient_accum.clone(), sf.denom.clone(), sf.max_radii2D.clone())
+        # (sharded SH update: a rank's copy of the SH moments may be current on its own rows only -- the snapshot keeps them as they
+        # are, with the flag that says so)
+        stats = (sf.xyz_gradient_accum.clone(), sf.denom.clone(), sf.max_radii2D.clone(), self._sh_moments_local)
         if hasattr(self.opt_surfels, "_origin"):   # the per-parameter Adam step origins are optimiser state too (host side)
             opt = opt + (list(self.opt_surfels._origin),)
         return state, opt, stats
@@ -570,6 +615,9 @@ class Trainer:
     def _restore(self, snap):
         sf = self.surfels
         state, opt, stats = snap
+        self._wait_gather()
+        if len(stats) > 3:
+            self._sh_moments_local = stats[3]
         for p, q in zip(self.bucket.params, state):
             p.copy_(q)
         self.opt_surfels.exp_avg.copy_(opt[0])
@@ -595,7 +643,10 @@ class Trainer:
             self._guard_steps = int(self.opt_surfels.status[2].item())
             self._guard_events.clear()
 
-    def _forward(self, cam, gt):
+    def _forward_head(self, cam):
+        """The forward in FRONT of the rasterizer: gradient-bucket handling and the deformation (neighbour search, node MLP, skinning,
+        surfel activations).  Reads every parameter except the SH coefficients -- which is why the sharded data-parallel step runs it
+        while the all-gather of the previous step's SH update is still on the wire (_gather_sh_start)."""
         s, d = self.surfels, self.deform
         # The gradient bucket (57 MB) is cleared by a fill in front of the step (10 us).  Two alternatives were built and measured
         # on the replayed step: (a) the flat Adam kernel clears the gradients behind its reads (FlatAdam.zero_grads; the bucket
@@ -618,16 +669,24 @@ class Trainer:
         if hasattr(d, "reuse_knn"):
             d.reuse_knn = adding             # the surfels and nodes have not moved since the step's first view: its neighbours stand
         self._bucket_clean = False
-        asm = None
+        asm = dv = None
         if assemble:
             with trace.stage("dgs.deform"):
                 asm = d.forward_assembled(s, t)
-            with trace.stage("dgs.rasterize"):
-                pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
         else:
             dv = d(s.get_xyz.detach(), t, s.feature, s.motion_mask)
             if self.warmup:
                 dv = {k: v.detach() for k, v in dv.items()}
+        return asm, dv, fused
+
+    def _forward(self, cam, gt, head=None):
+        """head: what _forward_head returned for this view when the caller ran it separately (sharded data-parallel step)."""
+        s = self.surfels
+        asm, dv, fused = self._forward_head(cam) if head is None else head
+        if asm is not None:
+            with trace.stage("dgs.rasterize"):
+                pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
+        else:
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
                          postprocess=not fused)
         lam = dict(lambda_normal=self.lambda_normal, lambda_dist=self.lambda_dist)
@@ -647,7 +706,7 @@ class Trainer:
             if lam > 0 and self.iteration > self.arap_from:
                 if getattr(self, "_arap_gen", None) is None:
                     self._arap_gen = torch.Generator(device=s.get_xyz.device).manual_seed(1234 + self.rank)
-                loss = loss + lam * arap.arap_loss(d, generator=self._arap_gen)
+                loss = loss + lam * arap.arap_loss(self.deform, generator=self._arap_gen)
         if fused and getattr(self, "_unit", None) is None:
             self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
         return loss, pkg, asm, fused
@@ -756,9 +815,9 @@ class Trainer:
                      and self.sh_grad_sink and self.n_sh > 0 and self.deform.can_assemble(s))
         return self.views_per_rank == 1 and split_step_allowed(self.world, self.overlap_allreduce, hip_fused, self._arap_active())
 
-    def _fwd_bwd_a(self, cam, gt):
+    def _fwd_bwd_a(self, cam, gt, head=None):
         """Forward, loss and the backward down to the rasterizer's inputs: afterwards the SH segment of the bucket is final."""
-        loss, pkg, asm, fused = self._forward(cam, gt)
+        loss, pkg, asm, fused = self._forward(cam, gt, head)
         leaf = pkg["viewspace_points"]
         grads = self._run_backward(lambda: torch.autograd.grad(loss, list(asm) + [leaf], grad_outputs=self._unit, allow_unused=True), fused)
         leaf.grad = grads[4]
@@ -822,6 +881,64 @@ class Trainer:
         w.copy_(sl)
         return self._Bf16Work(dist.all_reduce(w, op=dist.ReduceOp.SUM, async_op=True), sl, w)
 
+    # ---- sharded SH update (data parallel, split step) ------------------------------------------------------------------
+    def _shard_ok(self):
+        """Does the split step hand the SH update to the rows' owners (Trainer.shard_optimizer)?  Needs equal row ranges."""
+        if not (self.shard_optimizer and dist.is_available() and dist.is_initialized() and self._split_ok()):
+            return False
+        return self.P % dist.get_world_size() == 0 and self.n_sh % self.P == 0
+
+    def _shard_range(self):
+        """ELEMENT range of the SH segment (bucket and parameter alike) this rank owns: rows [rank P / N, (rank + 1) P / N)."""
+        n, r = dist.get_world_size(), dist.get_rank()
+        c = self.n_sh // n
+        return r * c, (r + 1) * c
+
+    def _scatter_sh_start(self):
+        """async reduce-scatter (SUM) of the SH gradients, in place: this rank's rows of the bucket receive the sum over the ranks
+        (the other rows keep this rank's own contribution and are overwritten by the next backward).  With wire_bf16 through the
+        persistent bfloat16 copy, like _sum_slice_start."""
+        lo, hi = self._shard_range()
+        sl = self.bucket.flat[:self.n_sh]
+        if not self.wire_bf16:
+            return dist.reduce_scatter_tensor(sl[lo:hi], sl, op=dist.ReduceOp.SUM, async_op=True)
+        wire = getattr(self, "_wire", None)
+        if wire is None or wire.numel() != self.bucket.flat.numel() or wire.device != sl.device:
+            wire = self._wire = torch.empty(self.bucket.flat.numel(), dtype=torch.bfloat16, device=sl.device)
+        w = wire[:self.n_sh]
+        w.copy_(sl)
+        return self._Bf16Work(dist.reduce_scatter_tensor(w[lo:hi], w, op=dist.ReduceOp.SUM, async_op=True), sl[lo:hi], w[lo:hi])
+
+    def _gather_sh_start(self):
+        """async all-gather of the SH rows every rank has just updated, IN PLACE into the parameter.  Nothing of this step reads the SH
+        coefficients any more; the next reader is the next step's preprocess kernel, behind that step's deformation head
+        (_wait_gather sits between the two) -- or whoever calls settle_shards()."""
+        self._sh_moments_local = True
+        if self.no_collectives:
+            return
+        f = self.surfels._features.data.view(-1)
+        lo, hi = self._shard_range()
+        self._ag_work = dist.all_gather_into_tensor(f, f[lo:hi], async_op=True)
+
+    def _wait_gather(self):
+        """The current stream waits for the outstanding all-gather of the SH coefficients (if any)."""
+        if self._ag_work is not None:
+            self._ag_work.wait()
+            self._ag_work = None
+
+    def settle_shards(self):
+        """Make this rank's copy of everything complete again: wait for the SH all-gather and, if the SH moments are only current
+        on their owners' rows, all-gather them too (two collectives: EVERY rank must call this at the same point -- it is called
+        by whatever reads moments across rows or replaces the optimiser state: densification, reordering, growth, checkpoints)."""
+        self._wait_gather()
+        if self._sh_moments_local and self.opt_deform is None and dist.is_available() and dist.is_initialized() and not self.no_collectives:
+            lo, hi = self._shard_range()
+            a = self.opt_surfels._offsets[0]
+            for m in (self.opt_surfels.exp_avg, self.opt_surfels.exp_avg_sq):
+                seg = m[a:a + self.n_sh]
+                dist.all_gather_into_tensor(seg, seg[lo:hi])
+        self._sh_moments_local = False
+
     def _reduce_mid_start(self):
         if self.no_collectives:
             return self._NoWork
@@ -841,6 +958,8 @@ class Trainer:
     def _reduce_sh_start(self):
         if self.no_collectives:
             return self._NoWork
+        if self._shard_ok():
+            return self._scatter_sh_start()
         return self._sum_slice_start(0, self.n_sh)
 
     def _reduce_radii_start(self):
@@ -885,7 +1004,10 @@ class Trainer:
         all-reduce is done -- while the rest of the bucket is still on the wire."""
         with torch.no_grad():
             self.opt_surfels.grad_scale = 1.0 / self.world
-            self.opt_surfels.step(0, 1)
+            if self._shard_ok():   # this rank's rows only (their gradient sum arrived by reduce-scatter); _gather_sh_start follows
+                self.opt_surfels.step_slice(0, *self._shard_range())
+            else:
+                self.opt_surfels.step(0, 1)
 
     def _finish(self, reduce=True, sh_done=False, mid_done=False):
         s = self.surfels
@@ -957,6 +1079,7 @@ class Trainer:
     # ---- adaptive density control (train_gui.py:410-423; dgs_amd/densify.py) -----------------------------------------
     def _moments(self):
         from . import densify
+        self.settle_shards()
         return self.opt_surfels.moments if self.opt_deform is None else densify.TorchAdamMoments(self.opt_surfels)
 
     def densify_and_prune(self, max_grad=0.0002, min_opacity=0.01, extent=1.0, max_screen_size=None, percent_dense=0.01,
@@ -1276,6 +1399,10 @@ class Trainer:
             loss = self._fwd_bwd(cam, gt)
         finally:
             self._accum_view = 0
+            if hasattr(self.deform, "reuse_knn"):
+                # (stored neighbours are for views 2 .. k of THIS step only: a render from outside -- evaluation, a hook, after an in-place
+                # densification that keeps the slot count -- must search again)
+                self.deform.reuse_knn = False
         with torch.no_grad():
             self._stats_accumulate(j)
             self._loss_accumulate(j, loss)
@@ -1351,6 +1478,9 @@ class Trainer:
                 self._vctr_host += 1
             else:
                 self._scam.load(self._vtab[v])   # one 256-byte copy: camera matrices, time, and the pointers of target / ray table
+            if self._g0 is not None:             # sharded SH update: deformation head | wait for the SH rows of the last update | the rest
+                self._g0.replay()
+                self._wait_gather()
             self._g1.replay()
             if self._g1b is not None:
                 rwork = self._reduce_radii_start()   # radii + overflow flag (small): first, the SH update's guard reads it
@@ -1366,6 +1496,8 @@ class Trainer:
                 rwork.wait()
                 work.wait()
                 self._g2a.replay()               # SH update while the rest of the bucket is on the wire
+                if self._g0 is not None:
+                    self._gather_sh_start()      # ... and its rows go out behind the rest, under the other updates and the next head
                 if mid is not None:
                     mid.wait()
                     self._g2b.replay()
@@ -1389,7 +1521,12 @@ class Trainer:
     def _split_step(self, cam, gt):
         """Data-parallel step, eager: backward half a | SH all-reduce (async) | backward half b | all-reduce of the rest
         (async) | SH update | update of everything else."""
-        loss = self._fwd_bwd_a(cam, gt)
+        shard = self._shard_ok()
+        head = None
+        if shard:
+            head = self._forward_head(cam)
+            self._wait_gather()
+        loss = self._fwd_bwd_a(cam, gt, head)
         rwork = self._reduce_radii_start()
         work = self._reduce_sh_start()
         mid = None
@@ -1404,6 +1541,8 @@ class Trainer:
         rwork.wait()
         work.wait()
         self._finish_sh()
+        if shard:
+            self._gather_sh_start()
         if mid is not None:
             mid.wait()
             self._finish_mid()

@@ -44,7 +44,8 @@ def test_bench_two_ranks_prints_one_valid_line():
     # the communication object (N > 1): every slice timed alone, the step without collectives, what stays exposed, the 2 / 3 piece choice
     c = r["comm"]
     assert c["world"] == 2 and c["backend"] == "gloo" and c["wire_bytes_per_step"]["total"] > 50e6
-    assert set(c["slices"]) >= {"sh", "rest", "radii"} and all(v["ms"] > 0 and v["bus_GBs"] > 0 for v in c["slices"].values())
+    assert set(c["slices"]) >= {"sh_reduce_scatter", "sh_all_gather", "rest", "radii"} and all(v["ms"] > 0 and v["bus_GBs"] > 0 for v in c["slices"].values())
+    assert c["sh_collective"].startswith("reduce_scatter") and c["levers"]["views_per_rank_2"]["views_per_step"] == 4 and c["levers"]["wire_bf16_on"]["ms_per_view"] > 0
     assert 0 < c["ms_per_step_no_collectives"] < r["ms_per_step"] and abs(c["exposed_ms_per_step"] - (r["ms_per_step"] - c["ms_per_step_no_collectives"])) < 1e-3
     assert c["split3"]["chosen"] in ("two", "three") and c["split3"]["ms_per_step_two_pieces"] > 0 and c["split3"]["ms_per_step_three_pieces"] > 0
 
@@ -72,3 +73,34 @@ def test_bench_two_ranks_two_views_per_rank():
     c = r["comm"]
     assert c["views_per_rank"] == 2 and c["split3"] is None and "sh" not in c["slices"] and set(c["slices"]) >= {"rest", "radii"}
     assert abs(c["exposed_ms_per_view"] - c["exposed_ms_per_step"] / 2) < 1e-3
+
+
+def test_bench_eight_ranks_dry_run():
+    """The driver's 8-GPU command, as eight processes sharing the one GPU of the test box over gloo: everything that is first-contact
+    code at world = 8 -- eight loaders on one library, the view schedule, the MAX-over-ranks votes, eight slices per collective, the
+    sharded SH update with eight owners, the levers of the communication object -- runs here first."""
+    world, port = 8, _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DGS_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--drift-gap", "10"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not any(l.startswith("{") for so, _ in outs[1:] for l in so.splitlines()), "exactly one JSON line, from rank 0"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["steps"] == 4 and r["warmup"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["views_per_step"] == 8 and r["config"]["parallelism"].startswith("dp8")
+    assert sorted(r["config"]["views_first_step"]) == list(range(8))          # every rank its own view of the step
+    assert r["value"] > 0 and abs(r["value"] - 8 * 1e3 / r["ms_per_step"]) <= 1e-2 * r["value"]
+    assert "cpu_baseline" not in r and r["twin"] is not None
+    c = r["comm"]
+    assert c["world"] == 8 and c["sh_collective"].startswith("reduce_scatter")
+    assert set(c["slices"]) >= {"sh_reduce_scatter", "sh_all_gather", "rest", "radii"} and all(v["ms"] > 0 for v in c["slices"].values())
+    assert c["wire_bytes_per_step"]["sh"] == 4 * 48 * 200_000
+    lv = c["levers"]
+    assert lv["wire_bf16_on"]["ms_per_view"] > 0 and lv["wire_bf16_on"]["wire_bytes_per_step"] < c["wire_bytes_per_step"]["total"]
+    assert lv["views_per_rank_2"]["views_per_step"] == 16 and lv["views_per_rank_2"]["ms_per_view"] > 0

@@ -41,6 +41,7 @@ def _graph_worker(rank, world, port, q):
         assert sum(counts) > 0, counts
         tr.reset_opacity()
         losses += [float(tr.step()) for _ in range(2)]
+        tr.settle_shards()   # (sharded SH update: the all-gather of the last step's rows is waited for by the next READER; raw access asks for it)
         torch.cuda.synchronize()
         assert not _C.read_overflow()
         params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params] + [tr.surfels.alive.float()]).cpu()
@@ -85,6 +86,7 @@ def _bf16_worker(rank, world, port, q):
                 tr.enable_graph(capacity=40 * 20000)
                 assert tr._split, "the split step is the one with separate slices"
                 losses = [float(tr.step()) for _ in range(3)]
+                tr.settle_shards()
                 torch.cuda.synchronize()
                 params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
                 gp = [torch.zeros_like(params) for _ in range(world)]
@@ -138,6 +140,7 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
         assert tr.world == world and tr.view_for(0) == rank
+        tr.shard_optimizer = False          # this test looks at the REDUCED bucket: with the sharded SH update a rank holds the sum on its own rows only
         tr.opt_surfels.zero_grads = False   # keep the reduced gradients of the step for the comparison below (the update can
         tr.step()                           # clear them behind its reads)
         flat_after = tr.bucket.flat.detach().cpu().numpy().copy()
@@ -256,6 +259,7 @@ def _split3_worker(rank, world, port, q, graph):
                 tr.enable_graph(capacity=40 * 20000)
                 assert (tr._g1c is not None) == split3 and (tr._g2b is not None) == split3
             losses = [float(tr.step()) for _ in range(4)]
+            tr.settle_shards()
             torch.cuda.synchronize()
             assert not _C.read_overflow()
             _C.set_capacity(0)
@@ -298,3 +302,142 @@ def test_third_split_keeps_replicas_identical_and_moves_the_wire_bytes(graph):
     # what leaves when: 48 SH floats per surfel first, then (third split) the 18 other per-surfel floats, then the rest
     assert w2["sh"] == w3["sh"] == 4 * 48 * P and "mid" not in w2
     assert w3["mid"] == 4 * (3 + 2 + 4 + 1 + 8) * P and w3["rest"] == w2["rest"] - w3["mid"] and w3["total"] == w2["total"] == 4 * (nflat + P + 4)
+
+
+def _shard_worker(rank, world, port, q, graph):
+    """Sharded SH update (Trainer.shard_optimizer, the default of the split step): reduce-scatter of the SH gradients, Adam on the rows
+    this rank owns, all-gather of the rows into the parameter under the next step's deformation head."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from diff_surfel_rasterization import _C
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        out = {}
+        for key, shard in (("allreduce", False), ("again", False), ("shard", True)):   # the same run twice: the yardstick for run-to-run noise
+            tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2, slots=30000)
+            tr.shard_optimizer = shard
+            assert tr._split_ok() and tr._shard_ok() == shard
+            wire = tr.wire_bytes_per_step()
+            if graph:
+                tr.enable_graph(capacity=40 * 20000)
+                assert (tr._g0 is not None) == shard
+            losses = [float(tr.step()) for _ in range(4)]
+            local = bool(tr._sh_moments_local)
+            tr.settle_shards()
+            torch.cuda.synchronize()
+            assert not _C.read_overflow()
+            n_sh = tr.n_sh
+            state = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params] + [tr.opt_surfels.exp_avg[:n_sh], tr.opt_surfels.exp_avg_sq[:n_sh]]).cpu()
+            gp = [torch.zeros_like(state) for _ in range(world)]
+            dist.all_gather(gp, state)
+            same = all(torch.equal(gp[0], g) for g in gp)
+            # density control on top of the sharded state: the surgery reads and permutes moment rows, so it must have gathered them
+            counts = tr.densify_and_prune(max_grad=2e-5, min_opacity=0.02, extent=5.0, max_screen_size=20, seed=11)
+            tr.sort_surfels()
+            losses += [float(tr.step()) for _ in range(2)]
+            tr.settle_shards()
+            torch.cuda.synchronize()
+            assert not _C.read_overflow()
+            _C.set_capacity(0)
+            state2 = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params] + [tr.opt_surfels.exp_avg[:n_sh], tr.opt_surfels.exp_avg_sq[:n_sh],
+                                                                                      tr.surfels.alive.float()]).cpu()
+            gp = [torch.zeros_like(state2) for _ in range(world)]
+            dist.all_gather(gp, state2)
+            same2 = all(torch.equal(gp[0], g) for g in gp)
+            out[key] = (same, same2, losses, state.numpy(), wire, local, sum(counts), n_sh, bool(torch.isfinite(state2).all()))
+            del tr
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_sharded_sh_update_matches_the_all_reduce_step(graph):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q, graph)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    import numpy as np
+    for key, (same, same2, losses, state, wire, local, n_densified, n_sh, finite) in res.items():
+        # replicas bit-identical: parameters AND (after settle_shards) both SH moments, before and after density control + reordering
+        assert same and same2 and finite, key
+        assert local == (key == "shard")      # the sharded step leaves the SH moments current on their owners' rows only
+        assert n_densified > 0 and all(0.0 < l < 10.0 for l in losses), (key, losses)
+    # the same bytes are handed to the collectives either way (reduce-scatter + all-gather of the SH segment = its all-reduce)
+    assert res["shard"][4] == res["allreduce"][4]
+    # the same training run: losses equal to rounding, parameters and moments within the run-to-run noise of the all-reduce step
+    l_ar, l_sh = res["allreduce"][2], res["shard"][2]
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l_ar[:4], l_sh[:4])), (l_ar, l_sh)
+    a, b, c = res["allreduce"][3], res["shard"][3], res["again"][3]
+    scale = float(np.abs(a).max())
+    d, noise = np.abs(a - b), np.abs(a - c)
+    assert float(np.median(d)) <= 1e-7 * scale
+    for qt in (0.99, 0.999, 1.0):
+        assert float(np.quantile(d, qt)) <= 2.0 * float(np.quantile(noise, qt)) + 1e-6 * scale, (qt, float(np.quantile(d, qt)), float(np.quantile(noise, qt)))
+
+
+def _one_rank_overflow_worker(rank, world, port, q):
+    """ONE rank's frame breaks the promised list length (reason bit 1), the other rank's does not: both must recover to the SAME
+    configuration (the reason was read from the rank-local flag, the clean rank took the 'reason 0' fallback)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from diff_surfel_rasterization import _C
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        tr = bench.build_trainer(20000, 128, 128, dev, n_views=4, n_targets=2)
+        tr.enable_graph(capacity=40 * 20000)
+        cap0, hint0 = tr._capacity, tr._list_hint
+        for _ in range(2):
+            tr.step()
+        torch.cuda.synchronize()
+        if rank == 1:
+            tr._oflag.fill_(1)    # what the rasterizer of THIS rank would have left: "list capacity exceeded"; rank 0's flag stays clean
+        for _ in range(tr.GUARD_LAG + 3):
+            tr.step()
+        tr.settle_shards()
+        torch.cuda.synchronize()
+        cfg = torch.tensor([tr._capacity, tr._list_hint, tr.iteration, tr.overflow_recoveries], dtype=torch.int64)
+        gc = [torch.zeros_like(cfg) for _ in range(world)]
+        dist.all_gather(gc, cfg)
+        params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
+        gp = [torch.zeros_like(params) for _ in range(world)]
+        dist.all_gather(gp, params)
+        if rank == 0:
+            q.put(([g.tolist() for g in gc], all(torch.equal(gp[0], g) for g in gp), cap0, hint0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overflow_on_one_rank_recovers_every_rank_to_the_same_configuration():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_rank_overflow_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    cfgs, same, cap0, hint0 = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert cfgs[0] == cfgs[1], cfgs                 # same capacity, same promise, same iteration, same number of recoveries
+    assert cfgs[0][3] >= 1 and cfgs[0][0] == 2 * cap0 and cfgs[0][1] == hint0, (cfgs, cap0, hint0)   # reason 1 on rank 1 only: capacity doubled on BOTH, promise kept
+    assert same
