@@ -578,11 +578,12 @@ struct AlphaEval {
 
 // (us, vs) = sqrt2 (pixel - tile centre).  Returns whether the pixel passes the alpha test of forward.cu:369-399 EXCEPT the
 // near-plane test on the depth (alpha_depth below), which needs Tw and is evaluated only when some pixel of the wave passes
-// here.  One comparison decides: everything that makes the reference skip the pair turns `a` into something that fails
-// `a >= 1/255` --
-//   * p.z == 0 (forward.cu:368): 1/p.z = inf, rho3d = inf or NaN, and `0 * rho3d` poisons rho with NaN (the only departure: a
-//     rho3d that OVERFLOWS, |s| > 1.8e19, is skipped too, where the reference would fall back to the low-pass disc);
-//   * a lane that is done or outside the image carries us = NaN: every quantity below is NaN for it.
+// here.  Two comparisons decide (their masks meet in one scalar AND):
+//   * p.z == 0 exactly (forward.cu:368) is the reference's own skip.  (Rounds 1-5 poisoned rho with `0 * rho3d` instead, which
+//     also skipped a pair whose rho3d merely OVERFLOWS -- |s| > 1.8e19, a splat axis below ~1e-19 -- where the reference falls back
+//     to the low-pass disc, forward.cu:381-382.  Now an infinite rho3d takes min(rho3d, rho2d) = rho2d like the reference; the
+//     compare replaces the multiply-add, the VALU count of the visit is unchanged.)
+//   * a lane that is done or outside the image carries us = NaN: every quantity below is NaN for it and fails `a >= 1/255`.
 DGS_HD bool alpha_affine(float us, float vs, const Quad& a0, const Quad& a1, const Quad& a2, AlphaEval& e)
 {
     e.dxs = a2.y - us; e.dys = a2.z - vs;
@@ -593,11 +594,11 @@ DGS_HD bool alpha_affine(float us, float vs, const Quad& a0, const Quad& a1, con
     e.sx = px * e.inv_pz; e.sy = py * e.inv_pz;
     e.rho3d = e.sy * e.sy + e.sx * e.sx;
     e.rho2d = e.dys * e.dys + e.dxs * e.dxs;
-    const float rho = e.rho3d * 0.0f + fminf(e.rho3d, e.rho2d);
+    const float rho = fminf(e.rho3d, e.rho2d);
     e.G = fast_exp2(rho * kNegHalfLog2e);
     e.a = a2.w * e.G;
     e.alpha = fminf(e.a, kAlphaMax);
-    return e.a >= kAlphaMin;
+    return (e.a >= kAlphaMin) & (e.pz != 0.0f);
 }
 
 // depth of the pair (forward.cu:385-387: the intersection's when the 3-D distance is the smaller one, the centre's otherwise)

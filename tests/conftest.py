@@ -31,7 +31,7 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """GPU sessions: what the parity comparisons measured (tests/gpu_utils.py PARITY_LOG) -> gpurun_out/parity_r05.json."""
+    """GPU sessions: what the parity comparisons measured (tests/gpu_utils.py PARITY_LOG) -> gpurun_out/parity_r06.json."""
     try:
         import gpu_utils
     except Exception:
@@ -43,7 +43,7 @@ def pytest_sessionfinish(session, exitstatus):
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, os.environ.get("DGS_PARITY_FILE", "parity_r05.json")), "w") as f:
+        with open(os.path.join(out, os.environ.get("DGS_PARITY_FILE", "parity_r06.json")), "w") as f:
             json.dump({"exitstatus": int(exitstatus), "records": log}, f, indent=0)
     except OSError:
         pass

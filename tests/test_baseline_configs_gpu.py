@@ -68,10 +68,14 @@ def test_config_matches_oracle_and_properties(name):
     # oracle than a small multiple of the fp32 oracle's own distance.
     o64 = oracle_from_case(case, dtype=np.float64)
     og64 = o64.backward(gc.astype(np.float64), go.astype(np.float64))
+    # untrimmed bound per gradient: <= 3x the worst value observed over C3 / C4 / C5 (profiles/r05_parity_margins.md: 8.3e-3, 7.3e-3, 1.4e-3,
+    # 8.8e-3, 1.5e-3, 3.3e-5) -- rounds 3-5 asserted max(5e-3, 4 x the fp32 oracle's own distance from the fp64 one), which came to 0.15-0.20
+    TOL_ALL = {"dL_dmeans3D": 2.5e-2, "dL_dmeans2D": 2.2e-2, "dL_dscales": 4.2e-3, "dL_drotations": 2.6e-2, "dL_dopacity": 4.5e-3, "dL_dsh": 1e-4}
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
         own = rel_l2(og[k], og64[k])
-        grad_close(a[k], og[k], k, tol_trim=5e-5, tol_all=max(5e-3, 4.0 * own))   # trimmed: observed <= 1.6e-5
-        assert rel_l2(a[k], og64[k]) <= max(5e-3, 4.0 * own), "%s: HIP vs fp64 oracle %.3e, fp32 oracle vs fp64 oracle %.3e" % (
+        grad_close(a[k], og[k], k, tol_trim=5e-5, tol_all=TOL_ALL[k])   # trimmed: observed <= 1.6e-5
+        # ... and the HIP path is no further from the fp64 oracle than the fp32 oracle itself is (observed ratio ~1.0), plus its own distance from the fp32 one
+        assert rel_l2(a[k], og64[k]) <= 1.5 * own + TOL_ALL[k], "%s: HIP vs fp64 oracle %.3e, fp32 oracle vs fp64 oracle %.3e" % (
             k, rel_l2(a[k], og64[k]), own)
 
 

@@ -156,7 +156,7 @@ def _degenerate_case():
     """A small scene in which a third of the surfels is made extreme: edge-on to within 1e-3 .. 1e-5 rad of the viewing ray (p.z of the
     ray-splat intersection ~ 0 on every pixel: 1 / p.z overflows towards the horizon line and the reference falls back to the
     low-pass disc), needle-shaped (1 : 1e4 axes), sub-pixel, larger than the image, and a few just behind / in front of the 0.2
-    near plane."""
+    near plane; and needles whose short axis (1e-28 .. 1e-30) makes rho3d overflow to infinity."""
     import math
     case = small_case(P=600, H=80, W=96, seed=21, view=2, scale_mul=1.5, sh_degree=1)
     g = np.random.default_rng(7)
@@ -171,6 +171,8 @@ def _degenerate_case():
         x = math.sqrt(max(0.0, 1.0 + R[0, 0] - R[1, 1] - R[2, 2])) / 2.0
         return np.array([0.0, x, (R[0, 1] + R[1, 0]) / (4 * x), (R[0, 2] + R[2, 0]) / (4 * x)]) if x > 1e-6 else np.array([0.0, 0.0, 1.0, 0.0])
 
+    for i in range(200, 240):   # one axis so short that 1 / p.z makes rho3d OVERFLOW (|s| > 1.8e19) on every pixel off the other axis' line while p.z
+        sc[i] = (1e-30, 0.3) if i % 2 else (0.2, 1e-28)   # itself stays a normal number: the reference takes min(inf, rho2d) = the low-pass disc (forward.cu:381-382)
     for i in range(0, 200):
         kind = i % 5
         if kind == 0:      # edge-on: the normal is perpendicular to the viewing ray up to a tiny tilt
@@ -198,9 +200,10 @@ def _degenerate_case():
 
 
 def test_degenerate_splats_match_oracle():
-    """Edge-on, needle, sub-pixel, image-filling and near-plane surfels: bounds the documented departure of alpha_affine
-    (a pair whose rho3d overflows is skipped where the reference would fall back to the low-pass disc) and exercises the conservative
-    footprint tests (block_hit_affine: not-an-ellipse branches) on real degenerate conics.  Same tolerances as the regular scenes."""
+    """Edge-on, needle, sub-pixel, image-filling and near-plane surfels, and needles whose rho3d OVERFLOWS (round 6: the
+    reference falls back to the low-pass disc there, forward.cu:381-382, and so does alpha_affine now -- rounds 1-5 skipped such pairs);
+    exercises the conservative footprint tests (block_hit_affine: not-an-ellipse branches) on real degenerate conics.  Same
+    tolerances as the regular scenes."""
     from gpu_utils import frac_close, img_close, hip_median_contrib, median_flips, rel_l2, run_hip
     case = _degenerate_case()
     gc, go = _cot(case)
@@ -480,7 +483,18 @@ def test_full_size_properties():
     orc = oracle_from_case(case)
     assert float((a["radii"] != orc.radii).mean()) <= 1e-4
     img_close(a["color"], orc.color, "color", max_bad_frac=2.7e-4, hard=4e-3)        # observed 8.8e-5 of the pixels, max 1.2e-3
-    img_close(a["allmap"], orc.allmap, "allmap", max_bad_frac=1.3e-3, hard=0.19)     # observed 4.1e-4, max 6.1e-2 (a median flip)
+    # the two median channels on PROVEN ties (median_flips: the same standard as the C3-C5 test and smoke()) are left out; every other
+    # pixel of every channel is held to the bound of the summed channels (rounds 3-5 held the whole allmap to hard=0.19: a median flip)
+    from gpu_utils import hip_median_contrib, median_flips
+    flips = median_flips(hip_median_contrib(case), orc)
+    am, om = a["allmap"].copy(), orc.allmap.copy()
+    for ch in (5, 7):
+        am[ch][flips] = om[ch][flips]
+    img_close(am, om, "allmap", max_bad_frac=1.3e-3, hard=1.2e-2)     # observed 4.1e-4 of the entries, max 4.2e-3
+    go = go.copy()
+    go[5][flips] = 0.0
+    go[7][flips] = 0.0
+    a = run_hip(case, gc, go, debug=False)
     og = orc.backward(gc, go)
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
         grad_close(a[k], og[k], k, tol_trim=4.5e-5, tol_all=2.5e-3)    # observed <= 1.4e-5 / 7.5e-4
@@ -624,7 +638,12 @@ def test_config_c2_static_forward_only_50k_800():
     hip = run_hip(case, debug=False)
     assert float((hip["radii"] != orc.radii).mean()) <= 1e-4
     img_close(hip["color"], orc.color, "color", max_bad_frac=1.5e-4, hard=2.5e-3)    # observed 4.8e-5, max 7.9e-4
-    img_close(hip["allmap"], orc.allmap, "allmap", max_bad_frac=6e-4, hard=0.14)   # observed 1.8e-4, max 4.5e-2
+    from gpu_utils import hip_median_contrib, median_flips
+    flips = median_flips(hip_median_contrib(case), orc)     # proven ties of the median pick: left out of channels 5 / 7 (see test_full_size_properties)
+    am, om = hip["allmap"].copy(), orc.allmap.copy()
+    for ch in (5, 7):
+        am[ch][flips] = om[ch][flips]
+    img_close(am, om, "allmap", max_bad_frac=6e-4, hard=1.1e-2)   # observed 1.8e-4, max 3.8e-3
     mse = float(((hip["color"] - orc.color) ** 2).mean())
     assert mse < 1e-9      # PSNR > 90 dB for a [0, 1] image
 

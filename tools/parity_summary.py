@@ -1,10 +1,10 @@
-"""gpurun_out/parity_r05.json (written by tests/conftest.py at the end of a `pytest -m gpu` session: what every parity comparison of the
-suite MEASURED, next to what it asserted) -> a markdown table, one row per assertion site.   usage: python tools/parity_summary.py [in] > profiles/r05_parity_margins.md"""
+"""gpurun_out/parity_r06.json (written by tests/conftest.py at the end of a `pytest -m gpu` session: what every parity comparison of the
+suite MEASURED, next to what it asserted) -> a markdown table, one row per assertion site.   usage: python tools/parity_summary.py [in] > profiles/r06_parity_margins.md"""
 import collections
 import json
 import sys
 
-path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/parity_r05.json"
+path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/parity_r06.json"
 d = json.load(open(path))
 by = collections.OrderedDict()
 for x in d["records"]:
