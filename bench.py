@@ -72,7 +72,7 @@ WORKLOADS = {
 
 
 def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None, fused_adam=None, packed_sh=None, slots=None,
-                  sort_surfels=None, views_per_rank=1):
+                  sort_surfels=None, views_per_rank=1, concurrent_views=False):
     from dgs_amd.cameras import orbit_cameras
     from dgs_amd.deform import ControlNodes
     from dgs_amd.model import SurfelModel
@@ -88,7 +88,8 @@ def build_trainer(P, H, W, device, n_views=64, n_targets=8, rasterizer_cls=None,
     cams = [c.to(device) for c in orbit_cameras(n_views, W, H)]
     targets = [target_image(H, W, seed=1 + v).to(device) for v in range(n_targets)]
     bg = torch.zeros(3, device=device)
-    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam, views_per_rank=views_per_rank)
+    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=fused_adam, views_per_rank=views_per_rank,
+                 concurrent_views=concurrent_views)
     if sort_surfels is None:
         sort_surfels = torch.device(device).type == "cuda" and rasterizer_cls is None and os.environ.get("DGS_SORT_SURFELS", "1") != "0"
     if sort_surfels:
@@ -134,7 +135,7 @@ def cpu_baseline(P, H, W, budget_s=25.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_raster_op import OracleRasterizer  # test-only operator: oracle/ is the checker, never shipped
     from oracle import surfel_oracle
-    ncores = min(os.cpu_count() or 1, 32)  # more threads only add contention on the accumulations
+    ncores = min(os.cpu_count() or 1, 32)  # THREADS used (more only add contention on the accumulations); `cores` reports what the box has
     torch.set_num_threads(ncores)
     surfel_oracle.set_threads(ncores)
     tr = build_trainer(P, H, W, torch.device("cpu"), n_views=8, n_targets=2, rasterizer_cls=OracleRasterizer, fused_adam=False)
@@ -148,8 +149,32 @@ def cpu_baseline(P, H, W, budget_s=25.0):
         n += 1
         per = (time.time() - t0) / n
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "views/s", "cores": ncores, "kind": "port",
+    return {"value": n / dt, "unit": "views/s", "cores": os.cpu_count() or 1, "threads": ncores, "kind": "port",
             "sample": "%d full train steps (views) of the same %dk-surfel %dx%d workload, %.1f s" % (n, P // 1000, W, H, dt)}
+
+
+def concurrent_views_report(args, P, H, W, device, ms_headline):
+    """Single GPU, after the headline: the same workload with TWO views per step IN FLIGHT AT THE SAME TIME (Trainer(views_per_rank=2,
+    concurrent_views=True): a lane per view -- own stream, captured graph, gradient bucket, rasterizer context -- and one update that
+    reads the sum of the two buckets), W warm-up + K timed steps from a fresh scene; next to it the same two views back to back
+    (the sequential views_per_rank=2 of round 5).  The headline stays one view per step; this object says what the idle half of that
+    step is worth when another view fills it."""
+    out = {"k": 2}
+    for name, conc in (("concurrent", True), ("sequential", False)):
+        tr = build_trainer(P, H, W, device, views_per_rank=2, concurrent_views=conc)
+        tr.enable_graph(capacity=24 * P)
+        for _ in range(args.warmup):
+            tr.step()
+        dt = timed_steps(tr, args.steps, 1)
+        clean = not bool(tr._oflag.item()) and tr.overflow_recoveries == 0
+        ms = dt / args.steps * 1e3
+        out[name] = {"ms_per_step": round(ms, 4), "ms_per_view": round(ms / 2, 4), "views_per_s": round(2 * args.steps / dt, 2), "clean": clean}
+        del tr
+        torch.cuda.empty_cache()
+    out["ms_per_view"] = out["concurrent"]["ms_per_view"]
+    out["views_per_s"] = out["concurrent"]["views_per_s"]
+    out["vs_one_view_per_step"] = round(ms_headline / out["concurrent"]["ms_per_view"], 3)
+    return out
 
 
 def trained_trainer(P, H, W, device, pre_iterations):
@@ -759,6 +784,16 @@ def main():
                                                  "method": "torch d2d copy / triad over 1 GiB fp32 buffers, 20 iterations, HIP events"}
         except Exception as ex:   # never lose the result line over the side measurement
             print("warning: HBM ceiling measurement failed: %r" % (ex,), file=sys.stderr)
+        if world == 1 and use_graph and args.views_per_rank == 1 and not args.no_roofline_legs and not args.densify_every and args.workload != "trained":
+            from diff_surfel_rasterization import _C as _C2
+            del tr
+            torch.cuda.empty_cache()
+            tr = None
+            try:
+                out["concurrent_views"] = concurrent_views_report(args, P, H, W, device, dt / args.steps * 1e3)
+            except Exception as ex:   # never lose the result line over the side measurement
+                out["concurrent_views"] = {"error": repr(ex)[:300]}
+            _C2.set_capacity(0)
         if world == 1 and not args.no_cpu_baseline and args.workload != "trained":
             del tr
             torch.cuda.empty_cache()

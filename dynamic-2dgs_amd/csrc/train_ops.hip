@@ -1898,9 +1898,11 @@ __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restric
     step_guard_body(skip, step_count, status, host_ring, ring_len, loss ? loss[0] : 0.0f);   // one thread
 }
 
+// grad2 (nullable): a second gradient buffer of the same layout, ADDED to the first on the fly -- the two views of a step that were
+// rendered concurrently keep a bucket each (Trainer.concurrent_views) and the update reads their sum without an adding pass.
 __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step_count,
-                                                   float b1, float b2, float eps, const int* __restrict__ skip)
+                                                   float b1, float b2, float eps, const int* __restrict__ skip, const float* __restrict__ grad2)
 {
     const bool sk = skip && skip[0] != 0;   // guarded step (see step_guard_kernel)
     if (sk && !sg.zero_grad) return;
@@ -1938,6 +1940,10 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
         float4* vq = reinterpret_cast<float4*>(v + base + i0);
         float4* pq = reinterpret_cast<float4*>(p + i0);
         float4 g4 = *gq;
+        if (grad2) {
+            const float4 h4 = *reinterpret_cast<const float4*>(grad2 + base + i0);
+            g4.x += h4.x; g4.y += h4.y; g4.z += h4.z; g4.w += h4.w;
+        }
         if (sg.zero_grad) *gq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sk) return;
         float4 m4 = *mq, v4 = *vq, p4 = *pq;
@@ -1952,7 +1958,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
     for (int k = 0; k < 4; k++) {
         const long long i = i0 + k;
         if (i < seg_len) {
-            const float g = grad[base + i] * sg.gscale;
+            const float g = (grad[base + i] + (grad2 ? grad2[base + i] : 0.0f)) * sg.gscale;
             if (sg.zero_grad) grad[base + i] = 0.0f;
             if (sk) continue;
             float mi = m[base + i], vi = v[base + i], pi = p[i];
@@ -2199,6 +2205,17 @@ int dgs_adam_step_origin(int nseg, float* const* params, const long long* offset
                          const float* step_origins, float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq,
                          const float* step_count, float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream)
 {
+    return dgs_adam_step_sum2(nseg, params, offsets, lrs, lrs2, periods, splits, lrs_final, sched_steps, sched_t0, step_origins, grad_scale, grad,
+                              nullptr, zero_grad, exp_avg, exp_avg_sq, step_count, beta1, beta2, eps, plan, skip, stream);
+}
+
+int dgs_adam_step_sum2(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                       const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                       const float* step_origins, float grad_scale, float* grad, const float* grad2, int zero_grad, float* exp_avg,
+                       float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, const int* skip,
+                       void* stream)
+{
+    if (grad2 && zero_grad) return fail(-1, "dgs_adam_step_sum2: zero_grad clears the first buffer only; clear both yourself");
     if ((lrs_final != nullptr) != (sched_steps != nullptr)) return fail(-1, "dgs_adam_step_sched: pass lrs_final and sched_steps together");
     if (nseg <= 0 || nseg > kAdamSeg || !params || !offsets || !lrs || !grad || !exp_avg || !exp_avg_sq || !step_count || !plan)
         return fail(-1, "dgs_adam_step: bad argument");
@@ -2225,7 +2242,7 @@ int dgs_adam_step_origin(int nseg, float* const* params, const long long* offset
     const long long nb = adam_blocks(nseg, offsets);
     if (nb == 0) return 0;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, grad, exp_avg,
-                       exp_avg_sq, step_count, beta1, beta2, eps, skip);
+                       exp_avg_sq, step_count, beta1, beta2, eps, skip, grad2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("adam_kernel: ") + hipGetErrorString(e));
     return 0;

@@ -18,7 +18,8 @@ _EXPORTS = ("dgs_train_ops_abi_version", "dgs_train_ops_last_error", "dgs_ssim_f
             "dgs_photo_backward", "dgs_loss_combine", "dgs_densify_view", "dgs_densify_accumulate", "dgs_knn_refine", "dgs_photo_blocks", "dgs_regloss_blocks", "dgs_regloss_forward_partials", "dgs_adam_step_pattern", "dgs_adam_step_sched", "dgs_lbs_supported", "dgs_regloss_backward_slot",
             "dgs_step_guard", "dgs_adam_step_guarded", "dgs_adam_step_zero", "dgs_densify_accumulate_guarded", "dgs_regloss_forward_partials_z",
             "dgs_regloss_fused", "dgs_regloss_fused_blocks", "dgs_photo_backward_combine", "dgs_knn_refine_mode", "dgs_deform_reduce", "dgs_photo_backward_combine_guard",
-            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged", "dgs_mlp_forward_select", "dgs_mlp_backward_reduce")
+            "dgs_adam_step_origin", "dgs_select_row", "dgs_loss_forward_merged", "dgs_mlp_forward_select", "dgs_mlp_backward_reduce",
+            "dgs_adam_step_sum2")
 
 
 def _deps():
@@ -152,8 +153,11 @@ def load():
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
         lib.dgs_densify_accumulate_guarded.restype = ci
         lib.dgs_densify_accumulate_guarded.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]
-        if lib.dgs_train_ops_abi_version() != 2:
-            raise RuntimeError("libdgs_train_ops.so ABI version mismatch (want 2, library says %d): rebuild it" % lib.dgs_train_ops_abi_version())
+        lib.dgs_adam_step_sum2.restype = ci
+        lib.dgs_adam_step_sum2.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_float, vp, vp, ci, vp, vp, vp,
+                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        if lib.dgs_train_ops_abi_version() != 3:
+            raise RuntimeError("libdgs_train_ops.so ABI version mismatch (want 3, library says %d): rebuild it" % lib.dgs_train_ops_abi_version())
         _lib = lib
     return _lib
 
@@ -308,6 +312,7 @@ class FlatAdam:
         # step origin per parameter (dgs_adam_step_origin): the bias corrections of parameter i use t - origin[i]; set_origin()
         self._origin = (ctypes.c_float * n_)(*([0.0] * n_))
         self.grad_scale = 1.0   # gradients are read as grad * grad_scale (1 / world when the bucket holds the sum over ranks)
+        self.grad2 = None       # optional second flat gradient buffer of the same layout, added on the fly (dgs_adam_step_sum2)
         # step guard (dgs_step_guard): `skip` = a device int32 that is non-zero when this step must not change anything (a
         # rank's rasterizer overflowed its list capacity); None = every step is applied
         self.skip = None
@@ -404,10 +409,12 @@ class FlatAdam:
         with torch.cuda.device(dev):
             if advance:
                 self.guard()
-            rc = lib.dgs_adam_step_origin(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, origin, float(self.grad_scale),
-                                        self.grad.data_ptr(), 1 if self.zero_grads else 0,
-                                        self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
-                                        self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
+            g2 = self.grad2
+            assert g2 is None or (g2.numel() >= self.grad.numel() and g2.is_contiguous() and g2.dtype == torch.float32 and g2.device == dev)
+            rc = lib.dgs_adam_step_sum2(k, ptrs, off, lr, lr2, period, split, lr_final, sched_steps, self.sched_t0, origin, float(self.grad_scale),
+                                      self.grad.data_ptr(), None if g2 is None else g2.data_ptr(), 1 if self.zero_grads else 0,
+                                      self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t.data_ptr(), self.betas[0],
+                                      self.betas[1], self.eps, plan.data_ptr(), skip, _stream(dev))
         _check(lib, rc, "dgs_adam_step")
 
     @torch.no_grad()

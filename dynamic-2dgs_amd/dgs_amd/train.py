@@ -94,6 +94,28 @@ def expon_lr(step, lr_init, lr_final, max_steps):
     return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
+# per-instance scratch of the two model classes (streams, neighbour seeds, persistent tables, hooks): an alias starts without it
+_ALIAS_SCRATCH = ("_side_stream", "_deferred", "_knn_seed", "_coherent_tables", "_g_attrs", "_pending_reduce", "_join_pending",
+                  "_deferred_active", "view_select", "_graphed", "_graphed_keys", "_screenspace_leaf", "_before_sh_read")
+
+
+def alias_module(m):
+    """A module of the same class and configuration whose parameters are NEW Parameter objects over the SAME storage (values shared,
+    an own .grad each) and whose buffers are the same tensors.  What a second view needs to run its forward and backward next to
+    the first one's: the autograd leaves, the gradient sinks and every per-instance scratch buffer are its own; an in-place update
+    or in-place surgery of the original is visible at once.  (Replacing a Parameter of the original breaks the alias: rebuild it.)"""
+    import copy
+    from collections import OrderedDict
+    c = copy.copy(m)
+    c.__dict__ = dict(m.__dict__)
+    for k in _ALIAS_SCRATCH:
+        c.__dict__.pop(k, None)
+    c._parameters = OrderedDict((n, None if p is None else torch.nn.Parameter(p.data, requires_grad=p.requires_grad)) for n, p in m._parameters.items())
+    c._buffers = OrderedDict(m._buffers)
+    c._modules = OrderedDict((n, None if sub is None else alias_module(sub)) for n, sub in m._modules.items())
+    return c
+
+
 def split_step_allowed(world, overlap_allreduce, hip_fused_path, arap_active):
     """May the data-parallel step be split at the rasterizer inputs (backward half a | SH all-reduce | half b)?
     Half a differentiates the loss with respect to the ASSEMBLED rasterizer inputs only.  The ARAP regulariser reaches the
@@ -121,8 +143,19 @@ class Trainer:
     SCHED_DEFORM = (0.00016 * 5, 0.0000016, 40_000)
 
     def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=LATE_DEFORM_LR, position_lr=LATE_POSITION_LR,
-                 fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False, views_per_rank=1, shard_optimizer=True):
+                 fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False, views_per_rank=1, shard_optimizer=True,
+                 concurrent_views=False):
         self.surfels, self.deform = surfels, deform
+        # views_per_rank = k > 1 with concurrent_views: the k views of a step are IN FLIGHT AT THE SAME TIME, each on its own stream --
+        # 55 % of a view's step are short launches that leave most of the device idle, and the two blend kernels issue at half the
+        # VALU rate; another view's work fills both.  Every view is a LANE: alias modules over the same parameter storage (own autograd
+        # leaves, own scratch), an own gradient bucket (every producer STORES, as in a one-view step: nothing adds into a shared
+        # buffer, so nothing races), an own library context of the rasterizer (diff_surfel_rasterization.Lane), an own captured graph.
+        # The update reads the sum of the buckets on the fly (dgs_adam_step_sum2); see _make_lanes / _capture_lanes / _step_lanes.
+        self.concurrent_views = bool(concurrent_views)
+        self._lane = None        # this trainer's own diff_surfel_rasterization.Lane when it IS a lane of another trainer (else the default context)
+        self._lanes = None       # lanes 1 .. k - 1 (Trainer objects over alias modules); lane 0 is this trainer itself
+        self._lane_of = None
         # Data parallel (N > 1), split step: the SH coefficients -- 2/3 of the bucket -- are updated by the rank that OWNS their rows
         # (contiguous slot range rank * P / N ...): reduce-scatter of the SH gradients instead of their all-reduce, Adam on P / N rows
         # instead of P (the update is HBM-bound and was replicated on every rank), all-gather of the updated rows IN PLACE into the
@@ -360,6 +393,177 @@ class Trainer:
         finally:
             self._in_recovery = False
 
+    def _ctx_option(self, key, value):
+        """dgs_set_option on the library context this trainer's renders run in: its lane's, or the device's default one."""
+        from diff_surfel_rasterization import _C
+        if self._lane is not None:
+            self._lane.context.set_option(key, value)
+        else:
+            _C.set_option(key, value, device=self.surfels.get_xyz.device)
+
+    def _ctx_overflow_flag(self, flag):
+        from diff_surfel_rasterization import _C
+        if self._lane is not None:
+            self._lane.context.set_overflow_flag(flag)
+        else:
+            _C.set_overflow_flag(flag)
+
+    # ---- k views of a step in flight at the same time (concurrent_views) ---------------------------------------------------------
+    def _concurrent(self):
+        """Are the k views of a step run concurrently, a lane each?  The fully fused HIP path with the flat Adam kernel only."""
+        s = self.surfels
+        return bool(self.concurrent_views and self.views_per_rank > 1 and self._lane_of is None and self.rasterizer_cls is None
+                    and self.opt_deform is None and s.get_xyz.is_cuda and self.fuse_deform and self.deform.can_assemble(s)
+                    and not self._arap_active())
+
+    def _lanes_key(self):
+        """What the lanes were built for: the parameter storage they alias and the configuration they copied."""
+        d, s = self.deform, self.surfels
+        return (tuple(p.data_ptr() for p in self.bucket.params), self.views_per_rank, self.warmup, self.lambda_normal, self.lambda_dist,
+                int(s.active_sh_degree), bool(getattr(d, "coherent_surfels", False)), getattr(d, "knn_refine_mode", None),
+                bool(getattr(d, "fixed_point_tables", False)), bool(self.sh_grad_sink), bool(self.store_grads), self.P)
+
+    def _make_lanes(self):
+        """Lanes 1 .. k - 1: a Trainer each over ALIAS modules (alias_module: same parameter storage, own Parameter objects) with its
+        own gradient bucket, rasterizer context and streams; used for _fwd_bwd only -- the optimiser, the statistics' accumulators,
+        the step guard and the overflow flag are lane 0's (this trainer's).  Rebuilt whenever a parameter was replaced (growth, node
+        densification) or the regime changed."""
+        key = self._lanes_key()
+        if self._lanes is not None and getattr(self, "_lanes_built_for", None) == key:
+            return self._lanes
+        import diff_surfel_rasterization as dsr
+        dev = self.surfels.get_xyz.device
+        lanes = []
+        for j in range(1, self.views_per_rank):
+            sf, df = alias_module(self.surfels), alias_module(self.deform)
+            ln = Trainer(sf, df, self.cameras, self.targets, self.bg, fused_adam=True, views_per_rank=self.views_per_rank, shard_optimizer=False)
+            ln._lane_of, ln._lane = self, dsr.Lane(dev)
+            ln._lane_index = j
+            ln.rank, ln.world = self.rank, self.world
+            ln.warmup, ln.lambda_normal, ln.lambda_dist = self.warmup, self.lambda_normal, self.lambda_dist
+            ln.sh_grad_sink, ln.store_grads, ln.fuse_deform = self.sh_grad_sink, self.store_grads, self.fuse_deform
+            ln._oflag = self._oflag          # ONE overflow flag for all lanes: any lane's overflow skips the step
+            ln._stream = torch.cuda.Stream(dev)
+            for k_, v_ in (("_deterministic", getattr(self, "_deterministic", False)),):
+                setattr(ln, k_, v_)
+            if getattr(self, "_deterministic", False):
+                ln._lane.context.set_option(7, 2)
+                ln._lane.context.set_option(9, 0)
+            lanes.append(ln)
+        if getattr(self, "_stream0", None) is None:
+            self._stream0 = torch.cuda.Stream(dev)
+        self._lanes, self._lanes_built_for = lanes, key
+        return lanes
+
+    def _lane_list(self):
+        """[(lane trainer, its stream)] of all k lanes, lane 0 = this trainer."""
+        others = self._make_lanes()   # (also creates lane 0's stream)
+        return [(self, self._stream0)] + [(ln, ln._stream) for ln in others]
+
+    def _capture_lanes(self, dev):
+        """One captured graph per lane -- view selection, deformation, render, loss, backward, the view's statistics -- on the lane's own
+        stream and in a memory pool of its own (graphs that replay side by side must not share intermediates), and one graph for the
+        update.  Replayed by _step_lanes."""
+        k = self.views_per_rank
+        lanes = self._lane_list()
+        for j, (ln, st) in enumerate(lanes):
+            if ln is not self:   # the lane's own capture state: its row of the view table, its counters -- the big tables are shared
+                ln._capacity, ln._list_hint = self._capacity, self._list_hint
+                ln._ctx_option(2, self._capacity)
+                ln._ctx_option(6, self._list_hint)
+                ln._ctx_overflow_flag(self._oflag)
+                ln._rays, ln._targets_c, ln._vtab = self._rays, self._targets_c, self._vtab
+                ln._scam = StaticCamera(self.cameras[0], dev, self._rays[0][0], self._targets_c[0])
+                ln._scam.load(self._vtab[0])
+                ln._dev_select, ln._select_rider = self._dev_select, self._select_rider
+                ln._vctr = torch.full((1,), int(self.iteration), dtype=torch.int32, device=dev)
+                ln._vovr = torch.full((1,), -1, dtype=torch.int32, device=dev)
+                ln._sgt = ln._scam.target
+            ln._sel_stride, ln._sel_offset = k * self.world, j * self.world + self.rank   # view_for(i, j) = ((i k + j) world + rank) mod V
+        self._vctr_host = int(self.iteration)
+        cur = torch.cuda.current_stream()
+        snap = self._snapshot()
+        for _ in range(3):      # warm-up: allocations, lazily created per-lane buffers -- on a snapshot, nothing trains
+            self._lanes_eager([(ln._scam, ln._sgt) for ln, _ in lanes])
+            self._finish_lanes(eager=True)
+        self._restore(snap)
+        torch.cuda.synchronize()
+        mode = {"capture_error_mode": "thread_local"}
+        self._glanes = []
+        for j, (ln, st) in enumerate(lanes):
+            st.wait_stream(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st, **mode):
+                ln._select_view_node()
+                ln._lane_loss = ln._fwd_bwd(ln._scam, ln._sgt)
+                ln._select_consumed()
+            self._glanes.append(g)
+            cur.wait_stream(st)
+        torch.cuda.synchronize()
+        self._g2 = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(cur)
+        with torch.cuda.graph(self._g2, stream=s, **mode):
+            self._lanes_loss()
+            self._finish_lanes(eager=False)
+        cur.wait_stream(s)
+        self._sloss = self._kloss
+        self._gk = self._g1 = self._g1b = self._g0 = None
+
+    def _lanes_eager(self, cams):
+        """The k lanes' forward + backward launched eagerly, each on its stream (the host issues them one after the other, the device
+        overlaps them), joined on the current stream."""
+        cur = torch.cuda.current_stream()
+        lanes = self._lane_list()
+        for (ln, st), (cam, gt) in zip(lanes, cams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ln._lane_loss = ln._fwd_bwd(cam, gt)
+        for ln, st in lanes:
+            cur.wait_stream(st)
+        self._lanes_loss()
+
+    def _lanes_loss(self):
+        """mean of the lanes' losses -> the step's loss (what the guard kernel reports)"""
+        lanes = self._lane_list()
+        if getattr(self, "_kloss", None) is None:
+            self._kloss = torch.zeros(1, dtype=torch.float32, device=self.bucket.flat.device)
+        torch.mean(torch.stack([ln._lane_loss.reshape(()) for ln, _ in lanes]), dim=0, keepdim=True, out=self._kloss)
+        self._note_loss(self._kloss)
+
+    def _step_lanes(self, views):
+        """Replay the k lane graphs side by side, then the update."""
+        k = self.views_per_rank
+        it = self.iteration - 1
+        cur = torch.cuda.current_stream()
+        lanes = self._lane_list()
+        for j, ((ln, st), v) in enumerate(zip(lanes, views)):
+            if self._dev_select:
+                if it != self._vctr_host:
+                    ln._vctr.fill_(it)
+                if v != ((it * k + j) * self.world + self.rank) % len(self.cameras):
+                    ln._vovr.fill_(v)
+            else:
+                ln._scam.load(self._vtab[v])
+        self._vctr_host = it + 1
+        for (ln, st), g in zip(lanes, self._glanes):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                g.replay()
+        for ln, st in lanes:
+            cur.wait_stream(st)
+        if self.world > 1:
+            self._lanes_fold()
+            self._reduce()
+        self._g2.replay()
+        return self._kloss
+
+    def _lanes_fold(self):
+        """Data parallel: the exchange works on ONE bucket -- add the other lanes' gradients and statistics into lane 0's first."""
+        for ln in self._make_lanes():
+            self.bucket.flat.add_(ln.bucket.flat)
+            torch.maximum(self._radii, ln._radii, out=self._radii)
+
     def _agree_reason(self, reason):
         """Overflow reason bits OR-ed over the ranks (collective: every rank calls it at the same point).  The bits travel as three
         0/1 words through a MAX all-reduce -- RCCL has no bitwise OR reduction."""
@@ -396,15 +600,15 @@ class Trainer:
         if hasattr(self.deform, "pick_knn_refine"):
             self.deform.pick_knn_refine(self.surfels)   # the neighbour-search kernel that fits the scene now is baked into the capture
         self._capacity = int(capacity)
-        _C.set_capacity(int(capacity), device=dev)   # (the context of THIS trainer's device, whatever the caller's current device is)
+        self._ctx_option(2, int(capacity))   # capacity mode (the context of THIS trainer's device -- or lane --, whatever the caller's current device is)
         # promise of the longest tile list (dgs_set_option key 6): one sort launch instead of three.  A frame that breaks it
         # counts as an overflow: at capture time (below) and in the step guard the promise is withdrawn first, the capacity
         # doubled only if that was not the reason
         if not hasattr(self, "_list_hint"):
             self._list_hint = 2048
-        _C.set_option(6, self._list_hint, device=dev)
+        self._ctx_option(6, self._list_hint)
         if getattr(self, "_oflag", None) is not None:
-            _C.set_overflow_flag(self._oflag)   # the captured launches keep THIS trainer's flag
+            self._ctx_overflow_flag(self._oflag)   # the captured launches keep THIS trainer's flag
             if not getattr(self, "_in_recovery", False):
                 self._oflag.zero_()             # read_overflow below reports overflows of THIS capture only
         # (rays_d [H*W,3], rays_o [3]) per view and the targets stay resident: the table rows point at them
@@ -422,7 +626,12 @@ class Trainer:
         self._vctr = torch.full((1,), int(self.iteration), dtype=torch.int32, device=dev)
         self._vovr = torch.full((1,), -1, dtype=torch.int32, device=dev)
         self._vctr_host = int(self.iteration)
+        self._sel_stride, self._sel_offset = self.world, self.rank   # row = (counter * stride + offset) mod V
         self._sgt = self._scam.target
+        if self._concurrent():
+            self._capture_lanes(dev)
+            self._graph = True
+            return self._validate_capture(capacity, validate, dev)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up on a side stream (allocations, lazily created buffers) as torch.cuda.graph requires
@@ -444,6 +653,7 @@ class Trainer:
         self._g1 = torch.cuda.CUDAGraph()
         self._g1b = None
         self._g0 = None
+        self._glanes = None
         # thread-local capture mode: with a process group alive, the collective library's watchdog thread polls events while
         # this thread captures; under the default ("global") mode such a call from ANOTHER thread invalidates the capture
         # and the watchdog dies with the error (seen once in three runs on ROCm 7 / RCCL 2.26)
@@ -522,6 +732,10 @@ class Trainer:
             with torch.cuda.graph(self._g2, pool=self._g1.pool(), **mode):
                 self._finish(reduce=False, sh_done=self._split, mid_done=self._split and self.split3)
         self._graph = True
+        return self._validate_capture(capacity, validate, dev)
+
+    def _validate_capture(self, capacity, validate, dev):
+        from diff_surfel_rasterization import _C
         # validate: render EVERY view once (forward only, nothing trains; ~0.3 ms each) -- a view whose tile lists break the
         # capacity or the promised list length is found now, not by the step guard in the middle of a run (which would skip
         # that step, double / withdraw and re-capture).  validate=False leaves it to the guard.
@@ -570,7 +784,7 @@ class Trainer:
         """First node of a captured step (see enable_graph): the view row of this replay, chosen on the device."""
         if self._dev_select:
             from . import _ops
-            args = (self._vtab, self._vctr, self._vovr, self.world, self.rank, self._scam.row)
+            args = (self._vtab, self._vctr, self._vovr, self._sel_stride, self._sel_offset, self._scam.row)
             s, d = self.surfels, self.deform
             if (self._select_rider and self.rasterizer_cls is None and s.get_xyz.is_cuda and self.fuse_deform and hasattr(d, "_node_attrs")
                     and d.can_assemble(s)):
@@ -685,9 +899,9 @@ class Trainer:
         asm, dv, fused = self._forward_head(cam) if head is None else head
         if asm is not None:
             with trace.stage("dgs.rasterize"):
-                pkg = render(cam, s, self.bg, rasterizer_cls=self.rasterizer_cls, postprocess=False, assembled=asm)
+                pkg = render(cam, s, self.bg, rasterizer_cls=self._raster_cls(), postprocess=False, assembled=asm)
         else:
-            pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self.rasterizer_cls,
+            pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self._raster_cls(),
                          postprocess=not fused)
         lam = dict(lambda_normal=self.lambda_normal, lambda_dist=self.lambda_dist)
         # unit_grad: every backward of this trainer starts from dL/dloss = 1 (self._unit; the ARAP term is added, not multiplied), so
@@ -742,6 +956,13 @@ class Trainer:
         s = self.surfels
         # (views 2 .. k of a multi-view step: the sink STORES the rows of the visible surfels, it does not add to them -- those views
         # take the operator's own dL/dSH tensor and autograd adds it to the bucket view: one 4 P M-byte pass more per extra view)
+        if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink and not getattr(self, "_accum_view", 0) and self._lane is not None:
+            # a lane's sink is a field of its own Lane object: nothing device-wide, nothing keyed by the (shared) parameter storage
+            self._lane.sink, self._lane.all_rows = s._features.grad, bool(getattr(self, "_store_now", False))
+            try:
+                return fn()
+            finally:
+                self._lane.sink = None
         if fused and getattr(s, "packed_sh", False) and self.sh_grad_sink and not getattr(self, "_accum_view", 0):
             import diff_surfel_rasterization as dsr
             # the sink belongs to THIS trainer's SH parameter (keyed by the tensor the forward was given): other trainers on the
@@ -752,6 +973,15 @@ class Trainer:
             finally:
                 dsr.set_sh_grad_sink(None, shs=s._features)
         return fn()
+
+    def _raster_cls(self):
+        """What render() instantiates: the injected operator (tests, CPU baseline), the HIP operator in this trainer's lane, or None
+        (= the HIP operator in the device's default context)."""
+        if self.rasterizer_cls is not None or self._lane is None:
+            return self.rasterizer_cls
+        import functools
+        from diff_surfel_rasterization import GaussianRasterizer
+        return functools.partial(GaussianRasterizer, lane=self._lane)
 
     def _statistics(self, pkg, fused, early_radii=False):
         with torch.no_grad():
@@ -1009,7 +1239,18 @@ class Trainer:
             else:
                 self.opt_surfels.step(0, 1)
 
-    def _finish(self, reduce=True, sh_done=False, mid_done=False):
+    def _finish_lanes(self, eager):
+        """Update behind the k concurrent lanes.  Single GPU: the lanes' buckets are summed by the Adam kernel itself (dgs_adam_step_sum2)
+        and their statistics accumulated one after the other.  Data parallel: the other lanes are folded into lane 0's bucket first
+        (the exchange works on one buffer) -- eagerly, in front of the all-reduce (`eager`; the captured update starts behind it)."""
+        if self.world > 1:
+            if eager:
+                self._lanes_fold()
+                self._reduce()
+            return self._finish(reduce=False)
+        return self._finish(reduce=False, lanes=self._make_lanes())
+
+    def _finish(self, reduce=True, sh_done=False, mid_done=False, lanes=()):
         s = self.surfels
         with torch.no_grad():
             if reduce:
@@ -1019,13 +1260,18 @@ class Trainer:
                 self.opt_surfels.grad_scale = (1.0 / self.world if self._fold_mean else 1.0) / k
             elif k > 1:
                 self.bucket.flat[:self.bucket.n_grad].mul_(1.0 / k)   # (torch.optim.Adam path: the bucket holds the mean over the ranks of the SUM over the k views)
+            if lanes:   # concurrent views on one GPU: lane 1's bucket is the update's second gradient buffer, further lanes are added into it
+                for ln in lanes[1:]:
+                    lanes[0].bucket.flat.add_(ln.bucket.flat)
+                self.opt_surfels.grad2 = lanes[0].bucket.flat
 
             def accumulate():
                 if self.rasterizer_cls is None and s.get_xyz.is_cuda:
                     from . import _ops
-                    _ops.densify_accumulate(self.bucket.extra[:self.P], self.bucket.extra[self.P:2 * self.P], self._radii[:self.P],
-                                            s.xyz_gradient_accum, s.denom, s.max_radii2D,
-                                            skip=self.opt_surfels.skip if self.opt_deform is None else None)
+                    for tr in (self,) + tuple(lanes):   # every lane's view statistics (add_densification_stats once per view, gaussian_model.py:484-486)
+                        _ops.densify_accumulate(tr.bucket.extra[:self.P], tr.bucket.extra[self.P:2 * self.P], tr._radii[:self.P],
+                                                s.xyz_gradient_accum, s.denom, s.max_radii2D,
+                                                skip=self.opt_surfels.skip if self.opt_deform is None else None)
                 else:
                     s.xyz_gradient_accum.add_(self.bucket.extra[:self.P, None])
                     s.denom.add_(self.bucket.extra[self.P:2 * self.P, None])
@@ -1075,6 +1321,8 @@ class Trainer:
                 accumulate()
             # every branch above ran the update over ALL parameters of the bucket (with _finish_sh in the split step)
             self._bucket_clean = self.opt_deform is None and bool(getattr(self.opt_surfels, "zero_grads", False))
+            if lanes:
+                self.opt_surfels.grad2 = None
 
     # ---- adaptive density control (train_gui.py:410-423; dgs_amd/densify.py) -----------------------------------------
     def _moments(self):
@@ -1408,6 +1656,12 @@ class Trainer:
             self._loss_accumulate(j, loss)
         return loss
 
+    def _multi_view_step_concurrent(self, views):
+        """Eager twin of _step_lanes: the k views on their lanes' streams, one update."""
+        self._lanes_eager([(self.cameras[v], self.targets[v % len(self.targets)]) for v in views])
+        self._finish_lanes(eager=True)
+        return self._kloss[0].detach().clone()
+
     def _multi_view_step(self, views):
         """One step over k views of this rank: gradients added view by view, then ONE exchange and ONE update -- the neighbour search,
         every all-reduce and the Adam kernels once per k views.  Not split (the SH all-reduce of the split step hides under ONE view's
@@ -1445,7 +1699,9 @@ class Trainer:
         """A multi-view step (views_per_rank > 1): replay the captured per-view graphs, or run eagerly."""
         if not self._graph:
             with trace.stage("dgs.step(%d views)" % len(views)):
-                return self._multi_view_step(views)
+                return self._multi_view_step_concurrent(views) if self._concurrent() else self._multi_view_step(views)
+        if getattr(self, "_glanes", None) is not None and self._gk is None:
+            return self._step_lanes(views)
         k = self.views_per_rank
         base = (self.iteration - 1) * k              # what the device's view counter must read in front of this step
         if self._dev_select:

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import _C
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "Lane"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -107,15 +107,29 @@ def _bwd_lock(dev):
         return lk
 
 
+class Lane:
+    """Extension (not in the reference): everything that lets SEVERAL renders of one process be in flight on one device at the same
+    time, each on its own stream -- an explicit library context (its own options, overflow flag, staging words: `_C.Context`) and
+    the lane's own dL/dSH sink.  `GaussianRasterizer(settings, lane=lane)` runs forward and backward in that context; without a lane
+    the operator uses the device's default context and the sinks registered with set_sh_grad_sink, as before.
+    dgs_amd.train.Trainer(concurrent_views=True) gives every view of a multi-view step its lane."""
+
+    def __init__(self, device=None):
+        self.context = _C.Context(device)
+        self.sink = None          # contiguous fp32 [P,M,3] tensor the backward stores dL/dSH into (see set_sh_grad_sink), or None
+        self.all_rows = False     # the backward also stores zeros in the rows of culled surfels (option 8 of the lane's context)
+
+
 class _SurfelRasterFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cfg):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cfg, lane=None):
         call = (cfg.bg, means3D, colors_precomp, opacities, scales, rotations, cfg.scale_modifier, cov3Ds_precomp,
                 cfg.viewmatrix, cfg.projmatrix, cfg.tanfovx, cfg.tanfovy, cfg.image_height, cfg.image_width, sh,
                 cfg.sh_degree, cfg.campos, cfg.prefiltered, cfg.debug)
-        n_rendered, color, allmap, radii, geom, binning, img = _guarded(
-            _C.rasterize_gaussians, call, cfg.debug, "snapshot_fw.dump", "forward")
+        fwd = _C.rasterize_gaussians if lane is None else (lambda *a: _C.rasterize_gaussians(*a, context=lane.context))
+        n_rendered, color, allmap, radii, geom, binning, img = _guarded(fwd, call, cfg.debug, "snapshot_fw.dump", "forward")
         ctx.cfg = cfg
+        ctx.lane = lane
         ctx.n_rendered = n_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
@@ -133,10 +147,20 @@ class _SurfelRasterFn(torch.autograd.Function):
         call = (cfg.bg, means3D, radii, colors_precomp, scales, rotations, cfg.scale_modifier, cov3Ds_precomp,
                 cfg.viewmatrix, cfg.projmatrix, cfg.tanfovx, cfg.tanfovy, g_color, g_allmap, sh, cfg.sh_degree, cfg.campos,
                 geom, ctx.n_rendered, binning, img, cfg.debug)
-        sink, all_rows = _sink_for(means3D.device, sh)
+        lane = ctx.lane
+        sink, all_rows = _sink_for(means3D.device, sh) if lane is None else (lane.sink, lane.all_rows)
         if sink is not None and not (sink.shape == sh.shape and sink.dtype == torch.float32 and sink.is_contiguous()
                                      and sink.device == sh.device):
             raise RuntimeError("set_sh_grad_sink: the sink must be a contiguous fp32 tensor of the shape of shs")
+        if lane is not None:
+            # the lane's context is its own: option 8 is set on it, no device-wide lock (other lanes' backwards run next to this one)
+            lane.context.set_option(8, 1 if (sink is not None and all_rows) else 0)
+            want = dict(want_colors=bool(ctx.needs_input_grad[3]), want_transmat=bool(ctx.needs_input_grad[7]), context=lane.context)
+            if sink is not None:
+                want["dL_dsh_out"] = sink
+            (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
+                lambda *a: _C.rasterize_gaussians_backward(*a, **want), call, cfg.debug, "snapshot_bw.dump", "backward")
+            return (g_means3D, g_means2D, None if sink is not None else g_sh, g_colors, g_opac, g_scales, g_rot, g_transMat, None, None)
         # option 8 (zeros for culled rows) belongs to the sink of THIS call; it is a switch of the device's default context, so it is
         # set and the launches are issued under one lock per device (the kernels read it at launch time, on the host)
         with _bwd_lock(means3D.device):
@@ -150,18 +174,19 @@ class _SurfelRasterFn(torch.autograd.Function):
             else:
                 (g_means2D, g_colors, g_opac, g_means3D, g_transMat, g_sh, g_scales, g_rot) = _guarded(
                     lambda *a: _C.rasterize_gaussians_backward(*a, **want), call, cfg.debug, "snapshot_bw.dump", "backward")
-        return (g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_transMat, None)
+        return (g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_transMat, None, None)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, lane=None):
     return _SurfelRasterFn.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                 raster_settings)
+                                 raster_settings, lane)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings):
+    def __init__(self, raster_settings, lane=None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.lane = lane   # extension: a `Lane` (own library context + dL/dSH sink) for renders that run concurrently on one device
 
     def markVisible(self, positions):
         """bool[P]: surfel centres in front of the near plane of this camera."""
@@ -186,4 +211,4 @@ class GaussianRasterizer(nn.Module):
 
         shs = empty() if shs is None else shs
         colors_precomp = empty() if colors_precomp is None else colors_precomp
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, empty(), cfg)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, empty(), cfg, self.lane)

@@ -18,8 +18,8 @@
 extern "C" {
 #endif
 
-#define DGS_TRAIN_OPS_ABI_VERSION 2   /* 2: the round-4 additions (dgs_adam_step_origin, dgs_select_row, dgs_loss_forward_merged,
-                                         dgs_mlp_forward_select, dgs_mlp_backward_reduce) are required exports */
+#define DGS_TRAIN_OPS_ABI_VERSION 3   /* 2: the round-4 additions (dgs_adam_step_origin, dgs_select_row, dgs_loss_forward_merged,
+                                         dgs_mlp_forward_select, dgs_mlp_backward_reduce) are required exports; 3: + dgs_adam_step_sum2 */
 
 int dgs_train_ops_abi_version(void);
 const char* dgs_train_ops_last_error(void);
@@ -143,6 +143,15 @@ int dgs_adam_step_origin(int nseg, float* const* params, const long long* offset
                          const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                          const float* step_origins, float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq,
                          const float* step_count, float beta1, float beta2, float eps, const void* plan, const int* skip, void* stream);
+/* The same reading the gradient as grad + grad2 (grad2: a second buffer of the same layout, or NULL): two views of one step that were
+ * rendered CONCURRENTLY keep a gradient buffer each (they cannot add into one without racing) and the update takes their sum on the
+ * fly -- one extra read instead of an adding pass over both.  zero_grad must be 0 when grad2 is given.  (Round 6; not in the
+ * reference, which renders one view per optimizer step: train_gui.py:258,426-432.) */
+int dgs_adam_step_sum2(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
+                       const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
+                       const float* step_origins, float grad_scale, float* grad, const float* grad2, int zero_grad, float* exp_avg,
+                       float* exp_avg_sq, const float* step_count, float beta1, float beta2, float eps, const void* plan, const int* skip,
+                       void* stream);
 
 /* Control-node deformation MLP (DeformNetwork, utils/time_utils.py:311-453, is_blender + local_frame configuration:
  * posenc(xyz,10) | timenet(posenc(t,6)): 13->256->30, 8 x 256 ReLU layers, skip concat after layer 4, heads

@@ -1,0 +1,81 @@
+"""-m gpu: Trainer(views_per_rank=2, concurrent_views=True) -- the two views of a step in flight at the same time, a lane each
+(alias modules over the same parameter storage, own gradient bucket, own rasterizer context, own stream / captured graph), one update
+that reads the sum of the two buckets (dgs_adam_step_sum2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_alias_modules_share_values_and_keep_their_own_gradients():
+    import bench
+    from dgs_amd.train import alias_module
+    dev = torch.device("cuda:0")
+    tr = bench.build_trainer(2000, 64, 64, dev, n_views=4, n_targets=1)
+    for m in (tr.surfels, tr.deform):
+        a = alias_module(m)
+        pm, pa = dict(m.named_parameters()), dict(a.named_parameters())
+        assert list(pm) == list(pa) and len(pm) > 0
+        for n in pm:
+            assert pa[n] is not pm[n] and pa[n].data_ptr() == pm[n].data_ptr() and pa[n].grad is None
+        for (n, b), (_, c) in zip(m.named_buffers(), a.named_buffers()):
+            assert b is c
+        with torch.no_grad():
+            next(iter(pm.values())).add_(1.0)
+        assert torch.equal(next(iter(pa.values())), next(iter(pm.values())))
+
+
+def test_concurrent_views_bucket_is_the_sum_of_the_single_view_gradients_and_graph_equals_eager():
+    import bench
+    from diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+
+    def bucket_of(views_per_rank, views, concurrent=False):
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2, views_per_rank=views_per_rank, concurrent_views=concurrent)
+        order = list(views)
+        tr.view_for = lambda it, j=0: order[j]
+        rec = []
+
+        def grab(*a, **k):
+            g2 = tr.opt_surfels.grad2
+            rec.append(tr.bucket.flat.clone() if g2 is None else tr.bucket.flat + g2)
+        tr.opt_surfels.step = grab
+        tr.step()
+        torch.cuda.synchronize()
+        assert (tr._lanes is not None) == concurrent
+        return rec[-1], tr.bucket.n_grad, float(tr.opt_surfels.grad_scale)
+
+    f0, n, s0 = bucket_of(1, [0])
+    f1, _, _ = bucket_of(1, [1])
+    f0b, _, _ = bucket_of(1, [0])     # the yardstick: two runs of ONE configuration differ by the float atomics of the backward
+    f1b, _, _ = bucket_of(1, [1])
+    fc, _, sc = bucket_of(2, [0, 1], concurrent=True)
+    assert s0 == 1.0 and sc == 0.5
+    tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2)
+    off, bad = 0, []
+    for i, m in enumerate([p.numel() for p in tr.bucket.params] + [fc.numel() - n]):
+        a, b = fc[off:off + m], (f0 + f1)[off:off + m]
+        noise = float((f0 - f0b)[off:off + m].norm()) + float((f1 - f1b)[off:off + m].norm())
+        if not float((a - b).norm()) <= 4.0 * noise + 2e-4 * float(b.norm()) + 1e-12:
+            bad.append((i, m, float((a - b).norm()), noise, float(b.norm())))
+        off += m
+    assert not bad, bad
+    res = {}
+    for mode in ("sequential", "eager", "graph"):
+        tr = bench.build_trainer(20000, 256, 256, dev, n_views=8, n_targets=2, views_per_rank=2, concurrent_views=mode != "sequential")
+        try:
+            if mode == "graph":
+                tr.enable_graph(capacity=24 * 20000)
+                assert tr._glanes is not None and len(tr._glanes) == 2
+            losses = [float(tr.step()) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert not _C.read_overflow()
+            assert tr.iteration == 3 and int(tr.surfels.denom.max()) == 6     # three steps of two views
+        finally:
+            _C.set_capacity(0)
+        res[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu())
+    for other in ("eager", "graph"):
+        for a, b in zip(res["sequential"][0], res[other][0]):
+            assert abs(a - b) <= 1e-4 * abs(a), (other, res["sequential"][0], res[other][0])
+        assert torch.isfinite(res[other][1]).all() and float((res["sequential"][1] - res[other][1]).abs().median()) < 1e-6
