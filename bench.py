@@ -160,20 +160,23 @@ def concurrent_views_report(args, P, H, W, device, ms_headline):
     (the sequential views_per_rank=2 of round 5).  The headline stays one view per step; this object says what the idle half of that
     step is worth when another view fills it."""
     out = {"k": 2}
-    for name, conc in (("concurrent", True), ("sequential", False)):
-        tr = build_trainer(P, H, W, device, views_per_rank=2, concurrent_views=conc)
+    for name, conc, k in (("concurrent", True, 2), ("sequential", False, 2), ("concurrent_k3", True, 3)):
+        tr = build_trainer(P, H, W, device, views_per_rank=k, concurrent_views=conc)
         tr.enable_graph(capacity=24 * P)
         for _ in range(args.warmup):
             tr.step()
         dt = timed_steps(tr, args.steps, 1)
         clean = not bool(tr._oflag.item()) and tr.overflow_recoveries == 0
         ms = dt / args.steps * 1e3
-        out[name] = {"ms_per_step": round(ms, 4), "ms_per_view": round(ms / 2, 4), "views_per_s": round(2 * args.steps / dt, 2), "clean": clean}
+        out[name] = {"k": k, "ms_per_step": round(ms, 4), "ms_per_view": round(ms / k, 4), "views_per_s": round(k * args.steps / dt, 2), "clean": clean}
         del tr
         torch.cuda.empty_cache()
     out["ms_per_view"] = out["concurrent"]["ms_per_view"]
     out["views_per_s"] = out["concurrent"]["views_per_s"]
     out["vs_one_view_per_step"] = round(ms_headline / out["concurrent"]["ms_per_view"], 3)
+    out["what_limits_it"] = ("the two blend kernels saturate every CU (5 workgroups of 96 VGPRs / 30 KB LDS each); a kernel of the other lane whose "
+                             "workgroups are large (1024 threads, tens of KB of LDS: scatter, offsets, node MLP, weight gradients) is placed only "
+                             "when the blend's grid drains: profiles/r06_concurrent_timeline.txt")
     return out
 
 

@@ -443,7 +443,7 @@ class Trainer:
             ln.warmup, ln.lambda_normal, ln.lambda_dist = self.warmup, self.lambda_normal, self.lambda_dist
             ln.sh_grad_sink, ln.store_grads, ln.fuse_deform = self.sh_grad_sink, self.store_grads, self.fuse_deform
             ln._oflag = self._oflag          # ONE overflow flag for all lanes: any lane's overflow skips the step
-            ln._stream = torch.cuda.Stream(dev)
+            ln._stream = torch.cuda.Stream(dev, priority=int(os.environ.get("DGS_LANE_PRIORITY", "0")))
             for k_, v_ in (("_deterministic", getattr(self, "_deterministic", False)),):
                 setattr(ln, k_, v_)
             if getattr(self, "_deterministic", False):
@@ -451,7 +451,7 @@ class Trainer:
                 ln._lane.context.set_option(9, 0)
             lanes.append(ln)
         if getattr(self, "_stream0", None) is None:
-            self._stream0 = torch.cuda.Stream(dev)
+            self._stream0 = torch.cuda.Stream(dev, priority=int(os.environ.get("DGS_LANE0_PRIORITY", "0")))
         self._lanes, self._lanes_built_for = lanes, key
         return lanes
 
@@ -466,6 +466,12 @@ class Trainer:
         update.  Replayed by _step_lanes."""
         k = self.views_per_rank
         lanes = self._lane_list()
+        # no fork INSIDE a lane (one-view steps run the node MLP next to the neighbour search and its backward on a side stream): the other
+        # lane is what fills the device here, and ROCm 7.2's graph instantiation segfaults on the nested forks of the one-graph form
+        # (DGS_LANES_FLAT=0 with separate graphs works and measures the same: 0.650 / 0.657 ms per view)
+        if os.environ.get("DGS_LANES_FLAT", "1") != "0":
+            for ln, _ in lanes:
+                ln.deform.overlap_streams = False
         for j, (ln, st) in enumerate(lanes):
             if ln is not self:   # the lane's own capture state: its row of the view table, its counters -- the big tables are shared
                 ln._capacity, ln._list_hint = self._capacity, self._list_hint
@@ -489,6 +495,41 @@ class Trainer:
         self._restore(snap)
         torch.cuda.synchronize()
         mode = {"capture_error_mode": "thread_local"}
+        self._gall = None
+        one_graph = os.environ.get("DGS_LANES_ONE_GRAPH", "1" if self.world == 1 else "0") != "0" and os.environ.get("DGS_LANES_FLAT", "1") != "0"
+        if one_graph:
+            # ONE graph: the lanes fork from the capture stream and join in front of the update (single GPU: the update is part of
+            # the graph) -- one replay per step, every lane starts at the same moment
+            s0 = self._stream0
+            s0.wait_stream(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s0, **mode):
+                for ln, st in lanes[1:]:
+                    st.wait_stream(s0)
+                for ln, st in lanes:
+                    with torch.cuda.stream(st):
+                        ln._select_view_node()
+                        ln._lane_loss = ln._fwd_bwd(ln._scam, ln._sgt)
+                        ln._select_consumed()
+                for ln, st in lanes[1:]:
+                    s0.wait_stream(st)
+                self._lanes_loss()
+                if self.world == 1:
+                    self._finish_lanes(eager=False)
+            cur.wait_stream(s0)
+            self._gall = g
+            self._glanes = []
+            self._g2 = None
+            if self.world > 1:
+                self._g2 = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream()
+                s.wait_stream(cur)
+                with torch.cuda.graph(self._g2, stream=s, **mode):
+                    self._finish_lanes(eager=False)
+                cur.wait_stream(s)
+            self._sloss = self._kloss
+            self._gk = self._g1 = self._g1b = self._g0 = None
+            return
         self._glanes = []
         for j, (ln, st) in enumerate(lanes):
             st.wait_stream(cur)
@@ -546,6 +587,13 @@ class Trainer:
             else:
                 ln._scam.load(self._vtab[v])
         self._vctr_host = it + 1
+        if getattr(self, "_gall", None) is not None:
+            self._gall.replay()
+            if self.world > 1:
+                self._lanes_fold()
+                self._reduce()
+                self._g2.replay()
+            return self._kloss
         for (ln, st), g in zip(lanes, self._glanes):
             st.wait_stream(cur)
             with torch.cuda.stream(st):

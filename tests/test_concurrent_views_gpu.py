@@ -67,7 +67,7 @@ def test_concurrent_views_bucket_is_the_sum_of_the_single_view_gradients_and_gra
         try:
             if mode == "graph":
                 tr.enable_graph(capacity=24 * 20000)
-                assert tr._glanes is not None and len(tr._glanes) == 2
+                assert tr._glanes is not None and (tr._gall is not None or len(tr._glanes) == 2)
             losses = [float(tr.step()) for _ in range(3)]
             torch.cuda.synchronize()
             assert not _C.read_overflow()

@@ -441,3 +441,60 @@ def test_overflow_on_one_rank_recovers_every_rank_to_the_same_configuration():
     assert cfgs[0] == cfgs[1], cfgs                 # same capacity, same promise, same iteration, same number of recoveries
     assert cfgs[0][3] >= 1 and cfgs[0][0] == 2 * cap0 and cfgs[0][1] == hint0, (cfgs, cap0, hint0)   # reason 1 on rank 1 only: capacity doubled on BOTH, promise kept
     assert same
+
+
+def _concurrent_dp_worker(rank, world, port, q, graph):
+    """Two ranks x two CONCURRENT views per rank (Trainer.concurrent_views): every rank folds its lanes' buckets into one before the
+    step's single exchange; replicas stay bit-identical and the step trains on four views."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from diff_surfel_rasterization import _C
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        out = {}
+        for conc in (False, True):
+            tr = bench.build_trainer(20000, 128, 128, dev, n_views=8, n_targets=2, views_per_rank=2, concurrent_views=conc)
+            if graph:
+                tr.enable_graph(capacity=40 * 20000)
+            losses = [float(tr.step()) for _ in range(3)]
+            tr.settle_shards()
+            torch.cuda.synchronize()
+            assert not _C.read_overflow()
+            _C.set_capacity(0)
+            assert (tr._lanes is not None) == conc and int(tr.surfels.denom.max()) == 3 * 2 * world
+            params = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu()
+            gp = [torch.zeros_like(params) for _ in range(world)]
+            dist.all_gather(gp, params)
+            out[conc] = (all(torch.equal(gp[0], g) for g in gp), bool(torch.isfinite(params).all()), losses, params.numpy())
+            del tr
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_concurrent_views_under_data_parallelism(graph):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_concurrent_dp_worker, args=(r, world, port, q, graph)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    import numpy as np
+    for conc, (same, finite, losses, _) in res.items():
+        assert same and finite and all(0.0 < l < 10.0 for l in losses), (conc, losses)
+    # the same four views per step either way: sequential and concurrent lanes train alike (float atomics aside)
+    for a, b in zip(res[False][2], res[True][2]):
+        assert abs(a - b) <= 1e-4 * abs(a), (res[False][2], res[True][2])
+    assert float(np.median(np.abs(res[False][3] - res[True][3]))) < 1e-6
