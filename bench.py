@@ -428,13 +428,15 @@ def comm_levers(tr, args, world, device, ms_headline):
     if tr._graph:
         cap = tr._capacity
         try:
-            tr.views_per_rank = 2
-            tr._graph = None
-            tr.enable_graph(cap, validate=False)
-            ms = window()
-            res["views_per_rank_2"] = {"ms_per_step": round(ms, 4), "ms_per_view": round(ms / 2, 4), "views_per_step": 2 * world}
+            for name, conc in (("views_per_rank_2", False), ("views_per_rank_2_concurrent", True)):   # back to back | in flight at the same time (a lane each)
+                tr.views_per_rank, tr.concurrent_views = 2, conc
+                tr._graph = None
+                tr.enable_graph(cap, validate=False)
+                ms = window()
+                res[name] = {"ms_per_step": round(ms, 4), "ms_per_view": round(ms / 2, 4), "views_per_step": 2 * world}
+                rewind(snap, it0)
         finally:
-            tr.views_per_rank = 1
+            tr.views_per_rank, tr.concurrent_views = 1, False
             rewind(snap, it0)
             tr._graph = None
             tr.enable_graph(cap, validate=False)

@@ -104,3 +104,4 @@ def test_bench_eight_ranks_dry_run():
     lv = c["levers"]
     assert lv["wire_bf16_on"]["ms_per_view"] > 0 and lv["wire_bf16_on"]["wire_bytes_per_step"] < c["wire_bytes_per_step"]["total"]
     assert lv["views_per_rank_2"]["views_per_step"] == 16 and lv["views_per_rank_2"]["ms_per_view"] > 0
+    assert lv["views_per_rank_2_concurrent"]["views_per_step"] == 16 and lv["views_per_rank_2_concurrent"]["ms_per_view"] > 0

@@ -20,9 +20,10 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 P, H, W = bench.WORKLOADS["metric"]
-for pretend in (1, 2):
-    tr = bench.build_trainer(P, H, W, dev)
+for pretend, shard in ((1, False), (2, False), (2, True)):   # shard: reduce-scatter / owner's Adam / all-gather of the SH segment (round 6) -- with
+    tr = bench.build_trainer(P, H, W, dev)                   # ONE real rank the owner's rows are all rows: the structure's cost, not its saving
     tr.world = pretend
+    tr.shard_optimizer = shard
     tr.enable_graph(capacity=24 * P)
     for _ in range(10):
         tr.step()
@@ -32,7 +33,7 @@ for pretend in (1, 2):
     for _ in range(n):
         tr.step()
     torch.cuda.synchronize()
-    print("world (pretended) %d: %.4f ms/step" % (pretend, (time.perf_counter() - t0) / n * 1e3), flush=True)
+    print("world (pretended) %d, sharded SH update %s: %.4f ms/step" % (pretend, shard, (time.perf_counter() - t0) / n * 1e3), flush=True)
     _C.set_capacity(0)
     del tr
 dist.destroy_process_group()
