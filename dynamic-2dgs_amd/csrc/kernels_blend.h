@@ -888,6 +888,9 @@ __device__ __forceinline__ unsigned long long to_fixed44(float v)
     return (unsigned long long)__float2ll_rn(v * 17592186044416.0f);   // 2^44; two's complement: unsigned wrap-around adds signed numbers
 }
 
+#ifdef DGS_COUNT_VISITS   // development build (tools/diag/visit_counts.py): what the backward's visits are made of
+__device__ unsigned long long g_visit_counts[4];   // visits of the real pass | of them with no blending lane | blending lanes of the others | staged entries
+#endif
 #ifndef DGS_BWD_CHUNK
 #define DGS_BWD_CHUNK 48
 #endif
@@ -960,6 +963,9 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
 
     // chunk lane l holds list entry e = top - l; the entries that can touch the quadrant are compacted in that (back to front) order
     const bool stager = kChunkB == 64 || lane < kChunkB;
+#ifdef DGS_COUNT_VISITS
+    unsigned long long n_visit = 0, n_empty = 0, n_lanes = 0, n_staged = 0;
+#endif
     auto walk = [&](auto light_tag) {
         constexpr bool kLight = decltype(light_tag)::value;
         uint32_t id_next = stager && hi - 1 - lane >= lo ? a.point_list[range.x + (uint32_t)(hi - 1 - lane)] : 0u;
@@ -986,6 +992,9 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
             }
             __builtin_amdgcn_wave_barrier();   // the slice is private to this wave: its LDS writes above are ordered before its reads below
             const int nhit = __builtin_popcountll(m);
+#ifdef DGS_COUNT_VISITS
+            if (!kLight) n_staged += (unsigned long long)__builtin_popcountll(ballot64(stager & (e_mine >= lo)));
+#endif
             f32x4 a0 = S.a[0][0], a1 = S.a[1][0], a2 = S.a[2][0];
             f32x4 tw = S.tw[0], tuv = S.tuv[0], q3 = S.q3[0], q4 = S.q4[0];
             for (int i = 0; i < nhit; i++) {
@@ -998,10 +1007,16 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
                 DGS_PIN4(a0); DGS_PIN4(a1); DGS_PIN4(a2);
                 const int e = __builtin_amdgcn_readfirstlane(__float_as_int(q4.z));  // 0-based list index == the reference's `contributor`
                 ok = ok & (e < st.last_contributor);
+#ifdef DGS_COUNT_VISITS
+                if (!kLight) { n_visit++; if (ballot64(ok) == 0ull) n_empty++; }
+#endif
                 if (ballot64(ok) != 0ull) {
                     bool use3d;
                     const float depth = alpha_depth(ev, tw.x, tw.y, tw.z, use3d);
                     ok = ok & (depth >= kNear);
+#ifdef DGS_COUNT_VISITS
+                    if (!kLight) n_lanes += (unsigned long long)__builtin_popcountll(ballot64(ok));
+#endif
                     if (kLight) {
                         // pass 1 of a long tile: only what the two recurrences need (pixbwd_step_affine's alpha, 1 / (1 - alpha) and u)
                         const float alpha = ok ? ev.alpha : 0.f;
@@ -1081,6 +1096,12 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
         __syncthreads();   // xfer lives in the reduction buffers, which the real pass writes
     }
     walk(std::false_type{});
+#ifdef DGS_COUNT_VISITS
+    if (lane == 0) {
+        atomicAdd(&g_visit_counts[0], n_visit); atomicAdd(&g_visit_counts[1], n_empty);
+        atomicAdd(&g_visit_counts[2], n_lanes); atomicAdd(&g_visit_counts[3], n_staged);
+    }
+#endif
 }
 
 template <int DET>

@@ -211,6 +211,7 @@ struct dgs_context {
     std::atomic<int> deterministic{0};   // key 7: 1 backward blend without atomics, fixed summation order (tests); 2 fixed-point integer atomics
     unsigned long long* acc64 = nullptr; // key 7 = 2: [P, kAccFloats] fixed-point accumulator rows, zero between backward passes
     size_t acc64_rows = 0;
+    std::vector<unsigned long long*> acc64_retired;   // outgrown rows: a captured graph may still point at them, freed with the context
     std::atomic<int> sh_all_rows{0};     // key 8: dL_dsh written for every row (zeros for culled surfels / unused bands)
     std::atomic<int> long_tiles{1};      // key 9: four workgroups (one per quadrant, four list quarters each) for the longest tiles
     // Measured (tools/diag/long_tune.py, blend fwd / bwd in ms; uniform 200k scene | ONE densified scene, 88 k surfels, kept as a checkpoint):
@@ -342,6 +343,7 @@ void dgs_context_destroy(dgs_context* c)
     }
     if (c->overflow_owned) (void)hipFree(c->overflow_owned);
     if (c->acc64) (void)hipFree(c->acc64);
+    for (auto* p : c->acc64_retired) (void)hipFree(p);
     if (c->stage.u) (void)hipHostFree(c->stage.u);
     if (c->prof.counters) (void)hipFree(c->prof.counters);
     if (c->prof.ring) (void)hipFree(c->prof.ring);
@@ -376,6 +378,29 @@ int dgs_context_set_option(dgs_context* c, int key, int value)
         return DGS_OK;
     }
     return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_set_option: unknown key / value");
+}
+
+int dgs_context_get_option(dgs_context* c, int key)
+{
+    if (!c) return fail(DGS_ERR_INVALID_ARGUMENT, "context is NULL");
+    switch (key) {
+    case 0: return c->tight_rects.load();
+    case 1: return c->tile_order.load();
+    case 2: return c->capacity.load();
+    case 3: return c->sort_regs.load();
+    case 4: return c->grid_limit_bwd.load();
+    case 5: return c->grid_limit_fwd.load();
+    case 6: return c->list_hint.load();
+    case 7: return c->deterministic.load();
+    case 8: return c->sh_all_rows.load();
+    case 9: return c->long_tiles.load();
+    case 10: return c->long_div_fwd.load();
+    case 11: return c->long_div_bwd.load();
+    case 12: return c->merged_offsets.load();
+    case 13: return c->order_rider.load();
+    case 14: return c->acc_rider.load() ? 1 : 0;
+    }
+    return fail(DGS_ERR_INVALID_ARGUMENT, "dgs_get_option: unknown key");
 }
 
 int dgs_context_set_overflow_flag(dgs_context* c, int* device_flag)
@@ -486,11 +511,25 @@ int dgs_context_profile_read(dgs_context* c, double* out, int cap)
 // ---- the same knobs on the default context of the calling thread's current device --------------------------------------
 void dgs_set_tight_rects(int on) { (void)dgs_context_set_option(default_context(), 0, on); }
 int dgs_set_option(int key, int value) { return dgs_context_set_option(default_context(), key, value); }
+int dgs_get_option(int key) { return dgs_context_get_option(default_context(), key); }
 int dgs_set_overflow_flag(int* device_flag) { return dgs_context_set_overflow_flag(default_context(), device_flag); }
 int dgs_read_overflow(int reset) { return dgs_context_read_overflow(default_context(), reset); }
 void dgs_profile_enable(int mode) { (void)dgs_context_profile_enable(default_context(), mode); }
 void dgs_profile_reset(void) { dgs_context_profile_reset(default_context()); }
 int dgs_profile_read(double* out, int cap) { return dgs_context_profile_read(default_context(), out, cap); }
+
+#ifdef DGS_COUNT_VISITS
+// development build only (-DDGS_COUNT_VISITS, tools/diag/visit_counts.py): the backward blend's visit counters, optionally cleared
+int dgs_debug_visit_counts(unsigned long long* out4, int reset)
+{
+    if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(dgs::g_visit_counts), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dgs::g_visit_counts), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int dgs_debug_layout(int which, int P, int width, int height, int R, size_t* offsets, int cap)
 {
@@ -881,7 +920,11 @@ int dgs_context_backward(dgs_context* ctx, int P, int D, int M, int R, const flo
                     if (cs != hipStreamCaptureStatusNone)
                         return fail(DGS_ERR_INVALID_ARGUMENT, "deterministic backward (option 7 = 2): the fixed-point rows must exist before a capture (run one eager backward at this size first)");
                     DGS_HIP(hipStreamSynchronize(stream));
-                    if (ctx->acc64) (void)hipFree(ctx->acc64);
+                    //  the outgrown rows are RETIRED, not freed: a graph captured at the smaller size has their address baked
+                    // in and may still be replayed (its sums then land in rows nobody converts -- a stale graph, but not a write into
+                    // freed memory).  Two backward passes on different streams of ONE context would still share the live rows: callers
+                    // that run views concurrently give each its own context (diff_surfel_rasterization.Lane).
+                    if (ctx->acc64) ctx->acc64_retired.push_back(ctx->acc64);
                     ctx->acc64 = nullptr; ctx->acc64_rows = 0;
                     const size_t rows = (size_t)P + (size_t)P / 4 + 1024;
                     DGS_HIP(hipMalloc((void**)&ctx->acc64, rows * dgs::kAccFloats * sizeof(unsigned long long)));

@@ -780,6 +780,13 @@ class Trainer:
             with torch.cuda.graph(self._g2, pool=self._g1.pool(), **mode):
                 self._finish(reduce=False, sh_done=self._split, mid_done=self._split and self.split3)
         self._graph = True
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "") != "0" and not getattr(self, "_store_now", False):
+            #  rounds 1-4 refused to capture without the knob; the requirement went when the DEFAULT step lost its last
+            # memset node -- this captured step still has one (the bucket's fill: gradients are not stored in place here), and ROCm 7.2's
+            # packet-replay path ran such nodes out of order now and then (an L1 term of exactly 0, or 1e18 gradients)
+            import warnings
+            warnings.warn("captured step contains fill nodes and DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: ROCm 7.2 has replayed such nodes out of order; "
+                          "set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime starts")
         return self._validate_capture(capacity, validate, dev)
 
     def _validate_capture(self, capacity, validate, dev):
@@ -1496,11 +1503,19 @@ class Trainer:
         assert dev.type == "cuda" and self.rasterizer_cls is None, "deterministic mode is a mode of the HIP path"
         self._flush_guard()
         self._deterministic = on
-        _C.set_option(7, 2 if on else 0, device=dev)
         # the long-tile path (four workgroups share a tile's list: sums taken stretch-wise, i.e. other roundings than the serial walk) is
         # given to the first 256 slots of the longest-first dispatch order, and the order of tiles of EQUAL length class in that
         # order comes from LDS atomics -- which tiles get it is not reproducible once more than 256 qualify.  Serial walks only.
-        _C.set_option(9, 0 if on else 1, device=dev)
+        # (the options live in the device's context, which other code may have configured -- DGS_LONG_TILES=0, a caller's own
+        # deterministic = 1: switching the mode off puts back what switching it on found, not the library's defaults.)
+        if on:
+            self._det_saved = (_C.get_option(7, device=dev), _C.get_option(9, device=dev))
+            _C.set_option(7, 2, device=dev)
+            _C.set_option(9, 0, device=dev)
+        else:
+            was7, was9 = getattr(self, "_det_saved", (0, 1))
+            _C.set_option(7, was7, device=dev)
+            _C.set_option(9, was9, device=dev)
         self.deform.fixed_point_tables = on   # the coherent skinning backward's node table: 64-bit fixed-point sums, integer atomics
         if self._graph:
             # (the fixed-point rows of the backward are allocated by the eager warm-up steps enable_graph runs before it captures)

@@ -28,7 +28,7 @@ _EXPORTS = ("dgs_abi_version", "dgs_last_error", "dgs_rasterizer_mark_visible", 
             "dgs_rasterizer_backward", "dgs_debug_layout", "dgs_set_tight_rects", "dgs_set_option", "dgs_read_overflow", "dgs_profile_enable", "dgs_profile_reset",
             "dgs_profile_read", "dgs_set_overflow_flag", "dgs_context_create", "dgs_context_destroy", "dgs_context_set_option",
             "dgs_context_set_overflow_flag", "dgs_context_read_overflow", "dgs_context_profile_enable", "dgs_context_profile_reset",
-            "dgs_context_profile_read", "dgs_context_forward", "dgs_context_backward")
+            "dgs_context_profile_read", "dgs_context_forward", "dgs_context_backward", "dgs_get_option", "dgs_context_get_option")
 
 
 def _deps():
@@ -115,6 +115,10 @@ def load():
     lib.dgs_context_destroy.argtypes = [vp]
     lib.dgs_context_set_option.restype = ci
     lib.dgs_context_set_option.argtypes = [vp, ci, ci]
+    lib.dgs_context_get_option.restype = ci
+    lib.dgs_context_get_option.argtypes = [vp, ci]
+    lib.dgs_get_option.restype = ci
+    lib.dgs_get_option.argtypes = [ci]
     lib.dgs_context_set_overflow_flag.restype = ci
     lib.dgs_context_set_overflow_flag.argtypes = [vp, vp]
     lib.dgs_context_read_overflow.restype = ci
@@ -141,7 +145,7 @@ def load():
     lib.dgs_profile_reset.argtypes = []
     lib.dgs_profile_read.restype = ci
     lib.dgs_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ci]
-    if lib.dgs_abi_version() != 2:
+    if lib.dgs_abi_version() != 3:
         raise RuntimeError("libdgs_surfel_rasterizer.so ABI version mismatch")
     _lib = lib
     return lib
@@ -211,6 +215,13 @@ class Context:
         rc = lib.dgs_context_set_option(self.handle, int(key), int(value))
         if rc < 0:
             _raise(lib, rc, "context.set_option")
+
+    def get_option(self, key):
+        lib = load()
+        v = lib.dgs_context_get_option(self.handle, int(key))
+        if v < 0:
+            _raise(lib, v, "context.get_option")
+        return int(v)
 
     def set_overflow_flag(self, tensor):
         lib = load()
@@ -379,6 +390,16 @@ def set_option(key, value, device=None):
         rc = lib.dgs_set_option(int(key), int(value))
     if rc < 0:
         _raise(lib, rc, "set_option")
+
+
+def get_option(key, device=None):
+    """Current value of an option of the device's default context (dgs_get_option)."""
+    lib = load()
+    with _on(device):
+        v = lib.dgs_get_option(int(key))
+    if v < 0:
+        _raise(lib, v, "get_option")
+    return int(v)
 
 
 def set_capacity(n_entries, device=None):

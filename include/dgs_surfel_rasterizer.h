@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 2
+#define DGS_ABI_VERSION 3   /* 3: + dgs_get_option / dgs_context_get_option (round 6) */
 
 /* Replaces std::function<char*(size_t N)> (rasterizer.h:31-33, rasterize_points.cu:31-37): must return a
  * device buffer of at least `bytes` bytes, 128-byte aligned, usable on `stream`. */
@@ -104,6 +104,7 @@ typedef struct dgs_context dgs_context;
 dgs_context* dgs_context_create(void);          /* bound to the calling thread's current HIP device */
 void dgs_context_destroy(dgs_context* ctx);
 int dgs_context_set_option(dgs_context* ctx, int key, int value);               /* keys: see dgs_set_option */
+int dgs_context_get_option(dgs_context* ctx, int key);                          /* current value (>= 0) or a negative status */
 int dgs_context_set_overflow_flag(dgs_context* ctx, int* device_flag);         /* see dgs_set_overflow_flag */
 int dgs_context_read_overflow(dgs_context* ctx, int reset);
 int dgs_context_profile_enable(dgs_context* ctx, int mode);
@@ -181,6 +182,9 @@ void dgs_set_tight_rects(int on);
  *         (0 = all); results are then incomplete -- for measuring how long the heaviest tiles run on an otherwise idle device.
  * Returns DGS_OK or an error. */
 int dgs_set_option(int key, int value);
+/* The current value of an option of the calling thread's device's default context (>= 0), or a negative status: a caller that
+ * switches an option for a while puts back what it found (the context is shared by everything that renders on the device). */
+int dgs_get_option(int key);
 
 /* The capacity-overflow flag is one int32 in device memory, OR-ed by the forward whose lists did not fit with the reason: bit 0 the
  * lists exceed the capacity, bit 1 a list is longer than promised (option 6), bit 2 that list is also beyond the segmented sort's

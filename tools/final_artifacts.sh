@@ -1,7 +1,7 @@
 # Round artefacts of the final code, two phases on the GPU box (the bench lines read the PMC files of phase 1 from profiles/):
-#   phase 1:  tools/final_artifacts.sh pmc      -> gpurun_out/pmc_r05_metric.json, pmc_r05_c5.json  (copy to profiles/r05_pmc_<workload>.json)
+#   phase 1:  tools/final_artifacts.sh pmc      -> gpurun_out/pmc_r06_metric.json, pmc_r06_c5.json  (copy to profiles/r06_pmc_<workload>.json)
 #   phase 2:  tools/final_artifacts.sh lines    -> gpurun_out/r04_bench_line*.json, kernel stats, per-step summary, timeline
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=r05
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=r06
 cd $R
 if [ "$1" = "det" ]; then   # what the deterministic mode costs per step (metric workload, captured step, same lease)
   python - <<'PY'
@@ -25,8 +25,8 @@ PY
   exit 0
 fi
 if [ "$1" = "pmc" ]; then
-  bash tools/pmc_kernels.sh r05_metric "dgs::" metric 2>&1 | tail -12
-  bash tools/pmc_kernels.sh r05_c5 "dgs::" c5 2>&1 | tail -12
+  bash tools/pmc_kernels.sh r06_metric "dgs::" metric 2>&1 | tail -12
+  bash tools/pmc_kernels.sh r06_c5 "dgs::" c5 2>&1 | tail -12
   exit 0
 fi
 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err; tail -c 200 $O/${TAG}_bench_line.json; echo

@@ -12,7 +12,7 @@ REGEX=$2
 WL=${3:-metric}
 mkdir -p $OUT
 export DGS_NO_GRAPHS=1
-CMD="python $R/bench.py --no-cpu-baseline --steps 3 --warmup 2 --workload $WL --no-roofline-legs"
+CMD="python $R/bench.py --no-cpu-baseline --steps 3 --warmup 2 --workload $WL --no-roofline-legs $BENCH_ARGS"
 P1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 P3="FETCH_SIZE GRBM_GUI_ACTIVE"
