@@ -42,6 +42,7 @@ def test_two_threads_two_contexts_interleaved():
         g = torch.Generator().manual_seed(7)
         cots.append((torch.randn(3, c["image_height"], c["image_width"], generator=g).to(dev),
                      torch.randn(8, c["image_height"], c["image_width"], generator=g).to(dev)))
+    _C.set_capacity(0)            # (a test that ran before may have left the device's DEFAULT context in capacity mode: num_rendered would be the capacity)
     ctxs = [_C.Context(dev), _C.Context(dev)]
     ctxs[1].set_option(0, 0)      # context 1: the reference's square rectangles -> different private lists / num_rendered
     ctxs[1].set_option(1, 0)      # ... and row-major tile order
