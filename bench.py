@@ -462,7 +462,14 @@ def main():
                     help="opt-in lever of the data-parallel step (Trainer.views_per_rank): k views per rank added before ONE exchange and update; "
                          "the line then reports views_per_step = k * N and the metric counts views, not steps")
     ap.add_argument("--drift-gap", type=int, default=100, help="steps between the headline window and the second (drift) window; 0: skip")
+    ap.add_argument("--concurrent-report", type=float, default=None, metavar="MS_HEADLINE",
+                    help="internal: print only the concurrent_views object (the main run starts this as a child process, so that nothing in it can cost the headline line)")
     args = ap.parse_args()
+    if args.concurrent_report is not None:
+        torch.cuda.set_device(0)
+        P_, H_, W_ = WORKLOADS[args.workload]
+        print(json.dumps(concurrent_views_report(args, P_, H_, W_, torch.device("cuda", 0), args.concurrent_report)), flush=True)
+        return
     # the per-step losses of the timed steps are read back from the step guard's pinned ring: size it for the run asked for
     from dgs_amd.train import Trainer as _Trainer
     _Trainer.GUARD_RING = max(_Trainer.GUARD_RING, 2 * (args.steps + args.warmup) + 64)
@@ -637,10 +644,13 @@ def main():
             # identical to ~1e-6 at first, then the trajectories drift apart (Adam turns the sign of a gradient that is zero to
             # rounding into a full step): 2e-6 after 20 steps on the metric workload, 1e-4 .. 2e-3 on the fast-moving "trained" one,
             # eager against eager just the same.  A replay that mis-orders a node is off by O(1) from the first step
-            tol_all = max(1e-3, 4.0 * noise)
+            # (the floor is 1e-2 on "trained": its two eager runs differ by 1.2e-3 .. 3.9e-3 themselves, a chaotic divergence with a heavy
+            # tail -- a single draw of it is a poor yardstick for another draw, and round 6 lost one of four runs to a 1e-3 floor)
+            floor = 1e-2 if args.workload == "trained" else 1e-3
+            tol_all = max(floor, 4.0 * noise)
             twin = {"steps": args.steps, "max_rel_loss_difference": float("%.3g" % rel), "max_rel_loss_difference_first_3_steps": float("%.3g" % rel_first),
                     "eager_vs_eager_max_rel_loss_difference": float("%.3g" % noise),
-                    "tolerance": {"first_3_steps": 1e-5, "all_steps": float("%.3g" % tol_all), "rule": "max(1e-3, 4 x eager-vs-eager)"},
+                    "tolerance": {"first_3_steps": 1e-5, "all_steps": float("%.3g" % tol_all), "rule": "max(%g, 4 x eager-vs-eager)" % floor},
                     "what": "graph-replayed vs eager steps from the same snapshot (parameters, Adam state, views); float atomics in the backward are the only difference"}
             twin_bad = not (rel <= tol_all and rel_first <= 1e-5) or any(l != l for l in replay_losses + timed_losses)
             if world > 1:   # one verdict for all ranks: a rank that left alone would leave the others inside a collective
@@ -790,15 +800,19 @@ def main():
         except Exception as ex:   # never lose the result line over the side measurement
             print("warning: HBM ceiling measurement failed: %r" % (ex,), file=sys.stderr)
         if world == 1 and use_graph and args.views_per_rank == 1 and not args.no_roofline_legs and not args.densify_every and args.workload != "trained":
-            from diff_surfel_rasterization import _C as _C2
             del tr
             torch.cuda.empty_cache()
             tr = None
+            # in a CHILD process: nothing in the side measurement -- an exception, or a crash inside graph instantiation, which the
+            # nested-fork form of the lanes' graph produced on ROCm 7.2 -- can cost the line of the headline
+            import subprocess
             try:
-                out["concurrent_views"] = concurrent_views_report(args, P, H, W, device, dt / args.steps * 1e3)
-            except Exception as ex:   # never lose the result line over the side measurement
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--concurrent-report", "%.6f" % (dt / args.steps * 1e3), "--workload", args.workload,
+                                     "--steps", str(args.steps), "--warmup", str(args.warmup)], capture_output=True, text=True, timeout=600)
+                lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                out["concurrent_views"] = json.loads(lines[-1]) if cp.returncode == 0 and lines else {"error": "child exited with %d: %s" % (cp.returncode, cp.stderr[-300:])}
+            except Exception as ex:
                 out["concurrent_views"] = {"error": repr(ex)[:300]}
-            _C2.set_capacity(0)
         if world == 1 and not args.no_cpu_baseline and args.workload != "trained":
             del tr
             torch.cuda.empty_cache()
