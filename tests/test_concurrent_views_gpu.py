@@ -79,3 +79,32 @@ def test_concurrent_views_bucket_is_the_sum_of_the_single_view_gradients_and_gra
         for a, b in zip(res["sequential"][0], res[other][0]):
             assert abs(a - b) <= 1e-4 * abs(a), (other, res["sequential"][0], res[other][0])
         assert torch.isfinite(res[other][1]).all() and float((res["sequential"][1] - res[other][1]).abs().median()) < 1e-6
+
+
+def test_concurrent_lanes_follow_in_place_densification_and_are_rebuilt_after_growth():
+    """The lanes alias the trainer's parameter STORAGE: in-place density control and reordering are visible to them at once (same
+    captured graph keeps replaying); growth replaces the parameters, so the lanes are rebuilt over the new ones and re-captured."""
+    import bench
+    from diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+    tr = bench.build_trainer(20000, 128, 128, dev, n_views=8, n_targets=2, slots=40000, views_per_rank=2, concurrent_views=True)
+    try:
+        tr.enable_graph(capacity=40 * 40000)
+        lanes0 = tr._lanes
+        losses = [float(tr.step()) for _ in range(3)]
+        counts = tr.densify_and_prune(max_grad=2e-5, min_opacity=0.02, extent=5.0, max_screen_size=20, seed=3)
+        assert sum(counts) > 0 and tr.P == 40000        # (room enough: no growth here)
+        tr.sort_surfels()
+        assert tr._lanes is lanes0                      # nothing was re-allocated: same lanes, same graph
+        for ln in tr._lanes:
+            for p, q in zip(ln.bucket.params, tr.bucket.params):
+                assert p.data_ptr() == q.data_ptr() and p.grad.data_ptr() != q.grad.data_ptr()
+        losses += [float(tr.step()) for _ in range(2)]
+        tr.grow(45056)
+        assert tr.P == 45056 and tr._lanes is not lanes0 and tr._lanes[0].P == 45056   # rebuilt over the new parameters by the re-capture
+        losses += [float(tr.step()) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert not _C.read_overflow() and all(np.isfinite(l) and 0.0 < l < 10.0 for l in losses), losses
+        assert int(tr.surfels.denom.max()) <= 2 * 7 and all(bool(torch.isfinite(p).all()) for p in tr.bucket.params)
+    finally:
+        _C.set_capacity(0)
