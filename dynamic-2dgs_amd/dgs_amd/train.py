@@ -1109,8 +1109,9 @@ class Trainer:
         self._note_loss(loss.detach())
         self._half = (asm, grads[:4], pkg)
         with torch.no_grad():   # final after the forward: their MAX all-reduce starts first (the guard of the SH update needs it)
-            self._radii[:self.P].copy_(pkg["radii"])   # radii are 0 for culled surfels: same as the masked copy of _statistics
-            self._radii[self.P:self.P + 1].copy_(self._oflag)
+            # radii (0 for culled surfels: same as the masked copy of _statistics) + the overflow flag behind them, in ONE launch (two
+            # copies were two 4-us launches with a gap between them on the boundary between graph 1 and graph 1b)
+            torch.cat((pkg["radii"], self._oflag), out=self._radii[:self.P + 1])
         return loss.detach()
 
     def _fwd_bwd_b(self):
