@@ -470,6 +470,7 @@ class Trainer:
         # lane is what fills the device here, and ROCm 7.2's graph instantiation segfaults on the nested forks of the one-graph form
         # (DGS_LANES_FLAT=0 with separate graphs works and measures the same: 0.650 / 0.657 ms per view)
         if os.environ.get("DGS_LANES_FLAT", "1") != "0":
+            self._overlap_was = bool(self.deform.overlap_streams)   # lane 0 is this trainer's own module: enable_graph puts the switch back
             for ln, _ in lanes:
                 ln.deform.overlap_streams = False
         for j, (ln, st) in enumerate(lanes):
@@ -642,6 +643,8 @@ class Trainer:
         # the tests still default the knob to 0, the configuration every committed number was measured in.)
         dev = self.surfels.get_xyz.device
         self._wait_gather()        # (sharded data-parallel step: the SH rows of the last step's update may still be on the wire)
+        if getattr(self, "_overlap_was", None) is not None:   # a capture of concurrent lanes ran this module without its inner forks (_capture_lanes)
+            self.deform.overlap_streams, self._overlap_was = self._overlap_was, None
         if self._graph:            # a live capture is being replaced: settle what its last steps reported first
             if self._flush_guard():
                 return             # the recovery re-captured already (with a larger capacity / without the promise)

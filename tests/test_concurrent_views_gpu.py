@@ -106,5 +106,12 @@ def test_concurrent_lanes_follow_in_place_densification_and_are_rebuilt_after_gr
         torch.cuda.synchronize()
         assert not _C.read_overflow() and all(np.isfinite(l) and 0.0 < l < 10.0 for l in losses), losses
         assert int(tr.surfels.denom.max()) <= 2 * 7 and all(bool(torch.isfinite(p).all()) for p in tr.bucket.params)
+        # back to one view per step (bench.py's lever windows do this): the module gets its inner forks back
+        assert tr.deform.overlap_streams is False
+        tr.views_per_rank, tr.concurrent_views = 1, False
+        tr._graph = None
+        tr.enable_graph(tr._capacity)
+        assert tr.deform.overlap_streams is True and tr._glanes is None
+        assert np.isfinite(float(tr.step()))
     finally:
         _C.set_capacity(0)
