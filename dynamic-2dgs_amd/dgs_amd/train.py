@@ -494,6 +494,10 @@ class Trainer:
             self._lanes_eager([(ln._scam, ln._sgt) for ln, _ in lanes])
             self._finish_lanes(eager=True)
         self._restore(snap)
+        # (the captured update runs the optimiser over two parameter ranges: their block plans are built by a kernel on first use --
+        # before the capture, not inside it)
+        self.opt_surfels._range(0, self.n_surfel_params)
+        self.opt_surfels._range(self.n_surfel_params, len(self.bucket.params))
         torch.cuda.synchronize()
         mode = {"capture_error_mode": "thread_local"}
         self._gall = None
@@ -507,16 +511,36 @@ class Trainer:
             with torch.cuda.graph(g, stream=s0, **mode):
                 for ln, st in lanes[1:]:
                     st.wait_stream(s0)
+                # single GPU: the LAST lane (it starts last and ends last) stops behind its skinning backward -- every per-surfel gradient
+                # of every lane is final there -- and the surfel update runs NEXT TO that lane's node-MLP backward chain, as in the
+                # one-view step, instead of behind it (the update is 68 us of the step's serial tail otherwise)
+                tail_overlap = self.world == 1 and os.environ.get("DGS_LANES_TAIL_OVERLAP", "1") != "0"
+                last_ln, last_st = lanes[-1]
                 for ln, st in lanes:
                     with torch.cuda.stream(st):
                         ln._select_view_node()
-                        ln._lane_loss = ln._fwd_bwd(ln._scam, ln._sgt)
+                        if tail_overlap and ln is last_ln:
+                            ln._lane_loss = ln._lane_backward_to_surfels(ln._scam, ln._sgt)
+                        else:
+                            ln._lane_loss = ln._fwd_bwd(ln._scam, ln._sgt)
                         ln._select_consumed()
                 for ln, st in lanes[1:]:
                     s0.wait_stream(st)
-                self._lanes_loss()
-                if self.world == 1:
-                    self._finish_lanes(eager=False)
+                if tail_overlap:
+                    loss_first = os.environ.get("DGS_LANES_TAIL_ORDER", "mlp") == "loss"   # (A/B: 0.6250 loss first, 0.6234 chain first, 0.6308 without the overlap)
+                    if loss_first:
+                        self._lanes_loss()
+                    if last_st is not s0:
+                        last_st.wait_stream(s0)          # (the fork; lane 0 as the last lane cannot happen with k > 1)
+                    with torch.cuda.stream(last_st):
+                        last_ln._lane_backward_rest()    # node-MLP backward, weight gradients, this lane's statistics
+                    if not loss_first:
+                        self._lanes_loss()
+                    self._finish_lanes(eager=False, join=last_st)
+                else:
+                    self._lanes_loss()
+                    if self.world == 1:
+                        self._finish_lanes(eager=False)
             cur.wait_stream(s0)
             self._gall = g
             self._glanes = []
@@ -551,6 +575,25 @@ class Trainer:
         cur.wait_stream(s)
         self._sloss = self._kloss
         self._gk = self._g1 = self._g1b = self._g0 = None
+
+    def _lane_backward_to_surfels(self, cam, gt):
+        """_fwd_bwd of a lane up to the end of autograd's backward (rasterizer + skinning backward): all per-surfel gradients of the
+        lane's bucket are final, the node-MLP backward is still to come (_lane_backward_rest)."""
+        loss, pkg, asm, fused = self._forward(cam, gt)
+        self._note_loss(loss.detach())
+        self._run_backward(lambda: loss.backward(self._unit if fused else None), fused)
+        self._lane_state = (pkg, fused)
+        return loss.detach()
+
+    def _lane_backward_rest(self):
+        pkg, fused = self._lane_state
+        self._lane_state = None
+        d = self.deform
+        if hasattr(d, "finish_backward") and not self.warmup:
+            d.finish_backward(join=True)
+        elif hasattr(d, "run_pending_reduce"):
+            d.run_pending_reduce()
+        self._statistics(pkg, fused)
 
     def _lanes_eager(self, cams):
         """The k lanes' forward + backward launched eagerly, each on its stream (the host issues them one after the other, the device
@@ -1298,18 +1341,20 @@ class Trainer:
             else:
                 self.opt_surfels.step(0, 1)
 
-    def _finish_lanes(self, eager):
+    def _finish_lanes(self, eager, join=None):
         """Update behind the k concurrent lanes.  Single GPU: the lanes' buckets are summed by the Adam kernel itself (dgs_adam_step_sum2)
         and their statistics accumulated one after the other.  Data parallel: the other lanes are folded into lane 0's bucket first
-        (the exchange works on one buffer) -- eagerly, in front of the all-reduce (`eager`; the captured update starts behind it)."""
+        (the exchange works on one buffer) -- eagerly, in front of the all-reduce (`eager`; the captured update starts behind it).
+        join: a stream on which the last lane's node-MLP backward is still running (_capture_lanes): the surfel parameters are
+        updated next to it, the stream is joined, then the statistics and the deformation parameters follow."""
         if self.world > 1:
             if eager:
                 self._lanes_fold()
                 self._reduce()
             return self._finish(reduce=False)
-        return self._finish(reduce=False, lanes=self._make_lanes())
+        return self._finish(reduce=False, lanes=self._make_lanes(), join=join)
 
-    def _finish(self, reduce=True, sh_done=False, mid_done=False, lanes=()):
+    def _finish(self, reduce=True, sh_done=False, mid_done=False, lanes=(), join=None):
         s = self.surfels
         with torch.no_grad():
             if reduce:
@@ -1339,7 +1384,7 @@ class Trainer:
             self._late_stats = None
             adv = not getattr(self, "_guard_early", False)   # the guard kernel of this step was launched by _fwd_bwd already
             self._guard_early = False
-            if late is None:
+            if late is None and join is None:
                 accumulate()
             n_train = self.n_surfel_params - 1 if self.warmup else None   # warm-up: everything up to (not including) `feature`
             if self.opt_deform is not None:
@@ -1363,6 +1408,15 @@ class Trainer:
                     self.opt_surfels.step(first, n_train, advance=False)
             elif self.warmup:
                 self.opt_surfels.step(0, n_train, advance=adv)
+                if join is not None:
+                    torch.cuda.current_stream(s.get_xyz.device).wait_stream(join)
+                    accumulate()
+            elif join is not None:
+                # concurrent lanes, single GPU: the surfels while the last lane's node-MLP backward runs on `join`; then everything else
+                self.opt_surfels.step(0, self.n_surfel_params, advance=adv)
+                torch.cuda.current_stream(s.get_xyz.device).wait_stream(join)
+                accumulate()
+                self.opt_surfels.step(self.n_surfel_params, None, advance=False)
             elif getattr(self.deform, "_join_pending", False):
                 # the node-MLP backward is still running on the side stream: update the surfels, which do
                 # not depend on it, meanwhile; then join and update the deformation parameters

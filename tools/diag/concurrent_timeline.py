@@ -6,7 +6,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+# a step ends with its LAST adam_kernel launch (the update may be two launches: surfels, then the deformation): the one that is followed by
+# the next step's first kernel (neighbour search or weight packing)
+adam = [i for i, r in enumerate(rows[:-1]) if "adam_kernel" in r["Kernel_Name"] and any(k in rows[i + 1]["Kernel_Name"] for k in ("knn_refine", "mlp_pack", "knn_kernel"))]
 i0, i1 = adam[-back - 1] + 1, adam[-back] + 1
 t0 = int(rows[i0]["Start_Timestamp"])
 short = lambda k: k.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "").split("(")[0][:48]
