@@ -350,3 +350,61 @@ def test_overflow_reason_bits_pick_the_next_configuration_in_one_recovery():
     # flag already consumed (reason 0): the promise is the first suspect, then the capacity
     assert after(2048, 1000, 0) == (57344, 1000)
     assert after(0, 1000, 0) == (0, 2000)
+
+
+def test_alias_modules_share_storage_and_keep_their_own_leaves():
+    """dgs_amd.train.alias_module (the lanes of Trainer(concurrent_views=True)): same class and configuration, NEW Parameter objects over
+    the SAME storage, the same buffer tensors, none of the original's per-instance scratch -- and gradients that do not meet."""
+    from dgs_amd.train import alias_module
+    surfels, deform, cams, targets, bg = _build()
+    deform._knn_seed = torch.zeros(3)            # per-instance scratch: must not travel
+    for m in (surfels, deform):
+        a = alias_module(m)
+        assert type(a) is type(m) and "_knn_seed" not in a.__dict__
+        pm, pa = dict(m.named_parameters()), dict(a.named_parameters())
+        assert list(pm) == list(pa) and len(pm) > 0
+        for n in pm:
+            assert pa[n] is not pm[n] and pa[n].data_ptr() == pm[n].data_ptr() and pa[n].requires_grad == pm[n].requires_grad
+        for (_, b), (_, c) in zip(m.named_buffers(), a.named_buffers()):
+            assert b is c
+    a = alias_module(surfels)
+    with torch.no_grad():
+        surfels._xyz.add_(1.0)                   # an in-place update of the original is the alias's value at once
+    assert torch.equal(a._xyz, surfels._xyz)
+    a._xyz.sum().backward()
+    assert surfels._xyz.grad is None and a._xyz.grad is not None    # own autograd leaves
+    assert a.active_sh_degree == surfels.active_sh_degree and a.packed_sh == surfels.packed_sh
+
+
+def _reason_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        render_mod.GaussianRasterizer = OracleRasterizer
+        surfels, deform, cams, targets, bg = _build()
+        tr = Trainer(surfels, deform, cams, targets, bg)
+        # what each rank's own overflow flag says: rank 0 nothing, rank 1 "capacity" (1); then rank 0 "promise" (2), rank 1 "beyond the segmented sort" (4 | 2)
+        got = [tr._agree_reason((0, 1)[rank]), tr._agree_reason((2, 6)[rank]), tr._agree_reason(0)]
+        tr.no_collectives = True
+        got.append(tr._agree_reason((0, 1)[rank]))      # the diagnostic mode issues no collective: the local value stands
+        q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overflow_reason_is_the_or_over_the_ranks():
+    """the reason bits of every rank's flag, OR-ed (three 0/1 words through a MAX all-reduce), so that all ranks pick the
+    same next capacity / promise -- max(1, 2) = 2 would have dropped the capacity bit."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reason_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get() for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][:3] == res[1][:3] == [1, 6, 0]
+    assert res[0][3] == 0 and res[1][3] == 1
