@@ -22,13 +22,15 @@ from .train import Trainer
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
-        arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False):
+        arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False, views_per_rank=1, concurrent_views=False):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot).  warm_up / regularize_from: the
     reference's stages (train_gui.py:282-285: deformation detached while iteration < opt.warm_up; :292-293: normal and
     distortion regularisers off until iteration 8000).  on_iteration(it, trainer): optional hook after every iteration.
     deterministic=True (HIP path): Trainer.set_deterministic -- order-free sums instead of float atomics; two fits with the same
-    arguments end bit-identical.  The trainer is returned in that mode (set_deterministic(False) restores the float atomics)."""
+    arguments end bit-identical.  The trainer is returned in that mode (set_deterministic(False) restores the float atomics).
+    views_per_rank / concurrent_views: k views per step and rank, added before one update -- back to back, or in flight at the same
+    time, a lane each (Trainer); an iteration is then a step of k views."""
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
@@ -43,7 +45,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     cams = [f.camera.to(device) for f in data["train"]]
     targets = [f.image.to(device).contiguous() for f in data["train"]]
     bg = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], device=device)
-    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True, arap=arap)
+    tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True, arap=arap,
+                 views_per_rank=views_per_rank, concurrent_views=concurrent_views)
     if graph is None:
         graph = on_gpu
     if deterministic:

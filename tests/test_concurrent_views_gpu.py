@@ -115,3 +115,51 @@ def test_concurrent_lanes_follow_in_place_densification_and_are_rebuilt_after_gr
         assert np.isfinite(float(tr.step()))
     finally:
         _C.set_capacity(0)
+
+
+def test_fit_with_concurrent_lanes_learns(tmp_path):
+    """fit() with two views of every step in flight at once: the lanes go through everything a run does -- the stages (re-captures), the
+    SH degree steps, in-place densification and reordering, opacity resets, growth (lanes rebuilt) -- and the scene is learnt."""
+    import math
+    from dgs_amd import io as dio
+    from dgs_amd.fit import fit
+    from dgs_amd.render import render
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    from diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+    data = str(tmp_path / "scene")
+    write_dynamic_dnerf(data, n_train=60, n_test=8, H=200, W=200, device=dev)
+    test = dio.load_dnerf(data, num_pts=20_000)["test"]
+    bg = torch.zeros(3, device=dev)
+
+    def heldout_psnr(tr):
+        vals = []
+        with torch.no_grad():
+            for f in test:
+                cam = f.camera.to(dev)
+                dv = tr.deform(tr.surfels.get_xyz.detach(), tr.deform.expand_time(cam.fid), tr.surfels.feature, tr.surfels.motion_mask)
+                img = render(cam, tr.surfels, bg, dv["d_xyz"], dv["d_rotation"], dv["d_scaling"])["render"]
+                vals.append(-10.0 * math.log10(max(float(((img.clamp(0, 1).cpu() - f.image) ** 2).mean()), 1e-12)))
+        return float(np.mean(vals))
+
+    probes, lanes_seen = {}, []
+
+    def hook(it, tr):
+        if it in (1, 3000):
+            probes[it] = heldout_psnr(tr)
+        if it % 500 == 0:
+            lanes_seen.append((tr._lanes is not None and len(tr._lanes) == 1, getattr(tr, "_gall", None) is not None, id(tr._lanes[0])))
+    try:
+        tr, losses = fit(data, str(tmp_path / "model"), iterations=3000, device=dev, num_pts=20_000, node_num=256, seed=0, warm_up=900,
+                         regularize_from=2400, on_iteration=hook, views_per_rank=2, concurrent_views=True)
+        torch.cuda.synchronize()
+    finally:
+        _C.set_capacity(0)
+    print("concurrent lanes: held-out PSNR", {k: round(v, 2) for k, v in probes.items()}, "live", tr.surfels.num_surfels, "slots", tr.P,
+          "distinct lane objects over the run", len({x[2] for x in lanes_seen}))
+    assert all(a and b for a, b, _ in lanes_seen), lanes_seen       # the one-graph lanes ran at every probe
+    assert len({x[2] for x in lanes_seen}) >= 2                      # ... and were rebuilt along the way (stages, SH degree, growth)
+    assert probes[3000] >= probes[1] + 8.0 and probes[3000] >= 17.0, probes
+    losses = np.asarray(losses)
+    assert np.isfinite(losses).all() and losses[-300:].mean() < 0.6 * losses[:300].mean()
+    assert all(bool(torch.isfinite(p).all()) for p in tr.bucket.params)
