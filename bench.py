@@ -149,7 +149,9 @@ def cpu_baseline(P, H, W, budget_s=25.0):
         n += 1
         per = (time.time() - t0) / n
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "views/s", "cores": os.cpu_count() or 1, "threads": ncores, "kind": "port",
+    # `cores` is what the bench contract defines it as -- the threads actually used; `host_cores` is what the box has (the north star
+    # asks for the core count to be stated: both are, under names that cannot be confused)
+    return {"value": n / dt, "unit": "views/s", "cores": ncores, "threads": ncores, "host_cores": os.cpu_count() or 1, "kind": "port",
             "sample": "%d full train steps (views) of the same %dk-surfel %dx%d workload, %.1f s" % (n, P // 1000, W, H, dt)}
 
 
