@@ -5,8 +5,8 @@ The loop is the part of GUI.train_step (train_gui.py:272-432) this build covers:
 with the normal and distortion regularisers on, densification every `densify_interval` iterations between `densify_from`
 and `densify_until` (size threshold 20 after the first opacity reset), opacity reset every `opacity_reset_interval`
 (arguments/__init__.py:115-122), the one forced node densification / pruning at iteration 10000, the SH degree ramp
-(one degree per 1000 iterations from 0).  Not here: the node warm-up
-stage, the flow losses and the GUI.  `arap=True` adds the control nodes' ARAP regulariser with the reference's weight schedule
+(one degree per 1000 iterations from 0).  `node_pretrain` runs the reference's node pre-training stage first
+(GUI.train_node_rendering_step: dgs_amd/node_pretrain.py).  Not here: the flow losses and the GUI.  `arap=True` adds the control nodes' ARAP regulariser with the reference's weight schedule
 (the step then runs eagerly until the weight reaches zero at iteration 20001, and captured from there).  Learning rates follow the reference's exponential schedules (Trainer(lr_schedule=True)).
 """
 import os
@@ -22,7 +22,8 @@ from .train import Trainer
 def fit(data_path, model_path, iterations, device="cuda:0", white_background=False, densify_from=500, densify_interval=100,
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
-        arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False, views_per_rank=1, concurrent_views=False):
+        arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False, views_per_rank=1, concurrent_views=False,
+        node_pretrain=None):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot).  warm_up / regularize_from: the
     reference's stages (train_gui.py:282-285: deformation detached while iteration < opt.warm_up; :292-293: normal and
@@ -30,7 +31,11 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     deterministic=True (HIP path): Trainer.set_deterministic -- order-free sums instead of float atomics; two fits with the same
     arguments end bit-identical.  The trainer is returned in that mode (set_deterministic(False) restores the float atomics).
     views_per_rank / concurrent_views: k views per step and rank, added before one update -- back to back, or in flight at the same
-    time, a lane each (Trainer); an iteration is then a step of k views."""
+    time, a lane each (Trainer); an iteration is then a step of k views.
+    node_pretrain: None / False = the control nodes start as a farthest-point sample of the initial points (as before); True = the
+    reference's default first stage (10 000 iterations: warm-up 2000, node sampling at 7500; arguments/__init__.py:128-131), or a dict
+    of NodePretrainer keyword arguments (iterations, node_warm_up, sampling_at, densify_interval ...).  Data parallel: rank 0 runs the
+    stage (it is a one-view-per-step loop over a few thousand small surfels), the others receive its result."""
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
@@ -41,12 +46,21 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     surfels = SurfelModel(scene, active_sh_degree=0 if oneup_sh_degree_step else 3, packed_sh=on_gpu, capacity=slots).to(device)
     torch.manual_seed(seed)
     deform = ControlNodes(node_num=min(node_num, P), K=3, hyper_dim=8, local_frame=True).to(device)
-    deform.init_from_points(surfels.get_xyz.detach()[surfels.alive], fps=True)
     cams = [f.camera.to(device) for f in data["train"]]
     targets = [f.image.to(device).contiguous() for f in data["train"]]
     bg = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], device=device)
+    extent = float(data["normalization"]["radius"])
+    pre = None
+    if node_pretrain:
+        pre = pretrain_nodes(deform, cams, targets, bg, surfels.get_xyz.detach()[surfels.alive], extent, seed=seed, log=log,
+                             white_background=white_background, densify_grad_threshold=densify_grad_threshold, rasterizer_cls=rasterizer_cls,
+                             **(node_pretrain if isinstance(node_pretrain, dict) else {}))
+    else:
+        deform.init_from_points(surfels.get_xyz.detach()[surfels.alive], fps=True)
     tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True, arap=arap,
                  views_per_rank=views_per_rank, concurrent_views=concurrent_views)
+    if pre is not None:
+        tr.adopt_deform_state(pre.opt_deform)
     if graph is None:
         graph = on_gpu
     if deterministic:
@@ -59,7 +73,6 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     graph_from = LAMBDA_ARAP_STEPS[-1] if (arap and graph) else 0      # the regulariser runs eagerly while its weight is non-zero
     if graph and not graph_from:
         tr.enable_graph(int(list_capacity or 96 * slots))
-    extent = float(data["normalization"]["radius"])
     losses = []
     # A captured step returns the SAME device tensor every time (it lives in the graph's pool and is rewritten by every replay), so
     # the history comes from the step guard's pinned ring instead (Trainer.loss_history: no copy kernel per step, one
@@ -102,6 +115,37 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
                 tr.reset_opacity()
     save(tr, model_path, iterations)
     return tr, losses
+
+
+def pretrain_nodes(deform, cams, targets, bg, points, extent, seed=0, log=None, **kw):
+    """The node pre-training stage in front of the joint stage (train_gui.py:207-213: node rendering steps until
+    iterations_node_rendering, then train_step).  Returns the NodePretrainer (its `opt_deform` carries on: Trainer.adopt_deform_state).
+    With more than one rank, rank 0 runs the stage and broadcasts the deformation parameters and their Adam state: the stage's float
+    atomics are not bit-reproducible across ranks, and replicas must start identical."""
+    import torch.distributed as dist
+    from .node_pretrain import Draws, NodePretrainer
+    pre = NodePretrainer(deform, cams, targets, bg, points, extent, draws=Draws(seed), log=log, **kw)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1 or dist.get_rank() == 0:
+        pre.run()
+    if world > 1:
+        for grp in pre.opt_deform.param_groups:
+            for p in grp["params"]:
+                dist.broadcast(p.data, 0)
+                st = pre.opt_deform.state.get(p)
+                has = torch.tensor([1.0 if st else 0.0], device=p.device)
+                dist.broadcast(has, 0)
+                if not bool(has.item()):
+                    continue
+                if not st:
+                    st = {"step": torch.zeros((), dtype=torch.float32), "exp_avg": torch.zeros_like(p.data), "exp_avg_sq": torch.zeros_like(p.data)}
+                    pre.opt_deform.state[p] = st
+                step = st["step"].to(p.device).reshape(1).float()
+                dist.broadcast(step, 0)
+                st["step"] = step.reshape(()).cpu()
+                dist.broadcast(st["exp_avg"], 0)
+                dist.broadcast(st["exp_avg_sq"], 0)
+    return pre
 
 
 def save(trainer, model_path, iteration):

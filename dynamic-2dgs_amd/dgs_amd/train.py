@@ -1728,6 +1728,32 @@ class Trainer:
             return self.opt_surfels.moments(p)
         return (None, None)
 
+    @torch.no_grad()
+    def adopt_deform_state(self, adam):
+        """Continue a torch.optim.Adam's state for the deformation parameters: in the reference ONE optimiser of the deformation
+        model runs through the node pre-training stage and the joint stage (scene/deform_model.py:26-33, train_gui.py:590-592 and
+        :429-431), so the joint stage starts with the moments and the per-parameter step counts the first stage left.  `adam`: the
+        optimiser of dgs_amd.node_pretrain.NodePretrainer (same Parameter objects).  Before enable_graph: the step origins are
+        kernel arguments.  Returns the number of parameters whose state was taken over."""
+        n = 0
+        if self.opt_deform is not None:
+            for p, st in adam.state.items():
+                self.opt_deform.state[p] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                n += 1
+            return n
+        assert self._graph is None, "adopt_deform_state before enable_graph"
+        flat = self.opt_surfels
+        for i, p in enumerate(flat.params):
+            st = adam.state.get(p)
+            if not st:
+                continue
+            m, v = flat.moments(p)
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            flat.set_origin(i, i + 1, float(self._steps_done) - float(st["step"]))   # bias corrections continue at step + 1
+            n += 1
+        return n
+
     def view_for(self, iteration, j=0):
         """Shared deterministic schedule: step i renders views {(i k + j) world + rank} mod V, j = 0 .. k - 1 (k = views_per_rank)."""
         return ((iteration * self.views_per_rank + j) * self.world + self.rank) % len(self.cameras)
