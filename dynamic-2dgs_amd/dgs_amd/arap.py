@@ -8,8 +8,8 @@ of this package is the regime after that, so the regulariser runs eagerly (Train
 The random draws of the reference (the time samples, the 512-node subsample) can be passed in, so that results are
 reproducible and comparable with the reference's.
 
-Also here (round 5): the two node regularisers of the reference's node PRE-TRAINING stage (train_gui.py:502-504, which this package
-does not run: SURVEY section 2, trainer shell) -- elastic_loss and acc_loss (utils/time_utils.py:1091-1120), pinned by the imported
+Also here (round 5): the two node regularisers of the reference's node PRE-TRAINING stage (train_gui.py:502-504; the stage itself is
+dgs_amd/node_pretrain.py since round 6) -- elastic_loss and acc_loss (utils/time_utils.py:1091-1120), pinned by the imported
 reference like arap_loss.  ControlNodeWarp.arap_loss_with_rot (:1035-1043) has no caller in the reference and is not restated.
 """
 import math
