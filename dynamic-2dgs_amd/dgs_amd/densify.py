@@ -83,6 +83,8 @@ def densify_and_prune(model, moments, max_grad, min_opacity, extent, max_screen_
     # children of the split surfels: N samples of the surfel's own (planar) Gaussian, scales shrunk by 0.8 N
     std = torch.exp(model._scaling[src_split]).repeat(N, 1)
     std = torch.cat((std, torch.zeros_like(std[:, :1])), dim=1)
+    if callable(noise):      # (tests: draws keyed by the parents' positions, whatever order the slots hold them in)
+        noise = noise(model._xyz[src_split])
     if noise is None:
         noise = torch.randn(std.shape, generator=generator, device=std.device, dtype=std.dtype)
     samples = noise.to(std) * std

@@ -23,7 +23,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
         arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False, views_per_rank=1, concurrent_views=False,
-        node_pretrain=None):
+        node_pretrain=None, reference_update_order=True):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot).  warm_up / regularize_from: the
     reference's stages (train_gui.py:282-285: deformation detached while iteration < opt.warm_up; :292-293: normal and
@@ -35,7 +35,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     node_pretrain: None / False = the control nodes start as a farthest-point sample of the initial points (as before); True = the
     reference's default first stage (10 000 iterations: warm-up 2000, node sampling at 7500; arguments/__init__.py:128-131), or a dict
     of NodePretrainer keyword arguments (iterations, node_warm_up, sampling_at, densify_interval ...).  Data parallel: rank 0 runs the
-    stage (it is a one-view-per-step loop over a few thousand small surfels), the others receive its result."""
+    stage (it is a one-view-per-step loop over a few thousand small surfels), the others receive its result.
+    reference_update_order: see run_iteration."""
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
@@ -79,12 +80,12 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     # synchronisation per RING/2 iterations); the eager CPU path returns a fresh tensor per step.
     ring = tr.opt_deform is None and getattr(tr, "_oflag", None) is not None
     pending = 0
+    sch = Schedule(warm_up=warm_up, regularize_from=regularize_from, oneup_sh_degree_step=oneup_sh_degree_step, densify_from=densify_from,
+                   densify_interval=densify_interval, densify_until=densify_until, opacity_reset_interval=opacity_reset_interval,
+                   densify_grad_threshold=densify_grad_threshold, node_densify_at=node_densify_at, extent=extent,
+                   white_background=white_background, seed=seed, reference_update_order=reference_update_order)
     for it in range(1, iterations + 1):
-        if oneup_sh_degree_step and it % oneup_sh_degree_step == 0:                # train_gui.py:233-235
-            tr.oneup_sh_degree()
-        on = it > regularize_from                                                  # train_gui.py:292-293
-        tr.set_regime(warmup=it < warm_up, lambda_normal=0.02 if on else 0.0, lambda_dist=1000.0 if on else 0.0)
-        loss = tr.step()
+        loss = run_iteration(tr, it, sch, log=log, on_gpu=on_gpu, after_step=None if on_iteration is None else (lambda: on_iteration(it, tr)))
         if ring:
             pending += 1
             if pending == tr.GUARD_RING // 2 or it == iterations:
@@ -92,29 +93,72 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
                 pending = 0
         else:
             losses.append(float(loss))
-        if on_iteration is not None:
-            tr._wait_gather()   # (data parallel, sharded SH update: the hook sees complete parameters)
-            on_iteration(it, tr)
         if graph_from and it == graph_from - 1:
             tr.enable_graph(int(list_capacity or 96 * tr.P))
-        if it < densify_until:                                                     # train_gui.py:410-423
-            if it == node_densify_at:       # node_force_densify_prune_step; the periodic variant is off by default in the reference
-                counts = tr.densify_nodes(densify_grad_threshold)
-                if log and counts:
-                    log("[%d] nodes: added %d, pruned %d -> %d" % ((it,) + tuple(counts) + (deform.node_num,)))
-            if it > densify_from and it % densify_interval == 0:
-                size_threshold = 20 if it > opacity_reset_interval else None
-                counts = tr.densify_and_prune(densify_grad_threshold, 0.01, extent, size_threshold, seed=seed)
-                if on_gpu:
-                    tr.sort_surfels()   # children landed in free slots anywhere: restore the node order (in place, no re-capture)
-                    if tr.refresh_knn_mode() and log:   # the hyper coordinates train: the neighbour search may need its other kernel
-                        log("[%d] neighbour search: %s (spatial share of the K-th distance %.2f)" % (it, deform.knn_refine_mode, deform.knn_spatial_share))
-                if log:
-                    log("[%d] cloned %d, split %d, pruned %d -> %d surfels (%d slots)" % ((it,) + tuple(counts) + (surfels.num_surfels, tr.P)))
-            if it % opacity_reset_interval == 0 or (white_background and it == densify_from):
-                tr.reset_opacity()
     save(tr, model_path, iterations)
     return tr, losses
+
+
+class Schedule:
+    """The joint stage's iteration schedule (the reference's defaults: arguments/__init__.py:101-122)."""
+
+    def __init__(self, warm_up=3000, regularize_from=8000, oneup_sh_degree_step=1000, densify_from=500, densify_interval=100, densify_until=50_000,
+                 opacity_reset_interval=3000, densify_grad_threshold=0.0002, node_densify_at=10_000, extent=1.0, white_background=False, seed=0,
+                 reference_update_order=True):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+def run_iteration(tr, it, sch, log=None, on_gpu=False, after_step=None, noise=None):
+    """Iteration `it` (1-based) of the joint stage, in the order of GUI.train_step (train_gui.py:215-439): SH degree step -> regime
+    (deformation detached below warm_up, regularisers behind regularize_from) -> the step (forward, backward, statistics, update)
+    -> node densification -> clone / split / prune -> opacity reset.  Returns the step's loss.
+    reference_update_order: the reference's density control REPLACES every surfel parameter before its optimiser steps
+    (cat_tensors_to_optimizer / _prune_optimizer, scene/gaussian_model.py:327-387), the new tensors have no gradient, and
+    torch.optim.Adam skips parameters without one: in an iteration that densifies, the surfels are not updated (values and moments
+    stay; the deformation model is).  The trainer's step contains its update, so the surfels' state is held across such a step
+    (Trainer.hold_surfels: two copies of the surfel rows per densification, every 100th iteration); likewise the node densification
+    reads the surfels as they were before the iteration's update (in the default schedule it falls on a densifying iteration anyway).
+    False: update in every iteration, density control behind it.  noise: the split's standard-normal draws (tests)."""
+    surfels, deform = tr.surfels, tr.deform
+    if sch.oneup_sh_degree_step and it % sch.oneup_sh_degree_step == 0:        # train_gui.py:233-235
+        tr.oneup_sh_degree()
+    on = it > sch.regularize_from                                              # train_gui.py:292-293
+    tr.set_regime(warmup=it < sch.warm_up, lambda_normal=0.02 if on else 0.0, lambda_dist=1000.0 if on else 0.0)
+    densifies = it < sch.densify_until and it > sch.densify_from and it % sch.densify_interval == 0
+    nodes_too = it < sch.densify_until and it == sch.node_densify_at
+    held = tr.hold_surfels() if ((densifies or nodes_too) and sch.reference_update_order) else None
+    held_nodes = tr.hold_surfels(nodes=True) if (nodes_too and sch.reference_update_order) else None   # replaced by the node densification
+    loss = tr.step()
+    updated = None
+    if held_nodes is not None:
+        tr.release_surfels(held_nodes)
+    if held is not None:
+        if not densifies:   # a node densification alone: it reads the surfels as they were BEFORE this iteration's update, which then applies
+            updated = tr.hold_surfels()
+        tr.release_surfels(held)
+    if after_step is not None:
+        tr._wait_gather()   # (data parallel, sharded SH update: the hook sees complete parameters)
+        after_step()
+    if it < sch.densify_until:                                                 # train_gui.py:410-423
+        if it == sch.node_densify_at:       # node_force_densify_prune_step; the periodic variant is off by default in the reference
+            counts = tr.densify_nodes(sch.densify_grad_threshold)
+            if log and counts:
+                log("[%d] nodes: added %d, pruned %d -> %d" % ((it,) + tuple(counts) + (deform.node_num,)))
+            if updated is not None:
+                tr.release_surfels(updated)
+        if densifies:
+            size_threshold = 20 if it > sch.opacity_reset_interval else None
+            counts = tr.densify_and_prune(sch.densify_grad_threshold, 0.01, sch.extent, size_threshold, seed=sch.seed, noise=noise)
+            if on_gpu:
+                tr.sort_surfels()   # children landed in free slots anywhere: restore the node order (in place, no re-capture)
+                if tr.refresh_knn_mode() and log:   # the hyper coordinates train: the neighbour search may need its other kernel
+                    log("[%d] neighbour search: %s (spatial share of the K-th distance %.2f)" % (it, deform.knn_refine_mode, deform.knn_spatial_share))
+            if log:
+                log("[%d] cloned %d, split %d, pruned %d -> %d surfels (%d slots)" % ((it,) + tuple(counts) + (surfels.num_surfels, tr.P)))
+        if it % sch.opacity_reset_interval == 0 or (sch.white_background and it == sch.densify_from):
+            tr.reset_opacity()
+    return loss
 
 
 def pretrain_nodes(deform, cams, targets, bg, points, extent, seed=0, log=None, **kw):

@@ -1683,6 +1683,13 @@ class Trainer:
             alive = s.alive
             old = {id(p): tuple(None if t is None else t.detach().clone() for t in self._any_moments(p)) for p in self.bucket.params}
             t_saved = self.opt_surfels.t.clone() if fused else None
+            # torch Adam counts steps per parameter (a parameter's count starts with its first gradient: the deformation's after the
+            # warm-up); the reference's surgery keeps each state's count, and the re-sized node tensors inherit their predecessors'
+            steps = {}
+            if not fused:
+                for opt in (self.opt_surfels, self.opt_deform):
+                    steps.update({id(p): st["step"].clone() for p, st in opt.state.items() if "step" in st})
+                node_steps = {n: steps.get(id(getattr(d, n))) for n in ("nodes", "_node_radius", "_node_weight")}
             res = d.densify_nodes(max_grad, s.get_xyz.detach()[alive], x_grad[alive], s.feature.detach()[alive], moments=self._any_moments,
                                   pad_to=64 if fused else 1)
             if res is None:
@@ -1695,6 +1702,8 @@ class Trainer:
                     delattr(self, a)
             self._build_state()
             new_nodes = {id(getattr(d, n)): mv for n, mv in node_moments.items()}
+            if not fused:
+                steps.update({id(getattr(d, n)): t for n, t in node_steps.items() if t is not None})
             if fused:
                 self.opt_surfels.t.copy_(t_saved)
             for p in self.bucket.params:
@@ -1703,7 +1712,7 @@ class Trainer:
                     continue
                 if not fused:
                     opt = self.opt_deform if any(p is q for g in self.opt_deform.param_groups for q in g["params"]) else self.opt_surfels
-                    opt.state[p] = {"step": torch.tensor(float(self._steps_done)), "exp_avg": m0.clone(), "exp_avg_sq": v0.clone()}
+                    opt.state[p] = {"step": steps.get(id(p), torch.tensor(float(self._steps_done))).clone(), "exp_avg": m0.clone(), "exp_avg_sq": v0.clone()}
                 else:
                     m, v = self.opt_surfels.moments(p)
                     m.copy_(m0)
@@ -1727,6 +1736,47 @@ class Trainer:
         if self.opt_deform is None:
             return self.opt_surfels.moments(p)
         return (None, None)
+
+    @torch.no_grad()
+    def hold_surfels(self, nodes=False):
+        """Copies of the per-surfel parameters (nodes=True: of the three node tensors instead) and of their Adam state;
+        release_surfels puts them back.  Around a step: the step trains everything else and gathers the densification statistics, the
+        held parameters stay where they were -- what the reference does to parameters its density control replaces in front of the
+        optimiser's step (dgs_amd.fit.run_iteration)."""
+        from . import densify
+        self.settle_shards()
+        d = self.deform
+        params = [d.nodes, d._node_radius, d._node_weight] if nodes else list(densify.surfel_rows(self.surfels).values())
+        held = []
+        for p in params:
+            m, v = self._any_moments(p)
+            st = self._torch_state(p)
+            held.append((p, p.detach().clone(), None if m is None else m.clone(), None if v is None else v.clone(),
+                         None if not st else st["step"].clone()))
+        return held
+
+    def _torch_state(self, p, pop=False):
+        """torch.optim.Adam's state entry of parameter p (CPU path; the optimisers may have been rebuilt since a hold), or None."""
+        if self.opt_deform is None:
+            return None
+        for opt in (self.opt_surfels, self.opt_deform):
+            if p in opt.state:
+                return opt.state.pop(p) if pop else opt.state[p]
+        return None
+
+    @torch.no_grad()
+    def release_surfels(self, held):
+        self.settle_shards()
+        for p, value, m0, v0, step in held:
+            p.copy_(value)
+            m, v = self._any_moments(p)
+            if m0 is not None:
+                m.copy_(m0)
+                v.copy_(v0)
+            elif m is not None:   # a parameter that saw its first update in this step (torch Adam): back to no state
+                self._torch_state(p, pop=True)
+            if step is not None:
+                self._torch_state(p)["step"].copy_(step)
 
     @torch.no_grad()
     def adopt_deform_state(self, adam):
