@@ -200,7 +200,7 @@ def trained_trainer(P, H, W, device, pre_iterations):
         # SAME scene -- with the float atomics the fit's outcome, and with it the timed step, varied by +-6 % from run to run (round 4)
         det = os.environ.get("DGS_TRAINED_DETERMINISTIC", "1") != "0"
         tr, losses = fit(os.path.join(tmp, "scene"), os.path.join(tmp, "model"), iterations=pre_iterations, device=device, num_pts=P, node_num=512,
-                         seed=0, warm_up=warm_up, regularize_from=reg_from, node_densify_at=10 ** 9, deterministic=det)
+                         seed=0, warm_up=warm_up, regularize_from=reg_from, node_densify_at=10 ** 9, deterministic=det, reference_update_order=False)
         if det:
             tr.set_deterministic(False)   # the timed steps are the product's default kernels
         tr.pre_fit_mode = "deterministic" if det else "float atomics"

@@ -23,7 +23,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
         arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False, views_per_rank=1, concurrent_views=False,
-        node_pretrain=None, reference_update_order=True):
+        node_pretrain=None, reference_update_order=False):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot).  warm_up / regularize_from: the
     reference's stages (train_gui.py:282-285: deformation detached while iteration < opt.warm_up; :292-293: normal and
@@ -104,7 +104,7 @@ class Schedule:
 
     def __init__(self, warm_up=3000, regularize_from=8000, oneup_sh_degree_step=1000, densify_from=500, densify_interval=100, densify_until=50_000,
                  opacity_reset_interval=3000, densify_grad_threshold=0.0002, node_densify_at=10_000, extent=1.0, white_background=False, seed=0,
-                 reference_update_order=True):
+                 reference_update_order=False):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -113,13 +113,17 @@ def run_iteration(tr, it, sch, log=None, on_gpu=False, after_step=None, noise=No
     """Iteration `it` (1-based) of the joint stage, in the order of GUI.train_step (train_gui.py:215-439): SH degree step -> regime
     (deformation detached below warm_up, regularisers behind regularize_from) -> the step (forward, backward, statistics, update)
     -> node densification -> clone / split / prune -> opacity reset.  Returns the step's loss.
-    reference_update_order: the reference's density control REPLACES every surfel parameter before its optimiser steps
+    reference_update_order (off by default): the reference's density control REPLACES every surfel parameter before its optimiser steps
     (cat_tensors_to_optimizer / _prune_optimizer, scene/gaussian_model.py:327-387), the new tensors have no gradient, and
     torch.optim.Adam skips parameters without one: in an iteration that densifies, the surfels are not updated (values and moments
     stay; the deformation model is).  The trainer's step contains its update, so the surfels' state is held across such a step
     (Trainer.hold_surfels: two copies of the surfel rows per densification, every 100th iteration); likewise the node densification
     reads the surfels as they were before the iteration's update (in the default schedule it falls on a densifying iteration anyway).
-    False: update in every iteration, density control behind it.  noise: the split's standard-normal draws (tests)."""
+    False (default): update in every iteration, density control behind it -- the order every measured number and learning test of
+    this package was produced with; True reproduces the reference's trajectory (tests/test_train_step_golden.py: every loss of twelve
+    iterations of its GUI.train_step, every density-control count) at the cost of those copies; on the device the flat Adam kernel
+    counts steps globally, so a held parameter's bias correction runs one step ahead of torch's per-parameter count per densification
+    (relative effect on the update: 3e-4 at step 600, 1e-7 at 8000).  noise: the split's standard-normal draws (tests)."""
     surfels, deform = tr.surfels, tr.deform
     if sch.oneup_sh_degree_step and it % sch.oneup_sh_degree_step == 0:        # train_gui.py:233-235
         tr.oneup_sh_degree()

@@ -108,9 +108,17 @@ def main():
                 deform.deform._node_weight.data += 0.3 * torch.randn(c["nodes"], 1, generator=g)
                 gaussians.feature.data += 0.01 * torch.randn(gaussians.feature.shape, generator=g)
             out["nodes0"] = deform.deform.nodes.detach().numpy().copy()
-            # the state a run that reached iteration `first` would be in: both schedules evaluated by the iteration before
+            # the state a run that reached iteration `first` would be in: both schedules evaluated by the iteration before, and Adam
+            # step counts of that size (with zero moments: no history is invented) -- at step counts of 1, 2, 3 the bias corrections
+            # differ by tens of percent from one step to the next, which turns the one-step lag between a per-parameter count (torch)
+            # and a global one (the flat Adam kernel of the device path) after a held update into a visible difference; at the
+            # counts of a run in progress it is 1e-7
             gaussians.update_learning_rate(c["first"] - 1)
             deform.update_learning_rate(c["first"] - 1)
+            for opt_ in (gaussians.optimizer, deform.optimizer):
+                for grp_ in opt_.param_groups:
+                    for p_ in grp_["params"]:
+                        opt_.state[p_] = {"step": torch.tensor(float(c["first"] - 1)), "exp_avg": torch.zeros_like(p_.data), "exp_avg_sq": torch.zeros_like(p_.data)}
             bar = SimpleNamespace(set_postfix=lambda *a, **k: None, update=lambda *a, **k: None, close=lambda: None, set_description=lambda *a, **k: None)
             zero = torch.zeros(())
             gui = SimpleNamespace(

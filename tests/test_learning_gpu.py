@@ -117,7 +117,9 @@ def test_the_run_to_run_spread_is_the_float_atomics(tmp_path, monkeypatch):
     assert not np.array_equal(lc, la)
     print("|delta loss| deterministic vs atomic run, mean over iterations 1-100 / 801-900: %.2e / %.2e; mean loss 801-900: %.4f vs %.4f"
           % (np.abs(lc[:100] - la[:100]).mean(), np.abs(lc[800:] - la[800:]).mean(), la[800:].mean(), lc[800:].mean()))
-    assert lc[800:].mean() == pytest.approx(la[800:].mean(), rel=0.25)   # the same optimisation, not the same trajectory
+    # the same optimisation, not the same trajectory: ten atomic runs ended this window between 0.067 and 0.091 (one beyond 0.085:
+    # the window starts at a densification) against the deterministic run's 0.0674
+    assert lc[800:].mean() == pytest.approx(la[800:].mean(), rel=0.45)
 
 
 def test_deterministic_captured_fits_are_bit_identical(tmp_path):
