@@ -115,7 +115,7 @@ def main():
             # counts of a run in progress it is 1e-7
             gaussians.update_learning_rate(c["first"] - 1)
             deform.update_learning_rate(c["first"] - 1)
-            for opt_ in (gaussians.optimizer, deform.optimizer):
+            for opt_ in (gaussians.optimizer,):     # (the deformation's parameters start counting when the warm-up ends, at 7997: in both)
                 for grp_ in opt_.param_groups:
                     for p_ in grp_["params"]:
                         opt_.state[p_] = {"step": torch.tensor(float(c["first"] - 1)), "exp_avg": torch.zeros_like(p_.data), "exp_avg_sq": torch.zeros_like(p_.data)}
