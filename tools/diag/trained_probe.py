@@ -27,6 +27,20 @@ def hook(it, t):
         print(it, "tr.it", t.iteration, "rec", t.overflow_recoveries, "status", st, "t", float(t.opt_surfels.t), "oflag", int(t._oflag.item()), "cap", getattr(t, "_capacity", 0), "hint", getattr(t, "_list_hint", 0),
               "|g| %.3e" % float(t.bucket.flat[:t.bucket.n_grad].abs().sum()), "xyz %.4f" % float(t.surfels._xyz.detach().double().abs().sum()),
               "warp %.5f" % float(t.deform.network.gaussian_warp.weight.detach().double().abs().sum()), "warmup", t.warmup, flush=True)
+    if os.environ.get("DEEP") and lo <= it <= hi:
+        with torch.no_grad():
+            sf, d = t.surfels, t.deform
+            a = sf.alive
+            for v in (0, 7, 19, 31):
+                cam = t.cameras[v]
+                dv = d(sf.get_xyz.detach(), d.expand_time(cam.fid), sf.feature, sf.motion_mask)
+                sc = torch.exp(sf._scaling.detach()) + dv["d_scaling"]
+                print("   view", v, "nan d_xyz %d d_rot %d d_scale %d" % tuple(int(torch.isnan(dv[k][a]).sum()) for k in ("d_xyz", "d_rotation", "d_scaling")),
+                      "max|d_xyz| %.3f max|d_scale| %.4f min scale+d %.5f max %.4f" % (float(dv["d_xyz"][a].abs().max()), float(dv["d_scaling"][a].abs().max()), float(sc[a].min()), float(sc[a].max())),
+                      "neg scale", int((sc[a] <= 0).any(dim=1).sum()), flush=True)
+            print("   nodes: radius %.4f..%.4f weight %.3f..%.3f hyper %.3f..%.3f | surfel hyper %.3f..%.3f opacity nan %d xyz nan %d" % (
+                float(d.node_radius.min()), float(d.node_radius.max()), float(d.node_weight.min()), float(d.node_weight.max()), float(d.nodes[:, 3:].min()), float(d.nodes[:, 3:].max()),
+                float(sf.feature[a].min()), float(sf.feature[a].max()), int(torch.isnan(sf._opacity[a]).sum()), int(torch.isnan(sf._xyz[a]).sum())), flush=True)
     if it % 100 == 0:
         s_ = t.surfels
         a = s_.alive
