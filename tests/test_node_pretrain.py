@@ -256,3 +256,58 @@ def test_stage_learns_where_the_scene_moves(tmp_path):
     r0, r1 = float(pts.norm(dim=-1).mean()), float(deform.nodes.detach()[:, :3].norm(dim=-1).mean())
     print("mean distance from the origin: initial points %.3f, control nodes %.3f" % (r0, r1))
     assert r1 < 0.85 * r0
+
+
+def _pretrain_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import dgs_amd.render as render_mod
+    from dgs_amd.fit import pretrain_nodes
+    from make_node_pretrain_golden import CASES, scene_inputs
+    from oracle_raster_op import OracleRasterizer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        render_mod.GaussianRasterizer = OracleRasterizer
+        c = CASES["clone"]
+        cams, targets, pts = scene_inputs("clone")
+        torch.manual_seed(0)
+        deform = ControlNodes(node_num=c["node_num"], K=3, hyper_dim=8, local_frame=True)
+        deform.network = DeformMLP(W=32, local_frame=True)
+        if rank == 1:      # a replica that would NOT arrive at rank 0's result on its own: the stage runs on rank 0 only
+            with torch.no_grad():
+                deform.network.gaussian_warp.weight.add_(0.01)
+        pre = pretrain_nodes(deform, cams, targets, torch.zeros(3), pts, c["extent"], seed=5, iterations=8, node_warm_up=2, sampling_at=5,
+                             densify_interval=2, opacity_reset_interval=4, densify_grad_threshold=c["densify_grad_threshold"], rasterizer_cls=OracleRasterizer)
+        flat = torch.cat([p.detach().reshape(-1) for p in deform.parameters()])
+        st = pre.opt_deform.state
+        moments = torch.cat([torch.cat([st[p]["exp_avg"].reshape(-1), st[p]["exp_avg_sq"].reshape(-1), st[p]["step"].reshape(1).float()])
+                             for grp in pre.opt_deform.param_groups for p in grp["params"] if st.get(p)])
+        both = torch.cat([flat, moments])
+        gathered = [torch.zeros_like(both) for _ in range(world)]
+        dist.all_gather(gathered, both)
+        if rank == 0:
+            q.put((all(torch.equal(gathered[0], x) for x in gathered), len(pre.losses), int(moments.numel())))
+        else:
+            assert len(pre.losses) == 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stage_under_data_parallelism_runs_on_rank_0_and_is_broadcast():
+    """pretrain_nodes with two ranks (gloo): rank 0 runs the stage, every rank ends with its deformation parameters AND the Adam state
+    the joint stage continues (moments, per-parameter step counts) -- bit-identical replicas."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_pretrain_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, n_losses, n_state = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert same and n_losses == 7 and n_state > 1000
