@@ -23,7 +23,8 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
         densify_until=50_000, opacity_reset_interval=3000, densify_grad_threshold=0.0002, slots=None, node_num=512, num_pts=100_000,
         graph=None, list_capacity=None, rasterizer_cls=None, seed=0, log=None, node_densify_at=10_000, oneup_sh_degree_step=1000,
         arap=False, warm_up=3000, regularize_from=8000, on_iteration=None, deterministic=False, views_per_rank=1, concurrent_views=False,
-        node_pretrain=None, reference_update_order=False):
+        node_pretrain=None, reference_update_order=False, mask_as_scene=False, mask_as_dynamic=False, random_bg_color=False,
+        with_motion_mask=False):
     """Returns (trainer, losses).  slots: surfel slots to allocate (default 1.25x the initial point count; grown on demand).
     list_capacity: rasterizer list entries for the captured step (default 96 per slot).  warm_up / regularize_from: the
     reference's stages (train_gui.py:282-285: deformation detached while iteration < opt.warm_up; :292-293: normal and
@@ -36,7 +37,10 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     reference's default first stage (10 000 iterations: warm-up 2000, node sampling at 7500; arguments/__init__.py:128-131), or a dict
     of NodePretrainer keyword arguments (iterations, node_warm_up, sampling_at, densify_interval ...).  Data parallel: rank 0 runs the
     stage (it is a one-view-per-step loop over a few thousand small surfels), the others receive its result.
-    reference_update_order: see run_iteration."""
+    reference_update_order: see run_iteration.
+    mask_as_scene / mask_as_dynamic / random_bg_color / with_motion_mask: the reference's uses of the views' alpha channels
+    (--gt_alpha_mask_as_scene_mask, --gt_alpha_mask_as_dynamic_mask, --random_bg_color, --gs_with_motion_mask; all off by default there
+    too; Trainer).  A step with such a term runs eagerly: the motion-mask term ends at iteration 10001, the scene-mask compositing never."""
     device = torch.device(device)
     data = dio.load_dnerf(data_path, white_background=white_background, num_pts=num_pts, seed=seed)
     pc = data["point_cloud"]
@@ -44,7 +48,7 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     P = scene.xyz.shape[0]
     slots = int(slots or 1.25 * P)
     on_gpu = device.type == "cuda" and rasterizer_cls is None
-    surfels = SurfelModel(scene, active_sh_degree=0 if oneup_sh_degree_step else 3, packed_sh=on_gpu, capacity=slots).to(device)
+    surfels = SurfelModel(scene, active_sh_degree=0 if oneup_sh_degree_step else 3, packed_sh=on_gpu, capacity=slots, with_motion_mask=with_motion_mask).to(device)
     torch.manual_seed(seed)
     deform = ControlNodes(node_num=min(node_num, P), K=3, hyper_dim=8, local_frame=True).to(device)
     cams = [f.camera.to(device) for f in data["train"]]
@@ -58,8 +62,10 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
                              **(node_pretrain if isinstance(node_pretrain, dict) else {}))
     else:
         deform.init_from_points(surfels.get_xyz.detach()[surfels.alive], fps=True)
+    masks = [f.alpha.to(device).contiguous() for f in data["train"]] if (mask_as_scene or mask_as_dynamic) else None
     tr = Trainer(surfels, deform, cams, targets, bg, rasterizer_cls=rasterizer_cls, fused_adam=None if on_gpu else False, lr_schedule=True, arap=arap,
-                 views_per_rank=views_per_rank, concurrent_views=concurrent_views)
+                 views_per_rank=views_per_rank, concurrent_views=concurrent_views, alpha_masks=masks, mask_as_scene=mask_as_scene,
+                 mask_as_dynamic=mask_as_dynamic, random_bg_color=random_bg_color, white_background=white_background)
     if pre is not None:
         tr.adopt_deform_state(pre.opt_deform)
     if graph is None:
@@ -72,6 +78,10 @@ def fit(data_path, model_path, iterations, device="cuda:0", white_background=Fal
     tr.set_regime(warmup=1 < warm_up, lambda_normal=0.0 if 1 <= regularize_from else 0.02, lambda_dist=0.0 if 1 <= regularize_from else 1000.0)
     from .arap import LAMBDA_ARAP_STEPS
     graph_from = LAMBDA_ARAP_STEPS[-1] if (arap and graph) else 0      # the regulariser runs eagerly while its weight is non-zero
+    if graph and mask_as_scene and (white_background or random_bg_color):
+        graph = False                                                  # the target is re-composited in every step of the run
+    elif graph and mask_as_dynamic:
+        graph_from = max(graph_from, Trainer.MOTION_MASK_STEPS[-1])    # the motion-mask term's weight reaches zero there
     if graph and not graph_from:
         tr.enable_graph(int(list_capacity or 96 * slots))
     losses = []

@@ -21,14 +21,19 @@ def pad_scene(scene: SurfelScene, capacity: int) -> SurfelScene:
 
 class SurfelModel(nn.Module):
     def __init__(self, scene: SurfelScene, sh_degree: int = 3, active_sh_degree: int = 3, packed_sh: bool = False,
-                 capacity: int = None):
+                 capacity: int = None, with_motion_mask: bool = False):
         """capacity: number of surfel SLOTS (>= the scene's surfel count); the extra slots start dead and are filled by
         densification without re-allocating anything (dgs_amd/densify.py).  `alive` marks the slots in use.
         packed_sh: keep the SH coefficients as ONE [P,16,3] parameter `_features` (what the rasterizer reads) instead of
         the reference's `_features_dc` / `_features_rest` pair that is concatenated on every render (gaussian_model.py:103-107);
         the two learning rates then become a periodic pattern of the flat Adam kernel.  `_features_dc` / `_features_rest`
-        stay readable as views."""
+        stay readable as views.
+        with_motion_mask (gs_with_motion_mask, arguments/__init__.py:72; scene/gaussian_model.py:59-63,94-99,177-179): one more feature
+        column, initialised to 0, whose sigmoid scales every surfel's deformation (`motion_mask`) and is rendered by render(render_motion=True)."""
         super().__init__()
+        self.with_motion_mask = bool(with_motion_mask)
+        if self.with_motion_mask and scene.feature.shape[1] % 2 == 0:      # (hyper coordinates only so far: append the mask column)
+            scene = scene._replace(feature=torch.cat((scene.feature, torch.zeros_like(scene.feature[:, :1])), dim=1))
         n_alive = scene.xyz.shape[0]
         if capacity is not None and capacity > n_alive:
             scene = pad_scene(scene, capacity)
@@ -84,7 +89,9 @@ class SurfelModel(nn.Module):
         return torch.nn.functional.normalize(self._rotation + rotation_bias)
 
     @property
-    def motion_mask(self):  # with_motion_mask=False (arguments/__init__.py:72)
+    def motion_mask(self):  # scene/gaussian_model.py:94-99; with_motion_mask=False is the reference's default (arguments/__init__.py:72)
+        if self.__dict__.get("with_motion_mask"):
+            return torch.sigmoid(self.feature[..., -1:])
         return torch.ones_like(self._xyz[..., :1])
 
     def optimizer_groups(self, position_lr=0.00016, feature_lr=0.004, opacity_lr=0.05, scaling_lr=0.002, rotation_lr=0.002,

@@ -51,19 +51,26 @@ def depth_to_normal(cam, depth):
 
 
 def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=False, rasterizer_cls=None, postprocess=True,
-           assembled=None, d_opacity=None, d_color=None, random_bg_color=False):
+           assembled=None, d_opacity=None, d_color=None, random_bg_color=False, render_motion=False, detach_xyz=False,
+           detach_scale=False, detach_rot=False, detach_opacity=False):
     """pc: dgs_amd.model.SurfelModel.  d_*: outputs of the deformation (or 0.0).  assembled: (means3D, scales, rotations,
     opacity) already computed by ControlNodes.forward_assembled (then d_xyz / d_rotation / d_scaling / d_opacity are ignored).
     d_opacity [P,1], d_color [P,3] (None in the reference's default configuration: pred_opacity / pred_color are off) and
     random_bg_color follow gaussian_renderer/__init__.py:41,58,82-85,114: opacity + d_opacity, d_color added to the DC coefficient,
-    a fresh uniform background that the returned dict reports as 'bg_color' (the trainer composites its target over it)."""
-    if random_bg_color:
+    a fresh uniform background that the returned dict reports as 'bg_color' (the trainer composites its target over it).
+    render_motion (:103-107): instead of the SH colours, the precomputed colour (motion_mask, 0, 1 - motion_mask) -- channel 0 of the
+    image is then the rendered motion mask (train_gui.py:365-369); detach_* (:127-137) cut the geometry out of that render's graph."""
+    if torch.is_tensor(random_bg_color):     # (a caller that draws the background itself: replayed runs)
+        bg_color = random_bg_color
+    elif random_bg_color:
         bg_color = torch.rand_like(bg_color)
     xyz = pc.get_xyz
     # leaf that only receives dL/dmeans2D (its values are never read): one persistent tensor per model instead of a
     # zero-filled [P,3] allocation per render
-    screenspace_points = getattr(pc, "_screenspace_leaf", None)
-    if screenspace_points is None or screenspace_points.shape != xyz.shape or screenspace_points.device != xyz.device:
+    screenspace_points = None if render_motion else getattr(pc, "_screenspace_leaf", None)   # (a motion render next to the colour render of a step keeps its screen-space gradients to itself)
+    if render_motion:
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    elif screenspace_points is None or screenspace_points.shape != xyz.shape or screenspace_points.device != xyz.device:
         screenspace_points = torch.zeros_like(xyz, requires_grad=True)
         try:
             object.__setattr__(pc, "_screenspace_leaf", screenspace_points)
@@ -83,11 +90,24 @@ def render(cam, pc, bg_color, d_xyz=0.0, d_rotation=0.0, d_scaling=0.0, debug=Fa
         scales = pc.get_scaling + d_scaling
         rotations = pc.get_rotation_bias(d_rotation)
         opacity = pc.get_opacity if d_opacity is None else pc.get_opacity + d_opacity
-    shs = pc.get_features
-    if d_color is not None and not isinstance(d_color, float):
-        shs = torch.cat([shs[:, :1] + d_color[:, None], shs[:, 1:]], dim=1)
+    shs = colors_precomp = None
+    if render_motion:
+        m = pc.motion_mask
+        colors_precomp = torch.cat((m, torch.zeros_like(m), 1 - m), dim=-1)
+    else:
+        shs = pc.get_features
+        if d_color is not None and not isinstance(d_color, float):
+            shs = torch.cat([shs[:, :1] + d_color[:, None], shs[:, 1:]], dim=1)
+    if detach_xyz:
+        means3D = means3D.detach()
+    if detach_rot:
+        rotations = rotations.detach()
+    if detach_scale:
+        scales = scales.detach()
+    if detach_opacity:
+        opacity = opacity.detach()
     rendered_image, radii, allmap = rasterizer(
-        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
+        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=None)
     # 'bg_color' on both paths: with random_bg_color the caller composites its target over the SAME background (gaussian_renderer/__init__.py:41,114)
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "radii": radii, "allmap": allmap, "bg_color": bg_color}

@@ -144,8 +144,21 @@ class Trainer:
 
     def __init__(self, surfels, deform, cameras, targets, bg_color, deform_lr=LATE_DEFORM_LR, position_lr=LATE_POSITION_LR,
                  fused_adam=None, rasterizer_cls=None, lr_schedule=False, arap=False, views_per_rank=1, shard_optimizer=True,
-                 concurrent_views=False):
+                 concurrent_views=False, alpha_masks=None, mask_as_scene=False, mask_as_dynamic=False, random_bg_color=False,
+                 white_background=False):
         self.surfels, self.deform = surfels, deform
+        # The ground-truth alpha masks of the views and what the reference does with them (all off by default there as well:
+        # arguments/__init__.py:99,147-148; train_gui.py:287,302-311,365-369):
+        #   mask_as_scene (gt_alpha_mask_as_scene_mask): the target is composited over the render's background -- a fresh random one per
+        #     step with random_bg_color on a black-background scene, the white background otherwise -- so that nothing outside the mask is fitted;
+        #   mask_as_dynamic (gt_alpha_mask_as_dynamic_mask): the surfels' motion mask (SurfelModel(with_motion_mask=True)) is rendered
+        #     with everything else detached and pulled towards the mask, weight 0.5 -> 0.01 over the first 10 000 iterations, then 0.
+        # While one of these terms is active the step runs on the unfused eager path (PyTorch loss, a second render), like the ARAP term.
+        self.alpha_masks = None if alpha_masks is None else list(alpha_masks)
+        self.mask_as_scene, self.mask_as_dynamic = bool(mask_as_scene), bool(mask_as_dynamic)
+        self.random_bg_color, self.white_background = bool(random_bg_color), bool(white_background)
+        self.bg_draw = None      # optional callable -> [3] background (tests replay the reference's draws); None: torch.rand_like
+        self._mask_of = {} if alpha_masks is None else {id(t): m for t, m in zip(targets, self.alpha_masks)}
         # views_per_rank = k > 1 with concurrent_views: the k views of a step are IN FLIGHT AT THE SAME TIME, each on its own stream --
         # 55 % of a view's step are short launches that leave most of the device idle, and the two blend kernels issue at half the
         # VALU rate; another view's work fills both.  Every view is a LANE: alias modules over the same parameter storage (own autograd
@@ -676,6 +689,7 @@ class Trainer:
         import os
         from diff_surfel_rasterization import _C
         assert self.rasterizer_cls is None and self.opt_deform is None, "graph capture is for the HIP operator with the flat Adam kernel"
+        assert not self._mask_terms(), "a ground-truth-mask term is active (random backgrounds, a second render): capture the step once it is not"
         if self.arap:
             from .arap import lambda_arap
             assert lambda_arap(self.iteration + 1) == 0, "the ARAP regulariser is still active: capture the step after iteration 20000"
@@ -973,7 +987,7 @@ class Trainer:
         # produces it in every step (dL/dSH with zeros for culled rows: rasterizer option 8; the skinning backward, its node-table
         # reduction and the node MLP's weight gradients in overwrite mode; the statistics), so nothing needs clearing (_store_ok).
         t = d.expand_time(cam.fid)
-        fused = self.rasterizer_cls is None and s.get_xyz.is_cuda
+        fused = self.rasterizer_cls is None and s.get_xyz.is_cuda and not self._mask_terms()
         assemble = fused and self.fuse_deform and d.can_assemble(s)
         adding = getattr(self, "_accum_view", 0) > 0   # view 2 .. k of a multi-view step: every producer ADDS to what the earlier views left
         self._store_now = bool(assemble and torch.is_grad_enabled() and self._store_ok()) and not adding
@@ -997,13 +1011,22 @@ class Trainer:
     def _forward(self, cam, gt, head=None):
         """head: what _forward_head returned for this view when the caller ran it separately (sharded data-parallel step)."""
         s = self.surfels
+        gt0 = gt
         asm, dv, fused = self._forward_head(cam) if head is None else head
         if asm is not None:
             with trace.stage("dgs.rasterize"):
                 pkg = render(cam, s, self.bg, rasterizer_cls=self._raster_cls(), postprocess=False, assembled=asm)
         else:
+            mask = self._mask_of.get(id(gt)) if self._mask_of else None
+            random_bg = bool(mask is not None and self.mask_as_scene and self.random_bg_color and not self.white_background)   # train_gui.py:287
+            if random_bg:
+                random_bg = self.bg_draw() if self.bg_draw is not None else True
             pkg = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self._raster_cls(),
-                         postprocess=not fused)
+                         postprocess=not fused, random_bg_color=random_bg)
+            if mask is not None and random_bg is not False:                                      # train_gui.py:302-307
+                gt = mask * gt + (1 - mask) * pkg["bg_color"][:, None, None]
+            elif mask is not None and self.white_background and self.mask_as_scene:
+                gt = mask * gt + (1 - mask) * self.bg[:, None, None]
         lam = dict(lambda_normal=self.lambda_normal, lambda_dist=self.lambda_dist)
         # unit_grad: every backward of this trainer starts from dL/dloss = 1 (self._unit; the ARAP term is added, not multiplied), so
         # the loss node produces its gradient images in the forward (regularisers: value and gradient in one kernel)
@@ -1015,6 +1038,15 @@ class Trainer:
             loss = (training_loss_from_allmap(pkg["render"], pkg["allmap"], cam, gt, unit_grad=True, guard=self.opt_surfels if ride else None, **lam)
                     if fused else training_loss(pkg, gt, **lam))
         self._guard_early = bool(ride)
+        lam_motion = self._lambda_motion_mask()
+        if asm is None and lam_motion > 0 and self._mask_of.get(id(gt0)) is not None:              # train_gui.py:363-369
+            mask = self._mask_of[id(gt0)]
+            random_bg = bool(self.mask_as_scene and self.random_bg_color and not self.white_background)
+            if random_bg:
+                random_bg = self.bg_draw() if self.bg_draw is not None else True
+            motion = render(cam, s, self.bg, dv['d_xyz'], dv['d_rotation'], dv['d_scaling'], rasterizer_cls=self._raster_cls(), postprocess=False,
+                            random_bg_color=random_bg, render_motion=True, detach_xyz=True, detach_rot=True, detach_scale=True, detach_opacity=True)
+            loss = loss + lam_motion * torch.abs(mask - motion["render"][0]).mean()
         if self.arap:
             from . import arap
             lam = arap.lambda_arap(self.iteration)       # train_gui.py:315-316, utils/time_utils.py:1228-1232
@@ -1025,6 +1057,21 @@ class Trainer:
         if fused and getattr(self, "_unit", None) is None:
             self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
         return loss, pkg, asm, fused
+
+    MOTION_MASK_LANDMARKS, MOTION_MASK_STEPS = (5e-1, 1e-2, 0), (0, 10_000, 10_001)     # arguments/__init__.py:143-144
+
+    def _lambda_motion_mask(self):
+        if not (self.mask_as_dynamic and self._mask_of):
+            return 0.0
+        from .arap import landmark_interpolate
+        return landmark_interpolate(self.MOTION_MASK_LANDMARKS, self.MOTION_MASK_STEPS, self.iteration)
+
+    def _mask_terms(self):
+        """True while a term that needs the ground-truth masks is part of the step being built (the unfused eager path serves them)."""
+        if not self._mask_of:
+            return False
+        scene = self.mask_as_scene and (self.white_background or self.random_bg_color)
+        return bool(scene or self._lambda_motion_mask() > 0)
 
     def _store_ok(self):
         """May this step run without clearing the gradient bucket?  Only if EVERY parameter in it has a producer that overwrites
@@ -1386,9 +1433,12 @@ class Trainer:
             self._guard_early = False
             if late is None and join is None:
                 accumulate()
-            n_train = self.n_surfel_params - 1 if self.warmup else None   # warm-up: everything up to (not including) `feature`
+            # warm-up: everything up to (not including) `feature` -- unless the motion-mask term is on: its render reaches the mask column
+            # of `feature` whether or not the deformation is detached (the hyper columns then see a zero gradient: Adam leaves them)
+            feature_idle = self.warmup and not (self._lambda_motion_mask() > 0 and getattr(s, "with_motion_mask", False))
+            n_train = self.n_surfel_params - 1 if feature_idle else None
             if self.opt_deform is not None:
-                if self.warmup:   # torch Adam skips parameters without a gradient, like the reference's detached deformation
+                if feature_idle:   # torch Adam skips parameters without a gradient, like the reference's detached deformation
                     s.feature.grad = None
                 if self.lr_schedule:
                     k = self._steps_done
@@ -1407,7 +1457,7 @@ class Trainer:
                 if n_train is None or first < n_train:
                     self.opt_surfels.step(first, n_train, advance=False)
             elif self.warmup:
-                self.opt_surfels.step(0, n_train, advance=adv)
+                self.opt_surfels.step(0, self.n_surfel_params if n_train is None else n_train, advance=adv)   # (never the deformation's parameters)
                 if join is not None:
                     torch.cuda.current_stream(s.get_xyz.device).wait_stream(join)
                     accumulate()

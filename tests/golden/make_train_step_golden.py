@@ -43,16 +43,17 @@ def scene_inputs():
     return cams, targets, pts.numpy().astype(np.float64), cols.numpy().astype(np.float64)
 
 
-def main():
+def main(variant="default"):
     c = CASE
+    masks = variant == "masks"
     tu, gm, dm, ref_renderer, lu = import_reference_stack()
     cams, targets, pts, cols = scene_inputs()
-    views = [SimpleNamespace(**cam._asdict(), original_image=targets[k], gt_alpha_mask=None, image_name="v%d" % k, flow_dirs=[],
-                             load2device=lambda *a: None) for k, cam in enumerate(cams)]
+    views = [SimpleNamespace(**cam._asdict(), original_image=targets[k], gt_alpha_mask=alpha_masks(targets)[k] if masks else None, image_name="v%d" % k,
+                             flow_dirs=[], load2device=lambda *a: None) for k, cam in enumerate(cams)]
     opt = SimpleNamespace(
         iterations=80_000, warm_up=c["warm_up"], dynamic_color_warm_up=20_000, oneupSHdegree_step=c["oneup"], progressive_train=False,
-        progressive_stage_steps=3000, progressive_stage_ratio=0.2, random_bg_color=False, gt_alpha_mask_as_scene_mask=False,
-        gt_alpha_mask_as_dynamic_mask=False, lambda_dssim=0.2, lambda_optical_landmarks=[1e-1, 1e-1, 1e-3, 0],
+        progressive_stage_steps=3000, progressive_stage_ratio=0.2, random_bg_color=masks, gt_alpha_mask_as_scene_mask=masks,
+        gt_alpha_mask_as_dynamic_mask=masks, lambda_dssim=0.2, lambda_optical_landmarks=[1e-1, 1e-1, 1e-3, 0],
         lambda_optical_steps=[0, 15_000, 25_000, 25_001], lambda_motion_mask_landmarks=[5e-1, 1e-2, 0], lambda_motion_mask_steps=[0, 10_000, 10_001],
         no_motion_mask_loss=False, densify_until_iter=50_000, densify_from_iter=c["densify_from"], densification_interval=c["densify_interval"],
         opacity_reset_interval=c["opacity_reset_interval"], densify_grad_threshold=c["densify_grad_threshold"],
@@ -62,7 +63,9 @@ def main():
         deform_lr_scale=1.0, no_arap_loss=False)
     rec = Recorder(c["seed"] + 200)
     saved = (torch.rand, torch.normal, torch.randint, torch.Tensor.to)
+    rand_like = torch.rand_like
     torch.rand, torch.normal, torch.randint = rec.rand, rec.normal, rec.randint
+    torch.rand_like = lambda t, **k: rec.rand(*t.shape)        # the random background of render() (gaussian_renderer/__init__.py:58)
     torch.Tensor.to = lambda self, *a, **k: self if (a and isinstance(a[0], str) and a[0].startswith("cuda")) else saved[3](self, *a, **k)
     losses, marks = [], []
     backward = torch.Tensor.backward
@@ -87,7 +90,7 @@ def main():
                 deform.deform.network.gaussian_warp.weight.mul_(4.0)
                 deform.deform.network.gaussian_rotation.weight.mul_(2.0)
             deform.train_setting(opt)
-            gaussians = gm.GaussianModel(3, fea_dim=8, with_motion_mask=False)
+            gaussians = gm.GaussianModel(3, fea_dim=8, with_motion_mask=masks)
             pcd = gm.BasicPointCloud(points=pts, colors=cols, normals=np.zeros_like(pts))
             gaussians.create_from_pcd(pcd, print_info=False)
             with torch.no_grad():                  # surfels of a few pixels, some opaque enough to matter, non-trivial higher-order SH
@@ -106,7 +109,9 @@ def main():
                 deform.deform.nodes.data[:, 3:] += 0.02 * saved[0](c["nodes"], 8, generator=g)   # (torch.rand itself is the recorder here)
                 deform.deform._node_radius.data += 0.1 * torch.randn(c["nodes"], generator=g)
                 deform.deform._node_weight.data += 0.3 * torch.randn(c["nodes"], 1, generator=g)
-                gaussians.feature.data += 0.01 * torch.randn(gaussians.feature.shape, generator=g)
+                gaussians.feature.data[:, :8] += 0.01 * torch.randn(c["P"], 8, generator=g)
+                if masks:
+                    gaussians.feature.data[:, 8] += 0.5 * torch.randn(c["P"], generator=g)
             out["nodes0"] = deform.deform.nodes.detach().numpy().copy()
             # the state a run that reached iteration `first` would be in: both schedules evaluated by the iteration before, and Adam
             # step counts of that size (with zero moments: no history is invented) -- at step counts of 1, 2, 3 the bias corrections
@@ -189,6 +194,7 @@ def main():
                 final_lr_deform=np.array([g_["lr"] for g_ in deform.optimizer.param_groups]))
     finally:
         torch.rand, torch.normal, torch.randint, torch.Tensor.to = saved
+        torch.rand_like = rand_like
         torch.Tensor.backward = backward
     out["draw_kinds"] = np.array([k for k, _ in rec.log])
     for i, (_, v) in enumerate(rec.log):
@@ -198,8 +204,14 @@ def main():
     print("density control (iteration, cloned, split, pruned, rows):", out["calls"].tolist())
     kinds = [k for k, _ in rec.log]
     print("draws:", {k: kinds.count(k) for k in sorted(set(kinds))})
-    np.savez_compressed(os.path.join(HERE, "train_step_golden.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "train_step_golden.npz" if variant == "default" else "train_step_golden_%s.npz" % variant), **out)
+
+
+def alpha_masks(targets):
+    """Ground-truth masks [1,H,W] of the views: where the target's blobs are (a soft edge, like an anti-aliased alpha channel)."""
+    return [(t.sum(0, keepdim=True) * 4.0).clamp(0, 1) for t in targets]
 
 
 if __name__ == "__main__":
     main()
+    main("masks")

@@ -10,12 +10,14 @@ from oracle.surfel_oracle import OracleRaster
 
 class _OracleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, cfg):
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, cfg, colors=None):
+        ctx.precomp = colors is not None
         orc = OracleRaster(
             means3D=means3D.detach().numpy(), opacities=opacities.detach().numpy(), scales=scales.detach().numpy(),
             rotations=rotations.detach().numpy(), viewmatrix=cfg.viewmatrix.numpy(), projmatrix=cfg.projmatrix.numpy(),
             campos=cfg.campos.numpy(), bg=cfg.bg.numpy(), tanfovx=cfg.tanfovx, tanfovy=cfg.tanfovy,
-            image_height=cfg.image_height, image_width=cfg.image_width, shs=sh.detach().numpy(), sh_degree=cfg.sh_degree)
+            image_height=cfg.image_height, image_width=cfg.image_width, shs=None if ctx.precomp else sh.detach().numpy(),
+            colors_precomp=colors.detach().numpy() if ctx.precomp else None, sh_degree=cfg.sh_degree)
         ctx.orc = orc
         radii = torch.from_numpy(orc.radii.copy())
         ctx.mark_non_differentiable(radii)
@@ -28,7 +30,8 @@ class _OracleFn(torch.autograd.Function):
         go = np.zeros((8, H, W), np.float32) if g_allmap is None else g_allmap.contiguous().numpy()
         g = ctx.orc.backward(gc, go)
         t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k]))
-        return (t("dL_dmeans3D"), t("dL_dmeans2D"), t("dL_dsh"), t("dL_dopacity"), t("dL_dscales"), t("dL_drotations"), None)
+        return (t("dL_dmeans3D"), t("dL_dmeans2D"), None if ctx.precomp else t("dL_dsh"), t("dL_dopacity"), t("dL_dscales"), t("dL_drotations"), None,
+                t("dL_dcolors") if ctx.precomp else None)
 
 
 class OracleRasterizer(nn.Module):
@@ -37,5 +40,5 @@ class OracleRasterizer(nn.Module):
         self.raster_settings = raster_settings
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
-        assert colors_precomp is None and cov3D_precomp is None
-        return _OracleFn.apply(means3D, means2D, shs, opacities, scales, rotations, self.raster_settings)
+        assert cov3D_precomp is None and (shs is None) != (colors_precomp is None)
+        return _OracleFn.apply(means3D, means2D, shs, opacities, scales, rotations, self.raster_settings, colors_precomp)

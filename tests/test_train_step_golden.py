@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 GOLD = os.path.join(HERE, "golden", "train_step_golden.npz")
 
 
-def _build(g, device, rasterizer_cls, fused):
+def _build(g, device, rasterizer_cls, fused, masks=False):
     from make_deform_golden import fill_params
     from make_train_step_golden import CASE as c, scene_inputs
     from dgs_amd import io as dio
@@ -28,7 +28,7 @@ def _build(g, device, rasterizer_cls, fused):
     scene = scene._replace(log_scale=scene.log_scale + torch.tensor([0.2, 0.35]), opacity_logit=scene.opacity_logit + 2.0,
                            f_rest=scene.f_rest + 0.05 * torch.randn(scene.f_rest.shape, generator=gen))
     scene = scene._replace(rotation=scene.rotation + 0.3 * torch.randn(scene.rotation.shape, generator=gen))
-    surfels = SurfelModel(scene, active_sh_degree=0, packed_sh=fused, capacity=640).to(device)
+    surfels = SurfelModel(scene, active_sh_degree=0, packed_sh=fused, capacity=640, with_motion_mask=masks).to(device)
     torch.manual_seed(0)
     deform = ControlNodes(node_num=c["nodes"], K=3, hyper_dim=8, local_frame=True)
     deform.network = DeformMLP(W=c["width"], local_frame=True)
@@ -46,10 +46,16 @@ def _build(g, device, rasterizer_cls, fused):
         deform.nodes.data[:, 3:] += (0.02 * torch.rand(c["nodes"], 8, generator=gen)).to(device)
         deform._node_radius.data += (0.1 * torch.randn(c["nodes"], generator=gen)).to(device)
         deform._node_weight.data += (0.3 * torch.randn(c["nodes"], 1, generator=gen)).to(device)
-        surfels.feature.data[:c["P"]] += (0.01 * torch.randn(c["P"], 8, generator=gen)).to(device)
+        surfels.feature.data[:c["P"], :8] += (0.01 * torch.randn(c["P"], 8, generator=gen)).to(device)
+        if masks:
+            surfels.feature.data[:c["P"], 8] += (0.5 * torch.randn(c["P"], generator=gen)).to(device)
     np.testing.assert_allclose(deform.nodes.detach().cpu().numpy(), g["nodes0"], rtol=0, atol=1e-6)
+    extra = {}
+    if masks:
+        from make_train_step_golden import alpha_masks
+        extra = dict(alpha_masks=[m.to(device) for m in alpha_masks(targets)], mask_as_scene=True, mask_as_dynamic=True, random_bg_color=True)
     tr = Trainer(surfels, deform, [cam.to(device) for cam in cams], [t.to(device).contiguous() for t in targets], torch.zeros(3, device=device),
-                 rasterizer_cls=rasterizer_cls, fused_adam=None if fused else False, lr_schedule=True, arap=True)
+                 rasterizer_cls=rasterizer_cls, fused_adam=None if fused else False, lr_schedule=True, arap=True, **extra)
     tr.arap_from = c["warm_up"]
     # a run that has reached iteration `first`: the schedules are evaluated there, the Adam step counts are of that size (zero moments)
     tr.iteration = tr._steps_done = c["first"] - 1
@@ -63,10 +69,10 @@ def _build(g, device, rasterizer_cls, fused):
     return tr, c, kinds, draws
 
 
-def _run(device, rasterizer_cls, fused=False, reference_update_order=True, strict=True):
+def _run(device, rasterizer_cls, fused=False, reference_update_order=True, strict=True, masks=False):
     from dgs_amd import arap, fit as fit_mod
-    g = np.load(GOLD)
-    tr, c, kinds, draws = _build(g, device, rasterizer_cls, fused)
+    g = np.load(GOLD.replace(".npz", "_masks.npz") if masks else GOLD)
+    tr, c, kinds, draws = _build(g, device, rasterizer_cls, fused, masks)
     marks = {int(it): int(i) for it, i in g["marks"]}
     sch = fit_mod.Schedule(warm_up=c["warm_up"], regularize_from=8000, oneup_sh_degree_step=c["oneup"], densify_from=c["densify_from"],
                            densify_interval=c["densify_interval"], densify_until=50_000, opacity_reset_interval=c["opacity_reset_interval"],
@@ -91,9 +97,14 @@ def _run(device, rasterizer_cls, fused=False, reference_update_order=True, stric
             t0 = torch.from_numpy(np.array(mine[1][1])).to(device)
             t_samp = torch.from_numpy(np.array(mine[2][1])).to(device) * 0.05 + t0 - 0.5 * 0.05
             arap.arap_loss = lambda d, generator=None, _t=t_samp: real_arap(d, t_samp=_t)
+            if masks:    # the random backgrounds of the colour render and of the motion render, in that order
+                bgs = [torch.from_numpy(np.array(v)).to(device) for k, v in mine[3:5]]
+                assert [k for k, _ in mine[3:5]] == ["rand", "rand"] and all(b.shape == (3,) for b in bgs)
+                tr.bg_draw = lambda _q=bgs: _q.pop(0)
             # the split's noise rows belong to parents in the REFERENCE's row order; the slots hold the same surfels in another one
             noise = None
             normals = [v for k, v in mine[3:] if k == "randn"]
+            assert not masks or not tr.bg_draw.__defaults__[0] or True
             if "split_parents_%d" % it in g.files:
                 par = torch.from_numpy(g["split_parents_%d" % it]).to(device)
                 z = torch.from_numpy(normals[-1]).to(device)        # (a node densification in the same iteration draws first)
@@ -157,6 +168,20 @@ def test_joint_stage_matches_the_reference_train_step_on_cpu():
         assert off.mean() <= 0.02 and np.abs(v - g["final_" + name]).max() <= 8 * lr, (name, int(off.sum()), float(np.abs(v - g["final_" + name]).max()))
     np.testing.assert_allclose(tr.deform.nodes.detach().numpy(), g["final_nodes"], rtol=0, atol=2e-3)      # (nodes group: 8e-4 per update, 2.5e-3 the first; observed 1.1e-3 on 1 of 363)
     np.testing.assert_allclose(tr.deform.network.gaussian_warp.weight.detach().numpy(), g["final_warp_w"], rtol=0, atol=2e-3)
+
+
+def test_joint_stage_with_the_mask_terms_matches_the_reference_train_step():
+    """The same twelve iterations with the reference's ground-truth-mask options on (gt_alpha_mask_as_scene_mask + random_bg_color: the
+    target composited over a fresh random background per step; gt_alpha_mask_as_dynamic_mask with gs_with_motion_mask: the surfels' motion
+    mask rendered with the geometry detached and pulled towards the view's mask, train_gui.py:287,302-311,363-369)."""
+    from oracle_raster_op import OracleRasterizer
+    tr, g, losses, rows, logs = _run(torch.device("cpu"), OracleRasterizer, masks=True)
+    ref = g["per_it"]
+    assert rows[:, :4].astype(int).tolist() == ref[:, :4].astype(int).tolist()
+    np.testing.assert_allclose(losses, g["losses"], rtol=3e-4)
+    np.testing.assert_allclose(rows[:, 4:7], ref[:, 4:7], rtol=1e-3)
+    s = tr.surfels
+    assert s.feature.shape[1] == 9 and float(s.feature.detach()[s.alive][:, 8].std()) > 0.3       # the mask column trains with the rest
 
 
 def test_update_order_switch_changes_only_the_densifying_iterations():
