@@ -225,11 +225,14 @@ class NodePretrainer:
     def __init__(self, deform, cameras, targets, bg_color, points, extent, iterations=10_000, node_warm_up=2_000, sampling_at=7_500,
                  densify_interval=100, opacity_reset_interval=3_000, densify_grad_threshold=0.0002, densify_from=500,
                  white_background=False, lambda_dssim=0.2, arap=True, is_blender=True, node_max_num_ratio=16, draws=None,
-                 rasterizer_cls=None, log=None, surfel_lrs=None):
+                 rasterizer_cls=None, log=None, surfel_lrs=None, alpha_masks=None, mask_as_scene=False, mask_as_dynamic=False):
         """deform: dgs_amd.deform.ControlNodes (its node count is the number of control nodes the stage ends with).  points [N,3]:
         the scene's initial point cloud (the surfels' positions); the control nodes start as a farthest-point sample of it
         (GUI.__init__, train_gui.py:156-170 -> ControlNodeWarp.init, utils/time_utils.py:886-927).  extent: the cameras' extent.
-        surfel_lrs: keyword arguments of NodeSurfels.training_setup (the reference's --feature_lr, --rotation_lr ... options)."""
+        surfel_lrs: keyword arguments of NodeSurfels.training_setup (the reference's --feature_lr, --rotation_lr ... options).
+        alpha_masks + mask_as_scene / mask_as_dynamic (train_gui.py:487,493-495): the node surfels are rendered over a fresh random
+        background per step and the target is composited over the same one, so that only what lies inside the view's mask is fitted
+        (the node surfels carry no motion mask of their own -- as_gs_force_with_motion_mask is off -- so no motion-mask term here)."""
         self.deform, self.cameras, self.targets, self.bg = deform, cameras, targets, bg_color
         self.extent = float(extent)
         self.iterations, self.node_warm_up, self.sampling_at = int(iterations), int(node_warm_up), int(sampling_at)
@@ -240,6 +243,8 @@ class NodePretrainer:
         self.draws = draws if draws is not None else Draws(0)
         self.rasterizer_cls, self.log = rasterizer_cls, log
         self.surfel_lrs = dict(surfel_lrs or {})
+        self.alpha_masks = None if alpha_masks is None else list(alpha_masks)
+        self.random_bg = bool(alpha_masks is not None and (mask_as_scene or mask_as_dynamic))
         self.iteration = 1
         self.stack = []
         self.losses = []
@@ -324,8 +329,14 @@ class NodePretrainer:
         d_xyz = d.network(x, t)["d_xyz"] * gs.motion_mask
         if it < self.node_warm_up:
             d_xyz = d_xyz.detach()
-        pkg = render(cam, gs, self.bg, d_xyz, 0.0, 0.0, rasterizer_cls=self.rasterizer_cls)
+        random_bg = False
+        if self.random_bg:
+            random_bg = self.draws.rand(3).to(x.device)
+        pkg = render(cam, gs, self.bg, d_xyz, 0.0, 0.0, rasterizer_cls=self.rasterizer_cls, random_bg_color=random_bg)
         image = pkg["render"]
+        if self.random_bg:
+            m = self.alpha_masks[v]
+            gt = gt * m + pkg["bg_color"][:, None, None] * (1 - m)
         loss = (1.0 - self.lambda_dssim) * l1_loss(image, gt) + self.lambda_dssim * (1.0 - ssim(image, gt))
         if it > self.node_warm_up:
             loss = loss + self._regularisers(cam.fid, time_interval)

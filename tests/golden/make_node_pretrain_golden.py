@@ -46,6 +46,8 @@ CASES = {
                   opacity_reset_interval=5, densify_grad_threshold=0.0095, extent=4.0, seed=3, width=32, rotation_lr=0.0, opacity_lr=0.05),
     "clone": dict(node_num=16, n_points=120, views=5, S=36, node_warm_up=3, sampling_at=9, iterations=13, densify_interval=4,
                   opacity_reset_interval=6, densify_grad_threshold=0.008, extent=60.0, seed=8, width=32, rotation_lr=0.0, opacity_lr=1.0),
+    "masks": dict(node_num=16, n_points=120, views=5, S=36, node_warm_up=3, sampling_at=7, iterations=10, densify_interval=4,
+                  opacity_reset_interval=6, densify_grad_threshold=0.002, extent=60.0, seed=8, width=32, rotation_lr=0.0, opacity_lr=0.05, masks=True),
     "default": dict(node_num=24, n_points=160, views=6, S=40, node_warm_up=4, sampling_at=10, iterations=15, densify_interval=3,
                     opacity_reset_interval=5, densify_grad_threshold=0.0095, extent=4.0, seed=3, width=32, rotation_lr=0.002, opacity_lr=0.05),
 }
@@ -164,19 +166,22 @@ def run(case):
     c = CASES[case]
     tu, gm, dm, ref_renderer, lu = import_reference_stack()
     cams, targets, pts = scene_inputs(case)
-    views = [SimpleNamespace(**cam._asdict(), original_image=targets[k], gt_alpha_mask=None, image_name="v%d" % k, flow_dirs=[])
+    masks = alpha_masks(targets) if c.get("masks") else [None] * len(cams)
+    views = [SimpleNamespace(**cam._asdict(), original_image=targets[k], gt_alpha_mask=masks[k], image_name="v%d" % k, flow_dirs=[])
              for k, cam in enumerate(cams)]
     opt = SimpleNamespace(
         progressive_train_node=False, progressive_stage_steps=3000, progressive_stage_ratio=0.2, node_warm_up=c["node_warm_up"],
         iterations_node_sampling=c["sampling_at"], iterations_node_rendering=c["iterations"], lambda_dssim=0.2, no_arap_loss=False,
-        gt_alpha_mask_as_scene_mask=False, gt_alpha_mask_as_dynamic_mask=False, densification_interval=c["densify_interval"],
+        gt_alpha_mask_as_scene_mask=bool(c.get("masks")), gt_alpha_mask_as_dynamic_mask=False, densification_interval=c["densify_interval"],
         opacity_reset_interval=c["opacity_reset_interval"], densify_grad_threshold=c["densify_grad_threshold"], densify_from_iter=500,
         node_max_num_ratio_during_init=16, deform_downsamp_strategy="samp_hyper", deform_downsamp_with_dynamic_mask=False,
         percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30_000,
         deform_lr_max_steps=40_000, feature_lr=0.004, opacity_lr=c["opacity_lr"], scaling_lr=0.002, rotation_lr=c["rotation_lr"], deform_lr_scale=1.0)
     rec = Recorder(c["seed"] + 100)
     saved = (torch.rand, torch.normal, torch.randint, torch.Tensor.to)
+    rand_like = torch.rand_like
     torch.rand, torch.normal, torch.randint = rec.rand, rec.normal, rec.randint
+    torch.rand_like = lambda t, **k: rec.rand(*t.shape)        # the random background of render() (gaussian_renderer/__init__.py:58)
     torch.Tensor.to = lambda self, *a, **k: self if (a and isinstance(a[0], str) and a[0].startswith("cuda")) else saved[3](self, *a, **k)
     losses, counts = [], []
     backward = torch.Tensor.backward
@@ -263,8 +268,14 @@ def run(case):
                 lr_gs=np.array([g_["lr"] for g_ in gs.optimizer.param_groups]))
     finally:
         torch.rand, torch.normal, torch.randint, torch.Tensor.to = saved
+        torch.rand_like = rand_like
         torch.Tensor.backward = backward
     return losses, per_it, rec.log, out
+
+
+def alpha_masks(targets):
+    """Ground-truth masks [1,H,W] of the views: where the target's blobs are, with a soft edge."""
+    return [(t.sum(0, keepdim=True) * 4.0).clamp(0, 1) for t in targets]
 
 
 def main():

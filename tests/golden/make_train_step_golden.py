@@ -207,9 +207,7 @@ def main(variant="default"):
     np.savez_compressed(os.path.join(HERE, "train_step_golden.npz" if variant == "default" else "train_step_golden_%s.npz" % variant), **out)
 
 
-def alpha_masks(targets):
-    """Ground-truth masks [1,H,W] of the views: where the target's blobs are (a soft edge, like an anti-aliased alpha channel)."""
-    return [(t.sum(0, keepdim=True) * 4.0).clamp(0, 1) for t in targets]
+from make_node_pretrain_golden import alpha_masks  # noqa: E402,F401  (ground-truth masks of the views, shared with the node stage's golden)
 
 
 if __name__ == "__main__":
