@@ -944,6 +944,16 @@ __device__ __forceinline__ void bwd_quadrant(const BlendBwdArgs& a, int tile, in
         }
         const int last = inside ? (int)a.n_contrib[slot_px] : 0;
         const int medc = inside ? (int)a.n_contrib[plane + slot_px] : 0;
+        // A pixel nothing contributed to never uses its gradient in the reference (backward.cu:283-300: the loop over its contributors is
+        // empty), whatever that gradient is -- and PyTorch hands such pixels NaN: the reference's own render() divides the depth map by an
+        // alpha of 0 there (gaussian_renderer/__init__.py:186-187; 0 / 0 in the division's backward).  Here the lanes of a visit multiply
+        // before they mask, so the value must not be read at all.
+        if (last == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) gpix[c] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) goth[c] = 0.f;
+        }
         pixbwd_init_affine(st, inside ? a.final_T[slot_px] : 0.f, a.final_T[plane + slot_px], a.final_T[2 * plane + slot_px], last, medc, gpix,
                            goth, a.bg);
     }

@@ -670,3 +670,57 @@ def test_uhd_images_bin_in_lds_with_the_order_rider(H, W):
     orc = oracle_from_case(case)
     assert np.array_equal(cap["radii"], orc.radii)
     img_close(cap["color"], orc.color, "color", max_bad_frac=3e-5, hard=5e-3)       # observed 7.9e-6, max 1.5e-3
+
+
+def test_backward_ignores_the_gradient_of_pixels_without_contributors():
+    """The reference never reads dL/dpixel where nothing contributed (backward.cu:283-300: the loop over a pixel's contributors is
+    empty) -- and PyTorch fills exactly those pixels with NaN when the caller is the reference's own render(): it divides the depth
+    map by an alpha of 0 there (gaussian_renderer/__init__.py:186-187; the division's backward is 0 / 0).  The HIP backward multiplies
+    before it masks, so it must not read such a pixel's gradient at all: NaN cotangents there change nothing, and the full
+    render() + PyTorch-loss path a user of the operator runs gives finite gradients equal to the oracle path's."""
+    from gpu_utils import run_hip
+    from scene_utils import small_case
+    case = small_case(P=40, H=64, W=64, seed=3, scale_mul=0.12)         # a sparse scene: most of the image is empty
+    rng = np.random.RandomState(0)
+    gc = rng.standard_normal((3, 64, 64)).astype(np.float32)
+    go = rng.standard_normal((8, 64, 64)).astype(np.float32)
+    base = run_hip(case, gc, go)
+    empty = base["allmap"][1] == 0.0                                      # alpha exactly 0: no contributor
+    assert 0.2 < empty.mean() < 0.98, float(empty.mean())
+    gc_nan, go_nan = gc.copy(), go.copy()
+    gc_nan[:, empty] = np.nan
+    go_nan[:, empty] = np.nan
+    poisoned = run_hip(case, gc_nan, go_nan)
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dsh"):
+        assert np.isfinite(poisoned[k]).all(), k
+        np.testing.assert_allclose(poisoned[k], base[k], rtol=2e-5, atol=1e-7, err_msg=k)   # (float atomics: order of arrival)
+
+
+def test_render_and_pytorch_loss_through_the_operator_gives_finite_gradients():
+    """dgs_amd.render.render (the restatement of the reference's render(), post-processing in PyTorch) + training_loss on the device:
+    what a user of the reference runs on top of the operator.  Gradients finite and equal to the same path over the CPU oracle."""
+    import dgs_amd.render as render_mod
+    from dgs_amd.cameras import orbit_cameras
+    from dgs_amd.losses import training_loss
+    from dgs_amd.model import SurfelModel
+    from dgs_amd.synthetic import make_scene, target_image
+    from oracle_raster_op import OracleRasterizer
+    scene = make_scene(60, seed=2)
+    scene = scene._replace(log_scale=scene.log_scale - 1.6, opacity_logit=scene.opacity_logit + 2.0)   # small splats: most pixels stay empty
+    cam = orbit_cameras(6, 72, 72)[1]
+    gt = target_image(72, 72, seed=4)
+    grads = {}
+    for tag, dev, rcls in (("cpu", torch.device("cpu"), OracleRasterizer), ("hip", torch.device("cuda:0"), None)):
+        pc = SurfelModel(scene).to(dev)
+        pkg = render_mod.render(cam.to(dev), pc, torch.zeros(3, device=dev), rasterizer_cls=rcls)
+        if tag == "hip":
+            assert float((pkg["alpha"] == 0).float().mean()) > 0.1       # there ARE empty pixels: the division by alpha meets 0 / 0
+        loss = training_loss(pkg, gt.to(dev), lambda_normal=0.02, lambda_dist=1000.0)
+        loss.backward()
+        grads[tag] = {n: p.grad.detach().cpu() for n, p in pc.named_parameters() if p.grad is not None}
+        grads[tag]["means2D"] = pkg["viewspace_points"].grad.detach().cpu()
+    for n, gcpu in grads["cpu"].items():
+        ghip = grads["hip"][n]
+        assert torch.isfinite(ghip).all(), n
+        scale = float(gcpu.abs().max()) + 1e-12
+        assert float((ghip - gcpu).abs().max()) <= 2e-3 * scale + 1e-9, (n, float((ghip - gcpu).abs().max()), scale)

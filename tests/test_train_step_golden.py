@@ -212,3 +212,17 @@ def test_joint_stage_on_the_hip_path_follows_the_reference_train_step():
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-2)                         # observed: 1e-2 at the last iteration
     assert np.abs(rows[:, 1] / ref[:, 1] - 1).max() < 0.03 and rows[:, 2].tolist() == ref[:, 2].tolist() and rows[:, 3].tolist() == ref[:, 3].tolist()
     np.testing.assert_allclose(rows[:, 6], ref[:, 6], rtol=5e-3)
+
+
+@pytest.mark.gpu
+def test_joint_stage_with_the_mask_terms_on_the_device():
+    """The mask terms through the HIP operator (the motion render uses its precomputed-colour input and that input's gradient), the
+    step on the unfused eager path with the flat Adam kernel: the reference's first iterations to float rounding, then within a percent."""
+    tr, g, losses, rows, logs = _run(torch.device("cuda:0"), None, fused=True, strict=False, masks=True)
+    ref = g["per_it"]
+    np.testing.assert_allclose(losses[:2], g["losses"][:2], rtol=2e-5)
+    assert rows[:5, :4].astype(int).tolist() == ref[:5, :4].astype(int).tolist()
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-2)
+    assert np.abs(rows[:, 1] / ref[:, 1] - 1).max() < 0.03 and rows[:, 3].tolist() == ref[:, 3].tolist()
+    s = tr.surfels
+    assert float(s.feature.detach()[s.alive][:, 8].std()) > 0.3
