@@ -2231,7 +2231,9 @@ int dgs_adam_step_sum2(int nseg, float* const* params, const long long* offsets,
         sg.lr_final[s] = lrs_final ? lrs_final[s] : lrs[s];
         sg.sched_steps[s] = sched_steps ? sched_steps[s] : 0.0f;
         sg.t_origin[s] = step_origins ? step_origins[s] : 0.0f;
-        if (!(sg.t_origin[s] >= 0.0f)) return fail(-1, "dgs_adam_step_origin: negative step origin");
+        // (a NEGATIVE origin is a parameter that arrives with steps already taken elsewhere: the deformation model's optimiser runs on
+        // from the node pre-training stage, Trainer.adopt_deform_state)
+        if (sg.t_origin[s] != sg.t_origin[s]) return fail(-1, "dgs_adam_step_origin: step origin is NaN");
         if (sg.sched_steps[s] > 0.0f && !(lrs[s] > 0.0f && sg.lr_final[s] > 0.0f))
             return fail(-1, "dgs_adam_step_sched: a scheduled segment needs positive initial and final rates");
     }

@@ -1642,7 +1642,10 @@ class Trainer:
             # `feature` and the deformation parameters join the optimisation now: torch.optim.Adam (the reference, train_gui.py:281-285,
             # 427-432) has skipped them so far, so their own step count starts at 1 -- not at the run's count, which would switch
             # the bias corrections off for moments that start from zero (3-6 x the learning rate for the first few hundred steps)
-            self.opt_surfels.set_origin(self.n_surfel_params - 1, None, float(self.opt_surfels.t.item()))
+            t_now = float(self.opt_surfels.t.item())
+            self.opt_surfels.set_origin(self.n_surfel_params - 1, None, t_now)
+            for i, steps in getattr(self, "_adopted_steps", {}).items():   # ... or continues where an adopted optimiser stood (adopt_deform_state)
+                self.opt_surfels.set_origin(i, i + 1, t_now - steps)
         self.warmup, self.lambda_normal, self.lambda_dist = new
         if self._graph:
             self._graph = None
@@ -1851,6 +1854,7 @@ class Trainer:
             m.copy_(st["exp_avg"])
             v.copy_(st["exp_avg_sq"])
             flat.set_origin(i, i + 1, float(self._steps_done) - float(st["step"]))   # bias corrections continue at step + 1
+            self.__dict__.setdefault("_adopted_steps", {})[i] = float(st["step"])   # (the end of the warm-up re-bases the origins: set_regime)
             n += 1
         return n
 

@@ -138,7 +138,8 @@ int dgs_adam_step_zero(int nseg, float* const* params, const long long* offsets,
  * max(step_count - step_origins[s], 1).  torch.optim.Adam keeps a step count per parameter and skips parameters whose .grad is
  * None, so a parameter that joins the optimisation late -- the reference's deformation network, control nodes and `feature`
  * after the warm-up (train_gui.py:281-285, 427-432) -- starts at step 1; pass the run's step count at that moment as its origin.
- * Learning-rate schedules keep using the run's counter. */
+ * A negative origin is a parameter that arrives with steps already taken (the deformation model's optimiser runs on from the node
+ * pre-training stage); NaN is rejected.  Learning-rate schedules keep using the run's counter. */
 int dgs_adam_step_origin(int nseg, float* const* params, const long long* offsets, const float* lrs, const float* lrs2,
                          const int* periods, const int* splits, const float* lrs_final, const float* sched_steps, float sched_t0,
                          const float* step_origins, float grad_scale, float* grad, int zero_grad, float* exp_avg, float* exp_avg_sq,

@@ -316,3 +316,41 @@ def test_stage_under_data_parallelism_runs_on_rank_0_and_is_broadcast():
         p.join(120)
         assert p.exitcode == 0
     assert same and n_losses == 7 and n_state > 1000
+
+
+@pytest.mark.gpu
+def test_fit_on_the_device_continues_the_stage_optimiser_in_the_flat_adam_state(tmp_path):
+    """fit(node_pretrain=...) on the device with the captured step: the node stage runs eagerly over the HIP operator, its Adam state is
+    loaded into the flat Adam kernel's moments with per-parameter step origins (Trainer.adopt_deform_state) BEFORE the capture, and the
+    joint stage trains on from there."""
+    from dgs_amd import fit as fit_mod
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    dev = torch.device("cuda:0")
+    data = str(tmp_path / "scene")
+    write_dynamic_dnerf(data, n_train=16, n_test=2, H=96, W=96, device=dev)
+    seen = {}
+    real = fit_mod.pretrain_nodes
+
+    def spy(deform, *a, **k):
+        pre = real(deform, *a, **k)
+        seen["steps"] = {n: float(pre.opt_deform.state[p]["step"]) for n, p in deform.named_parameters() if pre.opt_deform.state.get(p)}
+        seen["m_warp"] = pre.opt_deform.state[deform.network.gaussian_warp.weight]["exp_avg"].detach().clone()
+        return pre
+    fit_mod.pretrain_nodes = spy
+    try:
+        tr, losses = fit_mod.fit(data, str(tmp_path / "model"), iterations=60, device=dev, num_pts=3000, node_num=64, seed=0, warm_up=20, regularize_from=40,
+                                 densify_from=30, densify_interval=20, opacity_reset_interval=1000,
+                                 node_pretrain=dict(iterations=120, node_warm_up=30, sampling_at=90, densify_interval=20, opacity_reset_interval=60))
+    finally:
+        fit_mod.pretrain_nodes = real
+    assert tr._graph and len(losses) == 60 and np.isfinite(losses).all()
+    flat = tr.opt_surfels
+    idx = {id(p): i for i, p in enumerate(flat.params)}
+    i_warp = idx[id(tr.deform.network.gaussian_warp.weight)]
+    n_stage = seen["steps"]["network.gaussian_warp.weight"]
+    assert n_stage == 120 - 1 - 30 - 1                      # iterations 30 .. 118 without the sampling iteration 90
+    # the deformation rests during the joint stage's warm-up (19 steps of the run) and then continues at step n_stage + 1
+    assert float(flat._origin[i_warp]) == 19.0 - n_stage
+    assert float(flat._origin[idx[id(tr.surfels._xyz)]]) == 0.0
+    assert float(seen["m_warp"].abs().sum()) > 0
+    assert float(np.mean(losses[-10:])) < float(np.mean(losses[:10])) * 1.5
