@@ -222,7 +222,7 @@ def restore(model_path, iteration=-1, device="cpu", packed_sh=False, slots=None,
     """Surfels + deformation of a checkpoint directory written by `save` (or by the reference)."""
     it = dio.search_for_max_iteration(os.path.join(model_path, "point_cloud")) if iteration == -1 else iteration
     scene = dio.load_surfels(os.path.join(model_path, "point_cloud/iteration_{}".format(it), "point_cloud.ply"))
-    surfels = SurfelModel(scene, packed_sh=packed_sh, capacity=slots).to(device)
+    surfels = SurfelModel(scene, packed_sh=packed_sh, capacity=slots, with_motion_mask=scene.feature.shape[1] == 9).to(device)
     deform = ControlNodes(node_num=node_num, K=3, hyper_dim=8, local_frame=True).to(device)
     if not dio.load_deform(deform, model_path, iteration, pad_to=64 if (packed_sh and torch.device(device).type == "cuda") else 1):
         raise FileNotFoundError("no deform.pth under %s" % model_path)

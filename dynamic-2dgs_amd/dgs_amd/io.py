@@ -115,9 +115,10 @@ def save_surfels(model, path):
     write_ply(path, vertex)
 
 
-def load_surfels(path, sh_degree=3, fea_dim=8) -> SurfelScene:
+def load_surfels(path, sh_degree=3, fea_dim=None) -> SurfelScene:
     """GaussianModel.load_ply (gaussian_model.py:263-306): the pre-activation parameters as a SurfelScene
-    (feed it to SurfelModel(scene, capacity=...))."""
+    (feed it to SurfelModel(scene, capacity=...)).  fea_dim: the model's feature width (the reference zero-fills up to it: 8 hyper
+    coordinates, 9 with a motion mask); None = as many `fea_*` properties as the file holds, at least 8."""
     v = read_ply(path)
     names = v.dtype.names
     col = lambda n: np.asarray(v[n], np.float32)
@@ -129,8 +130,11 @@ def load_surfels(path, sh_degree=3, fea_dim=8) -> SurfelScene:
     f_rest = np.stack([col(n) for n in rest], axis=1).reshape(xyz.shape[0], 3, (sh_degree + 1) ** 2 - 1)
     scales = np.stack([col(n) for n in names if n.startswith("scale_")], axis=1)
     rots = np.stack([col(n) for n in names if n.startswith("rot")], axis=1)
+    fea_names = [n for n in names if n.startswith("fea")]
+    if fea_dim is None:
+        fea_dim = max(8, len(fea_names))
     feas = np.zeros((xyz.shape[0], fea_dim), np.float32)
-    for i, n in enumerate(n for n in names if n.startswith("fea")):
+    for i, n in enumerate(fea_names):
         feas[:, i] = col(n)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32))
     return SurfelScene(t(xyz), t(scales), t(rots), t(col("opacity")[:, None]), t(f_dc).transpose(1, 2).contiguous(),

@@ -354,3 +354,23 @@ def test_fit_on_the_device_continues_the_stage_optimiser_in_the_flat_adam_state(
     assert float(flat._origin[idx[id(tr.surfels._xyz)]]) == 0.0
     assert float(seen["m_warp"].abs().sum()) > 0
     assert float(np.mean(losses[-10:])) < float(np.mean(losses[:10])) * 1.5
+
+
+def test_fit_with_the_mask_options_end_to_end_on_cpu(tmp_path, monkeypatch):
+    """fit(mask_as_scene, mask_as_dynamic, random_bg_color, with_motion_mask) on the tiny D-NeRF dataset (its PNGs carry an alpha channel):
+    the options reach the trainer, the motion-mask column exists and trains, the run is finite."""
+    import shutil
+    import dgs_amd.render as render_mod
+    from dgs_amd import fit as fit_mod
+    from oracle_raster_op import OracleRasterizer
+    monkeypatch.setattr(render_mod, "GaussianRasterizer", OracleRasterizer)
+    root = tmp_path / "scene"
+    shutil.copytree(os.path.join(HERE, "golden", "dnerf_tiny"), root)
+    tr, losses = fit_mod.fit(str(root), str(tmp_path / "out"), iterations=5, device="cpu", densify_from=100, slots=260, node_num=16, num_pts=200,
+                             rasterizer_cls=OracleRasterizer, warm_up=2, mask_as_scene=True, mask_as_dynamic=True, random_bg_color=True, with_motion_mask=True)
+    s = tr.surfels
+    assert tr._mask_terms() and tr.alpha_masks is not None and tr.alpha_masks[0].shape[0] == 1
+    assert s.feature.shape[1] == 9 and float(s.feature.detach()[s.alive][:, 8].abs().max()) > 0        # the mask column moved off its zero initialisation
+    assert len(losses) == 5 and np.isfinite(losses).all()
+    saved = fit_mod.restore(str(tmp_path / "out"), node_num=16)[0]
+    assert saved.feature.shape[1] == 9
