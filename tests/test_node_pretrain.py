@@ -374,3 +374,27 @@ def test_fit_with_the_mask_options_end_to_end_on_cpu(tmp_path, monkeypatch):
     assert len(losses) == 5 and np.isfinite(losses).all()
     saved = fit_mod.restore(str(tmp_path / "out"), node_num=16)[0]
     assert saved.feature.shape[1] == 9
+
+
+@pytest.mark.gpu
+def test_fit_with_the_motion_mask_term_on_the_device_captures_when_the_term_ends(tmp_path, monkeypatch):
+    """fit(mask_as_dynamic, with_motion_mask) on the device: the step runs eagerly (a second render per step, PyTorch loss) while the
+    motion-mask weight is non-zero and is captured from the iteration where it reaches zero (10001 in the reference's schedule;
+    shortened here)."""
+    from dgs_amd.fit import fit
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    from dgs_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    data = str(tmp_path / "scene")
+    write_dynamic_dnerf(data, n_train=16, n_test=2, H=96, W=96, device=dev)
+    monkeypatch.setattr(Trainer, "MOTION_MASK_STEPS", (0, 40, 41))
+    states = {}
+    tr, losses = fit(data, str(tmp_path / "model"), iterations=70, device=dev, num_pts=3000, node_num=64, seed=0, warm_up=10, regularize_from=30,
+                     densify_from=20, densify_interval=20, opacity_reset_interval=1000, mask_as_dynamic=True, with_motion_mask=True,
+                     on_iteration=lambda it, t: states.__setitem__(it, (bool(t._graph), t._mask_terms())))
+    assert states[5] == (False, True) and states[39] == (False, True) and states[45] == (True, False) and states[70] == (True, False)
+    assert len(losses) == 70 and np.isfinite(losses).all()
+    s = tr.surfels
+    col = s.feature.detach()[s.alive][:, 8]
+    assert s.feature.shape[1] == 9 and float(col.abs().max()) > 0 and bool(torch.isfinite(col).all())
+    assert float(np.mean(losses[-10:])) < float(np.mean(losses[:10]))
