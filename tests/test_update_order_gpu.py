@@ -1,0 +1,96 @@
+"""-m gpu: fit(reference_update_order=True) on the device -- the surfels held across densifying iterations (Trainer.hold_surfels /
+release_surfels) under the captured step and under the sharded data-parallel step.  What the switch does is pinned against the
+reference's GUI.train_step on the CPU (tests/test_train_step_golden.py); here: the captured step gives the eager step's result bit for
+bit, and two ranks stay bit-identical replicas."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(iterations=260, num_pts=5000, node_num=128, seed=0, warm_up=100, regularize_from=180, densify_from=100, densify_interval=50,
+          opacity_reset_interval=200, reference_update_order=True)     # densifies at 150, 200 (+ opacity reset), 250
+
+
+def test_held_surfels_under_the_captured_step_match_the_eager_step_bit_for_bit(tmp_path):
+    from dgs_amd.fit import fit
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    dev = torch.device("cuda:0")
+    data = str(tmp_path / "scene")
+    write_dynamic_dnerf(data, n_train=24, n_test=2, H=128, W=128, device=dev)
+    runs = {}
+    for tag, graph in (("eager", False), ("captured", True)):
+        held = []
+        tr, losses = fit(data, str(tmp_path / tag), device=dev, graph=graph, deterministic=True,
+                         on_iteration=lambda it, t: held.append((it, float(t.surfels._xyz.detach().double().abs().sum()))) if it in (149, 150) else None, **KW)
+        tr.set_deterministic(False)
+        assert bool(tr._graph) == graph
+        runs[tag] = (np.asarray(losses), torch.cat([p.detach().reshape(-1) for p in tr.bucket.params]).cpu(), held, tr.surfels.num_surfels)
+    (la, pa, ha, na), (lb, pb, hb, nb) = runs["eager"], runs["captured"]
+    assert len(la) == 260 and np.isfinite(la).all() and na == nb
+    assert np.array_equal(la, lb), int(np.argmax(la != lb))
+    assert torch.equal(pa, pb)
+    # iteration 150 densifies: behind its step the surfels are where iteration 149 left them (the hook runs in front of the density control)
+    assert ha == hb and ha[0][1] == ha[1][1]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, data, out_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DEBUG_CLR_GRAPH_PACKET_CAPTURE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "dynamic-2dgs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from dgs_amd.fit import fit
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        seen = []
+        tr, losses = fit(data, os.path.join(out_dir, "model_%d" % rank), device=dev,
+                         on_iteration=lambda it, t: seen.append((bool(t._shard_ok()), bool(t._graph))) if it % 50 == 0 else None, **KW)
+        tr.settle_shards()
+        torch.cuda.synchronize()
+        n_sh = tr.n_sh
+        state = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params] + [tr.opt_surfels.exp_avg[:n_sh], tr.opt_surfels.exp_avg_sq[:n_sh],
+                                                                                  tr.surfels.alive.float()]).cpu()
+        gp = [torch.zeros_like(state) for _ in range(world)]
+        dist.all_gather(gp, state)
+        if rank == 0:
+            q.put((all(torch.equal(gp[0], g) for g in gp), bool(torch.isfinite(state).all()), [float(l) for l in losses], seen, int(tr.surfels.num_surfels)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_held_surfels_under_the_sharded_data_parallel_step_keep_the_replicas_identical(tmp_path):
+    """Two ranks (gloo, sharing the GPU): the hold gathers the SH moments that live on their owners, the release puts complete rows back on
+    every rank; parameters, gathered moments and the alive mask end bit-identical."""
+    from dgs_amd.synthetic import write_dynamic_dnerf
+    dev = torch.device("cuda:0")
+    data = str(tmp_path / "scene")
+    write_dynamic_dnerf(data, n_train=24, n_test=2, H=128, W=128, device=dev)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, data, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, finite, losses, seen, live = q.get()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert same and finite and len(losses) == 260 and np.isfinite(losses).all() and live > 1000
+    assert all(ok and g for ok, g in seen), seen       # the sharded, captured split step all the way
