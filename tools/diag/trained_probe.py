@@ -46,7 +46,7 @@ def hook(it, t):
         a = s_.alive
         rec[it] = (t.overflow_recoveries, float(torch.exp(s_._scaling.detach()[a]).max()), float(torch.exp(s_._scaling.detach()[a]).mean()), float(s_.get_opacity.detach()[a].mean()))
 tr, losses = fit(os.path.join(tmp, "scene"), os.path.join(tmp, "model"), iterations=int(os.environ.get("ITERS", "10000")), device=dev, num_pts=P, node_num=512,
-                 seed=int(os.environ.get("SEED", "0")), warm_up=3000, regularize_from=8000, node_densify_at=10 ** 9, deterministic=os.environ.get("DET", "1") == "1", log=lines.append, reference_update_order=order, on_iteration=hook, graph=None if os.environ.get("GRAPH", "1") == "1" else False,
+                 seed=int(os.environ.get("SEED", "0")), warm_up=int(os.environ.get("WARM", "3000")), regularize_from=8000, node_densify_at=10 ** 9, deterministic=os.environ.get("DET", "1") == "1", log=lines.append, reference_update_order=order, on_iteration=hook, graph=None if os.environ.get("GRAPH", "1") == "1" else False,
                  list_capacity=int(os.environ["CAP"]) if os.environ.get("CAP") else None)
 keep = [l for l in lines if "cloned" in l]
 for l in (lines[-12:] if os.environ.get("TAIL") else keep[:3] + keep[24:36] + keep[-14:]):
