@@ -151,3 +151,64 @@ def test_elastic_and_acc_loss_match_reference():
     b = arap.elastic_loss(d, t=torch.tensor([0.4]), delta_t=0.02, generator=torch.Generator().manual_seed(5))
     c = arap.acc_loss(d, t=torch.tensor([0.4]), generator=torch.Generator().manual_seed(6))
     assert float(a) == float(b) and torch.isfinite(c)
+
+
+def test_graph_distances_and_rotation_term_match_reference():
+    """The pieces off the default training path (tests/golden/make_floyd_golden.py, imported reference): Floyd-Warshall graph distances
+    (utils/time_utils.py:1122-1131), graph skinning weights (:969-984), connectivity from trajectories / in 'floyd' mode
+    (utils/deform_utils.py:58-110), and arap_loss_with_rot (time_utils.py:1035-1042 over deform_utils.py:246-289) with its gradients."""
+    g = np.load(os.path.join(HERE, "golden", "floyd_golden.npz"))
+    cur, x = torch.from_numpy(g["cur_node"].copy()), torch.from_numpy(g["x"].copy())
+    for K in (2, 4):
+        d = arap.geodesic_distance_floyd(cur, K=K).numpy()
+        assert np.array_equal(d, g["geo_K%d" % K]), K              # same operations in the same order: bit for bit
+        assert np.array_equal(d, d.T) and (np.diag(d) == 0).all()
+    assert np.isinf(g["geo_K2"]).any() and not np.isinf(g["geo_K4"]).any()   # the fixture has a disconnected and a connected graph
+    cache = {}
+    w, dist, idx = arap.nn_weight_floyd(x, cur, K=8, GraphK=3, temperature=1e-3, t0=torch.tensor([0.3]), cache=cache)
+    assert np.array_equal(idx.numpy(), g["floyd_idx"]) and np.array_equal(dist.numpy(), g["floyd_d"])
+    np.testing.assert_allclose(w.numpy(), g["floyd_w"], rtol=1e-6, atol=1e-30)
+    held = cache["nn_dist"]
+    arap.nn_weight_floyd(x, cur + 1.0, K=8, GraphK=3, temperature=1e-3, t0=torch.tensor([0.305]), cache=cache)
+    assert cache["nn_dist"] is held                               # within 1e-2 of the cached time: the graph is not rebuilt
+    arap.nn_weight_floyd(x, cur * 2.0, K=8, GraphK=3, temperature=1e-3, t0=torch.tensor([0.32]), cache=cache)
+    assert cache["nn_dist"] is not held and torch.allclose(cache["nn_dist"], 2.0 * held)
+    w, dist, idx = arap.nn_weight_floyd(cur, cur, K=9, GraphK=4, temperature=1e-1, XisNode=True, t0=torch.tensor([0.3]))
+    assert np.array_equal(idx.numpy(), g["floyd_self_idx"]) and np.array_equal(dist.numpy(), g["floyd_self_d"])
+    np.testing.assert_allclose(w.numpy(), g["floyd_self_w"], rtol=1e-6, atol=1e-30)
+    assert not (idx == torch.arange(cur.shape[0])[:, None]).any()  # the node itself is skipped
+    traj = torch.from_numpy(g["traj"].copy())
+    rad = torch.from_numpy(g["node_radius_conn"].copy())
+    for tag, kw in (("nn", dict(radius=0.15, K=6, trajectory=traj, GraphK=3)), ("floyd", dict(radius=0.15, K=6, trajectory=traj, mode="floyd", GraphK=3)),
+                    ("pts_floyd", dict(radius=0.15, K=6, mode="floyd", GraphK=3)), ("rad", dict(radius=0.2, K=6, node_radius=rad, adaptive_weighting=False))):
+        ii, jj, nn, weight = arap.connectivity_from_points(cur, **kw)
+        for name, v in (("ii", ii), ("jj", jj), ("nn", nn)):
+            assert np.array_equal(v.numpy(), g["conn_%s_%s" % (tag, name)]), (tag, name)
+        np.testing.assert_allclose(weight.numpy(), g["conn_%s_w" % tag], rtol=1e-6, equal_nan=True)
+    # the reference's adaptive weights as soon as ANY neighbour is dropped (the mean distance is inf): NaN in the rows with a dropped
+    # neighbour, uniform 1 / K in the others -- kept as it is
+    wf = g["conn_floyd_w"]
+    assert np.isnan(wf).any() and np.isfinite(g["conn_rad_w"]).all() and np.allclose(wf[np.isfinite(wf)], 1.0 / 6)
+    # ---- arap_loss_with_rot: absolute node rotations and the residual default
+    for tag, as_res in (("rot", False), ("norot", True)):
+        M = g["ball"].shape[0]
+        d = ControlNodes(node_num=M, K=3, hyper_dim=8, local_frame=True)
+        fill_params(d)
+        with torch.no_grad():
+            d.network.gaussian_warp.weight.mul_(50.0)
+            d.nodes.copy_(torch.cat([torch.from_numpy(g["ball"].copy()), 0.01 * torch.ones(M, 8)], -1))
+            d._node_radius.copy_(torch.from_numpy(g[tag + "_node_radius_raw"].copy()))
+        loss = arap.arap_loss_with_rot(d, d_rot_as_res=as_res, t_samp=torch.from_numpy(g[tag + "_t_samp"].copy()), fid=int(g[tag + "_fid"]))
+        d.zero_grad()
+        loss.backward()
+        want = float(g[tag + "_loss"])
+        assert abs(float(loss) - want) <= 2e-4 * abs(want), (tag, float(loss), want)
+        gw, ww = d.network.gaussian_warp.weight.grad.numpy(), g[tag + "_grad_warp"]
+        assert np.abs(gw - ww).max() <= 2e-3 * np.abs(ww).max(), (tag, np.abs(gw - ww).max(), np.abs(ww).max())
+        if not as_res:
+            gr, wr = d.network.gaussian_rotation.weight.grad.numpy(), g[tag + "_grad_rot"]
+            assert np.abs(wr).max() > 0 and np.abs(gr - wr).max() <= 2e-3 * np.abs(wr).max(), (np.abs(gr - wr).max(), np.abs(wr).max())
+    # drawing its own samples: reproducible per generator
+    a = arap.arap_loss_with_rot(d, t_samp_num=16, generator=torch.Generator().manual_seed(5))
+    b = arap.arap_loss_with_rot(d, t_samp_num=16, generator=torch.Generator().manual_seed(5))
+    assert float(a) == float(b)
