@@ -74,7 +74,11 @@ def _worker(rank, world, port, data, out_dir, q, extra):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("extra", [{}, {"node_pretrain": dict(iterations=100, node_warm_up=25, sampling_at=75, densify_interval=20, opacity_reset_interval=50)}],
+# (second case: no opacity reset in the joint stage -- behind the short node stage the opacities need more than the 50 iterations between
+# the reset at 200 and the pruning at 250 to come back above the threshold in some runs of the float-atomic backward, and a run that prunes
+# every surfel compares nothing: 2 of 4 runs ended with 0 / 34 live surfels)
+@pytest.mark.parametrize("extra", [{}, {"node_pretrain": dict(iterations=100, node_warm_up=25, sampling_at=75, densify_interval=20, opacity_reset_interval=50),
+                                        "opacity_reset_interval": 1000}],
                          ids=["update_order", "update_order+node_stage"])
 def test_held_surfels_under_the_sharded_data_parallel_step_keep_the_replicas_identical(tmp_path, extra):
     """Two ranks (gloo, sharing the GPU): the hold gathers the SH moments that live on their owners, the release puts complete rows back on
