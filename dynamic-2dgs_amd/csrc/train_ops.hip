@@ -1905,16 +1905,12 @@ __global__ void step_guard_kernel(const int* __restrict__ skip, float* __restric
 // backward chain that runs beside the update (the step's critical path)
 typedef float adam_f4 __attribute__((ext_vector_type(4)));
 template <int NT>
-__global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, float* __restrict__ grad,
-                                                   float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step_count,
-                                                   float b1, float b2, float eps, const int* __restrict__ skip, const float* __restrict__ grad2)
+__device__ __forceinline__ void adam_block(const AdamSegs& sg, const int2 pl, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                           const float t, float b1, float b2, float eps, const bool sk, const float* __restrict__ grad2)
 {
-    const bool sk = skip && skip[0] != 0;   // guarded step (see step_guard_kernel)
-    if (sk && !sg.zero_grad) return;
-    const int2 pl = plan[blockIdx.x];            // (segment, first element of this block inside the segment)
+    // pl = (segment, first element of this block inside the segment)
     const int s = pl.x;
     const long long seg_len = sg.off[s + 1] - sg.off[s];
-    const float t = step_count[0];
     const float ts = fmaxf(t - sg.t_origin[s], 1.0f);
     const float bc1 = 1.0f - powf(b1, ts), bc2 = 1.0f - powf(b2, ts);
     float lr = sg.lr[s];
@@ -1984,6 +1980,18 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __re
             p[i] = pi;
         }
     }
+}
+
+// nblocks plan entries over gridDim.x workgroups (at most 4096 by default: see the launch)
+template <int NT>
+__global__ void __launch_bounds__(256) adam_kernel(AdamSegs sg, const int2* __restrict__ plan, int nblocks, float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, const float* __restrict__ step_count,
+                                                   float b1, float b2, float eps, const int* __restrict__ skip, const float* __restrict__ grad2)
+{
+    const bool sk = skip && skip[0] != 0;   // guarded step (see step_guard_kernel)
+    if (sk && !sg.zero_grad) return;
+    const float t = step_count[0];
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) adam_block<NT>(sg, plan[b], grad, m, v, t, b1, b2, eps, sk, grad2);
 }
 
 long long adam_blocks(int nseg, const long long* off)
@@ -2260,14 +2268,18 @@ int dgs_adam_step_sum2(int nseg, float* const* params, const long long* offsets,
     const long long nb = adam_blocks(nseg, offsets);
     if (nb == 0) return 0;
     static const int nt = getenv("DGS_ADAM_NT") ? atoi(getenv("DGS_ADAM_NT")) : 1;   // default 1: -0.9 % per step (0.760 against 0.767 ms, three pairs); 2: noise
+    // grid cap: 16 workgroups per CU (two rounds of resident workgroups) walk the plan -- the surfel update beside the node-MLP
+    // backward chain: 0.754 against 0.763 ms per step (five pairs; 1024: +-0, 2048: 0.756, 6144 / 8192: +-0); DGS_ADAM_WGS=0: uncapped
+    static const long long cap = getenv("DGS_ADAM_WGS") ? atoll(getenv("DGS_ADAM_WGS")) : 4096;
+    const unsigned grid = (unsigned)(cap > 0 && cap < nb ? cap : nb);
     if (nt == 2)
-        hipLaunchKernelGGL(adam_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, grad, exp_avg,
+        hipLaunchKernelGGL(adam_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, (int)nb, grad, exp_avg,
                            exp_avg_sq, step_count, beta1, beta2, eps, skip, grad2);
     else if (nt == 1)
-        hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, grad, exp_avg,
+        hipLaunchKernelGGL(adam_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, (int)nb, grad, exp_avg,
                            exp_avg_sq, step_count, beta1, beta2, eps, skip, grad2);
     else
-        hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, grad, exp_avg,
+        hipLaunchKernelGGL(adam_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sg, (const int2*)plan, (int)nb, grad, exp_avg,
                            exp_avg_sq, step_count, beta1, beta2, eps, skip, grad2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-4, std::string("adam_kernel: ") + hipGetErrorString(e));
