@@ -430,7 +430,11 @@ def comm_levers(tr, args, world, device, ms_headline):
     if tr._graph:
         cap = tr._capacity
         try:
-            for name, conc in (("views_per_rank_2", False), ("views_per_rank_2_concurrent", True)):   # back to back | in flight at the same time (a lane each)
+            # back to back | in flight at the same time (a lane each).  The lanes' capture (alias modules, a rasterizer context and a stream per
+            # lane) is the one piece of this file that has never met RCCL with more than one rank: opt-in (DGS_LEVER_CONCURRENT=1), so that a
+            # first multi-GPU run cannot lose its headline line to the side measurement; the single-GPU line reports concurrent lanes anyway
+            kinds = (("views_per_rank_2", False),) + ((("views_per_rank_2_concurrent", True),) if os.environ.get("DGS_LEVER_CONCURRENT", "0") == "1" else ())
+            for name, conc in kinds:
                 tr.views_per_rank, tr.concurrent_views = 2, conc
                 tr._graph = None
                 tr.enable_graph(cap, validate=False)

@@ -83,7 +83,7 @@ def test_bench_eight_ranks_dry_run():
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DGS_DIST_BACKEND="gloo")
+                   DGS_DIST_BACKEND="gloo", DGS_LEVER_CONCURRENT="1")   # (the concurrent-lanes lever is opt-in at N > 1: covered here)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--drift-gap", "10"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=1500) for p in procs]
