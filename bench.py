@@ -33,6 +33,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 # ROCm 7.2 replays captured graphs through pre-recorded AQL packets by default; with this train step (memset nodes of
@@ -449,6 +450,31 @@ def comm_levers(tr, args, world, device, ms_headline):
     return res
 
 
+_WATCH = {"lock": threading.Lock(), "done": False, "timer": None}
+
+
+def arm_watchdog(headline, rank, seconds):
+    """Everything behind the timed region (communication report and its levers, drift window, roofline legs, twin check, CPU baseline) is a
+    side measurement, and some of it is first-contact code on a multi-GPU box.  If it has not finished after `seconds`, rank 0 prints the
+    HEADLINE line alone (same metric / value / config; the objects that were not measured are absent and `note` says why) and every rank
+    leaves: a collective that never returns must not cost the run its number.  Every rank arms its own timer right behind the barrier that
+    ends the timed region, so they fire together."""
+    def bail():
+        with _WATCH["lock"]:
+            if _WATCH["done"]:
+                return
+            _WATCH["done"] = True
+            if rank == 0:
+                print(json.dumps(dict(headline, note="measurements behind the timed region did not finish within %d s: headline only" % seconds)), flush=True)
+            sys.stderr.write("bench.py: watchdog after %d s (rank %d)\n" % (seconds, rank))
+            sys.stderr.flush()
+            os._exit(0)
+    t = threading.Timer(seconds, bail)
+    t.daemon = True
+    t.start()
+    _WATCH["timer"] = t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -582,6 +608,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     radius_headline = mean_radius(tr)
+    headline = {"metric": "train views/sec (fwd+bwd), 800x800, 200k surfels" if args.workload == "metric" else "train views/sec (fwd+bwd), %dx%d, %dk surfels" % (W, H, P // 1000),
+                "value": round(args.views_per_rank * world * args.steps / dt, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s: synthetic scene S(%d surfels, %dx%d, seed 0), full train step, 1 view per GPU per step" % (args.workload, P, W, H),
+                           "views_per_step": args.views_per_rank * world, "views_first_step": views_first_step, "parallelism": "dp%d" % world}}
+    arm_watchdog(headline, rank, int(os.environ.get("DGS_BENCH_WATCHDOG_S", "600")))
     comm = comm_report(tr, args, world, device, dt / args.steps * 1e3, split_choice) if world > 1 else None
 
     # ---- everything below is measured AFTER the headline and does not change it --------------------------------------------
@@ -823,7 +855,13 @@ def main():
             del tr
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(P, H, W)
-        print(json.dumps(out), flush=True)
+        with _WATCH["lock"]:
+            if _WATCH["done"]:
+                return
+            _WATCH["done"] = True
+            print(json.dumps(out), flush=True)
+    if _WATCH["timer"] is not None:
+        _WATCH["timer"].cancel()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -105,3 +105,19 @@ def test_bench_eight_ranks_dry_run():
     assert lv["wire_bf16_on"]["ms_per_view"] > 0 and lv["wire_bf16_on"]["wire_bytes_per_step"] < c["wire_bytes_per_step"]["total"]
     assert lv["views_per_rank_2"]["views_per_step"] == 16 and lv["views_per_rank_2"]["ms_per_view"] > 0
     assert lv["views_per_rank_2_concurrent"]["views_per_step"] == 16 and lv["views_per_rank_2_concurrent"]["ms_per_view"] > 0
+
+
+def test_bench_watchdog_prints_the_headline_alone():
+    """bench.py's watchdog: when the measurements behind the timed region do not finish in time (here: no time at all), rank 0 still
+    prints ONE line -- metric, value, steps, config -- and the process leaves with status 0."""
+    env = dict(os.environ, DGS_BENCH_WATCHDOG_S="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "4", "--warmup", "2"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert "headline only" in r["note"] and r["value"] > 0 and r["n_gpus"] == 1 and r["steps"] == 4 and r["unit"] == "views/s"
+    assert abs(r["value"] - 1e3 / r["ms_per_step"]) <= 1e-2 * r["value"] and "roofline" not in r
